@@ -1,0 +1,312 @@
+"""TEST INFRASTRUCTURE ONLY — CPU fp32 restatement of the ProNeRF render hot path.
+
+This file restates, from scratch, the algorithm of KAIST-VICLab/pronerf's inference
+``render_rays`` (run_S_eS_eN_alter_trt.py:599-696) and the operators it calls.  It is
+the *checker* for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  The product path
+(``pronerf_amd``) never does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  The reference has no tests/golden vectors of its own
+(SURVEY.md §4); this restatement is pinned against outputs of the reference itself,
+imported on CPU in the build container by ``oracle/gen_golden.py`` and committed as
+``tests/golden/*.npz`` (``tests/test_oracle_golden.py`` replays them).
+
+All tensors are fp32 torch CPU tensors (the reference is fp32 torch; the GEMMs here
+go through ``torch.nn.functional.linear`` exactly like ``nn.Linear`` there, so the
+agreement with the reference is at fp32 round-off).  Each function cites the
+reference ``file:line`` it follows (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+import torch
+import torch.nn.functional as F
+
+f32 = torch.float32
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=f32)
+
+
+# ----------------------------------------------------------------------------- rays
+def get_rays(H, W, K, c2w):
+    """Pixel grid -> world rays.  run_nerf_helpers.py:2705-2714 (get_rays)."""
+    K, c2w = _t(K), _t(c2w)
+    jj, ii = torch.meshgrid(torch.arange(H, dtype=f32), torch.arange(W, dtype=f32), indexing='ij')
+    dirs = torch.stack([(ii - K[0, 2]) / K[0, 0], -(jj - K[1, 2]) / K[1, 1], -torch.ones_like(ii)], -1)
+    rays_d = (dirs[..., None, :] * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """Shift to the near plane and project to NDC.  run_nerf_helpers.py:2776-2793."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    o = rays_o + t[..., None] * rays_d
+    sx = -1.0 / (W / (2.0 * focal))
+    sy = -1.0 / (H / (2.0 * focal))
+    o0 = sx * o[..., 0] / o[..., 2]
+    o1 = sy * o[..., 1] / o[..., 2]
+    o2 = 1.0 + 2.0 * near / o[..., 2]
+    d0 = sx * (rays_d[..., 0] / rays_d[..., 2] - o[..., 0] / o[..., 2])
+    d1 = sy * (rays_d[..., 1] / rays_d[..., 2] - o[..., 1] / o[..., 2])
+    d2 = -2.0 * near / o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def pluecker(o, d):
+    """[normalize(d), o x normalize(d)].  run_nerf_helpers.py:629-632 (Pluecker.forward)."""
+    dn = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    m = torch.linalg.cross(o, dn, dim=-1)
+    return torch.cat([dn, m], -1)
+
+
+def ray_points(o, d, t0, t1, n):
+    """o + t*d at t=linspace(t0,t1,n).  run_S_eS_eN_alter_trt.py:546-562."""
+    t = torch.linspace(t0, t1, n, dtype=f32)
+    return o[..., None, :] + d[..., None, :] * t[None, :, None]
+
+
+def mm_input_from_rays(o, d, n_pts=48):
+    """Sampler input [N, 6*n_pts].  run_S_eS_eN_alter_trt.py:274-277."""
+    pts = ray_points(o, d, 0.0, 1.0, n_pts)
+    pl = pluecker(pts, d[:, None, :].expand(-1, n_pts, -1))
+    return pl.reshape(o.shape[0], 6 * n_pts)
+
+
+def posenc(x, n_freq):
+    """[x, sin(2^k x), cos(2^k x)]_k.  run_nerf_helpers.py:666-671 / :677-692."""
+    out = [x]
+    for k in range(n_freq):
+        f = float(2.0 ** k)
+        out.append(torch.sin(x * f))
+        out.append(torch.cos(x * f))
+    return torch.cat(out, -1)
+
+
+# ----------------------------------------------------------------------------- MLPs
+def _lin(x, W, b):
+    return F.linear(x, _t(W), _t(b))
+
+
+def mlp_elu_backbone(x, Ws, bs):
+    """6x[Linear+ELU] + Linear, no skip (mmnetskips=[10000]).  run_nerf_helpers.py:1490-1497."""
+    h = x
+    for W, b in zip(Ws[:-1], bs[:-1]):
+        h = F.elu(_lin(h, W, b))
+    return _lin(h, Ws[-1], bs[-1])
+
+
+def sampler_forward(w, mm_input, n_samples=8):
+    """MinMaxRaySamplerTRT_Net.forward.  run_nerf_helpers.py:1490-1507.
+    Returns (mm_rgb, density_add, density_mul, depth)."""
+    S = n_samples
+    y = mlp_elu_backbone(mm_input, w['W'], w['b'])
+    return torch.sigmoid(y[:, 3 * S:]), y[:, S:2 * S], y[:, 2 * S:3 * S], torch.sigmoid(y[:, :S])
+
+
+def refine_forward(w, x, n_samples=8):
+    """MinMaxRayEpiSamplerTRT_Net.forward.  run_nerf_helpers.py:1526-1540.
+    Returns (refine_depth, refine_rgb, points_offset)."""
+    S = n_samples
+    y = mlp_elu_backbone(x, w['W'], w['b'])
+    return torch.sigmoid(y[:, :S]), torch.sigmoid(y[:, 4 * S:]), torch.tanh(y[:, S:4 * S])
+
+
+def nerf_forward(w, emb_pts, emb_dirs):
+    """DoNeRFTRT.forward (skip='auto': view encoding concatenated before the last layer).
+    run_nerf_helpers.py:1331-1343; layer table :1190-1239."""
+    h = emb_pts
+    n = len(w['W'])
+    for i in range(n):
+        if i == n - 1:
+            h = torch.cat([h, emb_dirs], -1)
+        h = _lin(h, w['W'][i], w['b'][i])
+        if i + 1 < n:
+            h = F.relu(h)
+    return h
+
+
+def nerfcls_forward(w, x, input_ch=63, input_ch_views=27, skips=(4,)):
+    """NeRF.forward (use_viewdirs=True).  run_nerf_helpers.py:824-847."""
+    pts, views = x[..., :input_ch], x[..., input_ch:input_ch + input_ch_views]
+    h = pts
+    for i, (W, b) in enumerate(w['pts_linears']):
+        h = F.relu(_lin(h, W, b))
+        if i in skips:
+            h = torch.cat([pts, h], -1)
+    alpha = _lin(h, *w['alpha_linear'])
+    feat = _lin(h, *w['feature_linear'])
+    h = torch.cat([feat, views], -1)
+    h = F.relu(_lin(h, *w['views_linears'][0]))
+    rgb = _lin(h, *w['rgb_linear'])
+    return torch.cat([rgb, alpha], -1)
+
+
+# ----------------------------------------------------------------------------- sort
+def sort_gather(depth, add, mul, near, far):
+    """depth affine + ascending sort + permute add/mul.  run_S_eS_eN_alter_trt.py:631-635.
+    ``torch.sort`` on CPU is stable (ties: lower original index first)."""
+    depth = depth * (far - near) + near
+    d_sorted, idx = torch.sort(depth, dim=-1, stable=True)
+    return d_sorted, idx, torch.gather(add, 1, idx), torch.gather(mul, 1, idx)
+
+
+# ----------------------------------------------------------------------------- projection
+def bilinear_zeros(img, X, Y):
+    """Bilinear fetch at pixel coordinates, zero padding per tap — what
+    ``grid_sample(bilinear, padding_mode='zeros', align_corners=True)`` computes after the
+    reference's normalisation.  inverse_warp.py:607-615.
+
+    img [C,Hf,Wf]; X,Y [n]  ->  [C,n].  The normalise/unnormalise round trip of the
+    reference (2X/(Wf-1)-1, then ((x+1)/2)*(Wf-1)) is replayed so that fp32 rounding agrees.
+    """
+    C, Hf, Wf = img.shape
+    xn = 2 * X / (Wf - 1) - 1
+    yn = 2 * Y / (Hf - 1) - 1
+    ix = ((xn + 1) / 2) * (Wf - 1)
+    iy = ((yn + 1) / 2) * (Hf - 1)
+    x0 = torch.floor(ix); y0 = torch.floor(iy)
+    x1 = x0 + 1; y1 = y0 + 1
+    wx1 = ix - x0; wx0 = x1 - ix
+    wy1 = iy - y0; wy0 = y1 - iy
+    flat = img.reshape(C, Hf * Wf)
+    finite = torch.isfinite(ix) & torch.isfinite(iy)
+
+    def tap(xx, yy, wgt):
+        ok = finite & (xx >= 0) & (xx <= Wf - 1) & (yy >= 0) & (yy <= Hf - 1)
+        xi = torch.where(ok, xx, torch.zeros_like(xx)).long()
+        yi = torch.where(ok, yy, torch.zeros_like(yy)).long()
+        v = flat[:, yi * Wf + xi]
+        return torch.where(ok, wgt, torch.zeros_like(wgt))[None] * v
+
+    return tap(x0, y0, wx0 * wy0) + tap(x1, y0, wx1 * wy0) + tap(x0, y1, wx0 * wy1) + tap(x1, y1, wx1 * wy1)
+
+
+def project_trt(images_nchw, proj, or_o, or_d, depth_ndc, eps=1e-5):
+    """NDC depth -> metric depth -> world point -> pixel in each neighbour -> bilinear RGB.
+    run_S_eS_eN_alter_trt.py:637-655 + inverse_warp.py:584-619.
+
+    images_nchw [NB,3,Hf,Wf]; proj [NB,3,4] (= K.diag(1,-1,-1).pose, trt.py:289-294);
+    or_o/or_d [N,3] un-normalised camera rays; depth_ndc [N,S] sorted sampler depths.
+    Returns epi [N, NB*S*3] with index (k*S+s)*3+c (neighbour-major, trt.py:653-655).
+    Non-finite pixel coordinates (p.z == 0) contribute 0 — the HIP kernel's defined behaviour.
+    """
+    N, S = depth_ndc.shape
+    NB = images_nchw.shape[0]
+    z3d = 1.0 / (1.0 - depth_ndc - eps)                                     # trt.py:637
+    ro1 = torch.cat([or_o, torch.ones(N, 1)], -1)                           # trt.py:256-258
+    rd1 = torch.cat([or_d, torch.zeros(N, 1)], -1)
+    out = torch.zeros(N, NB, S, 3)
+    for k in range(NB):
+        for s in range(S):
+            w = ro1 + rd1 * z3d[:, s:s + 1]                                 # inverse_warp.py:600
+            p = w @ proj[k].T                                               # inverse_warp.py:601 (bmm)
+            X = p[:, 0] / p[:, 2]; Y = p[:, 1] / p[:, 2]                    # :603-605
+            out[:, k, s, :] = bilinear_zeros(images_nchw[k], X, Y).T
+    return out.reshape(N, NB * S * 3)
+
+
+# ----------------------------------------------------------------------------- refine / composite
+def interval_refine(depth_sorted, refine, near, far):
+    """z = lower + (upper-lower)*refine over the sorted-depth midpoints.  trt.py:673-677."""
+    mids = 0.5 * (depth_sorted[..., 1:] + depth_sorted[..., :-1])
+    upper = torch.cat([mids, 0.5 * (far + depth_sorted[..., -1:])], -1)
+    lower = torch.cat([0.5 * (near + depth_sorted[..., :1]), mids], -1)
+    return lower + (upper - lower) * refine
+
+
+def raw2outputs(raw, z_vals, rays_d, add=None, mul=None, noise=None, clamp=0.0, white_bkgd=False):
+    """Alpha compositing with the sampler's density modulation.
+    Infer variant: run_S_eS_eN_alter_trt.py:564-597.  Training variants (clamp +-10,
+    additive sigma noise, white background; run_S_eS_eN_alter_base.py:501-551,
+    run_S_eS_eN_alter_base_refine2.py:475-522) are selected by the keyword arguments;
+    ``noise`` is the already-scaled [N,S] sample added to sigma_raw.
+    Returns (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    if clamp > 0:
+        raw = raw.clamp(-clamp, clamp)
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)
+    dists = dists * rays_d[..., None, :].norm(dim=-1)
+    rgb = torch.sigmoid(raw[..., :3])
+    sig = raw[..., 3]
+    if noise is not None:
+        sig = sig + noise
+    if add is not None:
+        sig = sig + add
+    alpha = 1.0 - torch.exp(-F.relu(sig) * dists)
+    if mul is not None:
+        alpha = alpha * F.relu(mul)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    weights = alpha * T
+    rgb_map = (weights[..., None] * rgb).sum(-2)
+    depth_map = (weights * z_vals).sum(-1)
+    acc_map = weights.sum(-1)
+    disp_map = 1.0 / torch.max(1e-10 * torch.ones_like(depth_map), depth_map / acc_map)
+    if white_bkgd:
+        rgb_map = rgb_map + (1.0 - acc_map[..., None])
+    return rgb_map, disp_map, acc_map, weights, depth_map
+
+
+# ----------------------------------------------------------------------------- frame setup + render
+def frame_setup(scene, n_samples=8, num_neighbor=4, n_pts=48, near=0.0, far=1.0, or_near=1.0, or_far=10.0):
+    """Per-frame inputs of ``render_rays`` built as ``render_path`` does.
+    run_S_eS_eN_alter_trt.py:245-302.  Returns rays [N,11], or_rays [N,11], mm_input
+    [N,288], ref_nos, neighbour images [NB,3,Hf,Wf] and projection matrices [NB,3,4]."""
+    H, W, K = scene['H'], scene['W'], _t(scene['K'])
+    c2w, poses, images = _t(scene['c2w']), _t(scene['poses']), _t(scene['images'])
+    rays_o, rays_d = get_rays(H, W, K, c2w)                                    # :245
+    viewdirs = (rays_d / rays_d.norm(dim=-1, keepdim=True)).reshape(-1, 3)     # :246-248
+    or_o = rays_o.reshape(-1, 3); or_d = rays_d.reshape(-1, 3)
+    N = or_o.shape[0]
+    or_rays = torch.cat([or_o, or_d, torch.full((N, 1), or_near), torch.full((N, 1), or_far), viewdirs], -1)
+    o, d = ndc_rays(H, W, float(K[0, 0]), 1.0, rays_o, rays_d)                 # :265
+    o = o.reshape(-1, 3); d = d.reshape(-1, 3)
+    rays = torch.cat([o, d, torch.full((N, 1), near), torch.full((N, 1), far), viewdirs], -1)
+    mm_input = mm_input_from_rays(o, d, n_pts)                                 # :274-277
+    dist = ((c2w[None, :, 3] - poses[:, :, 3]) ** 2).sum(1) ** 0.5             # :281
+    ref_nos = torch.sort(dist, dim=0, stable=True)[1][:num_neighbor]           # :282-283
+    nb_img = images[ref_nos].permute(0, 3, 1, 2).contiguous()                  # :286,296
+    flip = torch.diag(torch.tensor([1.0, -1.0, -1.0]))
+    proj = K[None] @ (flip[None] @ poses[ref_nos])                             # :289-294
+    return {'rays': rays.contiguous(), 'or_rays': or_rays.contiguous(), 'mm_input': mm_input.contiguous(),
+            'ref_nos': ref_nos, 'images': nb_img, 'proj': proj.contiguous(), 'sh': (H, W, 3)}
+
+
+def render_rays_infer(weights, rays, or_rays, images, proj, mm_input=None, n_samples=8, n_pts=48,
+                      multires=10, multires_views=4, eps=1e-5, nerf='donerf'):
+    """Inference ``render_rays``.  run_S_eS_eN_alter_trt.py:599-696.  Returns every
+    intermediate so each HIP stage can be checked on its own."""
+    S = n_samples
+    N = rays.shape[0]
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    viewdirs = rays[:, -3:]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    if mm_input is None:
+        mm_input = mm_input_from_rays(o, d, n_pts)
+    mm_rgb, add, mul, depth = sampler_forward(weights['sampler'], mm_input, S)          # :628
+    depth_sorted, idx, add_s, mul_s = sort_gather(depth, add, mul, near, far)           # :631-635
+    epi = project_trt(images, proj, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, eps)  # :637-655
+    epi_pts = o[:, None, :] + d[:, None, :] * depth_sorted[..., None]                   # :656
+    pl = pluecker(epi_pts, d[:, None, :].expand(-1, S, -1)).reshape(N, 6 * S)           # :657-658
+    refine_in = torch.cat([pl, epi], 1)                                                 # :661
+    rdepth, _, offs = refine_forward(weights['refine'], refine_in, S)                   # :668
+    z = interval_refine(depth_sorted, rdepth, near, far)                                # :673-677
+    pts = o[:, None, :] + d[:, None, :] * z[..., None] + 1e-2 * offs.reshape(N, S, 3)   # :679-681
+    emb = posenc(pts.reshape(-1, 3), multires)                                          # :198
+    emb_d = posenc(viewdirs[:, None, :].expand(-1, S, -1).reshape(-1, 3), multires_views)  # :200-204
+    if nerf == 'donerf':
+        raw = nerf_forward(weights['nerf'], emb, emb_d).reshape(N, S, 4)                # :206
+    else:
+        raw = nerfcls_forward(weights['nerfcls'], torch.cat([emb, emb_d], -1)).reshape(N, S, 4)
+    rgb, disp, acc, wts, dmap = raw2outputs(raw, z, d, add_s, mul_s)                    # :694
+    return {'mm_rgb': mm_rgb, 'depth_raw': depth, 'depth_sorted': depth_sorted, 'sort_idx': idx,
+            'add_sorted': add_s, 'mul_sorted': mul_s, 'epi': epi, 'refine_in': refine_in,
+            'refine_depth': rdepth, 'offsets': offs, 'z': z, 'pts': pts, 'raw': raw,
+            'rgb': rgb, 'disp': disp, 'acc': acc, 'weights': wts, 'depth': dmap}
+
+
+def psnr(a, b, peak=1.0):
+    mse = torch.mean((a.double() - b.double()) ** 2).item()
+    return float('inf') if mse == 0 else 10.0 * math.log10(peak * peak / mse)

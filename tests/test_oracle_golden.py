@@ -1,0 +1,106 @@
+"""CPU: pin the oracle (oracle/pronerf_oracle.py) against outputs of the reference itself.
+
+The fixtures in tests/golden/ were produced by oracle/gen_golden.py, which imports the
+reference on CPU.  Tolerances are fp32 round-off: the restatement runs the same torch
+CPU GEMMs, so anything larger than a few ulp signals an algorithmic difference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pronerf_oracle as orc
+from oracle import synth
+
+INFER_CASES = ['infer_trained_24x32', 'infer_default_24x32', 'infer_spread_20x28_img48x64',
+               'infer_trained_oob_16x24', 'infer_trained_fern_756x1008']
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + '.npz')))
+
+
+def rebuild(g):
+    scene = synth.make_scene(int(g['seed']), H=int(g['H']), W=int(g['W']), Hf=int(g['Hf']), Wf=int(g['Wf']),
+                             rotate=bool(g['rotate']), sigma_t=float(g['sigma_t']))
+    fr = orc.frame_setup(scene)
+    sel = torch.from_numpy(g['sel'])
+    w = synth.make_weights(int(g['seed']), str(g['kind']))
+    return scene, fr, sel, w
+
+
+@pytest.mark.parametrize('name', INFER_CASES)
+def test_frame_setup_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    _, fr, sel, _ = rebuild(g)
+    assert fr['rays'].shape[0] == int(g['n_full'])
+    np.testing.assert_allclose(fr['rays'][sel].numpy(), g['rays'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(fr['or_rays'][sel].numpy(), g['or_rays'], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(fr['ref_nos'].numpy(), g['ref_nos'])
+    np.testing.assert_allclose(fr['proj'].numpy(), g['proj'], rtol=1e-6, atol=1e-5)
+    mm = fr['mm_input'][sel].numpy()
+    np.testing.assert_allclose(mm[:, :12], g['mm_input_head'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(mm[:, -6:], g['mm_input_tail'], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', INFER_CASES)
+def test_render_rays_infer_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    _, fr, sel, w = rebuild(g)
+    # feed the reference's own rays so that this test isolates render_rays from frame setup
+    rays = torch.from_numpy(g['rays']); or_rays = torch.from_numpy(g['or_rays'])
+    out = orc.render_rays_infer(w, rays, or_rays, fr['images'], torch.from_numpy(g['proj']))
+    tie_free = np.diff(g['depth_sorted'], axis=1).min(axis=1) > 1e-6
+    np.testing.assert_allclose(out['depth_raw'].numpy(), g['depth_raw'], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(out['sort_idx'].numpy()[tie_free], g['sort_idx'][tie_free])
+    if str(g['kind']) != 'default':
+        assert tie_free.all()
+    m = tie_free
+    tol = dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out['depth_sorted'].numpy(), g['depth_sorted'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['add_sorted'].numpy()[m], g['add_sorted'][m], **tol)
+    np.testing.assert_allclose(out['mul_sorted'].numpy()[m], g['mul_sorted'][m], **tol)
+    np.testing.assert_allclose(out['mm_rgb'].numpy(), g['mm_rgb'], **tol)
+    np.testing.assert_allclose(out['epi'].numpy(), g['epi'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out['refine_in'].numpy()[:, :48], g['plucker8'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out['refine_depth'].numpy()[m], g['refine_depth'][m], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out['offsets'].numpy()[m], g['offsets'][m], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out['z'].numpy()[m], g['z'][m], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out['raw'].numpy()[m], g['raw'][m], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(out['rgb'].numpy()[m], g['rgb'][m], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out['depth'].numpy()[m], g['depth'][m], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out['weights'].numpy()[m], g['weights'][m], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out['acc'].numpy()[m], g['acc'][m], rtol=0, atol=2e-4)
+    assert orc.psnr(out['rgb'][m], torch.from_numpy(g['rgb'][m])) > 80.0
+
+
+def test_operator_goldens(golden_dir):
+    g = load(golden_dir, 'operators')
+    x = torch.from_numpy(g['pe_x'])
+    np.testing.assert_allclose(orc.posenc(x, 10).numpy(), g['pe10'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(orc.posenc(x, 4).numpy(), g['pe4'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(orc.pluecker(torch.from_numpy(g['pl_o']), torch.from_numpy(g['pl_d'])).numpy(), g['pl'], rtol=0, atol=1e-6)
+    ro, rd = orc.get_rays(9, 13, g['gr_K'], g['gr_c2w'])
+    np.testing.assert_allclose(ro.numpy(), g['gr_o'], atol=1e-7); np.testing.assert_allclose(rd.numpy(), g['gr_d'], atol=1e-6)
+    no, nd = orc.ndc_rays(9, 13, float(g['gr_K'][0, 0]), 1.0, ro, rd)
+    np.testing.assert_allclose(no.numpy(), g['ndc_o'], atol=2e-6); np.testing.assert_allclose(nd.numpy(), g['ndc_d'], atol=2e-6)
+    # warp: recompute pixel coordinates like inverse_warp.py:600-605, fetch with the oracle's bilinear
+    img = torch.from_numpy(g['wp_img']); B = img.shape[0]
+    ro1 = torch.from_numpy(g['wp_ro1']); rd1 = torch.from_numpy(g['wp_rd1']); w2c = torch.from_numpy(g['wp_w2c'])
+    depth = torch.from_numpy(g['wp_depth'])
+    frac_inside = 0.0
+    for b in range(B):
+        w = ro1 + rd1 * depth[b]
+        p = w2c[b] @ w
+        got = orc.bilinear_zeros(img[b], p[0] / p[2], p[1] / p[2])
+        np.testing.assert_allclose(got.numpy(), g['wp_out'][b, :, 0, :], rtol=0, atol=1e-5)
+        frac_inside += float((got.abs().sum(0) > 0).float().mean()) / B
+    assert 0.1 < frac_inside < 0.95          # the case really exercises zero padding
+    r = orc.raw2outputs(torch.from_numpy(g['c_raw']), torch.from_numpy(g['c_z']), torch.from_numpy(g['c_d']),
+                        torch.from_numpy(g['c_add']), torch.from_numpy(g['c_mul']))
+    for got, key in zip(r, ('c_rgb', 'c_disp', 'c_acc', 'c_w', 'c_depth')):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=1e-6)
+    wc = synth.make_nerfcls_weights(0)
+    y = orc.nerfcls_forward(wc, torch.from_numpy(g['nc_x']))
+    np.testing.assert_allclose(y.numpy(), g['nc_y'], rtol=1e-4, atol=1e-4)
