@@ -1,0 +1,142 @@
+/* pronerf_hip.h — C ABI of libpronerf_hip.so (MI355X / gfx950).
+ *
+ * The reference (KAIST-VICLab/pronerf) is pure Python over torch; it has no FFI layer.  Its
+ * "operator boundary" is the set of Python callables the driver scripts import by name
+ * (run_S_eS_eN_alter_trt.py:19,27).  Each entry point below replaces the torch-op sequence of
+ * one of those callables (cited per function, paths relative to the reference root) and is
+ * what a ctypes binding on the reference side would call.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is device memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); tensors are contiguous, fp32 unless noted; nothing is allocated per call;
+ *   - `stream` is a hipStream_t (NULL = default stream); all launches are asynchronous on it,
+ *     there is no hidden device synchronisation;
+ *   - return 0 = ok, < 0 = argument error (PNRF_E_*), > 0 = hipError_t; the message for the
+ *     last non-zero return of the calling thread is available from pnrf_last_error();
+ *   - handles are immutable after creation: entry points are re-entrant across streams.
+ */
+#ifndef PRONERF_HIP_H
+#define PRONERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNRF_ABI_VERSION 1
+
+#define PNRF_E_ARG (-1)      /* bad argument (null pointer, negative size, wrong dims) */
+#define PNRF_E_SHAPE (-2)    /* network shape not supported by the packed kernels */
+#define PNRF_E_STATE (-3)    /* handle/context misuse (e.g. more rays than the context was sized for) */
+
+/* network kinds for pnrf_mlp_pack */
+#define PNRF_NET_SAMPLER 0   /* MinMaxRaySamplerTRT_Net / MinMaxRay_Net, 288->6x256->27, ELU  (run_nerf_helpers.py:1440-1507) */
+#define PNRF_NET_REFINE 1    /* MinMaxRayEpiSamplerTRT_Net, 144->6x256->35, ELU                 (run_nerf_helpers.py:1509-1540) */
+#define PNRF_NET_NERF 2      /* DoNeRFTRT(skip='auto'), 63->7x256->[256+27]->4, ReLU            (run_nerf_helpers.py:1186-1343) */
+
+typedef struct pnrf_mlp pnrf_mlp_t;
+typedef struct pnrf_ctx pnrf_ctx_t;
+
+int pnrf_abi_version(void);
+const char* pnrf_last_error(void);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * Pack one network's nn.Linear parameters (HOST pointers, torch layout W[out][in], n_layers
+ * matrices) into the device-resident, pre-tiled weight stream consumed by the MFMA kernels.
+ * Replaces load_state_dict + .to(device) for the three inference nets
+ * (run_S_eS_eN_alter_trt.py:427-458, 468-481).  Synchronous; not on the render path. */
+int pnrf_mlp_pack(int net, const float* const* W, const float* const* b, const int* in_dim,
+                  const int* out_dim, int n_layers, pnrf_mlp_t** out);
+int pnrf_mlp_free(pnrf_mlp_t* h);
+
+/* Module-level forward y = net(x): the raw output of the last Linear, [m, out_dim], before the
+ * sigmoid/tanh slicing of the TRT wrapper classes.  x: dev [m, in_dim]; x_views: dev [m, 27]
+ * (PNRF_NET_NERF only: the view embedding concatenated before the last layer), else NULL.
+ * Replaces <module>.forward (run_nerf_helpers.py:1490-1497, 1526-1533, 1331-1343). */
+int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, void* stream);
+
+/* ---- element-wise operators --------------------------------------------------------------- */
+/* Embedder.embed: out[n, 3+6*n_freq] = [x, sin(2^k x), cos(2^k x)]_k  (run_nerf_helpers.py:666-671). */
+int pnrf_posenc_fwd(const float* x, float* out, int64_t n, int n_freq, void* stream);
+/* Pluecker.forward: out[n,6] = [d/|d|, o x d/|d|]  (run_nerf_helpers.py:629-632). */
+int pnrf_plucker_fwd(const float* o, const float* d, float* out, int64_t n, void* stream);
+/* Sampler input: mm_input[n, 6*n_pts] = Pluecker of n_pts points o + t d, t = linspace(0,1,n_pts);
+ * rays: dev [n, 11] NDC ray batch (run_S_eS_eN_alter_trt.py:274-277, 546-562). */
+int pnrf_ray_encode_fwd(const float* rays, float* mm_input, int64_t n, int n_pts, void* stream);
+/* Per-frame ray set-up: get_rays + viewdirs + ndc_rays -> rays[H*W,11] = [o',d',near,far,viewdir],
+ * or_rays[H*W,11] = [o,d,or_near,or_far,viewdir].  K (3x3) and c2w (3x4) are HOST pointers.
+ * (run_S_eS_eN_alter_trt.py:245-271; run_nerf_helpers.py:2705-2714, 2776-2793). */
+int pnrf_frame_rays_fwd(const float* K, const float* c2w, int H, int W, float near, float far,
+                        float or_near, float or_far, int64_t first, int64_t count,
+                        float* rays, float* or_rays, void* stream);
+/* ndc_rays on an arbitrary ray set: rays_o, rays_d dev [n,3] -> out_o, out_d dev [n,3]
+ * (run_nerf_helpers.py:2776-2793). */
+int pnrf_ndc_rays_fwd(const float* rays_o, const float* rays_d, int H, int W, float focal, float near,
+                      float* out_o, float* out_d, int64_t n, void* stream);
+/* inverse_warp_rod1_rt2_coords_trt: img dev [B,3,Hf,Wf]; depth dev [B,n]; ro1,rd1 dev [4,n] per
+ * batch entry with batch stride ray_bstride floats (0 = shared by all B, the reference's
+ * expand()); w2c dev [B,3,4]; out dev [B,3,n].
+ * Bilinear, zero padding, align_corners=True (inverse_warp.py:584-619). */
+int pnrf_warp_trt_fwd(const float* img, const float* depth, const float* ro1, const float* rd1,
+                      int64_t ray_bstride, const float* w2c, float* out, int B, int Hf, int Wf,
+                      int64_t n, void* stream);
+/* Neighbour images [nv,3,Hf,Wf] -> texel-interleaved [nv,Hf,Wf,4] used by the fused projection
+ * (replaces the x8 image replication of run_S_eS_eN_alter_trt.py:296-298). */
+int pnrf_images_pack(const float* img_nchw, float* out_nhwc4, int nv, int Hf, int Wf, void* stream);
+/* Projection + sample Pluecker: refine_in[n,144] = [pluecker(8 samples)(48), epi(96)] with
+ * epi index (k*8+s)*3+c  (run_S_eS_eN_alter_trt.py:637-661).  rays,or_rays dev [n,11];
+ * depth_sorted dev [n,8]; img4 dev [nb,Hf,Wf,4]; proj dev [nb,3,4]; eps = 1e-5 (stage 1: 1e-6). */
+int pnrf_refine_input_fwd(const float* rays, const float* or_rays, const float* depth_sorted,
+                          const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
+                          float* refine_in, int64_t n, void* stream);
+/* raw2outputs (infer variant; clamp/noise/white_bkgd select the training variants):
+ * raw dev [n,s,4]; z dev [n,s]; rays_d dev [n,3] with row stride d_stride floats; add,mul dev
+ * [n,s] or NULL; noise dev [n,s] or NULL.  Outputs (any may be NULL): rgb[n,3], disp[n],
+ * acc[n], weights[n,s], depth[n]  (run_S_eS_eN_alter_trt.py:564-597). */
+int pnrf_composite_fwd(const float* raw, const float* z, const float* rays_d, int d_stride,
+                       const float* add, const float* mul, const float* noise, float clamp,
+                       int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
+                       float* depth, int64_t n, int s, void* stream);
+
+/* ---- fused stages ---------------------------------------------------------------------------
+ * Sampler: Pluecker ray encoding -> fp32 MLP (exact f32 MFMA) -> sigmoid, depth affine, stable
+ * ascending sort of the 8 depths, permutation of add/mul.  rays dev [n,11].  Outputs dev:
+ * depth_sorted[n,8], add_sorted[n,8], mul_sorted[n,8]; optional (NULL to skip) sort_idx[n,8]
+ * (int64, the "sampler indices"), mm_rgb[n,3], depth_raw[n,8] (sigmoid output before the sort).
+ * (run_S_eS_eN_alter_trt.py:628-635) */
+int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted,
+                     float* add_sorted, float* mul_sorted, int64_t* sort_idx, float* mm_rgb,
+                     float* depth_raw, void* stream);
+/* Refine: bf16 MLP on refine_in[n,144] -> sigmoid/tanh -> interval refinement -> query points.
+ * Outputs dev: z[n,8], pts[n,8,3]  (run_S_eS_eN_alter_trt.py:668-681). */
+int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
+                    const float* depth_sorted, float* z, float* pts, int64_t n, void* stream);
+/* NeRF: positional encoding of pts/viewdirs -> bf16 MLP -> alpha compositing with the sampler's
+ * density modulation.  pts dev [n,8,3]; rays dev [n,11]; z, add_sorted, mul_sorted dev [n,8].
+ * Outputs dev: rgbd[n,4] = (r,g,b,depth); raw[n,8,4] optional (NULL to skip).
+ * (run_S_eS_eN_alter_trt.py:691-694; run_network :195-208) */
+int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
+                  const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
+                  int64_t n, void* stream);
+
+/* ---- whole path: render_rays (inference) ----------------------------------------------------
+ * A context owns the per-ray workspace for up to max_rays rays (allocated once). */
+int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refine, const pnrf_mlp_t* nerf,
+                    int64_t max_rays, pnrf_ctx_t** out);
+int pnrf_ctx_free(pnrf_ctx_t* ctx);
+/* render_rays(ray_batch, or_ray_batch, ...) -> rgbd[n,4] = (rgb_map, depth_map); sort_idx
+ * optional.  img4 dev [nb,Hf,Wf,4] (pnrf_images_pack), proj dev [nb,3,4].
+ * (run_S_eS_eN_alter_trt.py:599-696) */
+int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_rays,
+                         const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
+                         float* rgbd, int64_t* sort_idx, int64_t n, void* stream);
+
+/* Host helper: torch.linspace(start,end,n) in fp32, as used for the 48 ray points
+ * (run_S_eS_eN_alter_trt.py:556-557).  out: HOST [n]. */
+int pnrf_linspace(float start, float end, int n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRONERF_HIP_H */

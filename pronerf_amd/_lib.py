@@ -1,0 +1,84 @@
+"""ctypes binding of libpronerf_hip.so (include/pronerf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, a ``PnrfError`` is
+raised — the product path never silently degrades to eager PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpronerf_hip.so')
+
+NET_SAMPLER, NET_REFINE, NET_NERF = 0, 1, 2
+ABI_VERSION = 1
+
+
+class PnrfError(RuntimeError):
+    pass
+
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_f = C.c_float
+_i = C.c_int
+
+# name -> (restype, argtypes): every symbol include/pronerf_hip.h declares
+SIGNATURES = {
+    'pnrf_abi_version': (_i, []),
+    'pnrf_last_error': (C.c_char_p, []),
+    'pnrf_mlp_pack': (_i, [_i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, C.POINTER(_p)]),
+    'pnrf_mlp_free': (_i, [_p]),
+    'pnrf_mlp_fwd': (_i, [_p, _p, _p, _p, _i64, _p]),
+    'pnrf_posenc_fwd': (_i, [_p, _p, _i64, _i, _p]),
+    'pnrf_plucker_fwd': (_i, [_p, _p, _p, _i64, _p]),
+    'pnrf_ray_encode_fwd': (_i, [_p, _p, _i64, _i, _p]),
+    'pnrf_frame_rays_fwd': (_i, [C.POINTER(_f), C.POINTER(_f), _i, _i, _f, _f, _f, _f, _i64, _i64, _p, _p, _p]),
+    'pnrf_ndc_rays_fwd': (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _i64, _p]),
+    'pnrf_warp_trt_fwd': (_i, [_p, _p, _p, _p, _i64, _p, _p, _i, _i, _i, _i64, _p]),
+    'pnrf_images_pack': (_i, [_p, _p, _i, _i, _i, _p]),
+    'pnrf_refine_input_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i64, _p]),
+    'pnrf_composite_fwd': (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
+    'pnrf_sampler_fwd': (_i, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    'pnrf_refine_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i64, _p]),
+    'pnrf_nerf_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    'pnrf_ctx_create': (_i, [_p, _p, _p, _i64, C.POINTER(_p)]),
+    'pnrf_ctx_free': (_i, [_p]),
+    'pnrf_render_rays_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
+    'pnrf_linspace': (_i, [_f, _f, _i, C.POINTER(_f)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PnrfError(f'{LIB_PATH} is missing: run `python -m pronerf_amd.build` (or __graft_entry__.build()). '
+                        'pronerf_amd has no CPU fallback.')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise PnrfError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PnrfError(f'{LIB_PATH} does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.pnrf_abi_version()
+    if v != ABI_VERSION:
+        raise PnrfError(f'ABI version mismatch: library {v}, binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().pnrf_last_error()
+        raise PnrfError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')

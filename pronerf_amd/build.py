@@ -1,0 +1,78 @@
+"""Build libpronerf_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    python -m pronerf_amd.build [--force]
+
+The shared library lands in pronerf_amd/lib/ (git-ignored, but shipped to the GPU box by
+gpurun).  A content hash of the sources is stored next to it so that rebuilds are skipped
+when nothing changed.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libpronerf_hip.so')
+SOURCES = ['pnrf_pack.hip', 'pnrf_ops.hip', 'pnrf_mlp_kernels.hip']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil.which('hipcc')):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)')
+
+
+def _digest():
+    h = hashlib.sha256()
+    files = sorted(os.listdir(CSRC)) + ['../../include/pronerf_hip.h']
+    for f in files:
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p):
+            h.update(f.encode()); h.update(open(p, 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = LIB + '.sha256'
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(LIBDIR, s.replace('.hip', '.o'))
+        objs.append(o)
+        cmd = [hipcc] + FLAGS + ['-I', INCLUDE, '-c', os.path.join(CSRC, s), '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{out}')
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    for o in objs:
+        os.remove(o)
+    open(stamp, 'w').write(dig)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

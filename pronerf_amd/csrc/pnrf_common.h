@@ -1,0 +1,60 @@
+// pnrf_common.h — host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pronerf_hip.h"
+#include "pnrf_layout.h"
+
+namespace pnrf {
+
+void set_error(const char* fmt, ...);
+
+#define PNRF_REQUIRE(cond, code, ...)      \
+  do {                                     \
+    if (!(cond)) {                         \
+      pnrf::set_error(__VA_ARGS__);        \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+#define PNRF_HIP(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      pnrf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (int)e_;                                                                    \
+    }                                                                                    \
+  } while (0)
+
+#define PNRF_LAUNCH_CHECK()                                                              \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) {                                                              \
+      pnrf::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (int)e_;                                                                    \
+    }                                                                                    \
+  } while (0)
+
+}  // namespace pnrf
+
+// Packed, device-resident network (immutable after pnrf_mlp_pack).
+struct pnrf_mlp {
+  int net;               // PNRF_NET_*
+  int prec;              // pnrf::PREC_*
+  int in_dim, in_dim_x;  // input width, extra (view) input width
+  int out_dim;
+  void* d_blob;          // weight stream: nslots x 16 KiB
+  uint32_t nslots;
+  float* d_bias;         // packed biases
+  int nbias;
+  int* d_in0;            // layer-0 input map   (device copy, for the module-level forward)
+  int* d_inx;            // extra-input map (nerf view k-steps) or NULL
+  int* d_out;            // last-layer output map [tiles*64]: (tile, half, reg) -> output index
+  int n_in0, n_inx, n_out;
+  float* d_tvals;        // sampler only: t = torch.linspace(0,1,48) of the ray points (trt.py:556-557)
+  int device;
+};

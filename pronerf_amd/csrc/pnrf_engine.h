@@ -1,0 +1,178 @@
+// pnrf_engine.h — device-side fused-MLP engine for gfx950 (MI355X, CDNA4).
+//
+// Design ("transposed MLP, register-resident activations, LDS weight stream"):
+//   * Every MLP layer is computed as  H_out^T[256 x cols] = W[256 x K] * H_in^T[K x cols]
+//     with the WEIGHT matrix as the MFMA A operand and the ACTIVATIONS as the B operand.
+//     The 32x32 f32 result tile of v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 has its
+//     column (= ray / ray-sample) on the lane and its rows (= output features) in the 16
+//     accumulator registers, so after bias+activation(+bf16 pack) it *is* the B operand of the
+//     next layer: activations never leave the register file between layers.
+//   * Weights are pre-packed on the host into 1 KiB "fragments" (64 lanes x 16 B) in exactly
+//     the order the kernel consumes them, so the global->LDS copy is a linear LDS-DMA
+//     (global_load_lds_dwordx4) and every ds_read_b128 is lane-linear (conflict free).
+//   * The packed blob is streamed through a ring of NSLOTS x 16 KiB LDS slots shared by the 4
+//     waves (one per SIMD) of the workgroup; PD slots are kept in flight behind a counted
+//     s_waitcnt vmcnt(N) + raw s_barrier (one barrier per 16 KiB slot).
+//
+// This engine replaces the reference's chain of aten addmm + elu/relu launches
+// (run_nerf_helpers.py:1490-1497, 1526-1533, 1331-1343).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnrf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int FRAG_BYTES = 1024;                  // 64 lanes x 16 B
+constexpr int SLOT_FRAGS = 16;
+constexpr int SLOT_BYTES = SLOT_FRAGS * FRAG_BYTES;   // 16 KiB
+constexpr int NSLOTS = 4;                          // ring slots (64 KiB of LDS)
+constexpr int PD = 3;                              // slots in flight ahead of the consumer
+constexpr int WAVES = 4;                           // one wave per SIMD
+constexpr int LOADS_PER_WAVE = SLOT_FRAGS / WAVES; // LDS-DMA instructions per wave per slot
+constexpr int RING_BYTES = NSLOTS * SLOT_BYTES;
+
+enum { ACT_RELU = 0, ACT_ELU = 1 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ------------------------------------------------------------------------------------------
+// Weight stream: global blob -> LDS ring by LDS-DMA.  All members are wave-uniform except woff.
+struct WStream {
+  const char* g;       // packed blob
+  char* ring;          // LDS ring base
+  uint32_t nslots;     // slots in the blob (multiple of NSLOTS)
+  uint32_t src_slot;   // next source slot
+  uint32_t dst_pos;    // next ring position
+  uint32_t woff;       // per-lane byte offset inside a slot (source side)
+  uint32_t wbase;      // wave-uniform byte offset inside a slot (LDS side)
+
+  __device__ __forceinline__ void init(const void* blob, uint32_t nslots_, char* ring_) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    g = (const char*)blob; ring = ring_; nslots = nslots_;
+    src_slot = 0; dst_pos = 0;
+    wbase = wave * (LOADS_PER_WAVE * FRAG_BYTES);
+    woff = wbase + lane * 16;
+  }
+  __device__ __forceinline__ void issue() {
+    const char* src = g + (size_t)src_slot * SLOT_BYTES + woff;
+    char* dst = ring + dst_pos * SLOT_BYTES + wbase;
+#pragma unroll
+    for (int i = 0; i < LOADS_PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + i * FRAG_BYTES), (lptr_t)(dst + i * FRAG_BYTES), 16, 0, 0);
+    src_slot = (src_slot + 1 == nslots) ? 0u : src_slot + 1;
+    dst_pos = (dst_pos + 1) & (NSLOTS - 1);
+  }
+  // Fill the pipeline: PD slots in flight.
+  __device__ __forceinline__ void prologue() {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue();
+  }
+  // Called before the first read of every slot, by every wave, in the same order.
+  //  vmcnt(N): my share of the slot about to be read has landed (N = younger slots in flight);
+  //  barrier : every wave's share has landed AND every wave has finished reading the previous
+  //            slot, whose ring position (== position of slot q+PD since NSLOTS == PD+1) is
+  //            then refilled.
+  __device__ __forceinline__ void begin() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue();
+  }
+  // LDS-DMA still in flight at kernel end would land in another workgroup's LDS: drain.
+  __device__ __forceinline__ void drain() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+};
+static_assert(NSLOTS == PD + 1, "ring protocol assumes one free slot");
+
+__device__ __forceinline__ float act_f32(float v, int act) {
+  // torch: relu = max(x,0); elu(alpha=1) = x > 0 ? x : expm1(x)   (F.elu, helpers:1494)
+  return act == ACT_RELU ? fmaxf(v, 0.f) : (v > 0.f ? v : expm1f(v));
+}
+__device__ __forceinline__ float act_fast(float v, int act) {
+  // bf16 path: the result is rounded to 8 significant bits, v_exp_f32 is accurate enough.
+  return act == ACT_RELU ? fmaxf(v, 0.f) : (v > 0.f ? v : __expf(v) - 1.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// One bf16 layer:  NT output tiles of 32 rows, KS k-steps of 16, NCB column blocks of 32.
+//   ringlane  = ring + lane*16            (LDS)
+//   biaslane  = bias_layer + h*16 floats  (LDS; packed [tile][h][16])
+//   Bi(cb,ks) = B operand of k-step ks for column block cb
+//   epi(to, acc[NCB]) consumes a finished tile (accumulator already holds W*x + b).
+// Fragment f = to*KS + ks of the layer lives in slot f/16 (layer start is slot aligned);
+// POS0 = ring position of the layer's first slot (compile-time: see layout in pnrf_pack).
+template <int NCB, int KS, int NT, int POS0, class BFn, class Epi>
+__device__ __forceinline__ void layer_bf16(WStream& st, const char* ringlane, const float* biaslane, BFn Bi, Epi epi) {
+#pragma unroll
+  for (int to = 0; to < NT; ++to) {
+    f32x16 acc[NCB];
+    {
+      const f32x4* bp = (const f32x4*)(biaslane + to * 32);
+      f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[cb][i] = b0[i]; acc[cb][4 + i] = b1[i]; acc[cb][8 + i] = b2[i]; acc[cb][12 + i] = b3[i]; }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int f = to * KS + ks;
+      if (f % SLOT_FRAGS == 0) st.begin();
+      const int pos = (POS0 + f / SLOT_FRAGS) % NSLOTS;
+      const bf16x8 a = *(const bf16x8*)(ringlane + pos * SLOT_BYTES + (f % SLOT_FRAGS) * FRAG_BYTES);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
+    }
+    epi(to, acc);
+  }
+}
+template <int KS, int NT> constexpr int layer_slots_bf16() { return (KS * NT + SLOT_FRAGS - 1) / SLOT_FRAGS; }
+
+// One f32 layer (exact fp32 FMA chain, v_mfma_f32_32x32x2_f32), one column block of 32.
+//   KS4 = k-steps/4 = fragments per tile (a fragment carries the A values of 4 k-steps).
+//   Bf(kk) = B operand (one float per lane) of k-step kk.
+template <int KS4, int NT, int POS0, class BFn, class Epi>
+__device__ __forceinline__ void layer_f32(WStream& st, const char* ringlane, const float* biaslane, BFn Bf, Epi epi) {
+#pragma unroll
+  for (int to = 0; to < NT; ++to) {
+    f32x16 acc;
+    {
+      const f32x4* bp = (const f32x4*)(biaslane + to * 32);
+      f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+    }
+#pragma unroll
+    for (int fr = 0; fr < KS4; ++fr) {
+      const int f = to * KS4 + fr;
+      if (f % SLOT_FRAGS == 0) st.begin();
+      const int pos = (POS0 + f / SLOT_FRAGS) % NSLOTS;
+      const f32x4 a = *(const f32x4*)(ringlane + pos * SLOT_BYTES + (f % SLOT_FRAGS) * FRAG_BYTES);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bf(4 * fr + i), acc, 0, 0, 0);
+    }
+    epi(to, acc);
+  }
+}
+template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + SLOT_FRAGS - 1) / SLOT_FRAGS; }
+
+// Row of a 32x32 accumulator tile held in register g of a lane in half h (cdna guide §3).
+__host__ __device__ constexpr int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// Feature (row of the 256-wide activation) that element j of half h supplies in bf16 k-step ks
+// when the B operand is the previous layer's packed accumulator (hidden layers).
+__host__ __device__ constexpr int hidden_feat_bf16(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+// Same for the f32 engine: k-step kk of half h.
+__host__ __device__ constexpr int hidden_feat_f32(int kk, int h) { return 32 * (kk >> 4) + acc_row(kk & 15, h); }
+
+}  // namespace pnrf

@@ -1,0 +1,107 @@
+// pnrf_layout.h — compile-time layout of the three ProNeRF MLPs in the weight stream.
+// Shared by the host packer (pnrf_pack.hip) and the kernels (pnrf_mlp_kernels.hip).
+//
+// Networks (fern_trt.txt:15,25-34; run_S_eS_eN_alter_trt.py:434-458):
+//   SAMPLER  MinMaxRaySamplerTRT_Net     288 -> 6x256 (ELU) -> 27      fp32  (exact f32 MFMA)
+//   REFINE   MinMaxRayEpiSamplerTRT_Net  144 -> 6x256 (ELU) -> 35      bf16
+//   NERF     DoNeRFTRT(skip='auto')       63 -> 7x256 (ReLU) -> [256+27] -> 4   bf16
+#pragma once
+#include "pnrf_engine.h"
+
+namespace pnrf {
+
+enum { NET_SAMPLER = 0, NET_REFINE = 1, NET_NERF = 2 };
+enum { PREC_F32 = 0, PREC_BF16 = 1 };
+
+constexpr int W_HID = 256;
+constexpr int NT_HID = 8;                 // 256 / 32 output tiles per hidden layer
+
+// ---- sampler (f32): k-step = 2 features (one per lane half)
+constexpr int S_IN = 288, S_OUT = 27, S_NHID = 5;      // hidden 256->256 layers after layer 0
+constexpr int S_KS0 = S_IN / 2;                          // 144 k-steps
+constexpr int S_KS4_0 = S_KS0 / 4;                       // 36 fragments per tile
+constexpr int S_KS4_H = (W_HID / 2) / 4;                 // 32 fragments per tile
+constexpr int S_SLOTS_L0 = layer_slots_f32<S_KS4_0, NT_HID>();   // 18
+constexpr int S_SLOTS_H = layer_slots_f32<S_KS4_H, NT_HID>();    // 16
+constexpr int S_SLOTS_LAST = layer_slots_f32<S_KS4_H, 1>();      // 2
+constexpr int S_POS_H = S_SLOTS_L0 % NSLOTS;
+constexpr int S_POS_LAST = (S_POS_H + S_NHID * S_SLOTS_H) % NSLOTS;
+constexpr int S_SLOTS_USED = S_SLOTS_L0 + S_NHID * S_SLOTS_H + S_SLOTS_LAST;
+constexpr int S_SLOTS_PAD = (NSLOTS - S_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int S_NSLOTS = S_SLOTS_USED + S_SLOTS_PAD;
+constexpr int S_NBIAS = (1 + S_NHID) * W_HID + 32;      // packed bias floats
+static_assert(S_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
+
+// ---- refine (bf16): k-step = 16 features
+constexpr int R_IN = 144, R_OUT = 35, R_NHID = 5;
+constexpr int R_KS0 = R_IN / 16;                         // 9
+constexpr int KS_HID = W_HID / 16;                       // 16
+constexpr int R_NT_LAST = 2;                             // tile 0: refine+offsets (32 rows), tile 1: rgb (3 rows)
+constexpr int R_SLOTS_L0 = layer_slots_bf16<R_KS0, NT_HID>();    // 5
+constexpr int SLOTS_HID = layer_slots_bf16<KS_HID, NT_HID>();    // 8
+constexpr int R_SLOTS_LAST = layer_slots_bf16<KS_HID, R_NT_LAST>();  // 2
+constexpr int R_POS_H = R_SLOTS_L0 % NSLOTS;
+constexpr int R_POS_LAST = (R_POS_H + R_NHID * SLOTS_HID) % NSLOTS;
+constexpr int R_SLOTS_USED = R_SLOTS_L0 + R_NHID * SLOTS_HID + R_SLOTS_LAST;
+constexpr int R_SLOTS_PAD = (NSLOTS - R_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int R_NSLOTS = R_SLOTS_USED + R_SLOTS_PAD;
+constexpr int R_NBIAS = (1 + R_NHID) * W_HID + 32 * R_NT_LAST;
+static_assert(SLOTS_HID % NSLOTS == 0, "hidden layers must keep the ring position static");
+
+// ---- nerf (bf16)
+constexpr int N_IN = 63, N_INV = 27, N_OUT = 4, N_NHID = 6;
+constexpr int N_KS0 = 4;                                 // 63 padded to 64
+constexpr int N_KSX = 2;                                 // 27 view features padded to 32
+constexpr int N_KS_LAST = KS_HID + N_KSX;                // 18
+constexpr int N_SLOTS_L0 = layer_slots_bf16<N_KS0, NT_HID>();    // 2
+constexpr int N_SLOTS_LAST = layer_slots_bf16<N_KS_LAST, 1>();   // 2
+constexpr int N_POS_H = N_SLOTS_L0 % NSLOTS;
+constexpr int N_POS_LAST = (N_POS_H + N_NHID * SLOTS_HID) % NSLOTS;
+constexpr int N_SLOTS_USED = N_SLOTS_L0 + N_NHID * SLOTS_HID + N_SLOTS_LAST;
+constexpr int N_SLOTS_PAD = (NSLOTS - N_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int N_NSLOTS = N_SLOTS_USED + N_SLOTS_PAD;
+constexpr int N_NBIAS = (1 + N_NHID) * W_HID + 32;
+
+// ---- input-feature maps of layer 0 (and of the NeRF view k-steps); -1 = zero padding.
+// sampler: k-step kk, half h  ->  mm_input feature (natural pairing)
+__host__ __device__ constexpr int sampler_in0(int kk, int h) { return 2 * kk + h; }
+// refine: k-step ks, half h, element j -> refine_input feature (natural order)
+__host__ __device__ constexpr int refine_in0(int ks, int h, int j) { return 16 * ks + 8 * h + j; }
+// nerf layer 0: slot n = ks*8+j.  n<30: (freq k=n/3, coord c=n%3), half 0 = sin, half 1 = cos;
+// n=30: x0|x2, n=31: x1|pad.  Feature order of the embedder: [x, sin f0 x, cos f0 x, ...]
+// (run_nerf_helpers.py:666-671).
+__host__ __device__ constexpr int nerf_in0(int ks, int h, int j) {
+  const int n = ks * 8 + j;
+  if (n < 30) return 3 + 6 * (n / 3) + 3 * h + (n % 3);
+  if (n == 30) return h ? 2 : 0;
+  return h ? -1 : 1;
+}
+// nerf view k-steps (e = 0,1): index into the 27-wide view embedding (4 frequencies).
+__host__ __device__ constexpr int nerf_inx(int e, int h, int j) {
+  const int n = e * 8 + j;
+  if (n < 12) return 3 + 6 * (n / 3) + 3 * h + (n % 3);
+  if (n == 12) return h ? 2 : 0;
+  if (n == 13) return h ? -1 : 1;
+  return -1;
+}
+
+// ---- output-row maps of the last layers: tile row -> network output index (-1 = unused).
+// sampler: half 0 holds depth[0..7] (regs 0-7) and add[0..7] (regs 8-15); half 1 holds
+// mul[0..7] (regs 0-7) and rgb[0..2] (regs 8-10).  Output order of the net:
+// [depth(8), add(8), mul(8), rgb(3)] (run_nerf_helpers.py:1502-1505).
+__host__ __device__ constexpr int sampler_out(int g, int h) {
+  if (h == 0) return g;                       // depth g | add g-8  == outputs 0..15
+  if (g < 8) return 16 + g;                   // mul
+  if (g < 11) return 24 + (g - 8);            // rgb
+  return -1;
+}
+// refine tile 0: half h, reg g=4a+b -> sample s=4h+a; b=0 refine logit, b=1..3 offset xyz.
+// Net output order: [refine(8), offsets(24 = s*3+c), rgb(3)] (run_nerf_helpers.py:1536-1538).
+__host__ __device__ constexpr int refine_out0(int g, int h) {
+  const int s = 4 * h + (g >> 2), b = g & 3;
+  return b == 0 ? s : 8 + 3 * s + (b - 1);
+}
+__host__ __device__ constexpr int refine_out1(int g, int h) { return (h == 0 && g < 3) ? 32 + g : -1; }
+__host__ __device__ constexpr int nerf_out(int g, int h) { return (h == 0 && g < 4) ? g : -1; }
+
+}  // namespace pnrf

@@ -1,0 +1,656 @@
+// pnrf_mlp_kernels.hip — the three fused MLP stages of the ProNeRF render path + their
+// module-level (x -> y) variants.  gfx950 only.
+//
+//   sampler_kernel : [Pluecker ray encoding] -> fp32 MLP (v_mfma_f32_32x32x2_f32) -> sigmoid,
+//                    depth affine, stable sort-8, add/mul permutation      (trt.py:628-635)
+//   refine_kernel  : refine_in -> bf16 MLP (v_mfma_f32_32x32x16_bf16) -> sigmoid/tanh,
+//                    interval refinement, query points                      (trt.py:668-681)
+//   nerf_kernel    : positional encoding -> bf16 MLP -> alpha compositing   (trt.py:691-694)
+//
+// Workgroup = 256 threads = 4 waves, one per SIMD (launch bound 1 wave/SIMD: the kernels use
+// the 512-register budget to keep two layers of activations in registers).  A wave owns
+// 32*NCB columns (rays or ray-samples); the workgroup streams each network's packed weights
+// once per batch of 4*32*NCB columns through the LDS ring (pnrf_engine.h).
+#include <type_traits>
+
+#include "pnrf_common.h"
+
+using namespace pnrf;
+
+namespace {
+
+constexpr int TPB = 256;
+
+// compile-time loop: f(std::integral_constant<int,I>) for I in [0,N) — keeps register-array indices static
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
+  return r;
+}
+
+// Pluecker moment of point p=o+t*d with unit direction hd, arithmetic un-fused like the
+// reference's separate torch ops (trt.py:559-560 mul,add; helpers:630-631 cross).
+struct Pl6 { float hx, hy, hz; };
+__device__ __forceinline__ void unit_dir(float dx, float dy, float dz, float& hx, float& hy, float& hz) {
+  const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  const float den = fmaxf(__fsqrt_rn(n2), 1e-12f);
+  hx = __fdiv_rn(dx, den); hy = __fdiv_rn(dy, den); hz = __fdiv_rn(dz, den);
+}
+__device__ __forceinline__ void moment(float ox, float oy, float oz, float dx, float dy, float dz, float t,
+                                       float hx, float hy, float hz, float& m0, float& m1, float& m2) {
+  const float px = __fadd_rn(ox, __fmul_rn(dx, t)), py = __fadd_rn(oy, __fmul_rn(dy, t)), pz = __fadd_rn(oz, __fmul_rn(dz, t));
+  m0 = __fsub_rn(__fmul_rn(py, hz), __fmul_rn(pz, hy));
+  m1 = __fsub_rn(__fmul_rn(pz, hx), __fmul_rn(px, hz));
+  m2 = __fsub_rn(__fmul_rn(px, hy), __fmul_rn(py, hx));
+}
+
+// ------------------------------------------------------------------------------------------ sampler
+struct SamplerArgs {
+  const void* blob; const float* bias; uint32_t nslots; int nbias;
+  int64_t n; int nbatch;
+  const float* rays; const float* tvals;           // fused producer
+  const float* x; const int* in0;                  // module-level producer
+  float* depth_sorted; float* add_sorted; float* mul_sorted; int64_t* sort_idx; float* mm_rgb; float* depth_raw;
+  float* y; const int* outmap;                     // module-level consumer
+};
+
+#define PNRF_CSWAP(i, j)                                                              \
+  {                                                                                   \
+    const bool sw = (dep[i] > dep[j]) || (dep[i] == dep[j] && idx[i] > idx[j]);       \
+    const float td = sw ? dep[j] : dep[i]; dep[j] = sw ? dep[i] : dep[j]; dep[i] = td; \
+    const float ta = sw ? add[j] : add[i]; add[j] = sw ? add[i] : add[j]; add[i] = ta; \
+    const int ti = sw ? idx[j] : idx[i]; idx[j] = sw ? idx[i] : idx[j]; idx[i] = ti;   \
+  }
+
+template <bool FUSED>
+__global__ __launch_bounds__(TPB, 1) void sampler_kernel(SamplerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  WStream st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + h * 16;
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    const int64_t row = (int64_t)batch * 128 + wave * 32 + col;
+    const bool valid = row < a.n;
+    const int64_t rr = valid ? row : a.n - 1;
+    float B0[S_KS0];
+    float near = 0.f, far = 1.f;
+    if (FUSED) {
+      const float* r = a.rays + rr * 11;
+      const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
+      near = r[6]; far = r[7];
+      float hx, hy, hz;
+      unit_dir(dx, dy, dz, hx, hy, hz);
+#pragma unroll
+      for (int p = 0; p < S_KS0 / 3; ++p) {
+        float m0, m1, m2;
+        moment(ox, oy, oz, dx, dy, dz, a.tvals[p], hx, hy, hz, m0, m1, m2);
+        B0[3 * p] = h ? hy : hx;
+        B0[3 * p + 1] = h ? m0 : hz;
+        B0[3 * p + 2] = h ? m2 : m1;
+      }
+    } else {
+      const float* xr = a.x + rr * S_IN;
+#pragma unroll
+      for (int kk = 0; kk < S_KS0; ++kk) B0[kk] = xr[a.in0[kk * 2 + h]];
+    }
+
+    f32x16 Bo[NT_HID], Bn[NT_HID];
+    layer_f32<S_KS4_0, NT_HID, 0>(
+        st, ringlane, biaslane, [&](int kk) { return B0[kk]; },
+        [&](int to, f32x16& acc) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) Bo[to][g] = act_f32(acc[g], ACT_ELU);
+        });
+    for (int l = 0; l < S_NHID; ++l) {
+      layer_f32<S_KS4_H, NT_HID, S_POS_H>(
+          st, ringlane, biaslane + (1 + l) * W_HID, [&](int kk) { return Bo[kk >> 4][kk & 15]; },
+          [&](int to, f32x16& acc) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) Bn[to][g] = act_f32(acc[g], ACT_ELU);
+          });
+#pragma unroll
+      for (int t = 0; t < NT_HID; ++t) Bo[t] = Bn[t];
+    }
+    f32x16 fin;
+    layer_f32<S_KS4_H, 1, S_POS_LAST>(
+        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int kk) { return Bo[kk >> 4][kk & 15]; },
+        [&](int, f32x16& acc) { fin = acc; });
+#pragma unroll
+    for (int i = 0; i < S_SLOTS_PAD; ++i) st.begin();
+
+    if (!FUSED) {
+      if (valid) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int o = a.outmap[h * 16 + g];
+          if (o >= 0) a.y[row * S_OUT + o] = fin[g];
+        }
+      }
+      continue;
+    }
+    // ---- fused epilogue: half 0 holds depth logits (regs 0-7) + add (8-15); half 1 holds mul (0-7) + rgb (8-10)
+    float dep[8], add[8];
+    int idx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dep[i] = sigmoid_f(fin[i]);
+      add[i] = fin[8 + i];
+      idx[i] = i;
+    }
+    if (h == 0 && valid && a.depth_raw) {
+      float4* p = (float4*)(a.depth_raw + row * 8);
+      p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
+      p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
+    }
+    const float span = __fsub_rn(far, near);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
+    // stable ascending sort (19-comparator network on (value, index) keys)          // trt.py:632-635
+    PNRF_CSWAP(0, 1) PNRF_CSWAP(2, 3) PNRF_CSWAP(4, 5) PNRF_CSWAP(6, 7)
+    PNRF_CSWAP(0, 2) PNRF_CSWAP(1, 3) PNRF_CSWAP(4, 6) PNRF_CSWAP(5, 7)
+    PNRF_CSWAP(1, 2) PNRF_CSWAP(5, 6) PNRF_CSWAP(0, 4) PNRF_CSWAP(3, 7)
+    PNRF_CSWAP(1, 5) PNRF_CSWAP(2, 6)
+    PNRF_CSWAP(1, 4) PNRF_CSWAP(3, 6)
+    PNRF_CSWAP(2, 4) PNRF_CSWAP(3, 5)
+    PNRF_CSWAP(3, 4)
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) word |= (uint32_t)idx[i] << (3 * i);
+    const uint32_t w0 = __shfl(word, col);      // half 0's permutation for this column, in both halves
+    if (h == 0) {
+      if (valid) {
+        float4* p = (float4*)(a.depth_sorted + row * 8);
+        p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
+        float4* q = (float4*)(a.add_sorted + row * 8);
+        q[0] = make_float4(add[0], add[1], add[2], add[3]);
+        q[1] = make_float4(add[4], add[5], add[6], add[7]);
+        if (a.sort_idx) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a.sort_idx[row * 8 + i] = idx[i];
+        }
+      }
+    } else {
+      float ms[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = (w0 >> (3 * i)) & 7;
+        float m = fin[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) m = (k == j) ? fin[j] : m;
+        ms[i] = m;
+      }
+      if (valid) {
+        float4* q = (float4*)(a.mul_sorted + row * 8);
+        q[0] = make_float4(ms[0], ms[1], ms[2], ms[3]);
+        q[1] = make_float4(ms[4], ms[5], ms[6], ms[7]);
+        if (a.mm_rgb) {
+          a.mm_rgb[row * 3 + 0] = sigmoid_f(fin[8]);
+          a.mm_rgb[row * 3 + 1] = sigmoid_f(fin[9]);
+          a.mm_rgb[row * 3 + 2] = sigmoid_f(fin[10]);
+        }
+      }
+    }
+  }
+  st.drain();
+}
+
+// ------------------------------------------------------------------------------------------ bf16 nets
+template <int NCB, int ACT>
+struct HiddenEpi {
+  bf16x8 (&Bn)[NCB][KS_HID];
+  __device__ __forceinline__ void operator()(int to, f32x16 (&acc)[NCB]) const {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * s + j], ACT);
+        Bn[cb][2 * to + s] = pack_bf16(v);
+      }
+  }
+};
+
+struct RefineArgs {
+  const void* blob; const float* bias; uint32_t nslots; int nbias;
+  int64_t n; int nbatch;
+  const float* x;                                   // refine_in [n,144]
+  const float* rays; const float* depth_sorted;     // fused consumer
+  float* z; float* pts;
+  float* y; const int* outmap;                      // module-level consumer
+};
+
+template <int NCB, bool FUSED>
+__global__ __launch_bounds__(TPB, 1) void refine_kernel(RefineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  constexpr int COLS = 32 * NCB;
+  WStream st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + h * 16;
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    int64_t row[NCB];
+    bool valid[NCB];
+    bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID];
+    static_for<NCB>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      row[cb] = (int64_t)batch * (WAVES * COLS) + wave * COLS + cb * 32 + col;
+      valid[cb] = row[cb] < a.n;
+      const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN + 8 * h;      // natural order: refine_in0()
+#pragma unroll
+      for (int ks = 0; ks < R_KS0; ++ks) {
+        const float4 lo = *(const float4*)(xr + 16 * ks), hi = *(const float4*)(xr + 16 * ks + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        Bo[cb][ks] = pack_bf16(v);
+      }
+    });
+    HiddenEpi<NCB, ACT_ELU> epi{Bn};
+    layer_bf16<NCB, R_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+    for (int l = 0; l < R_NHID; ++l) {
+      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID,
+                                               [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+    }
+    const float* blast = biaslane + (1 + R_NHID) * W_HID;
+    if (!FUSED) {
+      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(
+          st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
+          [&](int to, f32x16(&acc)[NCB]) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              if (valid[cb]) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                  const int o = a.outmap[(to * 2 + h) * 16 + g];
+                  if (o >= 0) a.y[row[cb] * R_OUT + o] = acc[cb][g];
+                }
+              }
+          });
+#pragma unroll
+      for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
+      continue;
+    }
+    f32x16 fin[NCB];
+    layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(
+        st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
+        [&](int, f32x16(&acc)[NCB]) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) fin[cb] = acc[cb];
+        });
+#pragma unroll
+    for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
+
+    // ---- fused epilogue: lane (ray, h) owns samples 4h..4h+3: reg 4a = refine logit, 4a+1..3 = offset
+    static_for<NCB>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      const int64_t rr = valid[cb] ? row[cb] : a.n - 1;
+      const float* r = a.rays + rr * 11;
+      const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5], near = r[6], far = r[7];
+      const float4 d0 = *(const float4*)(a.depth_sorted + rr * 8), d1 = *(const float4*)(a.depth_sorted + rr * 8 + 4);
+      // e = [near, d0..d7, far]; window w[i] = e[4h+i], i=0..5
+      float w[6];
+      w[0] = h ? d0.w : near; w[1] = h ? d1.x : d0.x; w[2] = h ? d1.y : d0.y;
+      w[3] = h ? d1.z : d0.z; w[4] = h ? d1.w : d0.w; w[5] = h ? far : d1.x;
+      float zz[4], pp[12];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float lower = __fmul_rn(0.5f, __fadd_rn(w[s4 + 1], w[s4]));       // trt.py:673-675
+        const float upper = __fmul_rn(0.5f, __fadd_rn(w[s4 + 2], w[s4 + 1]));
+        const float rf = sigmoid_f(fin[cb][4 * s4]);
+        const float zv = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), rf));   // :676
+        zz[s4] = zv;
+        const float fx = tanhf(fin[cb][4 * s4 + 1]), fy = tanhf(fin[cb][4 * s4 + 2]), fz = tanhf(fin[cb][4 * s4 + 3]);
+        pp[3 * s4 + 0] = __fadd_rn(__fadd_rn(ox, __fmul_rn(dx, zv)), __fmul_rn(1e-2f, fx));   // :679-681
+        pp[3 * s4 + 1] = __fadd_rn(__fadd_rn(oy, __fmul_rn(dy, zv)), __fmul_rn(1e-2f, fy));
+        pp[3 * s4 + 2] = __fadd_rn(__fadd_rn(oz, __fmul_rn(dz, zv)), __fmul_rn(1e-2f, fz));
+      }
+      if (valid[cb]) {
+        *(float4*)(a.z + row[cb] * 8 + 4 * h) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        float4* pq = (float4*)(a.pts + row[cb] * 24 + 12 * h);
+        pq[0] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        pq[1] = make_float4(pp[4], pp[5], pp[6], pp[7]);
+        pq[2] = make_float4(pp[8], pp[9], pp[10], pp[11]);
+      }
+    });
+  }
+  st.drain();
+}
+
+struct NerfArgs {
+  const void* blob; const float* bias; uint32_t nslots; int nbias;
+  int64_t n;                                        // fused: rays; module-level: rows
+  int nbatch;
+  const float* pts; const float* rays;              // fused producer
+  const float* x; const float* xv; const int* in0; const int* inx;   // module-level producer
+  const float* z; const float* add; const float* mul;                // fused consumer
+  float* rgbd; float* raw;
+  float* y; const int* outmap;                      // module-level consumer
+};
+
+template <int NCB, bool FUSED>
+__global__ __launch_bounds__(TPB, 1) void nerf_kernel(NerfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  constexpr int COLS = 32 * NCB;
+  const int64_t nrows = FUSED ? a.n * 8 : a.n;
+  WStream st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + h * 16;
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    int64_t row[NCB];
+    bool valid[NCB];
+    bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID], Bx[NCB][N_KSX];
+    static_for<NCB>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      row[cb] = (int64_t)batch * (WAVES * COLS) + wave * COLS + cb * 32 + col;
+      valid[cb] = row[cb] < nrows;
+      const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
+      if (FUSED) {
+        // positional encoding in B-fragment order (nerf_in0 / nerf_inx): half 0 = sin, half 1 = cos.
+        // sin/cos(2^k x): one accurate sincosf at k=0, then the exact double-angle recurrence; its
+        // error (<= 2^k * 1e-7) is far below the bf16 rounding (2^-9) applied to the MLP input.
+        const float* pp = a.pts + rr * 3;
+        const float x3[3] = {pp[0], pp[1], pp[2]};
+        const float* vv = a.rays + (rr >> 3) * 11 + 8;
+        const float v3[3] = {vv[0], vv[1], vv[2]};
+        float f0[32], fx[16];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float s, co;
+          sincosf(x3[c], &s, &co);                                  // helpers:669-670: sin/cos(x * 2^k)
+#pragma unroll
+          for (int k = 0; k < 10; ++k) {
+            f0[3 * k + c] = h ? co : s;
+            const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
+            s = s2; co = c2;
+          }
+          sincosf(v3[c], &s, &co);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            fx[3 * k + c] = h ? co : s;
+            const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
+            s = s2; co = c2;
+          }
+        }
+        f0[30] = h ? x3[2] : x3[0];
+        f0[31] = h ? 0.f : x3[1];
+        fx[12] = h ? v3[2] : v3[0];
+        fx[13] = h ? 0.f : v3[1];
+        fx[14] = 0.f; fx[15] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < N_KS0; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = f0[ks * 8 + j];
+          Bo[cb][ks] = pack_bf16(v);
+        }
+#pragma unroll
+        for (int e = 0; e < N_KSX; ++e) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fx[e * 8 + j];
+          Bx[cb][e] = pack_bf16(v);
+        }
+      } else {
+        const float* xr = a.x + rr * N_IN;
+        const float* xv = a.xv + rr * N_INV;
+#pragma unroll
+        for (int ks = 0; ks < N_KS0; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = a.in0[(ks * 2 + h) * 8 + j];
+            v[j] = i >= 0 ? xr[i] : 0.f;
+          }
+          Bo[cb][ks] = pack_bf16(v);
+        }
+#pragma unroll
+        for (int e = 0; e < N_KSX; ++e) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = a.inx[(e * 2 + h) * 8 + j];
+            v[j] = i >= 0 ? xv[i] : 0.f;
+          }
+          Bx[cb][e] = pack_bf16(v);
+        }
+      }
+    });
+    HiddenEpi<NCB, ACT_RELU> epi{Bn};
+    layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+    for (int l = 0; l < N_NHID; ++l) {
+      layer_bf16<NCB, KS_HID, NT_HID, N_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID,
+                                               [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+    }
+    f32x16 fin[NCB];
+    layer_bf16<NCB, N_KS_LAST, 1, N_POS_LAST>(
+        st, ringlane, biaslane + (1 + N_NHID) * W_HID,
+        [&](int cb, int ks) { return ks < KS_HID ? Bo[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
+        [&](int, f32x16(&acc)[NCB]) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) fin[cb] = acc[cb];
+        });
+#pragma unroll
+    for (int i = 0; i < N_SLOTS_PAD; ++i) st.begin();
+
+    if (!FUSED) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        if (valid[cb] && h == 0) *(float4*)(a.y + row[cb] * 4) = make_float4(fin[cb][0], fin[cb][1], fin[cb][2], fin[cb][3]);
+      continue;
+    }
+    // ---- fused epilogue: raw rgb-sigma of column `col` sits in regs 0-3 of half 0; the 8 samples of
+    // a ray are 8 adjacent lanes.  Compositing in the reference's sequential order (cumprod, sum).
+    static_for<NCB>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
+      const int64_t ray = rr >> 3;
+      const int s = (int)(rr & 7);
+      const float* r = a.rays + ray * 11;
+      const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[3], r[3]), __fmul_rn(r[4], r[4])), __fmul_rn(r[5], r[5])));
+      const float zc = a.z[rr], ad = a.add[rr], mu = a.mul[rr];
+      const float r0 = fin[cb][0], r1 = fin[cb][1], r2 = fin[cb][2], r3 = fin[cb][3];
+      if (a.raw && valid[cb] && h == 0) *(float4*)(a.raw + row[cb] * 4) = make_float4(r0, r1, r2, r3);
+      const float znext = __shfl_down(zc, 1);
+      float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
+      dist = __fmul_rn(dist, dn);                                                   // :583
+      const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
+      const float sg = fmaxf(__fadd_rn(r3, ad), 0.f);
+      float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
+      alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                                     // :588
+      const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
+      const int base = lane & 0x38;
+      float T = 1.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const float xj = __shfl(xk, base + j);
+        T = (j < s) ? __fmul_rn(T, xj) : T;
+      }
+      const float wgt = __fmul_rn(alpha, T);
+      const float c0 = __fmul_rn(wgt, cr), c1 = __fmul_rn(wgt, cg), c2 = __fmul_rn(wgt, cbv), c3 = __fmul_rn(wgt, zc);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s0 = __fadd_rn(s0, __shfl(c0, base + j));                                   // :591 sum over samples
+        s1 = __fadd_rn(s1, __shfl(c1, base + j));
+        s2 = __fadd_rn(s2, __shfl(c2, base + j));
+        s3 = __fadd_rn(s3, __shfl(c3, base + j));                                   // :593 depth_map
+      }
+      if (valid[cb] && h == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(s0, s1, s2, s3);
+    });
+  }
+  st.drain();
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+int g_num_cu = 0;
+int num_cu() {
+  if (!g_num_cu) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cu = p.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+template <class K>
+int prep_kernel(K kern, size_t lds) {
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(max dynamic LDS=%zu) failed: %s", lds, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+constexpr int NERF_NCB = 2;
+constexpr int REFINE_NCB = 2;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted,
+                                float* add_sorted, float* mul_sorted, int64_t* sort_idx, float* mm_rgb,
+                                float* depth_raw, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd: handle is not a sampler net");
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
+  if (n == 0) return 0;
+  SamplerArgs a = {};
+  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  a.n = n; a.nbatch = (int)((n + 127) / 128);
+  a.rays = rays; a.tvals = h->d_tvals;
+  a.depth_sorted = depth_sorted; a.add_sorted = add_sorted; a.mul_sorted = mul_sorted;
+  a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
+  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  static int prepped = prep_kernel(sampler_kernel<true>, RING_BYTES + S_NBIAS * 4);
+  if (prepped) return prepped;
+  const int grid = a.nbatch < num_cu() ? a.nbatch : num_cu();
+  hipLaunchKernelGGL(sampler_kernel<true>, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
+                               const float* depth_sorted, float* z, float* pts, int64_t n, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_REFINE, PNRF_E_ARG, "pnrf_refine_fwd: handle is not a refine net");
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (refine_in && rays && depth_sorted && z && pts)), PNRF_E_ARG, "pnrf_refine_fwd: null pointer / negative n");
+  if (n == 0) return 0;
+  RefineArgs a = {};
+  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  constexpr int ROWS = WAVES * 32 * REFINE_NCB;
+  a.n = n; a.nbatch = (int)((n + ROWS - 1) / ROWS);
+  a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
+  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  static int prepped = prep_kernel(refine_kernel<REFINE_NCB, true>, RING_BYTES + R_NBIAS * 4);
+  if (prepped) return prepped;
+  const int grid = a.nbatch < num_cu() ? a.nbatch : num_cu();
+  hipLaunchKernelGGL((refine_kernel<REFINE_NCB, true>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
+                             const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
+                             int64_t n, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_NERF, PNRF_E_ARG, "pnrf_nerf_fwd: handle is not a nerf net");
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (pts && rays && z && add_sorted && mul_sorted && rgbd)), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer / negative n");
+  if (n == 0) return 0;
+  NerfArgs a = {};
+  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  constexpr int ROWS = WAVES * 32 * NERF_NCB;
+  a.n = n; a.nbatch = (int)((n * 8 + ROWS - 1) / ROWS);
+  a.pts = pts; a.rays = rays; a.z = z; a.add = add_sorted; a.mul = mul_sorted; a.rgbd = rgbd; a.raw = raw;
+  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  static int prepped = prep_kernel(nerf_kernel<NERF_NCB, true>, RING_BYTES + N_NBIAS * 4);
+  if (prepped) return prepped;
+  const int grid = a.nbatch < num_cu() ? a.nbatch : num_cu();
+  hipLaunchKernelGGL((nerf_kernel<NERF_NCB, true>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, void* stream) {
+  PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_fwd: null handle");
+  PNRF_REQUIRE(m >= 0 && (m == 0 || (x && y)), PNRF_E_ARG, "pnrf_mlp_fwd: null pointer / negative m");
+  PNRF_REQUIRE(h->net != PNRF_NET_NERF || m == 0 || x_views, PNRF_E_ARG, "pnrf_mlp_fwd: the nerf net needs x_views [m,27]");
+  if (m == 0) return 0;
+  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  const int ncu = num_cu();
+  if (h->net == PNRF_NET_SAMPLER) {
+    SamplerArgs a = {};
+    a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+    a.n = m; a.nbatch = (int)((m + 127) / 128);
+    a.x = x; a.in0 = h->d_in0; a.y = y; a.outmap = h->d_out;
+    static int prepped = prep_kernel(sampler_kernel<false>, RING_BYTES + S_NBIAS * 4);
+    if (prepped) return prepped;
+    hipLaunchKernelGGL(sampler_kernel<false>, dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
+  } else if (h->net == PNRF_NET_REFINE) {
+    RefineArgs a = {};
+    a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+    constexpr int ROWS = WAVES * 32;
+    a.n = m; a.nbatch = (int)((m + ROWS - 1) / ROWS);
+    a.x = x; a.y = y; a.outmap = h->d_out;
+    static int prepped = prep_kernel(refine_kernel<1, false>, RING_BYTES + R_NBIAS * 4);
+    if (prepped) return prepped;
+    hipLaunchKernelGGL((refine_kernel<1, false>), dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
+  } else {
+    NerfArgs a = {};
+    a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+    constexpr int ROWS = WAVES * 32;
+    a.n = m; a.nbatch = (int)((m + ROWS - 1) / ROWS);
+    a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out;
+    static int prepped = prep_kernel(nerf_kernel<1, false>, RING_BYTES + N_NBIAS * 4);
+    if (prepped) return prepped;
+    hipLaunchKernelGGL((nerf_kernel<1, false>), dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
+  }
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+

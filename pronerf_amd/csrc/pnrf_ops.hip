@@ -1,0 +1,463 @@
+// pnrf_ops.hip — element-wise / gather operators of the render path, the render context and
+// the whole-path entry point.  All kernels are HBM/L2-bound streaming kernels: one thread per
+// output element group, coalesced 16-byte accesses where the layout allows, grid-stride loops.
+#include "pnrf_common.h"
+
+using namespace pnrf;
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(int64_t work, int per_block = TPB) {
+  int64_t g = (work + per_block - 1) / per_block;
+  const int64_t cap = 256 * 16;     // 256 CUs x 16 blocks: enough to fill the chip, grid-stride the rest
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---------------------------------------------------------------- positional encoding (helpers:666-671)
+__global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n3, int n_freq) {
+  // one thread per input scalar; output row width = 3 + 6*n_freq
+  const int width = 3 + 6 * n_freq;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / 3;
+    const int c = (int)(i - row * 3);
+    const float v = x[i];
+    float* o = out + row * width;
+    o[c] = v;
+    for (int k = 0; k < n_freq; ++k) {
+      const float arg = v * (float)(1u << k);        // x * 2^k is exact in fp32
+      o[3 + 6 * k + c] = sinf(arg);
+      o[3 + 6 * k + 3 + c] = cosf(arg);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- Pluecker (helpers:629-632)
+__device__ __forceinline__ void unit_dir(float dx, float dy, float dz, float& hx, float& hy, float& hz) {
+  const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  const float den = fmaxf(__fsqrt_rn(n2), 1e-12f);
+  hx = __fdiv_rn(dx, den); hy = __fdiv_rn(dy, den); hz = __fdiv_rn(dz, den);
+}
+__device__ __forceinline__ void cross_rn(float ax, float ay, float az, float bx, float by, float bz, float& m0, float& m1, float& m2) {
+  m0 = __fsub_rn(__fmul_rn(ay, bz), __fmul_rn(az, by));
+  m1 = __fsub_rn(__fmul_rn(az, bx), __fmul_rn(ax, bz));
+  m2 = __fsub_rn(__fmul_rn(ax, by), __fmul_rn(ay, bx));
+}
+__global__ void plucker_kernel(const float* __restrict__ o, const float* __restrict__ d, float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float hx, hy, hz, m0, m1, m2;
+    unit_dir(d[i * 3], d[i * 3 + 1], d[i * 3 + 2], hx, hy, hz);
+    cross_rn(o[i * 3], o[i * 3 + 1], o[i * 3 + 2], hx, hy, hz, m0, m1, m2);
+    float* q = out + i * 6;
+    q[0] = hx; q[1] = hy; q[2] = hz; q[3] = m0; q[4] = m1; q[5] = m2;
+  }
+}
+// mm_input[n, 6*n_pts]: one thread per (ray, point)  (trt.py:274-277)
+__global__ void ray_encode_kernel(const float* __restrict__ rays, const float* __restrict__ tvals, float* __restrict__ out, int64_t n, int n_pts) {
+  const int64_t total = n * n_pts;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ray = i / n_pts;
+    const int p = (int)(i - ray * n_pts);
+    const float* r = rays + ray * 11;
+    const float t = tvals[p];
+    float hx, hy, hz, m0, m1, m2;
+    unit_dir(r[3], r[4], r[5], hx, hy, hz);
+    const float px = __fadd_rn(r[0], __fmul_rn(r[3], t)), py = __fadd_rn(r[1], __fmul_rn(r[4], t)), pz = __fadd_rn(r[2], __fmul_rn(r[5], t));
+    cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
+    float* q = out + i * 6;        // [ray][p][6] == ray*6*n_pts + p*6
+    q[0] = hx; q[1] = hy; q[2] = hz; q[3] = m0; q[4] = m1; q[5] = m2;
+  }
+}
+
+// ---------------------------------------------------------------- frame rays (trt.py:245-271; helpers:2705-2714, 2776-2793)
+struct FrameArgs {
+  float K00, K02, K11, K12;
+  float R[9], T[3];
+  int H, W;
+  float near, far, or_near, or_far;
+  int64_t first, count;
+};
+__global__ void frame_rays_kernel(FrameArgs a, float* __restrict__ rays, float* __restrict__ or_rays) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < a.count; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = a.first + q;
+    const int j = (int)(pix / a.W), i = (int)(pix - (int64_t)j * a.W);
+    // dirs = ((i-cx)/fx, -(j-cy)/fy, -1);  rays_d[c] = sum_k dirs[k]*R[c][k]  (products, then a 3-term sum)
+    const float d0 = __fdiv_rn(__fsub_rn((float)i, a.K02), a.K00);
+    const float d1 = -__fdiv_rn(__fsub_rn((float)j, a.K12), a.K11);
+    const float d2 = -1.f;
+    float rd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      rd[c] = __fadd_rn(__fadd_rn(__fmul_rn(d0, a.R[c * 3]), __fmul_rn(d1, a.R[c * 3 + 1])), __fmul_rn(d2, a.R[c * 3 + 2]));
+    const float ro[3] = {a.T[0], a.T[1], a.T[2]};
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rd[0], rd[0]), __fmul_rn(rd[1], rd[1])), __fmul_rn(rd[2], rd[2])));
+    const float v0 = __fdiv_rn(rd[0], nrm), v1 = __fdiv_rn(rd[1], nrm), v2 = __fdiv_rn(rd[2], nrm);
+    float* orr = or_rays + q * 11;
+    orr[0] = ro[0]; orr[1] = ro[1]; orr[2] = ro[2]; orr[3] = rd[0]; orr[4] = rd[1]; orr[5] = rd[2];
+    orr[6] = a.or_near; orr[7] = a.or_far; orr[8] = v0; orr[9] = v1; orr[10] = v2;
+    // ndc_rays(H, W, focal=K00, near=1.)
+    const float nearp = 1.f;
+    const float t = __fdiv_rn(-__fadd_rn(nearp, ro[2]), rd[2]);
+    const float ox = __fadd_rn(ro[0], __fmul_rn(t, rd[0])), oy = __fadd_rn(ro[1], __fmul_rn(t, rd[1])), oz = __fadd_rn(ro[2], __fmul_rn(t, rd[2]));
+    const float sx = __fdiv_rn(-1.f, __fdiv_rn((float)a.W, __fmul_rn(2.f, a.K00)));
+    const float sy = __fdiv_rn(-1.f, __fdiv_rn((float)a.H, __fmul_rn(2.f, a.K00)));
+    const float o0 = __fdiv_rn(__fmul_rn(sx, ox), oz);
+    const float o1 = __fdiv_rn(__fmul_rn(sy, oy), oz);
+    const float o2 = __fadd_rn(1.f, __fdiv_rn(__fmul_rn(2.f, nearp), oz));
+    const float e0 = __fmul_rn(sx, __fsub_rn(__fdiv_rn(rd[0], rd[2]), __fdiv_rn(ox, oz)));
+    const float e1 = __fmul_rn(sy, __fsub_rn(__fdiv_rn(rd[1], rd[2]), __fdiv_rn(oy, oz)));
+    const float e2 = __fdiv_rn(__fmul_rn(-2.f, nearp), oz);
+    float* r = rays + q * 11;
+    r[0] = o0; r[1] = o1; r[2] = o2; r[3] = e0; r[4] = e1; r[5] = e2; r[6] = a.near; r[7] = a.far; r[8] = v0; r[9] = v1; r[10] = v2;
+  }
+}
+
+// ndc_rays on arbitrary ray sets (helpers:2776-2793)
+__global__ void ndc_rays_kernel(const float* __restrict__ o, const float* __restrict__ d, int H, int W, float focal, float nearp,
+                                float* __restrict__ oo, float* __restrict__ od, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float r0 = o[i * 3], r1 = o[i * 3 + 1], r2 = o[i * 3 + 2], d0 = d[i * 3], d1 = d[i * 3 + 1], d2 = d[i * 3 + 2];
+    const float t = __fdiv_rn(-__fadd_rn(nearp, r2), d2);
+    const float ox = __fadd_rn(r0, __fmul_rn(t, d0)), oy = __fadd_rn(r1, __fmul_rn(t, d1)), oz = __fadd_rn(r2, __fmul_rn(t, d2));
+    const float sx = __fdiv_rn(-1.f, __fdiv_rn((float)W, __fmul_rn(2.f, focal)));
+    const float sy = __fdiv_rn(-1.f, __fdiv_rn((float)H, __fmul_rn(2.f, focal)));
+    oo[i * 3] = __fdiv_rn(__fmul_rn(sx, ox), oz);
+    oo[i * 3 + 1] = __fdiv_rn(__fmul_rn(sy, oy), oz);
+    oo[i * 3 + 2] = __fadd_rn(1.f, __fdiv_rn(__fmul_rn(2.f, nearp), oz));
+    od[i * 3] = __fmul_rn(sx, __fsub_rn(__fdiv_rn(d0, d2), __fdiv_rn(ox, oz)));
+    od[i * 3 + 1] = __fmul_rn(sy, __fsub_rn(__fdiv_rn(d1, d2), __fdiv_rn(oy, oz)));
+    od[i * 3 + 2] = __fdiv_rn(__fmul_rn(-2.f, nearp), oz);
+  }
+}
+
+// ---------------------------------------------------------------- bilinear fetch, zero padding, align_corners=True
+// grid_sample's coordinate round trip (inverse_warp.py:607-608 then unnormalise) is replayed in fp32.
+__device__ __forceinline__ void bilinear_setup(float X, float Y, int Hf, int Wf, int& x0, int& y0, float& wx0, float& wx1, float& wy0, float& wy1, bool& finite) {
+  const float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, X), (float)(Wf - 1)), 1.f);
+  const float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, Y), (float)(Hf - 1)), 1.f);
+  const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(Wf - 1));
+  const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(Hf - 1));
+  finite = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  wx1 = __fsub_rn(ix, fx); wx0 = __fsub_rn(__fadd_rn(fx, 1.f), ix);
+  wy1 = __fsub_rn(iy, fy); wy0 = __fsub_rn(__fadd_rn(fy, 1.f), iy);
+  x0 = finite ? (int)fx : -4; y0 = finite ? (int)fy : -4;
+}
+
+// inverse_warp_rod1_rt2_coords_trt on planar images: one thread per (b, pixel)  (inverse_warp.py:584-619)
+__global__ void warp_trt_kernel(const float* __restrict__ img, const float* __restrict__ depth, const float* __restrict__ ro1,
+                                const float* __restrict__ rd1, int64_t ray_bstride, const float* __restrict__ w2c,
+                                float* __restrict__ out, int B, int Hf, int Wf, int64_t n) {
+  const int64_t total = (int64_t)B * n;
+  const int64_t plane = (int64_t)Hf * Wf;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(q / n);
+    const int64_t i = q - (int64_t)b * n;
+    const float dep = depth[q];
+    float w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = __fadd_rn(ro1[b * ray_bstride + c * n + i], __fmul_rn(rd1[b * ray_bstride + c * n + i], dep));   // :600
+    const float* M = w2c + b * 12;
+    float p[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)                                                                     // :601 bmm, K=4
+      p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[r * 4], w[0]), __fmul_rn(M[r * 4 + 1], w[1])), __fmul_rn(M[r * 4 + 2], w[2])), __fmul_rn(M[r * 4 + 3], w[3]));
+    const float X = __fdiv_rn(p[0], p[2]), Y = __fdiv_rn(p[1], p[2]);                               // :603-605
+    int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
+    bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
+    const bool okx0 = x0 >= 0 && x0 < Wf, okx1 = x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
+    const float* im = img + (int64_t)b * 3 * plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* pc = im + c * plane;
+      float acc = 0.f;
+      if (oky0 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0], __fmul_rn(wx0, wy0)));
+      if (oky0 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0 + 1], __fmul_rn(wx1, wy0)));
+      if (oky1 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0], __fmul_rn(wx0, wy1)));
+      if (oky1 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0 + 1], __fmul_rn(wx1, wy1)));
+      out[((int64_t)b * 3 + c) * n + i] = acc;
+    }
+  }
+}
+
+// [nv,3,Hf,Wf] -> [nv,Hf,Wf,4] texel-interleaved (one 16-byte load per tap in the fused projection)
+__global__ void images_pack_kernel(const float* __restrict__ in, float4* __restrict__ out, int nv, int64_t plane) {
+  const int64_t total = (int64_t)nv * plane;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(q / plane);
+    const int64_t i = q - (int64_t)v * plane;
+    const float* p = in + (int64_t)v * 3 * plane + i;
+    out[q] = make_float4(p[0], p[plane], p[2 * plane], 0.f);
+  }
+}
+
+// Projection + sample Pluecker -> refine_in[n,144]   (trt.py:637-661)
+// 32 threads per ray: thread t = k*8+s projects sample s into neighbour k (4 taps x 16 B);
+// threads 0..7 additionally write the Pluecker 6-vector of sample s.
+__global__ void refine_input_kernel(const float* __restrict__ rays, const float* __restrict__ or_rays, const float* __restrict__ depth_sorted,
+                                    const float4* __restrict__ img4, const float* __restrict__ proj, int nb, int Hf, int Wf, float eps,
+                                    float* __restrict__ out, int64_t n) {
+  __shared__ float sM[8 * 12];
+  if (threadIdx.x < nb * 12) sM[threadIdx.x] = proj[threadIdx.x];
+  __syncthreads();
+  const int per_ray = nb * 8;                   // 32 for nb = 4
+  const int64_t total = n * per_ray;
+  const int64_t plane = (int64_t)Hf * Wf;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ray = q / per_ray;
+    const int t = (int)(q - ray * per_ray);
+    const int k = t >> 3, s = t & 7;
+    const float dn = depth_sorted[ray * 8 + s];
+    const float* orr = or_rays + ray * 11;
+    const float z3d = __fdiv_rn(1.f, __fsub_rn(__fsub_rn(1.f, dn), eps));                    // trt.py:637
+    const float w0 = __fadd_rn(orr[0], __fmul_rn(orr[3], z3d)), w1 = __fadd_rn(orr[1], __fmul_rn(orr[4], z3d)),
+                w2 = __fadd_rn(orr[2], __fmul_rn(orr[5], z3d));                              // inverse_warp.py:600 (w3 = 1)
+    const float* M = sM + k * 12;
+    float p[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[r * 4], w0), __fmul_rn(M[r * 4 + 1], w1)), __fmul_rn(M[r * 4 + 2], w2)), M[r * 4 + 3]);
+    const float X = __fdiv_rn(p[0], p[2]), Y = __fdiv_rn(p[1], p[2]);
+    int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
+    bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
+    const bool okx0 = x0 >= 0 && x0 < Wf, okx1 = x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
+    const float4* im = img4 + (int64_t)k * plane;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 t00 = (oky0 && okx0) ? im[(int64_t)y0 * Wf + x0] : zero;
+    const float4 t01 = (oky0 && okx1) ? im[(int64_t)y0 * Wf + x0 + 1] : zero;
+    const float4 t10 = (oky1 && okx0) ? im[(int64_t)(y0 + 1) * Wf + x0] : zero;
+    const float4 t11 = (oky1 && okx1) ? im[(int64_t)(y0 + 1) * Wf + x0 + 1] : zero;
+    const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx1, wy0), a10 = __fmul_rn(wx0, wy1), a11 = __fmul_rn(wx1, wy1);
+    float* o = out + ray * 144 + 48 + t * 3;                                                  // epi index (k*8+s)*3+c
+    o[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.x, a00), __fmul_rn(t01.x, a01)), __fmul_rn(t10.x, a10)), __fmul_rn(t11.x, a11));
+    o[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.y, a00), __fmul_rn(t01.y, a01)), __fmul_rn(t10.y, a10)), __fmul_rn(t11.y, a11));
+    o[2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.z, a00), __fmul_rn(t01.z, a01)), __fmul_rn(t10.z, a10)), __fmul_rn(t11.z, a11));
+    if (k == 0) {                                                                             // trt.py:656-658
+      const float* r = rays + ray * 11;
+      float hx, hy, hz, m0, m1, m2;
+      unit_dir(r[3], r[4], r[5], hx, hy, hz);
+      const float px = __fadd_rn(r[0], __fmul_rn(r[3], dn)), py = __fadd_rn(r[1], __fmul_rn(r[4], dn)), pz = __fadd_rn(r[2], __fmul_rn(r[5], dn));
+      cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
+      float* pl = out + ray * 144 + s * 6;
+      pl[0] = hx; pl[1] = hy; pl[2] = hz; pl[3] = m0; pl[4] = m1; pl[5] = m2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- raw2outputs (trt.py:564-597; base.py:501-551; refine2.py:475-522)
+__global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
+                                 const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
+                                 int white_bkgd, float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc_out,
+                                 float* __restrict__ weights, float* __restrict__ depth, int64_t n, int S) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* d = rays_d + i * d_stride;
+    const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    float T = 1.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, sd = 0.f, sa = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const int64_t e = i * S + s;
+      float r0 = raw[e * 4], r1 = raw[e * 4 + 1], r2 = raw[e * 4 + 2], r3 = raw[e * 4 + 3];
+      if (clampv > 0.f) {
+        r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv);
+        r2 = fminf(fmaxf(r2, -clampv), clampv); r3 = fminf(fmaxf(r3, -clampv), clampv);
+      }
+      const float zc = z[e];
+      float dist = (s + 1 < S) ? __fsub_rn(z[e + 1], zc) : 1e10f;
+      dist = __fmul_rn(dist, dn);
+      float sg = r3;
+      if (noise) sg = __fadd_rn(sg, noise[e]);
+      if (add) sg = __fadd_rn(sg, add[e]);
+      sg = fmaxf(sg, 0.f);
+      float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));
+      if (mul) alpha = __fmul_rn(alpha, fmaxf(mul[e], 0.f));
+      const float w = __fmul_rn(alpha, T);
+      T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
+      s0 = __fadd_rn(s0, __fmul_rn(w, sigmoid_f(r0)));
+      s1 = __fadd_rn(s1, __fmul_rn(w, sigmoid_f(r1)));
+      s2 = __fadd_rn(s2, __fmul_rn(w, sigmoid_f(r2)));
+      sd = __fadd_rn(sd, __fmul_rn(w, zc));
+      sa = __fadd_rn(sa, w);
+      if (weights) weights[e] = w;
+    }
+    if (white_bkgd) { const float bg = __fsub_rn(1.f, sa); s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg); }
+    if (rgb) { rgb[i * 3] = s0; rgb[i * 3 + 1] = s1; rgb[i * 3 + 2] = s2; }
+    if (depth) depth[i] = sd;
+    if (acc_out) acc_out[i] = sa;
+    if (disp) disp[i] = __fdiv_rn(1.f, fmaxf(1e-10f, __fdiv_rn(sd, sa)));
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int pnrf_posenc_fwd(const float* x, float* out, int64_t n, int n_freq, void* stream) {
+  PNRF_REQUIRE(n >= 0 && n_freq >= 0 && n_freq <= 16 && (n == 0 || (x && out)), PNRF_E_ARG, "pnrf_posenc_fwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(n * 3)), dim3(TPB), 0, (hipStream_t)stream, x, out, n * 3, n_freq);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_plucker_fwd(const float* o, const float* d, float* out, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (o && d && out)), PNRF_E_ARG, "pnrf_plucker_fwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(plucker_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, o, d, out, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+// small per-device cache of linspace tables for pnrf_ray_encode_fwd (n_pts <= 256)
+#include <map>
+#include <mutex>
+static const float* tvals_for(int n_pts) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, float*> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, n_pts);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  std::vector<float> host(n_pts);
+  pnrf_linspace(0.f, 1.f, n_pts, host.data());
+  float* d = nullptr;
+  if (hipMalloc((void**)&d, n_pts * sizeof(float)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, host.data(), n_pts * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  cache[key] = d;
+  return d;
+}
+
+extern "C" int pnrf_ray_encode_fwd(const float* rays, float* mm_input, int64_t n, int n_pts, void* stream) {
+  PNRF_REQUIRE(n >= 0 && n_pts >= 1 && n_pts <= 256 && (n == 0 || (rays && mm_input)), PNRF_E_ARG, "pnrf_ray_encode_fwd: bad arguments");
+  if (n == 0) return 0;
+  const float* tv = tvals_for(n_pts);      // first call per (device, n_pts) allocates; later calls are launch-only
+  PNRF_REQUIRE(tv, PNRF_E_STATE, "pnrf_ray_encode_fwd: could not allocate the ray-point table");
+  hipLaunchKernelGGL(ray_encode_kernel, dim3(grid_for(n * n_pts)), dim3(TPB), 0, (hipStream_t)stream, rays, tv, mm_input, n, n_pts);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_frame_rays_fwd(const float* K, const float* c2w, int H, int W, float near, float far, float or_near,
+                                   float or_far, int64_t first, int64_t count, float* rays, float* or_rays, void* stream) {
+  PNRF_REQUIRE(K && c2w && H > 0 && W > 0 && first >= 0 && count >= 0 && first + count <= (int64_t)H * W, PNRF_E_ARG,
+               "pnrf_frame_rays_fwd: bad arguments (H=%d W=%d first=%lld count=%lld)", H, W, (long long)first, (long long)count);
+  if (count == 0) return 0;
+  PNRF_REQUIRE(rays && or_rays, PNRF_E_ARG, "pnrf_frame_rays_fwd: null output");
+  FrameArgs a;
+  a.K00 = K[0]; a.K02 = K[2]; a.K11 = K[4]; a.K12 = K[5];
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) a.R[r * 3 + c] = c2w[r * 4 + c]; a.T[r] = c2w[r * 4 + 3]; }
+  a.H = H; a.W = W; a.near = near; a.far = far; a.or_near = or_near; a.or_far = or_far; a.first = first; a.count = count;
+  hipLaunchKernelGGL(frame_rays_kernel, dim3(grid_for(count)), dim3(TPB), 0, (hipStream_t)stream, a, rays, or_rays);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_ndc_rays_fwd(const float* rays_o, const float* rays_d, int H, int W, float focal, float near,
+                                 float* out_o, float* out_d, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && H > 0 && W > 0, PNRF_E_ARG, "pnrf_ndc_rays_fwd: bad sizes");
+  if (n == 0) return 0;
+  PNRF_REQUIRE(rays_o && rays_d && out_o && out_d, PNRF_E_ARG, "pnrf_ndc_rays_fwd: null pointer");
+  hipLaunchKernelGGL(ndc_rays_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, rays_o, rays_d, H, W, focal, near, out_o, out_d, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_warp_trt_fwd(const float* img, const float* depth, const float* ro1, const float* rd1, int64_t ray_bstride,
+                                 const float* w2c, float* out, int B, int Hf, int Wf, int64_t n, void* stream) {
+  PNRF_REQUIRE(B >= 0 && n >= 0 && Hf >= 2 && Wf >= 2 && ray_bstride >= 0, PNRF_E_ARG, "pnrf_warp_trt_fwd: bad sizes");
+  if (B == 0 || n == 0) return 0;
+  PNRF_REQUIRE(img && depth && ro1 && rd1 && w2c && out, PNRF_E_ARG, "pnrf_warp_trt_fwd: null pointer");
+  hipLaunchKernelGGL(warp_trt_kernel, dim3(grid_for((int64_t)B * n)), dim3(TPB), 0, (hipStream_t)stream, img, depth, ro1, rd1, ray_bstride, w2c, out, B, Hf, Wf, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_images_pack(const float* img_nchw, float* out_nhwc4, int nv, int Hf, int Wf, void* stream) {
+  PNRF_REQUIRE(nv >= 0 && Hf > 0 && Wf > 0, PNRF_E_ARG, "pnrf_images_pack: bad sizes");
+  if (nv == 0) return 0;
+  PNRF_REQUIRE(img_nchw && out_nhwc4, PNRF_E_ARG, "pnrf_images_pack: null pointer");
+  const int64_t plane = (int64_t)Hf * Wf;
+  hipLaunchKernelGGL(images_pack_kernel, dim3(grid_for((int64_t)nv * plane)), dim3(TPB), 0, (hipStream_t)stream, img_nchw, (float4*)out_nhwc4, nv, plane);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_refine_input_fwd(const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
+                                     const float* proj, int nb, int Hf, int Wf, float eps, float* refine_in, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && nb == 4 && Hf >= 2 && Wf >= 2, PNRF_E_ARG, "pnrf_refine_input_fwd: bad sizes (nb must be 4, got %d)", nb);
+  if (n == 0) return 0;
+  PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && proj && refine_in, PNRF_E_ARG, "pnrf_refine_input_fwd: null pointer");
+  hipLaunchKernelGGL(refine_input_kernel, dim3(grid_for(n * nb * 8)), dim3(TPB), 0, (hipStream_t)stream, rays, or_rays, depth_sorted,
+                     (const float4*)img4, proj, nb, Hf, Wf, eps, refine_in, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_composite_fwd(const float* raw, const float* z, const float* rays_d, int d_stride, const float* add,
+                                  const float* mul, const float* noise, float clampv, int white_bkgd, float* rgb, float* disp,
+                                  float* acc, float* weights, float* depth, int64_t n, int s, void* stream) {
+  PNRF_REQUIRE(n >= 0 && s >= 1 && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_fwd: bad sizes");
+  if (n == 0) return 0;
+  PNRF_REQUIRE(raw && z && rays_d, PNRF_E_ARG, "pnrf_composite_fwd: null pointer");
+  hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise,
+                     clampv, white_bkgd, rgb, disp, acc, weights, depth, n, s);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ context + whole path
+struct pnrf_ctx {
+  const pnrf_mlp* sampler;
+  const pnrf_mlp* refine;
+  const pnrf_mlp* nerf;
+  int64_t max_rays;
+  float* ws;             // one allocation: depth[8] add[8] mul[8] refine_in[144] z[8] pts[24] per ray
+  int device;
+};
+static constexpr int WS_FLOATS_PER_RAY = 8 + 8 + 8 + 144 + 8 + 24;
+
+extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refine, const pnrf_mlp_t* nerf, int64_t max_rays, pnrf_ctx_t** out) {
+  PNRF_REQUIRE(sampler && refine && nerf && out && max_rays > 0, PNRF_E_ARG, "pnrf_ctx_create: bad arguments");
+  PNRF_REQUIRE(sampler->net == PNRF_NET_SAMPLER && refine->net == PNRF_NET_REFINE && nerf->net == PNRF_NET_NERF, PNRF_E_ARG,
+               "pnrf_ctx_create: handles must be (sampler, refine, nerf)");
+  pnrf_ctx* c = new pnrf_ctx();
+  c->sampler = sampler; c->refine = refine; c->nerf = nerf; c->max_rays = max_rays; c->ws = nullptr;
+  hipError_t e = hipGetDevice(&c->device);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ws, (size_t)max_rays * WS_FLOATS_PER_RAY * sizeof(float));
+  if (e != hipSuccess) {
+    set_error("pnrf_ctx_create: workspace allocation failed: %s", hipGetErrorString(e));
+    delete c;
+    return (int)e;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int pnrf_ctx_free(pnrf_ctx_t* c) {
+  if (!c) return 0;
+  if (c->ws) (void)hipFree(c->ws);
+  delete c;
+  return 0;
+}
+
+extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const float* or_rays, const float* img4, const float* proj,
+                                    int nb, int Hf, int Wf, float eps, float* rgbd, int64_t* sort_idx, int64_t n, void* stream) {
+  PNRF_REQUIRE(c, PNRF_E_ARG, "pnrf_render_rays_fwd: null context");
+  PNRF_REQUIRE(n >= 0 && n <= c->max_rays, PNRF_E_STATE, "pnrf_render_rays_fwd: %lld rays exceed the context's capacity %lld",
+               (long long)n, (long long)c->max_rays);
+  if (n == 0) return 0;
+  PNRF_REQUIRE(rays && or_rays && img4 && proj && rgbd, PNRF_E_ARG, "pnrf_render_rays_fwd: null pointer");
+  float* depth = c->ws;
+  float* add = depth + c->max_rays * 8;
+  float* mul = add + c->max_rays * 8;
+  float* rin = mul + c->max_rays * 8;
+  float* z = rin + c->max_rays * 144;
+  float* pts = z + c->max_rays * 8;
+  int rc;
+  if ((rc = pnrf_sampler_fwd(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, stream))) return rc;   // trt.py:628-635
+  if ((rc = pnrf_refine_input_fwd(rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, rin, n, stream))) return rc;      // :637-661
+  if ((rc = pnrf_refine_fwd(c->refine, rin, rays, depth, z, pts, n, stream))) return rc;                               // :668-681
+  if ((rc = pnrf_nerf_fwd(c->nerf, pts, rays, z, add, mul, rgbd, nullptr, n, stream))) return rc;                      // :691-694
+  return 0;
+}

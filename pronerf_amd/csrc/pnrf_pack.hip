@@ -1,0 +1,238 @@
+// pnrf_pack.hip — host side: error state, weight packing into the MFMA weight stream.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "pnrf_common.h"
+
+namespace pnrf {
+
+static thread_local std::string g_err = "";
+
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+// fp32 -> bf16, round to nearest even; NaN stays NaN.
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct Layer {
+  const float* W;
+  const float* b;
+  int in_dim, out_dim;
+  int nt;                    // output tiles of 32 rows
+  int nk;                    // k-steps (bf16: 16 features each; f32: 2 features each, multiple of 4)
+  std::vector<int> in_map;   // bf16: [nk][2][8]; f32: [nk][2]   -> input feature or -1
+  std::vector<int> out_map;  // [nt][32] tile row -> output index or -1
+};
+
+static size_t layer_frags(const Layer& L, int prec) { return (size_t)L.nt * (prec == PREC_BF16 ? L.nk : L.nk / 4); }
+static size_t layer_slots(const Layer& L, int prec) { return (layer_frags(L, prec) + SLOT_FRAGS - 1) / SLOT_FRAGS; }
+
+static inline float wval(const Layer& L, int out, int in) { return (out >= 0 && in >= 0) ? L.W[(size_t)out * L.in_dim + in] : 0.f; }
+
+static void pack_layer(const Layer& L, int prec, char* dst) {
+  if (prec == PREC_BF16) {
+    for (int to = 0; to < L.nt; ++to)
+      for (int ks = 0; ks < L.nk; ++ks) {
+        uint16_t* frag = (uint16_t*)(dst + ((size_t)to * L.nk + ks) * FRAG_BYTES);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 31, h = lane >> 5;
+          const int out = L.out_map[to * 32 + r];
+          for (int j = 0; j < 8; ++j) frag[lane * 8 + j] = f2bf(wval(L, out, L.in_map[(ks * 2 + h) * 8 + j]));
+        }
+      }
+  } else {
+    const int ks4 = L.nk / 4;
+    for (int to = 0; to < L.nt; ++to)
+      for (int fr = 0; fr < ks4; ++fr) {
+        float* frag = (float*)(dst + ((size_t)to * ks4 + fr) * FRAG_BYTES);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 31, h = lane >> 5;
+          const int out = L.out_map[to * 32 + r];
+          for (int i = 0; i < 4; ++i) frag[lane * 4 + i] = wval(L, out, L.in_map[(4 * fr + i) * 2 + h]);
+        }
+      }
+  }
+}
+
+static void pack_bias(const Layer& L, float* dst) {
+  for (int to = 0; to < L.nt; ++to)
+    for (int h = 0; h < 2; ++h)
+      for (int g = 0; g < 16; ++g) {
+        const int out = L.out_map[to * 32 + acc_row(g, h)];
+        dst[(to * 2 + h) * 16 + g] = out >= 0 ? L.b[out] : 0.f;
+      }
+}
+
+static std::vector<int> identity_out(int nt) {
+  std::vector<int> m(nt * 32);
+  for (int i = 0; i < nt * 32; ++i) m[i] = i;
+  return m;
+}
+static std::vector<int> hidden_in(int prec) {
+  std::vector<int> m;
+  if (prec == PREC_BF16) {
+    m.resize(KS_HID * 16);
+    for (int ks = 0; ks < KS_HID; ++ks)
+      for (int h = 0; h < 2; ++h)
+        for (int j = 0; j < 8; ++j) m[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
+  } else {
+    m.resize((W_HID / 2) * 2);
+    for (int kk = 0; kk < W_HID / 2; ++kk)
+      for (int h = 0; h < 2; ++h) m[kk * 2 + h] = hidden_feat_f32(kk, h);
+  }
+  return m;
+}
+
+}  // namespace pnrf
+
+using namespace pnrf;
+
+extern "C" int pnrf_abi_version(void) { return PNRF_ABI_VERSION; }
+extern "C" const char* pnrf_last_error(void) { return pnrf::g_err.c_str(); }
+
+extern "C" int pnrf_linspace(float start, float end, int n, float* out) {
+  PNRF_REQUIRE(out && n >= 1, PNRF_E_ARG, "pnrf_linspace: bad arguments");
+  // torch.linspace (CPU, float): step = (end-start)/(n-1); i < n/2 ? start + step*i : end - step*(n-1-i)
+  if (n == 1) { out[0] = start; return 0; }
+  const float step = (end - start) / (float)(n - 1);
+  const int half = n / 2;
+  // torch's vectorised kernel evaluates start + step*i / end - step*(n-1-i) with one rounding (FMA)
+  for (int i = 0; i < n; ++i) out[i] = i < half ? fmaf(step, (float)i, start) : fmaf(-step, (float)(n - 1 - i), end);
+  return 0;
+}
+
+extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const* b, const int* in_dim,
+                             const int* out_dim, int n_layers, pnrf_mlp_t** out) {
+  PNRF_REQUIRE(W && b && in_dim && out_dim && out, PNRF_E_ARG, "pnrf_mlp_pack: null argument");
+  PNRF_REQUIRE(net == PNRF_NET_SAMPLER || net == PNRF_NET_REFINE || net == PNRF_NET_NERF, PNRF_E_ARG,
+               "pnrf_mlp_pack: unknown net kind %d", net);
+  const int prec = net == PNRF_NET_SAMPLER ? PREC_F32 : PREC_BF16;
+  const int nhid = net == PNRF_NET_SAMPLER ? S_NHID : net == PNRF_NET_REFINE ? R_NHID : N_NHID;
+  const int in0 = net == PNRF_NET_SAMPLER ? S_IN : net == PNRF_NET_REFINE ? R_IN : N_IN;
+  const int outN = net == PNRF_NET_SAMPLER ? S_OUT : net == PNRF_NET_REFINE ? R_OUT : N_OUT;
+  const int last_in = net == PNRF_NET_NERF ? W_HID + N_INV : W_HID;
+  PNRF_REQUIRE(n_layers == nhid + 2, PNRF_E_SHAPE, "pnrf_mlp_pack: net %d expects %d layers, got %d", net, nhid + 2, n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    const int ei = l == 0 ? in0 : (l == n_layers - 1 ? last_in : W_HID);
+    const int eo = l == n_layers - 1 ? outN : W_HID;
+    PNRF_REQUIRE(W[l] && b[l], PNRF_E_ARG, "pnrf_mlp_pack: null weight/bias at layer %d", l);
+    PNRF_REQUIRE(in_dim[l] == ei && out_dim[l] == eo, PNRF_E_SHAPE,
+                 "pnrf_mlp_pack: net %d layer %d is %dx%d, kernels are built for %dx%d", net, l, out_dim[l], in_dim[l], eo, ei);
+  }
+
+  std::vector<Layer> Ls(n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    Layer& L = Ls[l];
+    L.W = W[l]; L.b = b[l]; L.in_dim = in_dim[l]; L.out_dim = out_dim[l];
+    L.nt = NT_HID; L.out_map = identity_out(NT_HID);
+    L.nk = prec == PREC_BF16 ? KS_HID : W_HID / 2;
+    L.in_map = hidden_in(prec);
+  }
+  std::vector<int> in0_map, inx_map, out_map;
+  Layer& F = Ls[0];
+  Layer& Z = Ls[n_layers - 1];
+  if (net == PNRF_NET_SAMPLER) {
+    F.nk = S_KS0; F.in_map.assign(S_KS0 * 2, -1);
+    for (int kk = 0; kk < S_KS0; ++kk) for (int h = 0; h < 2; ++h) F.in_map[kk * 2 + h] = sampler_in0(kk, h);
+    Z.nt = 1; Z.out_map.assign(32, -1);
+    for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g) Z.out_map[acc_row(g, h)] = sampler_out(g, h);
+  } else if (net == PNRF_NET_REFINE) {
+    F.nk = R_KS0; F.in_map.assign(R_KS0 * 16, -1);
+    for (int ks = 0; ks < R_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) F.in_map[(ks * 2 + h) * 8 + j] = refine_in0(ks, h, j);
+    Z.nt = R_NT_LAST; Z.out_map.assign(64, -1);
+    for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g) {
+      Z.out_map[acc_row(g, h)] = refine_out0(g, h);
+      Z.out_map[32 + acc_row(g, h)] = refine_out1(g, h);
+    }
+  } else {
+    F.nk = N_KS0; F.in_map.assign(N_KS0 * 16, -1);
+    for (int ks = 0; ks < N_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) F.in_map[(ks * 2 + h) * 8 + j] = nerf_in0(ks, h, j);
+    Z.nt = 1; Z.nk = N_KS_LAST; Z.in_map.resize(N_KS_LAST * 16);
+    inx_map.assign(N_KSX * 16, -1);
+    for (int e = 0; e < N_KSX; ++e) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) {
+      const int v = nerf_inx(e, h, j);
+      inx_map[(e * 2 + h) * 8 + j] = v;
+      Z.in_map[((KS_HID + e) * 2 + h) * 8 + j] = v >= 0 ? W_HID + v : -1;
+    }
+    Z.out_map.assign(32, -1);
+    for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g) Z.out_map[acc_row(g, h)] = nerf_out(g, h);
+  }
+  in0_map = F.in_map;
+  out_map.assign(Z.nt * 32, -1);
+  for (int to = 0; to < Z.nt; ++to) for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g)
+    out_map[(to * 2 + h) * 16 + g] = Z.out_map[to * 32 + acc_row(g, h)];
+
+  size_t slots = 0;
+  for (auto& L : Ls) slots += layer_slots(L, prec);
+  slots += (NSLOTS - slots % NSLOTS) % NSLOTS;
+  const uint32_t expect = net == PNRF_NET_SAMPLER ? S_NSLOTS : net == PNRF_NET_REFINE ? R_NSLOTS : N_NSLOTS;
+  PNRF_REQUIRE(slots == expect, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (%zu slots, kernels expect %u)", slots, expect);
+
+  std::vector<char> blob(slots * SLOT_BYTES, 0);
+  size_t nbias = 0;
+  for (auto& L : Ls) nbias += (size_t)L.nt * 32;
+  std::vector<float> bias(nbias, 0.f);
+  size_t so = 0, bo = 0;
+  for (auto& L : Ls) {
+    pack_layer(L, prec, blob.data() + so * SLOT_BYTES);
+    pack_bias(L, bias.data() + bo);
+    so += layer_slots(L, prec);
+    bo += (size_t)L.nt * 32;
+  }
+
+  pnrf_mlp* h = new pnrf_mlp();
+  memset(h, 0, sizeof(*h));
+  h->net = net; h->prec = prec; h->in_dim = in0; h->in_dim_x = net == PNRF_NET_NERF ? N_INV : 0; h->out_dim = outN;
+  h->nslots = (uint32_t)slots; h->nbias = (int)nbias;
+  h->n_in0 = (int)in0_map.size(); h->n_inx = (int)inx_map.size(); h->n_out = (int)out_map.size();
+  hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipMalloc(&h->d_blob, blob.size());
+  if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, nbias * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->d_bias, bias.data(), nbias * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_in0, in0_map.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(h->d_in0, in0_map.data(), in0_map.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !inx_map.empty()) {
+    e = hipMalloc((void**)&h->d_inx, inx_map.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(h->d_inx, inx_map.data(), inx_map.size() * sizeof(int), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, out_map.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(h->d_out, out_map.data(), out_map.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
+    float tv[S_KS0 / 3];
+    pnrf_linspace(0.f, 1.f, S_KS0 / 3, tv);
+    e = hipMalloc((void**)&h->d_tvals, sizeof(tv));
+    if (e == hipSuccess) e = hipMemcpy(h->d_tvals, tv, sizeof(tv), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    set_error("pnrf_mlp_pack: device allocation/copy failed: %s", hipGetErrorString(e));
+    pnrf_mlp_free(h);
+    return (int)e;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
+  if (!h) return 0;
+  if (h->d_blob) (void)hipFree(h->d_blob);
+  if (h->d_bias) (void)hipFree(h->d_bias);
+  if (h->d_in0) (void)hipFree(h->d_in0);
+  if (h->d_inx) (void)hipFree(h->d_inx);
+  if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_tvals) (void)hipFree(h->d_tvals);
+  delete h;
+  return 0;
+}

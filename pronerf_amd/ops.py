@@ -1,0 +1,238 @@
+"""Thin torch-tensor wrappers over the C ABI (device memory + stream plumbing only).
+
+Every function takes contiguous fp32 CUDA(ROCm) tensors, allocates its outputs with torch and
+launches on ``torch.cuda.current_stream()``.  No arithmetic happens on the Python side.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NET_NERF, NET_REFINE, NET_SAMPLER, PnrfError, check
+
+f32 = torch.float32
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, shape_tail=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise PnrfError(f'{name}: expected a GPU tensor (pronerf_amd has no CPU path)')
+    if t.dtype != f32:
+        raise PnrfError(f'{name}: expected float32, got {t.dtype}')
+    if shape_tail is not None and tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise PnrfError(f'{name}: expected trailing shape {shape_tail}, got {tuple(t.shape)}')
+    return t.contiguous()
+
+
+class PackedMLP:
+    """Device-resident pre-tiled weights of one network (pnrf_mlp_pack)."""
+
+    def __init__(self, net: int, weights, biases):
+        lib = _lib.load()
+        n = len(weights)
+        ws = [np.ascontiguousarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b, dtype=np.float32) for b in biases]
+        Wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        ind = (C.c_int * n)(*[w.shape[1] for w in ws])
+        outd = (C.c_int * n)(*[w.shape[0] for w in ws])
+        h = C.c_void_p()
+        check(lib.pnrf_mlp_pack(net, Wp, bp, ind, outd, n, C.byref(h)), 'pnrf_mlp_pack')
+        self.handle = h
+        self.net = net
+        self.in_dim = ws[0].shape[1]
+        self.out_dim = ws[-1].shape[0]
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.load().pnrf_mlp_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, x, x_views=None):
+        """Raw output of the last Linear, [m, out_dim]."""
+        x = _chk(x, 'x', (self.in_dim,))
+        m = x.shape[0]
+        y = torch.empty(m, self.out_dim, device=x.device, dtype=f32)
+        if x_views is not None:
+            x_views = _chk(x_views, 'x_views', (27,))
+        check(_lib.load().pnrf_mlp_fwd(self.handle, _ptr(x), _ptr(x_views), _ptr(y), m, _stream()), 'pnrf_mlp_fwd')
+        return y
+
+
+def posenc(x, n_freq):
+    x = _chk(x, 'x', (3,))
+    lead = x.shape[:-1]
+    xf = x.reshape(-1, 3)
+    out = torch.empty(xf.shape[0], 3 + 6 * n_freq, device=x.device, dtype=f32)
+    check(_lib.load().pnrf_posenc_fwd(_ptr(xf), _ptr(out), xf.shape[0], n_freq, _stream()), 'pnrf_posenc_fwd')
+    return out.reshape(*lead, 3 + 6 * n_freq)
+
+
+def plucker(o, d):
+    o = _chk(o, 'rays_o', (3,)); d = _chk(d, 'rays_d', (3,))
+    if o.shape != d.shape:
+        raise PnrfError(f'plucker: shape mismatch {tuple(o.shape)} vs {tuple(d.shape)}')
+    lead = o.shape[:-1]
+    of, df = o.reshape(-1, 3), d.reshape(-1, 3)
+    out = torch.empty(of.shape[0], 6, device=o.device, dtype=f32)
+    check(_lib.load().pnrf_plucker_fwd(_ptr(of), _ptr(df), _ptr(out), of.shape[0], _stream()), 'pnrf_plucker_fwd')
+    return out.reshape(*lead, 6)
+
+
+def ray_encode(rays, n_pts=48):
+    rays = _chk(rays, 'rays', (11,))
+    out = torch.empty(rays.shape[0], 6 * n_pts, device=rays.device, dtype=f32)
+    check(_lib.load().pnrf_ray_encode_fwd(_ptr(rays), _ptr(out), rays.shape[0], n_pts, _stream()), 'pnrf_ray_encode_fwd')
+    return out
+
+
+def frame_rays(K, c2w, H, W, near=0.0, far=1.0, or_near=1.0, or_far=10.0, first=0, count=None, device='cuda'):
+    """rays[count,11], or_rays[count,11] for flat pixel range [first, first+count)."""
+    count = H * W - first if count is None else count
+    Kh = np.ascontiguousarray(np.asarray(K.detach().cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float32).reshape(3, 3))
+    Ch = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)[:3, :4])
+    rays = torch.empty(count, 11, device=device, dtype=f32)
+    orr = torch.empty(count, 11, device=device, dtype=f32)
+    fp = C.POINTER(C.c_float)
+    check(_lib.load().pnrf_frame_rays_fwd(Kh.ctypes.data_as(fp), Ch.ctypes.data_as(fp), H, W, near, far, or_near, or_far,
+                                          first, count, _ptr(rays), _ptr(orr), _stream()), 'pnrf_frame_rays_fwd')
+    return rays, orr
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    rays_o = _chk(rays_o, 'rays_o', (3,)); rays_d = _chk(rays_d, 'rays_d', (3,))
+    lead = rays_o.shape
+    of, df = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    oo = torch.empty_like(of); od = torch.empty_like(df)
+    check(_lib.load().pnrf_ndc_rays_fwd(_ptr(of), _ptr(df), int(H), int(W), float(focal), float(near), _ptr(oo), _ptr(od), of.shape[0], _stream()),
+          'pnrf_ndc_rays_fwd')
+    return oo.reshape(lead), od.reshape(lead)
+
+
+def warp_trt(img, depth, ro1, rd1, w2c):
+    """img [B,3,Hf,Wf]; depth [B,n]; ro1, rd1 [4,n] (shared) or [B,4,n]; w2c [B,3,4] -> [B,3,n]."""
+    img = _chk(img, 'img'); depth = _chk(depth, 'depth'); w2c = _chk(w2c, 'w2c', (3, 4))
+    B, _, Hf, Wf = img.shape
+    n = depth.shape[-1]
+    if ro1.dim() == 3 and ro1.stride(0) == 0:       # the reference's expand(): one copy shared by all B
+        ro1, rd1 = ro1[0], rd1[0]
+    ro1 = _chk(ro1, 'ro1'); rd1 = _chk(rd1, 'rd1')
+    bstride = 4 * n if ro1.dim() == 3 else 0
+    out = torch.empty(B, 3, n, device=img.device, dtype=f32)
+    check(_lib.load().pnrf_warp_trt_fwd(_ptr(img), _ptr(depth), _ptr(ro1), _ptr(rd1), bstride, _ptr(w2c), _ptr(out), B, Hf, Wf, n, _stream()),
+          'pnrf_warp_trt_fwd')
+    return out
+
+
+def images_pack(img_nchw):
+    img = _chk(img_nchw, 'images')
+    nv, c, Hf, Wf = img.shape
+    if c != 3:
+        raise PnrfError(f'images_pack: expected [nv,3,H,W], got {tuple(img.shape)}')
+    out = torch.empty(nv, Hf, Wf, 4, device=img.device, dtype=f32)
+    check(_lib.load().pnrf_images_pack(_ptr(img), _ptr(out), nv, Hf, Wf, _stream()), 'pnrf_images_pack')
+    return out
+
+
+def refine_input(rays, or_rays, depth_sorted, img4, proj, eps=1e-5):
+    rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
+    nb, Hf, Wf, _ = img4.shape
+    n = rays.shape[0]
+    out = torch.empty(n, 144, device=rays.device, dtype=f32)
+    check(_lib.load().pnrf_refine_input_fwd(_ptr(rays), _ptr(or_rays), _ptr(depth_sorted), _ptr(img4), _ptr(proj), nb, Hf, Wf, eps,
+                                            _ptr(out), n, _stream()), 'pnrf_refine_input_fwd')
+    return out
+
+
+def composite(raw, z, rays_d, add=None, mul=None, noise=None, clamp=0.0, white_bkgd=False):
+    raw = _chk(raw, 'raw', (4,)); z = _chk(z, 'z_vals'); rays_d = _chk(rays_d, 'rays_d', (3,))
+    n, s = z.shape
+    add = None if add is None else _chk(add, 'mm_density_add')
+    mul = None if mul is None else _chk(mul, 'mm_density_mul')
+    noise = None if noise is None else _chk(noise, 'noise')
+    dev = raw.device
+    rgb = torch.empty(n, 3, device=dev, dtype=f32); disp = torch.empty(n, device=dev, dtype=f32)
+    acc = torch.empty(n, device=dev, dtype=f32); w = torch.empty(n, s, device=dev, dtype=f32); depth = torch.empty(n, device=dev, dtype=f32)
+    check(_lib.load().pnrf_composite_fwd(_ptr(raw), _ptr(z), _ptr(rays_d), 3, _ptr(add), _ptr(mul), _ptr(noise), float(clamp),
+                                         int(bool(white_bkgd)), _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(w), _ptr(depth), n, s, _stream()),
+          'pnrf_composite_fwd')
+    return rgb, disp, acc, w, depth
+
+
+def sampler_fwd(mlp: PackedMLP, rays, want_idx=True, want_rgb=True, want_raw=False):
+    rays = _chk(rays, 'rays', (11,))
+    n, dev = rays.shape[0], rays.device
+    depth = torch.empty(n, 8, device=dev, dtype=f32); add = torch.empty_like(depth); mul = torch.empty_like(depth)
+    idx = torch.empty(n, 8, device=dev, dtype=torch.int64) if want_idx else None
+    rgb = torch.empty(n, 3, device=dev, dtype=f32) if want_rgb else None
+    draw = torch.empty(n, 8, device=dev, dtype=f32) if want_raw else None
+    check(_lib.load().pnrf_sampler_fwd(mlp.handle, _ptr(rays), n, _ptr(depth), _ptr(add), _ptr(mul), _ptr(idx), _ptr(rgb), _ptr(draw), _stream()),
+          'pnrf_sampler_fwd')
+    return depth, idx, add, mul, rgb, draw
+
+
+def refine_fwd(mlp: PackedMLP, refine_in, rays, depth_sorted):
+    refine_in = _chk(refine_in, 'refine_in', (144,)); rays = _chk(rays, 'rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    n, dev = rays.shape[0], rays.device
+    z = torch.empty(n, 8, device=dev, dtype=f32); pts = torch.empty(n, 8, 3, device=dev, dtype=f32)
+    check(_lib.load().pnrf_refine_fwd(mlp.handle, _ptr(refine_in), _ptr(rays), _ptr(depth_sorted), _ptr(z), _ptr(pts), n, _stream()), 'pnrf_refine_fwd')
+    return z, pts
+
+
+def nerf_fwd(mlp: PackedMLP, pts, rays, z, add, mul, want_raw=False):
+    pts = _chk(pts, 'pts', (8, 3)); rays = _chk(rays, 'rays', (11,)); z = _chk(z, 'z', (8,)); add = _chk(add, 'add', (8,)); mul = _chk(mul, 'mul', (8,))
+    n, dev = rays.shape[0], rays.device
+    rgbd = torch.empty(n, 4, device=dev, dtype=f32)
+    raw = torch.empty(n, 8, 4, device=dev, dtype=f32) if want_raw else None
+    check(_lib.load().pnrf_nerf_fwd(mlp.handle, _ptr(pts), _ptr(rays), _ptr(z), _ptr(add), _ptr(mul), _ptr(rgbd), _ptr(raw), n, _stream()), 'pnrf_nerf_fwd')
+    return rgbd, raw
+
+
+class RenderContext:
+    """pnrf_ctx: per-ray workspace for the whole inference path (sized once)."""
+
+    def __init__(self, sampler: PackedMLP, refine: PackedMLP, nerf: PackedMLP, max_rays: int):
+        self._keep = (sampler, refine, nerf)
+        h = C.c_void_p()
+        check(_lib.load().pnrf_ctx_create(sampler.handle, refine.handle, nerf.handle, int(max_rays), C.byref(h)), 'pnrf_ctx_create')
+        self.handle = h
+        self.max_rays = int(max_rays)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.load().pnrf_ctx_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def render_rays(self, rays, or_rays, img4, proj, eps=1e-5, want_idx=False, out=None):
+        rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,))
+        img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
+        n = rays.shape[0]
+        nb, Hf, Wf, _ = img4.shape
+        rgbd = out if out is not None else torch.empty(n, 4, device=rays.device, dtype=f32)
+        idx = torch.empty(n, 8, device=rays.device, dtype=torch.int64) if want_idx else None
+        check(_lib.load().pnrf_render_rays_fwd(self.handle, _ptr(rays), _ptr(or_rays), _ptr(img4), _ptr(proj), nb, Hf, Wf, eps,
+                                               _ptr(rgbd), _ptr(idx), n, _stream()), 'pnrf_render_rays_fwd')
+        return rgbd, idx
+
+
+def linspace(start, end, n):
+    out = (C.c_float * n)()
+    check(_lib.load().pnrf_linspace(start, end, n, out), 'pnrf_linspace')
+    return np.array(out[:], dtype=np.float32)

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pronerf_hip.h declares;
+host-only helpers agree with torch; the sort network used by the sampler epilogue sorts."""
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from pronerf_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from pronerf_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'pronerf_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(pnrf_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pnrf_abi_version() == 1
+
+
+def test_linspace_matches_torch(lib):
+    from pronerf_amd import ops
+    for n in (1, 2, 7, 48, 64, 255):
+        np.testing.assert_array_equal(ops.linspace(0.0, 1.0, n), torch.linspace(0, 1, n).numpy())
+
+
+def test_argument_errors_are_reported(lib):
+    from pronerf_amd import _lib
+    rc = lib.pnrf_posenc_fwd(None, None, 5, 10, None)
+    assert rc == -1
+    assert b'pnrf_posenc_fwd' in lib.pnrf_last_error()
+    with pytest.raises(_lib.PnrfError):
+        _lib.check(rc, 'posenc')
+    assert lib.pnrf_posenc_fwd(None, None, 0, 10, None) == 0      # empty input is a no-op
+
+
+def test_cpu_tensors_are_refused():
+    from pronerf_amd import ops, _lib
+    with pytest.raises(_lib.PnrfError):
+        ops.posenc(torch.zeros(4, 3), 10)
+
+
+NETWORK = [(0, 1), (2, 3), (4, 5), (6, 7), (0, 2), (1, 3), (4, 6), (5, 7), (1, 2), (5, 6), (0, 4), (3, 7),
+           (1, 5), (2, 6), (1, 4), (3, 6), (2, 4), (3, 5), (3, 4)]
+
+
+def test_sort_network_is_a_sorting_network_and_stable_with_index_keys():
+    src = open(os.path.join(ROOT, 'pronerf_amd', 'csrc', 'pnrf_mlp_kernels.hip')).read()
+    pairs = [(int(a), int(b)) for a, b in re.findall(r'PNRF_CSWAP\((\d), (\d)\)', src)]
+    assert pairs == NETWORK           # the kernel uses exactly the network verified here
+    for bits in itertools.product((0, 1), repeat=8):      # zero-one principle
+        v = list(bits)
+        for i, j in NETWORK:
+            if v[i] > v[j]:
+                v[i], v[j] = v[j], v[i]
+        assert v == sorted(v)
+    rs = np.random.RandomState(0)
+    for _ in range(2000):                                   # ties: (value, index) keys == stable sort
+        vals = rs.randint(0, 4, 8).astype(np.float32)
+        keys = [(float(vals[i]), i) for i in range(8)]
+        for i, j in NETWORK:
+            if keys[i] > keys[j]:
+                keys[i], keys[j] = keys[j], keys[i]
+        ref = torch.sort(torch.from_numpy(vals), stable=True)[1].tolist()
+        assert [k[1] for k in keys] == ref
