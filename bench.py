@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — rays/s of the ProNeRF inference hot path (render_rays) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one 1008x756 LLFF-Fern-geometry frame =
+762 048 rays, 8 samples/ray, 4 neighbour views, 48 ray-encoding points; synthetic poses/images
+and seeded "trained-like" weights (no dataset/checkpoint ships).  A step = one pass of the hot
+path (sampler MLP fp32 -> neighbour projection -> refine MLP bf16 -> NeRF MLP bf16 -> alpha
+compositing) over one frame; the kernels tile the frame into 1024-ray chunks (4 workgroup
+batches of 256 columns) inside a single launch per stage.  Rays, images and weights are resident
+in HBM before the timed region, exactly like the reference's timed loop
+(run_S_eS_eN_alter_trt.py:327-332).  At N>1 the frame's rays are split into contiguous ranges,
+one per rank, and the per-rank [n,4] rgb+depth tiles are all-gathered over RCCL inside the timed
+region ("strong" scaling: the frame is fixed).
+
+Rank 0 prints ONE JSON line (see the driver contract); `roofline` and `cpu_baseline` are added
+at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, FOCAL = 756, 1008, 815.13
+# algorithmic dense-MLP FLOPs per ray: 2 x MAC, bias/activations/encodings excluded
+MAC_SAMPLER = 288 * 256 + 5 * 256 * 256 + 256 * 27            # 408 320
+MAC_REFINE = 144 * 256 + 5 * 256 * 256 + 256 * 35             # 373 504
+MAC_NERF = 8 * (63 * 256 + 6 * 256 * 256 + 283 * 4)           # 8 x 410 476
+FLOP_PER_RAY = 2 * (MAC_SAMPLER + MAC_REFINE + MAC_NERF)      # 8 131 264
+PEAK_BF16 = 2500.0     # TFLOP/s dense, MI355X_MICROARCH.md chip table
+PEAK_F32 = 157.3       # TFLOP/s, f32-input MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (rank 0, N=1)')
+    ap.add_argument('--cpu-sample-rays', type=int, default=16384)
+    return ap.parse_args()
+
+
+def stage_profile(rend, rays, or_rays, reps=5):
+    """Per-kernel durations with HIP events on the launch stream (torch's current stream is the
+    stream the C ABI launches on).  Returns {kernel: ms}."""
+    from pronerf_amd import ops
+    n = rays.shape[0]
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    acc = {'sampler_kernel': 0.0, 'refine_input_kernel': 0.0, 'refine_kernel': 0.0, 'nerf_kernel': 0.0}
+    for it in range(reps + 1):
+        e = [ev() for _ in range(5)]
+        e[0].record()
+        depth, _, add, mul, _, _ = ops.sampler_fwd(rend.sampler, rays, want_idx=False, want_rgb=False)
+        e[1].record()
+        rin = ops.refine_input(rays, or_rays, depth, rend.img4, rend.proj)
+        e[2].record()
+        z, pts = ops.refine_fwd(rend.refine, rin, rays, depth)
+        e[3].record()
+        rgbd, _ = ops.nerf_fwd(rend.nerf, pts, rays, z, add, mul)
+        e[4].record()
+        torch.cuda.synchronize()
+        if it == 0:
+            continue          # warm-up
+        for k, (a, b) in zip(acc, zip(e[:-1], e[1:])):
+            acc[k] += a.elapsed_time(b) / reps
+    return acc
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, capped at the GPU
+    box's per-GPU CPU share (16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(weights, scene, n_rays, budget_s=20.0):
+    """The CPU oracle (oracle/, a from-scratch port of the reference's torch path) timed on this
+    box's host cores over a bounded sample of the same frame.  Checker-side code: imported here
+    only, never on the measured path."""
+    from oracle import pronerf_oracle as orc
+    torch.set_num_threads(host_cores())
+    fr = orc.frame_setup(scene)
+    n_total = fr['rays'].shape[0]
+    sel = torch.linspace(0, n_total - 1, n_rays).long()
+    rays, or_rays = fr['rays'][sel].contiguous(), fr['or_rays'][sel].contiguous()
+    best, reps, t_start = float('inf'), 0, time.perf_counter()
+    with torch.no_grad():
+        while reps < 3 or (time.perf_counter() - t_start < budget_s and reps < 10):
+            t0 = time.perf_counter()
+            orc.render_rays_infer(weights, rays, or_rays, fr['images'], fr['proj'])
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+            if time.perf_counter() - t_start > budget_s:
+                break
+    return {'value': n_rays / best, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n_rays} rays evenly strided over the same 1008x756 frame, full-size neighbour images, '
+                      f'best of {reps} passes of oracle.render_rays_infer (fp32 torch CPU)'}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary, if any."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get('dominant_kernel_hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks')
+        raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from pronerf_amd import synthetic
+    from pronerf_amd.render import Renderer, shard_range
+
+    weights = synthetic.make_weights(0, 'trained')
+    scene = synthetic.make_scene(0, H=H, W=W, focal=FOCAL, rotate=True)
+    n_total = H * W
+    first, count = shard_range(n_total, rank, world)
+    rend = Renderer(weights, max_rays=count, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W, first=first, count=count)
+    out = torch.empty(count, 4, device=dev)
+    counts = [shard_range(n_total, r, world)[1] for r in range(world)]
+    even = len(set(counts)) == 1
+    if world > 1:
+        full = torch.empty(n_total, 4, device=dev)
+        chunks = list(full.split(counts))
+
+    def step():
+        rend.render_rays(rays, or_rays, out=out)
+        if world > 1:
+            if even:
+                dist.all_gather_into_tensor(full, out)
+            else:
+                dist.all_gather(chunks, out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(out).all().item())
+
+    res = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = n_total * args.steps / dt
+        res = {
+            'metric': 'rays/sec (and ms/1008x756 frame) LLFF Fern 8-sample infer',
+            'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms, 'ms_per_frame': ms, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'bf16 (refine+NeRF MLP, fp32 accumulate) + f32 (sampler MLP, exact f32 MFMA)',
+            'data': 'synthetic',
+            'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, '
+                                   '48 ray-encoding points, 1024-ray chunks (4x256-column workgroup batches), bf16 MLP',
+                       'rays_per_step': n_total, 'rays_per_gpu': counts[0],
+                       'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
+            'outputs_finite': finite,
+            'algorithmic_flop_per_ray': FLOP_PER_RAY,
+            'e2e_mfma_tflops': value * FLOP_PER_RAY / 1e12,
+        }
+        if world == 1:
+            prof = stage_profile(rend, rays, or_rays)
+            flops = {'sampler_kernel': 2 * MAC_SAMPLER, 'refine_kernel': 2 * MAC_REFINE, 'nerf_kernel': 2 * MAC_NERF}
+            peaks = {'sampler_kernel': PEAK_F32, 'refine_kernel': PEAK_BF16, 'nerf_kernel': PEAK_BF16}
+            kern = {}
+            for k, ms_k in prof.items():
+                kern[k] = {'ms': ms_k}
+                if k in flops:
+                    ach = flops[k] * n_total / (ms_k * 1e-3) / 1e12
+                    kern[k].update(achieved_tflops=ach, peak_tflops=peaks[k], frac=ach / peaks[k])
+            dom = max(flops, key=lambda k: prof[k])
+            res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
+                               'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': pmc_traffic(),
+                               'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total}
+            res['kernels'] = kern
+            if not args.no_cpu_baseline:
+                res['cpu_baseline'] = cpu_baseline(weights, scene, args.cpu_sample_rays)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == '__main__':
+    main()

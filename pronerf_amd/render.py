@@ -1,0 +1,88 @@
+"""Frame-level host logic of the inference path: neighbour selection, projection matrices,
+image packing, ray-range sharding — the part of the reference's ``render_path`` that runs once
+per frame outside its timed region (run_S_eS_eN_alter_trt.py:245-302) — and the ``Renderer``
+object that owns the packed networks and the per-ray workspace.
+
+All per-ray work is done by the HIP kernels behind ``pronerf_amd.ops``; what is computed here on
+the host is O(number of cameras) (a 20-element sort and four 3x4 matrix products per frame).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+N_SAMPLES = 8
+NUM_NEIGHBOR = 4
+FLIP = np.diag([1.0, -1.0, -1.0]).astype(np.float32)
+
+
+def select_neighbors(c2w, poses, num_neighbor=NUM_NEIGHBOR):
+    """Indices of the ``num_neighbor`` source cameras closest to the target camera centre,
+    ascending (run_S_eS_eN_alter_trt.py:281-283)."""
+    c2w = np.asarray(c2w, dtype=np.float32); poses = np.asarray(poses, dtype=np.float32)
+    d = np.sqrt(((c2w[None, :3, 3] - poses[:, :3, 3]) ** 2).sum(1, dtype=np.float32))
+    return np.argsort(d, kind='stable')[:num_neighbor]
+
+
+def projection_matrices(K, poses):
+    """M_k = K . diag(1,-1,-1) . pose_k, each 3x4 (run_S_eS_eN_alter_trt.py:289-294).
+    The kernel is agnostic to what the 3x4 means; like the reference this passes the stored
+    pose as-is."""
+    K = np.asarray(K, dtype=np.float32); poses = np.asarray(poses, dtype=np.float32)
+    return np.stack([K @ (FLIP @ p[:3, :4]) for p in poses], 0).astype(np.float32)
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous flat ray range of ``rank``: [first, first+count).  Sizes differ by at most one
+    ray; concatenating the ranges in rank order gives back [0, n_total)."""
+    base, rem = divmod(int(n_total), int(world))
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+class Renderer:
+    """Packed networks + workspace for ``render_rays`` (inference).
+
+    weights: dict with 'sampler'/'refine'/'nerf' -> {'W': [...], 'b': [...]} (torch layout
+    ``W[out,in]``, numpy or torch) — e.g. ``pronerf_amd.synthetic.make_weights`` or the tensors of
+    a checkpoint's state dicts (see ``run_nerf_helpers.weights_from_state_dicts``).
+    """
+
+    def __init__(self, weights, max_rays: int, device='cuda:0'):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise ops.PnrfError('Renderer needs a GPU device (pronerf_amd has no CPU path)')
+        with torch.cuda.device(self.device):
+            self.sampler = ops.PackedMLP(ops.NET_SAMPLER, weights['sampler']['W'], weights['sampler']['b'])
+            self.refine = ops.PackedMLP(ops.NET_REFINE, weights['refine']['W'], weights['refine']['b'])
+            self.nerf = ops.PackedMLP(ops.NET_NERF, weights['nerf']['W'], weights['nerf']['b'])
+            self.ctx = ops.RenderContext(self.sampler, self.refine, self.nerf, max_rays)
+        self.img4 = None
+        self.proj = None
+        self.ref_nos = None
+
+    # ---- per frame (outside the timed region, like run_S_eS_eN_alter_trt.py:281-302)
+    def set_views(self, c2w, poses, images_nhwc, K, num_neighbor=NUM_NEIGHBOR):
+        """Pick the neighbours of the target pose, upload + interleave their images, build the
+        projection matrices.  images_nhwc: [n_views,H,W,3] numpy/torch in [0,1]."""
+        ref = select_neighbors(c2w, poses, num_neighbor)
+        self.ref_nos = ref
+        imgs = images_nhwc[ref] if isinstance(images_nhwc, np.ndarray) else images_nhwc[torch.as_tensor(ref)]
+        nchw = torch.as_tensor(imgs, dtype=torch.float32).permute(0, 3, 1, 2).contiguous().to(self.device)   # H2D (trt.py:286)
+        with torch.cuda.device(self.device):
+            self.img4 = ops.images_pack(nchw)
+        self.proj = torch.from_numpy(projection_matrices(K, np.asarray(poses)[ref])).to(self.device)
+        return ref
+
+    def frame_rays(self, K, c2w, H, W, first=0, count=None):
+        with torch.cuda.device(self.device):
+            return ops.frame_rays(K, c2w, H, W, first=first, count=count, device=self.device)
+
+    # ---- the hot path (the reference's timed region, trt.py:327-332)
+    def render_rays(self, rays, or_rays, eps=1e-5, want_idx=False, out=None):
+        if self.img4 is None:
+            raise ops.PnrfError('Renderer.render_rays: call set_views() first')
+        with torch.cuda.device(self.device):
+            return self.ctx.render_rays(rays, or_rays, self.img4, self.proj, eps=eps, want_idx=want_idx, out=out)

@@ -1,0 +1,196 @@
+"""Deterministic synthetic weights / scenes (no dataset or checkpoint ships with the repo).
+
+Shared by ``bench.py``, ``__graft_entry__.smoke()``, the tests and the golden generator
+(``oracle/gen_golden.py``, via ``oracle/synth.py``) so that weights never have to be committed as
+fixtures: everything is regenerated from a seed with ``numpy.random.RandomState`` (MT19937, stable
+across numpy versions).  Pure numpy — no compute path lives here.  Shapes follow the reference's ``create_nerf``
+(run_S_eS_eN_alter_trt.py:412-458) with the fern_trt.txt hyper-parameters
+(configs/llff/fern/fern_trt.txt:14-34).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# fern_trt.txt / script defaults (run_S_eS_eN_alter_trt.py:62-65,132-135)
+N_SAMPLES = 8
+NUM_NEIGHBOR = 4
+N_POINT_RAY_ENC = 48
+MULTIRES = 10
+MULTIRES_VIEWS = 4
+NETDEPTH = 8
+NETWIDTH = 256
+MMNETDEPTH = 6
+MMNETWIDTH = 256
+
+SAMPLER_DIMS = [6 * N_POINT_RAY_ENC] + [MMNETWIDTH] * MMNETDEPTH + [3 * N_SAMPLES + 3]
+REFINE_DIMS = [6 * N_SAMPLES + 3 * NUM_NEIGHBOR * N_SAMPLES] + [MMNETWIDTH] * MMNETDEPTH + [4 * N_SAMPLES + 3]
+POS_CH = 3 + 6 * MULTIRES          # 63
+DIR_CH = 3 + 6 * MULTIRES_VIEWS    # 27
+
+
+def nerf_layer_dims():
+    """(in,out) of DoNeRFTRT(D=8,W=256,skip='auto') (run_nerf_helpers.py:1190-1239)."""
+    dims = [(POS_CH, NETWIDTH)] + [(NETWIDTH, NETWIDTH)] * (NETDEPTH - 2) + [(NETWIDTH + DIR_CH, 4)]
+    return dims
+
+
+def nerfcls_layer_dims():
+    """Layer table of the ``NeRF`` class (run_nerf_helpers.py:792-822), skips=[4]."""
+    W = NETWIDTH
+    pts = [(POS_CH, W)] + [((W + POS_CH) if i == 4 else W, W) for i in range(NETDEPTH - 1)]
+    return {
+        'pts_linears': pts,
+        'views_linears': [(DIR_CH + W, W // 2)],
+        'feature_linear': (W, W),
+        'alpha_linear': (W, 1),
+        'rgb_linear': (W // 2, 3),
+    }
+
+
+def _uniform(rs, shape, bound):
+    return rs.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def _mlp(rs, dims, kind):
+    Ws, bs = [], []
+    for i in range(len(dims) - 1):
+        fi, fo = dims[i], dims[i + 1]
+        if kind == 'default':
+            wb = 1.0 / np.sqrt(fi)          # nn.Linear default (kaiming_uniform, a=sqrt(5))
+        else:
+            wb = np.sqrt(6.0 / fi)          # signal-preserving: every layer matters to the output
+        Ws.append(_uniform(rs, (fo, fi), wb))
+        bs.append(_uniform(rs, (fo,), 1.0 / np.sqrt(fi)))
+    return Ws, bs
+
+
+def make_weights(seed: int = 0, kind: str = 'trained'):
+    """Three weight sets as lists of numpy arrays (torch layout ``W[out,in]``).
+
+    kind:
+      'default'  module default initialisation (sampler/refine: nn.Linear default;
+                 nerf: kaiming-normal weights, run_nerf_helpers.py:1243-1244).  Sampler
+                 depths collapse into a narrow band -> worst case for sort ties.
+      'spread'   'default' with the sampler head scaled x8 and a spread depth bias
+                 (tie-free sort-index test).
+      'trained'  signal-preserving hidden layers and head biases chosen so that depths
+                 spread over (0,1), alpha/weights are non-degenerate and rgb spans [0,1].
+    """
+    assert kind in ('default', 'spread', 'trained')
+    rs = np.random.RandomState(1000003 * (seed + 1) + {'default': 0, 'spread': 1, 'trained': 2}[kind])
+    S = N_SAMPLES
+    sW, sb = _mlp(rs, SAMPLER_DIMS, 'default' if kind != 'trained' else 'trained')
+    rW, rb = _mlp(rs, REFINE_DIMS, 'default' if kind != 'trained' else 'trained')
+    nW, nb = [], []
+    for fi, fo in nerf_layer_dims():
+        nW.append((rs.randn(fo, fi) * np.sqrt(2.0 / fi)).astype(np.float32))
+        nb.append(_uniform(rs, (fo,), 1.0 / np.sqrt(fi)))
+    perm = np.array([5, 2, 7, 0, 3, 6, 1, 4])
+    if kind == 'spread':
+        sW[-1] = sW[-1].copy(); sb[-1] = sb[-1].copy()
+        sW[-1][:S] *= 8.0
+        sb[-1][:S] = np.linspace(-2.5, 2.5, S, dtype=np.float32)[perm]
+    if kind == 'trained':
+        sW[-1] = sW[-1].copy(); sb[-1] = sb[-1].copy()
+        sW[-1] *= 0.35
+        sb[-1][:S] = np.linspace(-2.0, 2.0, S, dtype=np.float32)[perm]
+        sb[-1][S:2 * S] += 2.0           # density add
+        sb[-1][2 * S:3 * S] += 1.0       # density mul
+        rW[-1] = rW[-1] * 0.35
+        nW[-1] = nW[-1] * 0.5
+        nb[-1] = nb[-1].copy(); nb[-1][3] += 1.0
+    return {
+        'sampler': {'W': sW, 'b': sb},
+        'refine': {'W': rW, 'b': rb},
+        'nerf': {'W': nW, 'b': nb},
+    }
+
+
+def make_nerfcls_weights(seed: int = 0):
+    """Weights of the ``NeRF`` class fine net (default nn.Linear-style init, gain 2)."""
+    rs = np.random.RandomState(7919 * (seed + 1))
+    t = nerfcls_layer_dims()
+    out = {}
+
+    def lin(fi, fo):
+        return _uniform(rs, (fo, fi), np.sqrt(6.0 / fi)), _uniform(rs, (fo,), 1.0 / np.sqrt(fi))
+
+    out['pts_linears'] = [lin(fi, fo) for fi, fo in t['pts_linears']]
+    out['views_linears'] = [lin(*t['views_linears'][0])]
+    out['feature_linear'] = lin(*t['feature_linear'])
+    out['alpha_linear'] = lin(*t['alpha_linear'])
+    out['rgb_linear'] = lin(*t['rgb_linear'])
+    return out
+
+
+def state_dicts(weights):
+    """numpy weights -> the reference modules' ``state_dict`` key layout.
+
+    sampler/refine: ``fc_backbone.{i}.*``, ``fc_output.*`` (run_nerf_helpers.py:1484-1488);
+    DoNeRFTRT: ``layers.{i}.*`` (run_nerf_helpers.py:1235-1239).
+    """
+    import torch
+    out = {}
+    for name in ('sampler', 'refine'):
+        W, b = weights[name]['W'], weights[name]['b']
+        sd = {}
+        for i in range(len(W) - 1):
+            sd[f'fc_backbone.{i}.weight'] = torch.from_numpy(W[i].copy())
+            sd[f'fc_backbone.{i}.bias'] = torch.from_numpy(b[i].copy())
+        sd['fc_output.weight'] = torch.from_numpy(W[-1].copy())
+        sd['fc_output.bias'] = torch.from_numpy(b[-1].copy())
+        out[name] = sd
+    W, b = weights['nerf']['W'], weights['nerf']['b']
+    sd = {}
+    for i in range(len(W)):
+        sd[f'layers.{i}.weight'] = torch.from_numpy(W[i].copy())
+        sd[f'layers.{i}.bias'] = torch.from_numpy(b[i].copy())
+    out['nerf'] = sd
+    return out
+
+
+def nerfcls_state_dict(w):
+    import torch
+    sd = {}
+    for i, (W, b) in enumerate(w['pts_linears']):
+        sd[f'pts_linears.{i}.weight'] = torch.from_numpy(W.copy()); sd[f'pts_linears.{i}.bias'] = torch.from_numpy(b.copy())
+    W, b = w['views_linears'][0]
+    sd['views_linears.0.weight'] = torch.from_numpy(W.copy()); sd['views_linears.0.bias'] = torch.from_numpy(b.copy())
+    for k in ('feature_linear', 'alpha_linear', 'rgb_linear'):
+        W, b = w[k]
+        sd[f'{k}.weight'] = torch.from_numpy(W.copy()); sd[f'{k}.bias'] = torch.from_numpy(b.copy())
+    return sd
+
+
+def make_scene(seed: int = 0, H: int = 24, W: int = 32, Hf: int | None = None, Wf: int | None = None,
+               focal: float | None = None, n_views: int = NUM_NEIGHBOR, sigma_t: float = 0.05,
+               rotate: bool = False):
+    """A synthetic forward-facing scene (SURVEY.md §8(d) / BASELINE.md §4).
+
+    Returns a dict with ``H, W, focal, K[3,3], c2w[3,4]`` (target), ``poses[n,3,4]``
+    (neighbour cameras) and ``images[n,Hf,Wf,3]`` in [0,1).  The Fern geometry is
+    H=756, W=1008, focal=815.13.
+    """
+    rs = np.random.RandomState(424243 * (seed + 1))
+    Hf = H if Hf is None else Hf
+    Wf = W if Wf is None else Wf
+    if focal is None:
+        focal = 815.13 * W / 1008.0
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+
+    def pose(sig):
+        R = np.eye(3, dtype=np.float64)
+        if rotate:
+            a = rs.randn(3) * 0.03
+            cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+            Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+            Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+            Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+            R = Rz @ Ry @ Rx
+        t = rs.randn(3) * sig
+        return np.concatenate([R, t[:, None]], 1).astype(np.float32)
+
+    c2w = pose(sigma_t)
+    poses = np.stack([pose(sigma_t) for _ in range(n_views)], 0)
+    images = rs.rand(n_views, Hf, Wf, 3).astype(np.float32)
+    return {'H': H, 'W': W, 'focal': float(focal), 'K': K, 'c2w': c2w, 'poses': poses, 'images': images}

@@ -1,0 +1,106 @@
+"""GPU: the whole inference path (pnrf_render_rays_fwd through Renderer) against the oracle and
+the committed golden fixtures.
+
+Tolerance (BASELINE.json north_star / BASELINE.md §4): sampler sort indices identical; RGB
+PSNR >= 46.4 dB vs the fp32 oracle (moves a 27 dB image PSNR by <= 0.05 dB); depth within 2e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pronerf_oracle as orc
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['infer_trained_24x32', 'infer_spread_20x28_img48x64', 'infer_trained_oob_16x24', 'infer_default_24x32']
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from pronerf_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def relrms(a, b):
+    a = a.double(); b = b.double()
+    return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_render_rays_vs_golden(dev, golden_dir, name):
+    """Same seeded inputs as the reference-generated fixture; compare with the REFERENCE's outputs."""
+    from pronerf_amd.render import Renderer
+    g = dict(np.load(os.path.join(golden_dir, name + '.npz')))
+    seed, kind = int(g['seed']), str(g['kind'])
+    Hh, Ww = int(g['H']), int(g['W'])
+    scene = synth.make_scene(seed, H=Hh, W=Ww, Hf=int(g['Hf']), Wf=int(g['Wf']), rotate=bool(g['rotate']), sigma_t=float(g['sigma_t']))
+    rend = Renderer(synth.make_weights(seed, kind), max_rays=Hh * Ww, device=dev)
+    ref_nos = rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    np.testing.assert_array_equal(ref_nos, g['ref_nos'])
+    np.testing.assert_allclose(rend.proj.cpu().numpy(), g['proj'], rtol=1e-6, atol=1e-5)
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+    np.testing.assert_allclose(rays.cpu().numpy(), g['rays'], rtol=0, atol=2e-6)
+    rgbd, idx = rend.render_rays(rays, or_rays, want_idx=True)
+    rgbd = rgbd.cpu(); idx = idx.cpu().numpy()
+    tie_free = np.diff(g['depth_sorted'], axis=1).min(axis=1) > 1e-6
+    np.testing.assert_array_equal(idx[tie_free], g['sort_idx'][tie_free])
+    if kind != 'default':
+        assert tie_free.all()
+    m = torch.from_numpy(tie_free)
+    ps = orc.psnr(rgbd[m, :3], torch.from_numpy(g['rgb'])[m])
+    assert ps > 46.4, ps
+    if kind == 'trained':          # signal-carrying outputs: also bound the error relative to the signal
+        assert relrms(rgbd[m, :3], torch.from_numpy(g['rgb'])[m]) < 1e-2
+        np.testing.assert_allclose(rgbd[m, 3].numpy(), g['depth'][tie_free], rtol=0, atol=2e-2)
+
+
+def test_render_rays_fern_geometry_subset(dev, golden_dir):
+    """Full 756x1008 frame geometry: render the 512 fixture rays of the reference's frame."""
+    from pronerf_amd.render import Renderer
+    g = dict(np.load(os.path.join(golden_dir, 'infer_trained_fern_756x1008.npz')))
+    seed = int(g['seed'])
+    scene = synth.make_scene(seed, H=756, W=1008, rotate=True)
+    rend = Renderer(synth.make_weights(seed, 'trained'), max_rays=756 * 1008, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], 756, 1008)
+    sel = torch.from_numpy(g['sel']).to(dev)
+    np.testing.assert_allclose(rays[sel].cpu().numpy(), g['rays'], rtol=0, atol=2e-6)
+    rgbd, idx = rend.render_rays(rays[sel].contiguous(), or_rays[sel].contiguous(), want_idx=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), g['sort_idx'])
+    assert orc.psnr(rgbd[:, :3].cpu(), torch.from_numpy(g['rgb'])) > 46.4
+    # full-size properties that need no oracle: the full frame equals the concatenation of ray shards
+    # (ray independence -> the 8-GPU sharding is exact), and every output is finite and in range
+    full, _ = rend.render_rays(rays, or_rays)
+    from pronerf_amd.render import shard_range
+    parts = []
+    for r in range(8):
+        f, c = shard_range(756 * 1008, r, 8)
+        parts.append(rend.render_rays(rays[f:f + c].contiguous(), or_rays[f:f + c].contiguous())[0].clone())
+    assert torch.equal(torch.cat(parts, 0), full)
+    assert bool(torch.isfinite(full).all())
+    assert float(full[:, :3].min()) >= 0.0 and float(full[:, :3].max()) <= 3.0
+    np.testing.assert_allclose(full[sel, :3].cpu().numpy(), rgbd[:, :3].cpu().numpy(), rtol=0, atol=0)
+
+
+def test_empty_and_ragged(dev):
+    from pronerf_amd.render import Renderer
+    scene = synth.make_scene(0, H=8, W=9)
+    w = synth.make_weights(0, 'trained')
+    rend = Renderer(w, max_rays=300, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], 8, 9)
+    full, _ = rend.render_rays(rays, or_rays)
+    full = full.clone()
+    assert rend.render_rays(rays[:0], or_rays[:0])[0].shape == (0, 4)
+    for n in (1, 31, 33, 71):
+        part, _ = rend.render_rays(rays[:n].contiguous(), or_rays[:n].contiguous())
+        assert torch.equal(part, full[:n])
+    from pronerf_amd import _lib
+    with pytest.raises(_lib.PnrfError):
+        big = torch.zeros(301, 11, device=dev)
+        rend.render_rays(big, big)
