@@ -50,11 +50,15 @@ int pnrf_mlp_pack(int net, const float* const* W, const float* const* b, const i
                   const int* out_dim, int n_layers, pnrf_mlp_t** out);
 int pnrf_mlp_free(pnrf_mlp_t* h);
 
-/* Module-level forward y = net(x): the raw output of the last Linear, [m, out_dim], before the
- * sigmoid/tanh slicing of the TRT wrapper classes.  x: dev [m, in_dim]; x_views: dev [m, 27]
- * (PNRF_NET_NERF only: the view embedding concatenated before the last layer), else NULL.
- * Replaces <module>.forward (run_nerf_helpers.py:1490-1497, 1526-1533, 1331-1343). */
-int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, void* stream);
+/* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear
+ * (MinMaxRay_Net.forward, DoNeRFTRT.forward); head_act = 1: with the head activations of the TRT
+ * wrapper classes applied in place of their slicing ops — sampler: sigmoid on y[0:8] and y[24:27];
+ * refine: sigmoid on y[0:8] and y[32:35], tanh on y[8:32] (run_nerf_helpers.py:1502-1505, 1536-1538).
+ * x: dev [m, in_dim]; x_views: dev [m, 27] (PNRF_NET_NERF only: the view embedding concatenated
+ * before the last layer), else NULL.
+ * Replaces <module>.forward (run_nerf_helpers.py:1490-1507, 1526-1540, 1331-1343). */
+int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m,
+                 int head_act, void* stream);
 
 /* ---- element-wise operators --------------------------------------------------------------- */
 /* Embedder.embed: out[n, 3+6*n_freq] = [x, sin(2^k x), cos(2^k x)]_k  (run_nerf_helpers.py:666-671). */

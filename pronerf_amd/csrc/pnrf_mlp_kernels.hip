@@ -62,7 +62,7 @@ struct SamplerArgs {
   const float* rays; const float* tvals;           // fused producer
   const float* x; const int* in0;                  // module-level producer
   float* depth_sorted; float* add_sorted; float* mul_sorted; int64_t* sort_idx; float* mm_rgb; float* depth_raw;
-  float* y; const int* outmap;                     // module-level consumer
+  float* y; const int* outmap; int head_act;       // module-level consumer
 };
 
 #define PNRF_CSWAP(i, j)                                                              \
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(TPB, 1) void sampler_kernel(SamplerArgs a) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const int o = a.outmap[h * 16 + g];
-          if (o >= 0) a.y[row * S_OUT + o] = fin[g];
+          // head_act: depth = sigmoid(y[0:8]), rgb = sigmoid(y[24:27]) (helpers:1502-1505)
+          if (o >= 0) a.y[row * S_OUT + o] = (a.head_act && (o < 8 || o >= 24)) ? sigmoid_f(fin[g]) : fin[g];
         }
       }
       continue;
@@ -236,7 +237,7 @@ struct RefineArgs {
   const float* x;                                   // refine_in [n,144]
   const float* rays; const float* depth_sorted;     // fused consumer
   float* z; float* pts;
-  float* y; const int* outmap;                      // module-level consumer
+  float* y; const int* outmap; int head_act;        // module-level consumer
 };
 
 template <int NCB, bool FUSED>
@@ -294,7 +295,9 @@ __global__ __launch_bounds__(TPB, 1) void refine_kernel(RefineArgs a) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                   const int o = a.outmap[(to * 2 + h) * 16 + g];
-                  if (o >= 0) a.y[row[cb] * R_OUT + o] = acc[cb][g];
+                  // head_act: refine = sigmoid(y[0:8]), offsets = tanh(y[8:32]), rgb = sigmoid(y[32:35]) (helpers:1536-1538)
+                  const float v = acc[cb][g];
+                  if (o >= 0) a.y[row[cb] * R_OUT + o] = !a.head_act ? v : ((o < 8 || o >= 32) ? sigmoid_f(v) : tanhf(v));
                 }
               }
           });
@@ -616,7 +619,7 @@ extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float*
   return 0;
 }
 
-extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, void* stream) {
+extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, int head_act, void* stream) {
   PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_fwd: null handle");
   PNRF_REQUIRE(m >= 0 && (m == 0 || (x && y)), PNRF_E_ARG, "pnrf_mlp_fwd: null pointer / negative m");
   PNRF_REQUIRE(h->net != PNRF_NET_NERF || m == 0 || x_views, PNRF_E_ARG, "pnrf_mlp_fwd: the nerf net needs x_views [m,27]");
@@ -627,7 +630,7 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
     SamplerArgs a = {};
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
-    a.x = x; a.in0 = h->d_in0; a.y = y; a.outmap = h->d_out;
+    a.x = x; a.in0 = h->d_in0; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
     static int prepped = prep_kernel(sampler_kernel<false>, RING_BYTES + S_NBIAS * 4);
     if (prepped) return prepped;
     hipLaunchKernelGGL(sampler_kernel<false>, dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
@@ -636,7 +639,7 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     constexpr int ROWS = WAVES * 32;
     a.n = m; a.nbatch = (int)((m + ROWS - 1) / ROWS);
-    a.x = x; a.y = y; a.outmap = h->d_out;
+    a.x = x; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
     static int prepped = prep_kernel(refine_kernel<1, false>, RING_BYTES + R_NBIAS * 4);
     if (prepped) return prepped;
     hipLaunchKernelGGL((refine_kernel<1, false>), dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);

@@ -61,14 +61,14 @@ class PackedMLP:
         except Exception:
             pass
 
-    def forward(self, x, x_views=None):
-        """Raw output of the last Linear, [m, out_dim]."""
+    def forward(self, x, x_views=None, head_act=False):
+        """Output of the last Linear, [m, out_dim]; head_act applies the TRT classes' sigmoid/tanh heads."""
         x = _chk(x, 'x', (self.in_dim,))
         m = x.shape[0]
         y = torch.empty(m, self.out_dim, device=x.device, dtype=f32)
         if x_views is not None:
             x_views = _chk(x_views, 'x_views', (27,))
-        check(_lib.load().pnrf_mlp_fwd(self.handle, _ptr(x), _ptr(x_views), _ptr(y), m, _stream()), 'pnrf_mlp_fwd')
+        check(_lib.load().pnrf_mlp_fwd(self.handle, _ptr(x), _ptr(x_views), _ptr(y), m, int(bool(head_act)), _stream()), 'pnrf_mlp_fwd')
         return y
 
 

@@ -1,0 +1,237 @@
+"""Host-side mirror of the reference's inference driver functions
+(run_S_eS_eN_alter_trt.py): ``render_rays``, ``raw2outputs``, ``run_network``, ``render``,
+``compute_query_points_from_rays``, ``render_path`` and a ``create_nerf`` that builds the four
+modules.  Signatures, kwargs and return values follow the reference so that a driver written
+against it runs unchanged; the per-ray work is one fused launch sequence
+(pnrf_render_rays_fwd) instead of ~150 aten launches.
+
+Not provided here: the TensorRT/ONNX export path (``use_trt=True``, ``model2onnx``) — NVIDIA
+only and excluded by BASELINE.json's north_star; ``render_rays(use_trt=True)`` raises.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import zlib
+
+import numpy as np
+import torch
+
+from . import inverse_warp, ops
+from .ops import PnrfError
+from .render import Renderer, projection_matrices, select_neighbors
+from .run_nerf_helpers import (DoNeRFTRT, MinMaxRayEpiSamplerTRT_Net, MinMaxRaySamplerTRT_Net, Pluecker, get_embedder,  # noqa: F401
+                               get_rays, img2mse, mse2psnr, ndc_rays, to8b, weights_from_modules)
+
+
+def batchify(fn, chunk):
+    if chunk is None:
+        return fn
+    return lambda inputs: torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """Embed points and view directions, apply ``fn`` (run_S_eS_eN_alter_trt.py:195-208)."""
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]]).contiguous()
+    embedded = embed_fn(inputs_flat)
+    embedded_dirs = None
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        embedded_dirs = embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]).contiguous())
+    outputs_flat = fn(embedded, embedded_dirs)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+def compute_query_points_from_rays(ray_origins, ray_directions, near_thresh, far_thresh, N_point_ray_enc, randomize=True):
+    """(query_points [..., P, 3], depth_values [1, P])  (run_S_eS_eN_alter_trt.py:546-562).
+    Kept for API parity: the sampler kernel derives these 48 points itself; prefer
+    ``ops.ray_encode`` for the whole mm_input."""
+    t = torch.from_numpy(ops.linspace(float(near_thresh), float(far_thresh), int(N_point_ray_enc))).to(ray_origins)[None]
+    return ray_origins[..., None, :] + ray_directions[..., None, :] * t[..., :, None], t
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, mm_density_add=None,
+                mm_density_mul=None, iter=1e6):
+    """-> (rgb_map, disp_map, acc_map, weights, depth_map)  (run_S_eS_eN_alter_trt.py:564-597).
+    Like the reference's inference variant this ignores raw_noise_std and white_bkgd."""
+    if mm_density_add is None or mm_density_mul is None:
+        raise PnrfError('raw2outputs: the inference variant needs mm_density_add and mm_density_mul')   # the reference would fail on None + tensor
+    return ops.composite(raw, z_vals, rays_d, add=mm_density_add, mul=mm_density_mul)
+
+
+# ------------------------------------------------------------------------------------ render_rays
+_RENDERERS = {}
+
+
+def _renderer(min_max_ray_net, refine_net, network_fine, n_rays, device):
+    mods = (min_max_ray_net, refine_net, network_fine)
+    for m, cls in zip(mods, (MinMaxRaySamplerTRT_Net, MinMaxRayEpiSamplerTRT_Net, DoNeRFTRT)):
+        if not hasattr(m, 'weights'):
+            raise PnrfError(f'render_rays: expected a pronerf_amd.run_nerf_helpers.{cls.__name__}, got {type(m).__name__}')
+    key = tuple(id(m) for m in mods)
+    ver = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+    ent = _RENDERERS.get(key)
+    if ent is None or ent[0] != ver or ent[1].ctx.max_rays < n_rays or ent[1].device != device:
+        cap = max(n_rays, ent[1].ctx.max_rays if ent else 0)
+        _RENDERERS[key] = ent = (ver, Renderer(weights_from_modules(*mods), max_rays=cap, device=device))
+    return ent[1]
+
+
+_VIEWS = {}
+
+
+def _packed_views(ref_rgb, ref_pose, n_samples, num_neighbor):
+    """The reference hands over the neighbour images replicated x N_samples ([nb*S,3,Hf,Wf],
+    trt.py:296-298) and the matrices likewise ([nb*S,3,4], :299-300): take one copy of each."""
+    key = (ref_rgb.data_ptr(), ref_rgb._version, ref_pose.data_ptr(), ref_pose._version, tuple(ref_rgb.shape))
+    ent = _VIEWS.get(key)
+    if ent is None:
+        if ref_rgb.shape[0] == num_neighbor * n_samples:
+            imgs, mats = ref_rgb[::n_samples], ref_pose[::n_samples]
+        elif ref_rgb.shape[0] == num_neighbor:
+            imgs, mats = ref_rgb, ref_pose
+        else:
+            raise PnrfError(f'render_rays: ref_rgb has {ref_rgb.shape[0]} images, expected num_neighbor*N_samples = {num_neighbor * n_samples}')
+        _VIEWS.clear()
+        _VIEWS[key] = ent = (ops.images_pack(imgs.contiguous()), mats.contiguous())
+    return ent
+
+
+def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., min_max_ray_net=None, refine_net=None,
+                N_point_ray_enc=0, embed_fn=None, embeddirs_fn=None, randomize=True, verbose=False, pytest=False, **kwargs):
+    """Inference render of a ray batch (run_S_eS_eN_alter_trt.py:599-696).
+
+    ray_batch [N,11] = [o'(3), d'(3), near, far, viewdir(3)] (NDC); or_ray_batch [N,11] the same in
+    camera/world space.  kwargs consumed: ``use_trt, num_neighbor, ref_rgb, ref_pose`` (``mm_input,
+    ro1, rd1, embed_rays`` are accepted and ignored: the kernels recompute the ray encoding and the
+    homogeneous rays from ray_batch / or_ray_batch, of which they are pure functions,
+    trt.py:250-277).  Returns ``{'rgb_map0', 'rgb_map1', 'depth_map'}``.
+    """
+    if kwargs.get('use_trt'):
+        raise PnrfError('render_rays(use_trt=True): TensorRT engines do not exist on ROCm; the fused HIP path is used with use_trt=False')
+    num_neighbor = kwargs['num_neighbor']
+    if N_samples != 8 or num_neighbor != 4 or N_point_ray_enc not in (0, 48):
+        raise PnrfError(f'render_rays: kernels are built for N_samples=8, num_neighbor=4, N_point_ray_enc=48 '
+                        f'(got {N_samples}, {num_neighbor}, {N_point_ray_enc})')
+    if ray_batch.shape[-1] != 11 or or_ray_batch.shape[-1] != 11:
+        raise PnrfError('render_rays: ray batches must be [N,11] (use_viewdirs=True)')
+    rend = _renderer(min_max_ray_net, refine_net, network_fine, ray_batch.shape[0], ray_batch.device)
+    img4, proj = _packed_views(kwargs['ref_rgb'], kwargs['ref_pose'], N_samples, num_neighbor)
+    rgbd, _ = rend.ctx.render_rays(ray_batch, or_ray_batch, img4, proj)
+    rgb_map, depth_map = rgbd[:, :3], rgbd[:, 3]
+    return {'rgb_map0': rgb_map, 'rgb_map1': rgb_map, 'depth_map': depth_map}
+
+
+def render(rays, or_rays, sh, **kwargs):
+    """Render and reshape to the image (run_S_eS_eN_alter_trt.py:211-221)."""
+    all_ret = render_rays(rays, or_rays, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map0', 'rgb_map1', 'depth_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+# ------------------------------------------------------------------------------------ model construction
+def create_nerf(args, device='cuda'):
+    """Build the inference modules and the test-time render kwargs (run_S_eS_eN_alter_trt.py:412-544),
+    optionally loading ``args.ft_path`` (keys of :476-481).  No ONNX side effects."""
+    embed_fn, input_ch = get_embedder(args.multires, getattr(args, 'i_embed', 0))
+    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, getattr(args, 'i_embed', 0))
+    model_fine = DoNeRFTRT(D=args.netdepth, W=args.netwidth, n_in=input_ch + input_ch_views, n_out=4, skip='auto').to(device)
+    model_mmray = MinMaxRaySamplerTRT_Net(D=args.mmnetdepth, W=args.mmnetwidth, input_ch=6 * args.N_point_ray_enc,
+                                          output_ch=3 * args.N_samples + 3, skips=args.mmnetskips, N_samples=args.N_samples).to(device)
+    model_refine = MinMaxRayEpiSamplerTRT_Net(D=args.mmnetdepth, W=args.mmnetwidth,
+                                              input_ch=6 * args.N_samples + 3 * args.num_neighbor * args.N_samples,
+                                              output_ch=4 * args.N_samples + 3, skips=args.mmnetskips, N_samples=args.N_samples).to(device)
+    start = 0
+    ft = getattr(args, 'ft_path', None)
+    if ft is not None and ft != 'None':
+        ckpt = torch.load(ft, map_location=device)
+        start = ckpt.get('global_step', 0)
+        model_mmray.load_state_dict(ckpt['mmr_network_fn_state_dict'])
+        model_refine.load_state_dict(ckpt['refine_net_state_dict'])
+        model_fine.load_state_dict(ckpt['network_fine_state_dict'])       # DoNeRFTRT keys; see weights_from_state_dicts
+    network_query_fn = lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                        embeddirs_fn=embeddirs_fn, netchunk=getattr(args, 'netchunk', 1024 * 64))
+    kw = {'network_query_fn': network_query_fn, 'perturb': False, 'N_importance': 0, 'network_fine': model_fine,
+          'N_samples': args.N_samples, 'network_fn': None, 'white_bkgd': getattr(args, 'white_bkgd', False), 'raw_noise_std': 0.,
+          'min_max_ray_net': model_mmray, 'refine_net': model_refine, 'N_point_ray_enc': args.N_point_ray_enc,
+          'embed_rays': Pluecker(), 'embed_fn': embed_fn, 'embeddirs_fn': embeddirs_fn, 'num_neighbor': args.num_neighbor,
+          'use_trt': False, 'randomize': False, 'count_flops': False}
+    return kw, start
+
+
+# ------------------------------------------------------------------------------------ render_path
+def _write_png(path, img_u8):
+    """Minimal 8-bit RGB/gray PNG writer (imageio is not a dependency of this package)."""
+    img_u8 = np.ascontiguousarray(img_u8)
+    h, w = img_u8.shape[:2]
+    ch = 1 if img_u8.ndim == 2 else img_u8.shape[2]
+    ctype = {1: 0, 3: 2, 4: 6}[ch]
+    rows = img_u8.reshape(h, w * ch)
+    raw = b''.join(b'\x00' + rows[i].tobytes() for i in range(h))
+
+    def chunk(tag, data):
+        c = struct.pack('>I', len(data)) + tag + data
+        return c + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, ctype, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0, near=0., far=1.,
+                or_near=1., or_far=10., n_timing_reps=20, verbose=True):
+    """Render every pose (run_S_eS_eN_alter_trt.py:223-375): per-frame set-up, ``n_timing_reps``
+    timed ``render()`` calls bracketed by device events (:327-332), PSNR and PNG output.
+    ``render_kwargs`` needs ``poses`` [n,3,4], ``images`` [n,H,W,3], ``ref_K`` in addition to the
+    ``create_nerf`` entries.  Returns (rgbs0, rgbs1, depths, depths) and stores the per-frame
+    milliseconds in ``render_kwargs['render_ms']``."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    S, NB = render_kwargs['N_samples'], render_kwargs['num_neighbor']
+    Kh = np.asarray(K.detach().cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float32)
+    poses = render_kwargs['poses']
+    poses_h = np.asarray(poses.detach().cpu() if isinstance(poses, torch.Tensor) else poses, dtype=np.float32)
+    images = render_kwargs['images']
+    ref_K = render_kwargs.get('ref_K', K)
+    ref_Kh = np.asarray(ref_K.detach().cpu() if isinstance(ref_K, torch.Tensor) else ref_K, dtype=np.float32)
+    dev = next(render_kwargs['network_fine'].parameters()).device
+    rgbs0, rgbs1, depths, psnrs, times = [], [], [], [], []
+    t1, t2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fwd = {k: render_kwargs[k] for k in ('network_fn', 'network_query_fn', 'N_samples', 'network_fine', 'min_max_ray_net', 'refine_net',
+                                          'N_point_ray_enc', 'embed_fn', 'embeddirs_fn', 'num_neighbor', 'use_trt', 'embed_rays')
+           if k in render_kwargs}
+    for i, c2w in enumerate(render_poses):
+        c2w_h = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)
+        rays, or_rays = ops.frame_rays(Kh, c2w_h, H, W, near=near, far=far, or_near=or_near, or_far=or_far, device=dev)   # :245-271
+        ref_nos = select_neighbors(c2w_h, poses_h, NB)                                                                     # :281-284
+        nb = images[ref_nos] if isinstance(images, np.ndarray) else images[torch.as_tensor(ref_nos)]
+        ref_rgb = torch.as_tensor(nb, dtype=torch.float32).permute(0, 3, 1, 2).contiguous().to(dev)                        # :286,296
+        ref_pose = torch.from_numpy(projection_matrices(ref_Kh, poses_h[ref_nos])).to(dev)                                  # :289-294
+        sh = (H, W, 3)
+        frame_ms = []
+        for _ in range(n_timing_reps):                                                                                     # :327-332
+            t1.record()
+            rgb0, rgb1, depth_map, _ = render(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)
+            t2.record()
+            torch.cuda.synchronize(device=dev)
+            frame_ms.append(t1.elapsed_time(t2))
+            if verbose:
+                print('Render path time:', frame_ms[-1])
+        times.append(frame_ms)
+        rgbs0.append(rgb0.cpu().numpy()); rgbs1.append(rgb1.cpu().numpy()); depths.append(depth_map.cpu().numpy())
+        if gt_imgs is not None and render_factor == 0:
+            psnrs.append(mse2psnr(img2mse(rgb1, torch.as_tensor(gt_imgs[i], dtype=torch.float32).to(dev))))
+        if savedir is not None:
+            os.makedirs(savedir, exist_ok=True)
+            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs1[-1]))
+            _write_png(os.path.join(savedir, 'depth_{:03d}.png'.format(i)), to8b(depths[-1] / np.max(depths[-1])))
+    render_kwargs['render_ms'] = times
+    if len(psnrs) > 0 and verbose:
+        print(psnrs)
+        print(f'Mean Test PSNR {float(sum(psnrs) / len(psnrs))}')
+    render_kwargs['psnrs'] = [float(p) for p in psnrs]
+    return np.stack(rgbs0, 0), np.stack(rgbs1, 0), np.stack(depths, 0), np.stack(depths, 0)

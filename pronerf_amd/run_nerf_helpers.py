@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's ``run_nerf_helpers`` for the render hot path.
+
+Same names, argument meaning and error behaviour as the live subset of the reference module
+(run_nerf_helpers.py), every operator backed by a HIP kernel through the C ABI:
+
+    get_embedder / Embedder        helpers:635-692   -> pnrf_posenc_fwd
+    Pluecker                       helpers:613-632   -> pnrf_plucker_fwd
+    MinMaxRay_Net                  helpers:1440-1471 -> pnrf_mlp_fwd (fp32 MFMA)
+    MinMaxRaySamplerTRT_Net        helpers:1473-1507 -> pnrf_mlp_fwd (+ sigmoid heads)
+    MinMaxRayEpiSamplerTRT_Net     helpers:1509-1540 -> pnrf_mlp_fwd (bf16 MFMA, sigmoid/tanh heads)
+    DoNeRFTRT                      helpers:1186-1343 -> pnrf_mlp_fwd (bf16 MFMA)
+    get_rays / ndc_rays            helpers:2705-2714, 2776-2793 -> pnrf_frame_rays_fwd / pnrf_ndc_rays_fwd
+
+The model classes keep the reference's ``state_dict`` keys (``fc_backbone.{i}.*``, ``fc_output.*``,
+``layers.{i}.*``) so checkpoints interchange; their parameters are re-packed into the device weight
+stream lazily whenever they change.  There is no eager-PyTorch fallback: on a machine without the
+HIP library or a GPU these operators raise ``PnrfError``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import PnrfError
+
+# Misc (helpers:129-135) — frame-level metrics on finished images, not part of the per-ray path
+img2mse = lambda x, y: torch.mean((x - y) ** 2)
+mse2psnr = lambda x: -10. * torch.log10(x)
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------- encodings
+class Embedder(nn.Module):
+    """Positional encoding [x, sin(2^k x), cos(2^k x)] (helpers:635-671)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.kwargs = kwargs
+        d = kwargs['input_dims']
+        n = kwargs['num_freqs']
+        if not (kwargs.get('include_input', True) and kwargs.get('log_sampling', True) and d == 3
+                and kwargs['max_freq_log2'] == n - 1):
+            raise PnrfError('Embedder: the HIP kernel implements include_input=True, log_sampling=True, input_dims=3 '
+                            '(the only configuration get_embedder() creates)')
+        self.num_freqs = n
+        self.freq_bands = 2. ** torch.linspace(0., kwargs['max_freq_log2'], steps=n) if n > 0 else torch.zeros(0)
+        self.out_dim = d + 2 * d * n
+
+    def embed(self, inputs):
+        return ops.posenc(inputs, self.num_freqs)
+
+    forward = embed
+
+
+def get_embedder(multires, i=0):
+    """(embed_fn, out_dim); ``i == -1`` -> (Identity, 3)  (helpers:677-692)."""
+    if i == -1:
+        return nn.Identity(), 3
+    eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                  log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return (lambda x, eo=eo: eo.embed(x)), eo.out_dim
+
+
+class Pluecker(nn.Module):
+    """[normalize(d), o x normalize(d)] (helpers:613-632)."""
+
+    def __init__(self, origin=None):
+        super().__init__()
+        self.in_channels = 6
+        self.out_channels = 6
+        self.direction_multiplier = 1.0
+        self.moment_multiplier = 1.0
+        self.origin = origin
+
+    def forward(self, rays_o, rays_d):
+        if rays_o.shape != rays_d.shape:
+            rays_o, rays_d = torch.broadcast_tensors(rays_o, rays_d)
+        return ops.plucker(rays_o.contiguous(), rays_d.contiguous())
+
+
+# ------------------------------------------------------------------------------- networks
+class _PackedNet(nn.Module):
+    """nn.Linear parameters + a lazily refreshed packed copy for the MFMA kernels."""
+    _NET = None
+
+    def _linears(self):
+        raise NotImplementedError
+
+    def packed(self) -> ops.PackedMLP:
+        lins = self._linears()
+        key = tuple((p.data_ptr(), p._version) for l in lins for p in (l.weight, l.bias))
+        if getattr(self, '_pack_key', None) != key:
+            dev = lins[0].weight.device
+            if dev.type != 'cuda':
+                raise PnrfError(f'{type(self).__name__}: parameters live on {dev}; move the module to the GPU '
+                                '(pronerf_amd has no CPU path)')
+            with torch.cuda.device(dev):
+                self._packed = ops.PackedMLP(self._NET, [l.weight for l in lins], [l.bias for l in lins])
+            self._pack_key = key
+        return self._packed
+
+    def weights(self):
+        lins = self._linears()
+        return {'W': [l.weight.detach() for l in lins], 'b': [l.bias.detach() for l in lins]}
+
+
+class MinMaxRay_Net(_PackedNet):
+    """Sampler backbone, raw outputs (helpers:1440-1471).  The kernels are built for the fern
+    configuration: D=6, W=256, no skip inside the stack, input 288 / output 27 (sampler) or
+    input 144 / output 35 (refine)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, output_ch=3, skips=[4]):
+        super().__init__()
+        self.D, self.W, self.input_ch, self.skips = D, W, input_ch, skips
+        self.fc_backbone = nn.ModuleList([nn.Linear(input_ch, W)] +
+                                         [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + input_ch, W) for i in range(D - 1)])
+        self.fc_output = nn.Linear(W, output_ch)
+        if (input_ch, output_ch) == (288, 27):
+            self._NET = ops.NET_SAMPLER
+        elif (input_ch, output_ch) == (144, 35):
+            self._NET = ops.NET_REFINE
+        self._supported = (D == 6 and W == 256 and not any(0 <= s < D - 1 for s in skips) and self._NET is not None)
+
+    def _linears(self):
+        if not self._supported:
+            raise PnrfError(f'{type(self).__name__}(D={self.D}, W={self.W}, input_ch={self.input_ch}, skips={self.skips}): '
+                            'the HIP kernels are built for D=6, W=256, no skips, 288->27 or 144->35')
+        return list(self.fc_backbone) + [self.fc_output]
+
+    def forward(self, x):
+        return self.packed().forward(x)
+
+
+class MinMaxRaySamplerTRT_Net(MinMaxRay_Net):
+    """-> (mm_rgb, mm_density_add, mm_density_mul, depth_values)  (helpers:1473-1507)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, output_ch=3, skips=[4], N_samples=8):
+        super().__init__(D, W, input_ch, output_ch, skips)
+        self.N_samples = N_samples
+
+    def forward(self, x):
+        S = self.N_samples
+        y = self.packed().forward(x, head_act=True)
+        return y[:, 3 * S:], y[:, S:2 * S], y[:, 2 * S:3 * S], y[:, :S]
+
+
+class MinMaxRayEpiSamplerTRT_Net(MinMaxRay_Net):
+    """-> (refine_depth_values, refine_rgb, points_offset)  (helpers:1509-1540)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, output_ch=3, skips=[4], N_samples=8):
+        super().__init__(D, W, input_ch, output_ch, skips)
+        self.N_samples = N_samples
+
+    def forward(self, x):
+        S = self.N_samples
+        y = self.packed().forward(x, head_act=True)
+        return y[:, :S], y[:, 4 * S:], y[:, S:4 * S]
+
+
+class DoNeRFTRT(_PackedNet):
+    """8-layer ReLU MLP, view encoding concatenated before the last layer (skip='auto')
+    (helpers:1186-1343).  ``forward(input_pts[M,63], input_views[M,27]) -> [M,4]``."""
+    _NET = ops.NET_NERF
+
+    def __init__(self, D, W, skip, n_in, n_out):
+        super().__init__()
+        self.D, self.W, self.n_in, self.n_out = D, W, n_in, n_out
+        pos_in = 63
+        self._supported = (D == 8 and W == 256 and skip == 'auto' and n_in == 90 and n_out == 4)
+        self.inputLocations = {0: (0, pos_in), D - 1: (pos_in, n_in)}
+        layers = [nn.Linear(pos_in, W)]
+        for i in range(1, D):
+            layers.append(nn.Linear((n_in - pos_in) + W if i == D - 1 else W, W if i != D - 1 else n_out))
+        self.layers = nn.ModuleList(layers)
+        for l in self.layers:
+            nn.init.kaiming_normal_(l.weight)          # helpers:1243-1244
+
+    def _linears(self):
+        if not self._supported:
+            raise PnrfError("DoNeRFTRT: the HIP kernels are built for D=8, W=256, skip='auto', n_in=90, n_out=4")
+        return list(self.layers)
+
+    def forward(self, input_pts, input_views):
+        return self.packed().forward(input_pts, input_views)
+
+
+def weights_from_modules(min_max_ray_net, refine_net, network_fine):
+    """{'sampler','refine','nerf'} weight dict for ``pronerf_amd.render.Renderer``."""
+    return {'sampler': min_max_ray_net.weights(), 'refine': refine_net.weights(), 'nerf': network_fine.weights()}
+
+
+def weights_from_state_dicts(mmr_sd, refine_sd, fine_sd):
+    """Checkpoint state dicts (keys of run_S_eS_eN_alter_trt.py:476-481) -> weight dict.
+    ``fine_sd`` must carry DoNeRFTRT keys (``layers.{i}.*``); the ``NeRF``-class fine net that the
+    released stage-2 trainer saves is not handled by the kernels yet."""
+    def stack(sd):
+        n = len([k for k in sd if k.startswith('fc_backbone.') and k.endswith('.weight')])
+        return {'W': [sd[f'fc_backbone.{i}.weight'] for i in range(n)] + [sd['fc_output.weight']],
+                'b': [sd[f'fc_backbone.{i}.bias'] for i in range(n)] + [sd['fc_output.bias']]}
+    if not any(k.startswith('layers.') for k in fine_sd):
+        raise PnrfError("fine-network state dict has no 'layers.*' keys: it was saved from the NeRF class "
+                        '(pts_linears.*), which the HIP kernels do not implement yet')
+    n = len([k for k in fine_sd if k.endswith('.weight')])
+    nerf = {'W': [fine_sd[f'layers.{i}.weight'] for i in range(n)], 'b': [fine_sd[f'layers.{i}.bias'] for i in range(n)]}
+    return {'sampler': stack(mmr_sd), 'refine': stack(refine_sd), 'nerf': nerf}
+
+
+# ------------------------------------------------------------------------------- ray helpers
+def get_rays(H, W, K, c2w):
+    """rays_o, rays_d [H,W,3] on the GPU (helpers:2705-2714)."""
+    dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else torch.device('cuda')
+    _, orr = ops.frame_rays(K, c2w, H, W, device=dev)
+    return orr[:, 0:3].reshape(H, W, 3), orr[:, 3:6].reshape(H, W, 3)
+
+
+def get_rays_np(H, W, K, c2w):
+    o, d = get_rays(H, W, K, c2w)
+    return o.cpu().numpy(), d.cpu().numpy()
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """(helpers:2776-2793)."""
+    return ops.ndc_rays(H, W, float(focal), float(near), rays_o.contiguous(), rays_d.contiguous())

@@ -1,0 +1,138 @@
+"""GPU: the host-side mirror of the reference's operator interface (pronerf_amd.run_nerf_helpers,
+.inverse_warp, .run_S_eS_eN_alter_trt) driven the way the reference's driver drives it
+(run_S_eS_eN_alter_trt.py:245-332), against the reference-generated goldens and the oracle."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pronerf_oracle as orc
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from pronerf_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _args():
+    return SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, mmnetdepth=6, mmnetwidth=256,
+                           mmnetskips=[10000], N_point_ray_enc=48, N_samples=8, num_neighbor=4, ft_path=None)
+
+
+def _models(dev, seed, kind):
+    from pronerf_amd import run_S_eS_eN_alter_trt as trt
+    kw, _ = trt.create_nerf(_args(), device=dev)
+    sd = synth.state_dicts(synth.make_weights(seed, kind))
+    kw['min_max_ray_net'].load_state_dict(sd['sampler']); kw['refine_net'].load_state_dict(sd['refine']); kw['network_fine'].load_state_dict(sd['nerf'])
+    return trt, kw
+
+
+def test_state_dict_keys_match_reference(dev):
+    trt, kw = _models(dev, 0, 'trained')
+    assert sorted(kw['min_max_ray_net'].state_dict()) == sorted([f'fc_backbone.{i}.{p}' for i in range(6) for p in ('weight', 'bias')] + ['fc_output.weight', 'fc_output.bias'])
+    assert sorted(kw['network_fine'].state_dict()) == sorted(f'layers.{i}.{p}' for i in range(8) for p in ('weight', 'bias'))
+    assert [tuple(l.weight.shape) for l in kw['network_fine'].layers] == [(256, 63)] + [(256, 256)] * 6 + [(4, 283)]
+
+
+def test_module_forwards_and_operators(dev, golden_dir):
+    from pronerf_amd import inverse_warp as iw
+    from pronerf_amd import run_nerf_helpers as h
+    trt, kw = _models(dev, 0, 'trained')
+    w = synth.make_weights(0, 'trained')
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.uniform(-1, 1, (500, 288)).astype(np.float32))
+    mm_rgb, add, mul, depth = kw['min_max_ray_net'](x.to(dev))
+    r = orc.sampler_forward(w['sampler'], x)
+    for got, ref in zip((mm_rgb, add, mul, depth), r):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    x = torch.from_numpy(rs.uniform(-1, 1, (500, 144)).astype(np.float32))
+    rd, rrgb, offs = kw['refine_net'](x.to(dev))
+    r = orc.refine_forward(w['refine'], x)
+    for got, ref in zip((rd, rrgb, offs), r):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-2)        # bf16 MLP behind sigmoid/tanh
+    # network_query_fn = run_network(embed -> DoNeRFTRT): raw rgb-sigma of points
+    pts = torch.from_numpy(rs.uniform(-1, 1, (64, 8, 3)).astype(np.float32)); vd = torch.from_numpy(rs.randn(64, 3).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    raw = kw['network_query_fn'](pts.to(dev), vd.to(dev), kw['network_fine']).cpu()
+    ref = orc.nerf_forward(w['nerf'], orc.posenc(pts.reshape(-1, 3), 10), orc.posenc(vd[:, None].expand(-1, 8, -1).reshape(-1, 3), 4)).reshape(64, 8, 4)
+    rel = float(((raw - ref).double() ** 2).mean().sqrt() / (ref.double() ** 2).mean().sqrt())
+    assert rel < 2e-2, rel
+    # operators from the operators fixture, through the mirror's names
+    g = dict(np.load(os.path.join(golden_dir, 'operators.npz')))
+    emb, out_dim = h.get_embedder(10, 0)
+    assert out_dim == 63 and h.get_embedder(4, 0)[1] == 27 and h.get_embedder(10, -1)[1] == 3
+    np.testing.assert_allclose(emb(torch.from_numpy(g['pe_x']).to(dev)).cpu().numpy(), g['pe10'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(h.Pluecker()(torch.from_numpy(g['pl_o']).to(dev), torch.from_numpy(g['pl_d']).to(dev)).cpu().numpy(), g['pl'], rtol=0, atol=1e-6)
+    ro, rd_ = h.get_rays(9, 13, torch.from_numpy(g['gr_K']), torch.from_numpy(g['gr_c2w']).to(dev))
+    np.testing.assert_allclose(rd_.cpu().numpy(), g['gr_d'], atol=1e-6)
+    no, nd = h.ndc_rays(9, 13, float(g['gr_K'][0, 0]), 1., ro, rd_)
+    np.testing.assert_allclose(no.cpu().numpy(), g['ndc_o'], atol=2e-6); np.testing.assert_allclose(nd.cpu().numpy(), g['ndc_d'], atol=2e-6)
+    B, n = g['wp_depth'].shape[0], g['wp_depth'].shape[2]
+    ro1 = torch.from_numpy(g['wp_ro1']).to(dev)[None].expand(B, -1, -1); rd1 = torch.from_numpy(g['wp_rd1']).to(dev)[None].expand(B, -1, -1)
+    warped, none = iw.inverse_warp_rod1_rt2_coords_trt(torch.from_numpy(g['wp_img']).to(dev), torch.from_numpy(g['wp_depth']).to(dev),
+                                                       ro1, rd1, torch.from_numpy(g['wp_w2c']).to(dev), padding_mode='zeros')
+    assert none is None and warped.shape == (B, 3, 1, n)
+    np.testing.assert_allclose(warped.cpu().numpy(), g['wp_out'], rtol=0, atol=1e-5)
+    from pronerf_amd.ops import PnrfError
+    with pytest.raises(PnrfError):
+        iw.inverse_warp_rod1_rt2_coords_trt(torch.from_numpy(g['wp_img']).to(dev), torch.from_numpy(g['wp_depth']).to(dev), ro1, rd1,
+                                            torch.from_numpy(g['wp_w2c']).to(dev), padding_mode='border')
+    out = trt.raw2outputs(torch.from_numpy(g['c_raw']).to(dev), torch.from_numpy(g['c_z']).to(dev), torch.from_numpy(g['c_d']).to(dev), 0., False,
+                          mm_density_add=torch.from_numpy(g['c_add']).to(dev), mm_density_mul=torch.from_numpy(g['c_mul']).to(dev))
+    for got, key in zip(out, ('c_rgb', 'c_disp', 'c_acc', 'c_w', 'c_depth')):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', ['infer_trained_24x32', 'infer_spread_20x28_img48x64'])
+def test_render_rays_like_the_reference_driver(dev, golden_dir, name):
+    """Build the kwargs exactly as render_path does in the reference (x8 replicated ref_rgb / ref_pose,
+    expanded ro1/rd1, mm_input) and call render() — compare with the reference's own outputs."""
+    g = dict(np.load(os.path.join(golden_dir, name + '.npz')))
+    seed, kind, Hh, Ww = int(g['seed']), str(g['kind']), int(g['H']), int(g['W'])
+    trt, kw = _models(dev, seed, kind)
+    scene = synth.make_scene(seed, H=Hh, W=Ww, Hf=int(g['Hf']), Wf=int(g['Wf']), rotate=bool(g['rotate']), sigma_t=float(g['sigma_t']))
+    fr = orc.frame_setup(scene)          # checker-side frame set-up, pinned to the reference by test_oracle_golden
+    S, NB = 8, 4
+    rays, or_rays = fr['rays'].to(dev), fr['or_rays'].to(dev)
+    ref_rgb = fr['images'].to(dev).unsqueeze(1).expand(-1, S, -1, -1, -1).contiguous().view(NB * S, 3, int(g['Hf']), int(g['Wf']))
+    ref_pose = fr['proj'].to(dev).unsqueeze(1).expand(-1, S, -1, -1).contiguous().view(NB * S, 3, 4)
+    ro1 = torch.cat([or_rays[:, 0:3].t()[None], torch.ones(1, 1, rays.shape[0], device=dev)], 1).expand(NB * S, -1, -1)
+    rd1 = torch.cat([or_rays[:, 3:6].t()[None], torch.zeros(1, 1, rays.shape[0], device=dev)], 1).expand(NB * S, -1, -1)
+    fwd = {k: kw[k] for k in ('network_fn', 'network_query_fn', 'N_samples', 'network_fine', 'min_max_ray_net', 'refine_net', 'N_point_ray_enc',
+                              'embed_fn', 'embeddirs_fn', 'num_neighbor', 'use_trt', 'embed_rays')}
+    rgb0, rgb1, depth_map, extras = trt.render(rays, or_rays, (Hh, Ww, 3), mm_input=fr['mm_input'].to(dev), ref_rgb=ref_rgb, ref_pose=ref_pose,
+                                               ro1=ro1, rd1=rd1, **fwd)
+    assert rgb1.shape == (Hh, Ww, 3) and depth_map.shape == (Hh, Ww) and extras == {}
+    assert orc.psnr(rgb1.reshape(-1, 3).cpu(), torch.from_numpy(g['rgb'])) > 46.4
+    np.testing.assert_allclose(depth_map.reshape(-1).cpu().numpy(), g['depth'], rtol=0, atol=2e-2)
+    from pronerf_amd.ops import PnrfError
+    with pytest.raises(PnrfError):
+        trt.render(rays, or_rays, (Hh, Ww, 3), ref_rgb=ref_rgb, ref_pose=ref_pose, **{**fwd, 'use_trt': True})
+    with pytest.raises(PnrfError):
+        trt.render(rays, or_rays, (Hh, Ww, 3), ref_rgb=ref_rgb, ref_pose=ref_pose, **{**fwd, 'N_samples': 16})
+
+
+def test_render_path_frame_loop(dev, tmp_path):
+    """render_path: per-frame set-up + timed loop + PSNR + PNG, on a tiny synthetic 'dataset'."""
+    trt, kw = _models(dev, 0, 'trained')
+    scene = synth.make_scene(0, H=24, W=32, n_views=6)
+    kw.update(poses=scene['poses'], images=scene['images'], ref_K=scene['K'])
+    targets = [scene['c2w'], scene['poses'][0]]
+    fr = orc.frame_setup({**scene, 'c2w': scene['c2w']}, num_neighbor=4)
+    ref = orc.render_rays_infer(synth.make_weights(0, 'trained'), fr['rays'], fr['or_rays'], fr['images'], fr['proj'])
+    gt = [ref['rgb'].reshape(24, 32, 3).numpy(), np.zeros((24, 32, 3), np.float32)]
+    rgbs0, rgbs1, depths, _ = trt.render_path(targets, (24, 32, scene['focal']), scene['K'], None, kw, gt_imgs=gt, savedir=str(tmp_path),
+                                              n_timing_reps=2, verbose=False)
+    assert rgbs1.shape == (2, 24, 32, 3) and depths.shape == (2, 24, 32)
+    assert kw['psnrs'][0] > 46.4                      # frame 0 vs the oracle's image of the same pose
+    assert len(kw['render_ms']) == 2 and all(len(t) == 2 and min(t) > 0 for t in kw['render_ms'])
+    png = open(os.path.join(str(tmp_path), '000.png'), 'rb').read()
+    assert png[:8] == b'\x89PNG\r\n\x1a\n' and os.path.exists(os.path.join(str(tmp_path), 'depth_001.png'))
