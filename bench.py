@@ -162,18 +162,15 @@ def main():
     rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W, first=first, count=count)
     out = torch.empty(count, 4, device=dev)
     counts = [shard_range(n_total, r, world)[1] for r in range(world)]
-    even = len(set(counts)) == 1
+    cmax = max(counts)
     if world > 1:
-        full = torch.empty(n_total, 4, device=dev)
-        chunks = list(full.split(counts))
+        out = torch.zeros(cmax, 4, device=dev)                  # padded to the largest shard (sizes differ by <= 1 ray)
+        full = torch.empty(world * cmax, 4, device=dev)         # rank r's pixels are full[r*cmax : r*cmax+counts[r]]
 
     def step():
         rend.render_rays(rays, or_rays, out=out)
         if world > 1:
-            if even:
-                dist.all_gather_into_tensor(full, out)
-            else:
-                dist.all_gather(chunks, out)
+            dist.all_gather_into_tensor(full, out)
 
     def fence():
         torch.cuda.synchronize()
