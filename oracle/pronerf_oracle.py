@@ -64,7 +64,7 @@ def pluecker(o, d):
 
 def ray_points(o, d, t0, t1, n):
     """o + t*d at t=linspace(t0,t1,n).  run_S_eS_eN_alter_trt.py:546-562."""
-    t = torch.linspace(t0, t1, n, dtype=f32)
+    t = torch.linspace(t0, t1, n, dtype=f32).to(o.device)      # computed on CPU: the reference's linspace runs there too before .to()
     return o[..., None, :] + d[..., None, :] * t[None, :, None]
 
 
@@ -196,9 +196,9 @@ def project_trt(images_nchw, proj, or_o, or_d, depth_ndc, eps=1e-5):
     N, S = depth_ndc.shape
     NB = images_nchw.shape[0]
     z3d = 1.0 / (1.0 - depth_ndc - eps)                                     # trt.py:637
-    ro1 = torch.cat([or_o, torch.ones(N, 1)], -1)                           # trt.py:256-258
-    rd1 = torch.cat([or_d, torch.zeros(N, 1)], -1)
-    out = torch.zeros(N, NB, S, 3)
+    ro1 = torch.cat([or_o, torch.ones(N, 1, device=or_o.device)], -1)       # trt.py:256-258
+    rd1 = torch.cat([or_d, torch.zeros(N, 1, device=or_o.device)], -1)
+    out = torch.zeros(N, NB, S, 3, device=or_o.device)
     for k in range(NB):
         for s in range(S):
             w = ro1 + rd1 * z3d[:, s:s + 1]                                 # inverse_warp.py:600

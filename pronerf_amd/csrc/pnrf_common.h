@@ -49,6 +49,8 @@ struct pnrf_mlp {
   int out_dim;
   void* d_blob;          // weight stream: nslots x 16 KiB
   uint32_t nslots;
+  void* d_blob_fold;     // sampler only: stream with the folded 6->256 first layer (fused path)
+  uint32_t nslots_fold;
   float* d_bias;         // packed biases
   int nbias;
   int* d_in0;            // layer-0 input map   (device copy, for the module-level forward)

@@ -32,8 +32,6 @@ constexpr int SLOT_FRAGS = 16;
 constexpr int SLOT_BYTES = SLOT_FRAGS * FRAG_BYTES;   // 16 KiB
 constexpr int NSLOTS = 4;                          // ring slots (64 KiB of LDS)
 constexpr int PD = 3;                              // slots in flight ahead of the consumer
-constexpr int WAVES = 4;                           // one wave per SIMD
-constexpr int LOADS_PER_WAVE = SLOT_FRAGS / WAVES; // LDS-DMA instructions per wave per slot
 constexpr int RING_BYTES = NSLOTS * SLOT_BYTES;
 
 enum { ACT_RELU = 0, ACT_ELU = 1 };
@@ -43,7 +41,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ------------------------------------------------------------------------------------------
 // Weight stream: global blob -> LDS ring by LDS-DMA.  All members are wave-uniform except woff.
+// NW = waves per workgroup (4 = one per SIMD, 8 = two per SIMD); every wave issues 16/NW of the
+// sixteen 1 KiB LDS-DMA instructions of a slot.
+template <int NW>
 struct WStream {
+  static constexpr int LOADS_PER_WAVE = SLOT_FRAGS / NW;
   const char* g;       // packed blob
   char* ring;          // LDS ring base
   uint32_t nslots;     // slots in the blob (multiple of NSLOTS)
@@ -93,13 +95,34 @@ struct WStream {
 };
 static_assert(NSLOTS == PD + 1, "ring protocol assumes one free slot");
 
+// expm1(x) for x <= 0, branch-free (ocml's expm1f compiles to divergent branch blocks that cannot be
+// interleaved with MFMAs).  x > -0.5: degree-8 Taylor polynomial in Horner form; else expf(x) - 1.
+// <= 1 ulp against the exact value over the whole negative axis (same as torch/Sleef expm1).
+__device__ __forceinline__ float expm1_neg(float x) {
+  float p = 2.48015873e-5f;                 // 1/8!
+  p = fmaf(p, x, 1.98412698e-4f);           // 1/7!
+  p = fmaf(p, x, 1.38888889e-3f);           // 1/6!
+  p = fmaf(p, x, 8.33333333e-3f);           // 1/5!
+  p = fmaf(p, x, 4.16666667e-2f);           // 1/4!
+  p = fmaf(p, x, 1.66666667e-1f);           // 1/3!
+  p = fmaf(p, x, 0.5f);
+  const float small = fmaf(p, x * x, x);
+  const float large = expf(x) - 1.f;
+  return x > -0.5f ? small : large;
+}
 __device__ __forceinline__ float act_f32(float v, int act) {
   // torch: relu = max(x,0); elu(alpha=1) = x > 0 ? x : expm1(x)   (F.elu, helpers:1494)
-  return act == ACT_RELU ? fmaxf(v, 0.f) : (v > 0.f ? v : expm1f(v));
+  // evaluated unconditionally: a source-level `v > 0 ? v : f(v)` is a real branch per value, which the
+  // scheduler cannot interleave with MFMAs.  max(v,0) + expm1(min(v,0)) is exact in both cases.
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  const float e = expm1_neg(fminf(v, 0.f));
+  return fmaxf(v, 0.f) + e;
 }
 __device__ __forceinline__ float act_fast(float v, int act) {
   // bf16 path: the result is rounded to 8 significant bits, v_exp_f32 is accurate enough.
-  return act == ACT_RELU ? fmaxf(v, 0.f) : (v > 0.f ? v : __expf(v) - 1.f);
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  const float e = __expf(fminf(v, 0.f)) - 1.f;       // unconditional, see act_f32
+  return fmaxf(v, 0.f) + e;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -107,11 +130,19 @@ __device__ __forceinline__ float act_fast(float v, int act) {
 //   ringlane  = ring + lane*16            (LDS)
 //   biaslane  = bias_layer + h*16 floats  (LDS; packed [tile][h][16])
 //   Bi(cb,ks) = B operand of k-step ks for column block cb
-//   epi(to, acc[NCB]) consumes a finished tile (accumulator already holds W*x + b).
+//   pre()     = runs right after the layer's first slot barrier (the caller's deferred work, e.g. the
+//               previous layer's last epilogue)
+//   epi(to, acc[NCB]) consumes finished tile `to` (accumulator holds W*x + b).  It is DEFERRED by one
+//               tile: it is issued at the head of tile to+1, behind that tile's slot barrier, so the
+//               scheduler can overlap its VALU work with tile to+1's MFMAs (slot barriers are
+//               scheduling boundaries).  The LAST tile is not passed to epi: its raw accumulators are
+//               returned in `last` and the caller defers them into whatever comes next.
 // Fragment f = to*KS + ks of the layer lives in slot f/16 (layer start is slot aligned);
 // POS0 = ring position of the layer's first slot (compile-time: see layout in pnrf_pack).
-template <int NCB, int KS, int NT, int POS0, class BFn, class Epi>
-__device__ __forceinline__ void layer_bf16(WStream& st, const char* ringlane, const float* biaslane, BFn Bi, Epi epi) {
+template <int NCB, int KS, int NT, int POS0, class ST, class BFn, class Epi, class Pre>
+__device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const float* biaslane, BFn Bi, Epi epi, Pre pre,
+                                           f32x16 (&last)[NCB]) {
+  f32x16 pend[NCB];
 #pragma unroll
   for (int to = 0; to < NT; ++to) {
     f32x16 acc[NCB];
@@ -128,21 +159,29 @@ __device__ __forceinline__ void layer_bf16(WStream& st, const char* ringlane, co
     for (int ks = 0; ks < KS; ++ks) {
       const int f = to * KS + ks;
       if (f % SLOT_FRAGS == 0) st.begin();
+      if (ks == 0) {
+        if (to == 0) pre();
+        else epi(to - 1, pend);
+      }
       const int pos = (POS0 + f / SLOT_FRAGS) % NSLOTS;
       const bf16x8 a = *(const bf16x8*)(ringlane + pos * SLOT_BYTES + (f % SLOT_FRAGS) * FRAG_BYTES);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
     }
-    epi(to, acc);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) pend[cb] = acc[cb];
   }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) last[cb] = pend[cb];
 }
 template <int KS, int NT> constexpr int layer_slots_bf16() { return (KS * NT + SLOT_FRAGS - 1) / SLOT_FRAGS; }
 
 // One f32 layer (exact fp32 FMA chain, v_mfma_f32_32x32x2_f32), one column block of 32.
 //   KS4 = k-steps/4 = fragments per tile (a fragment carries the A values of 4 k-steps).
-//   Bf(kk) = B operand (one float per lane) of k-step kk.
-template <int KS4, int NT, int POS0, class BFn, class Epi>
-__device__ __forceinline__ void layer_f32(WStream& st, const char* ringlane, const float* biaslane, BFn Bf, Epi epi) {
+//   Bf(kk) = B operand (one float per lane) of k-step kk.  pre / epi / last: as in layer_bf16.
+template <int KS4, int NT, int POS0, class ST, class BFn, class Epi, class Pre>
+__device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi epi, Pre pre, f32x16& last) {
+  f32x16 pend;
 #pragma unroll
   for (int to = 0; to < NT; ++to) {
     f32x16 acc;
@@ -156,13 +195,18 @@ __device__ __forceinline__ void layer_f32(WStream& st, const char* ringlane, con
     for (int fr = 0; fr < KS4; ++fr) {
       const int f = to * KS4 + fr;
       if (f % SLOT_FRAGS == 0) st.begin();
+      if (fr == 0) {
+        if (to == 0) pre();
+        else epi(to - 1, pend);
+      }
       const int pos = (POS0 + f / SLOT_FRAGS) % NSLOTS;
       const f32x4 a = *(const f32x4*)(ringlane + pos * SLOT_BYTES + (f % SLOT_FRAGS) * FRAG_BYTES);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bf(4 * fr + i), acc, 0, 0, 0);
     }
-    epi(to, acc);
+    pend = acc;
   }
+  last = pend;
 }
 template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + SLOT_FRAGS - 1) / SLOT_FRAGS; }
 

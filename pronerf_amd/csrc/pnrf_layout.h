@@ -31,6 +31,16 @@ constexpr int S_SLOTS_PAD = (NSLOTS - S_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int S_NSLOTS = S_SLOTS_USED + S_SLOTS_PAD;
 constexpr int S_NBIAS = (1 + S_NHID) * W_HID + 32;      // packed bias floats
 static_assert(S_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
+// folded layer 0 (fused path only): the 48 Pluecker 6-vectors of a ray are the same vector in exact
+// arithmetic (the moment (o+t d) x d^ does not depend on t), so W0[256x288] acts on them as
+// Wf[256x6] = sum_p W0[:, 6p:6p+6].  K = 6 padded to 8 = 4 k-steps = 1 fragment per tile.
+constexpr int SF_KS4_0 = 1;
+constexpr int SF_SLOTS_L0 = layer_slots_f32<SF_KS4_0, NT_HID>();   // 1
+constexpr int SF_POS_H = SF_SLOTS_L0 % NSLOTS;
+constexpr int SF_POS_LAST = (SF_POS_H + S_NHID * S_SLOTS_H) % NSLOTS;
+constexpr int SF_SLOTS_USED = SF_SLOTS_L0 + S_NHID * S_SLOTS_H + S_SLOTS_LAST;
+constexpr int SF_SLOTS_PAD = (NSLOTS - SF_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int SF_NSLOTS = SF_SLOTS_USED + SF_SLOTS_PAD;
 
 // ---- refine (bf16): k-step = 16 features
 constexpr int R_IN = 144, R_OUT = 35, R_NHID = 5;

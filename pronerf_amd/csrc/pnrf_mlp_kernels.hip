@@ -7,10 +7,10 @@
 //                    interval refinement, query points                      (trt.py:668-681)
 //   nerf_kernel    : positional encoding -> bf16 MLP -> alpha compositing   (trt.py:691-694)
 //
-// Workgroup = 256 threads = 4 waves, one per SIMD (launch bound 1 wave/SIMD: the kernels use
-// the 512-register budget to keep two layers of activations in registers).  A wave owns
-// 32*NCB columns (rays or ray-samples); the workgroup streams each network's packed weights
-// once per batch of 4*32*NCB columns through the LDS ring (pnrf_engine.h).
+// Workgroup = NW waves (4 = one per SIMD with the 512-register budget, 8 = two per SIMD with 256).
+// A wave owns 32*NCB columns (rays or ray-samples) and keeps two layers of activations in
+// registers (ping-pong, no copies); the workgroup streams each network's packed weights once per
+// batch of NW*32*NCB columns through the LDS ring (pnrf_engine.h).
 #include <type_traits>
 
 #include "pnrf_common.h"
@@ -19,7 +19,6 @@ using namespace pnrf;
 
 namespace {
 
-constexpr int TPB = 256;
 
 // compile-time loop: f(std::integral_constant<int,I>) for I in [0,N) — keeps register-array indices static
 template <int N, int I = 0, class F>
@@ -73,14 +72,22 @@ struct SamplerArgs {
     const int ti = sw ? idx[j] : idx[i]; idx[j] = sw ? idx[i] : idx[j]; idx[i] = ti;   \
   }
 
-template <bool FUSED>
-__global__ __launch_bounds__(TPB, 1) void sampler_kernel(SamplerArgs a) {
+// MODE 0: module-level (x -> y); 1: fused, full K=288 first layer; 2: fused, folded 6->256 first layer
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void sampler_kernel(SamplerArgs a) {
+  constexpr bool FUSED = MODE != 0;
+  constexpr int TPB = 256;
+  constexpr int KS0 = MODE == 2 ? 4 * SF_KS4_0 : S_KS0;
+  constexpr int KS4_0 = MODE == 2 ? SF_KS4_0 : S_KS4_0;
+  constexpr int POS_H = MODE == 2 ? SF_POS_H : S_POS_H;
+  constexpr int POS_LAST = MODE == 2 ? SF_POS_LAST : S_POS_LAST;
+  constexpr int SLOTS_PAD = MODE == 2 ? SF_SLOTS_PAD : S_SLOTS_PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
-  WStream st;
+  WStream<4> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
   const char* ringlane = smem + lane * 16;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(TPB, 1) void sampler_kernel(SamplerArgs a) {
     const int64_t row = (int64_t)batch * 128 + wave * 32 + col;
     const bool valid = row < a.n;
     const int64_t rr = valid ? row : a.n - 1;
-    float B0[S_KS0];
+    float B0[KS0];
     float near = 0.f, far = 1.f;
     if (FUSED) {
       const float* r = a.rays + rr * 11;
@@ -98,43 +105,54 @@ __global__ __launch_bounds__(TPB, 1) void sampler_kernel(SamplerArgs a) {
       near = r[6]; far = r[7];
       float hx, hy, hz;
       unit_dir(dx, dy, dz, hx, hy, hz);
-#pragma unroll
-      for (int p = 0; p < S_KS0 / 3; ++p) {
+      if (MODE == 2) {           // one Pluecker 6-vector (moment at t = 0) against the folded weights
         float m0, m1, m2;
-        moment(ox, oy, oz, dx, dy, dz, a.tvals[p], hx, hy, hz, m0, m1, m2);
-        B0[3 * p] = h ? hy : hx;
-        B0[3 * p + 1] = h ? m0 : hz;
-        B0[3 * p + 2] = h ? m2 : m1;
+        moment(ox, oy, oz, dx, dy, dz, 0.f, hx, hy, hz, m0, m1, m2);
+        B0[0] = h ? hy : hx; B0[1] = h ? m0 : hz; B0[2] = h ? m2 : m1; B0[3] = 0.f;
+      } else {
+#pragma unroll
+        for (int p = 0; p < S_KS0 / 3; ++p) {
+          float m0, m1, m2;
+          moment(ox, oy, oz, dx, dy, dz, a.tvals[p], hx, hy, hz, m0, m1, m2);
+          B0[(3 * p) % KS0] = h ? hy : hx;
+          B0[(3 * p + 1) % KS0] = h ? m0 : hz;
+          B0[(3 * p + 2) % KS0] = h ? m2 : m1;
+        }
       }
     } else {
       const float* xr = a.x + rr * S_IN;
 #pragma unroll
-      for (int kk = 0; kk < S_KS0; ++kk) B0[kk] = xr[a.in0[kk * 2 + h]];
+      for (int kk = 0; kk < KS0; ++kk) B0[kk] = xr[a.in0[kk * 2 + h]];
     }
 
-    f32x16 Bo[NT_HID], Bn[NT_HID];
-    layer_f32<S_KS4_0, NT_HID, 0>(
-        st, ringlane, biaslane, [&](int kk) { return B0[kk]; },
-        [&](int to, f32x16& acc) {
+    // activations ping-pong between X and Y (fp32 accumulators are the next layer's B operand as they stand);
+    // `pend` = raw accumulators of the previous layer's last tile, whose ELU is deferred into the next layer
+    f32x16 X[NT_HID], Y[NT_HID], pend;
+    auto elu_into = [&](f32x16(&dst)[NT_HID], int to, f32x16& acc) {
 #pragma unroll
-          for (int g = 0; g < 16; ++g) Bo[to][g] = act_f32(acc[g], ACT_ELU);
-        });
-    for (int l = 0; l < S_NHID; ++l) {
-      layer_f32<S_KS4_H, NT_HID, S_POS_H>(
-          st, ringlane, biaslane + (1 + l) * W_HID, [&](int kk) { return Bo[kk >> 4][kk & 15]; },
-          [&](int to, f32x16& acc) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) Bn[to][g] = act_f32(acc[g], ACT_ELU);
-          });
-#pragma unroll
-      for (int t = 0; t < NT_HID; ++t) Bo[t] = Bn[t];
+      for (int g = 0; g < 16; ++g) dst[to][g] = act_f32(acc[g], ACT_ELU);
+    };
+    auto hidden = [&](f32x16(&in)[NT_HID], f32x16(&out)[NT_HID], int l) {
+      f32x16 np;
+      layer_f32<S_KS4_H, NT_HID, POS_H>(
+          st, ringlane, biaslane + (1 + l) * W_HID, [&](int kk) { return in[kk >> 4][kk & 15]; },
+          [&](int to, f32x16& acc) { elu_into(out, to, acc); }, [&] { elu_into(in, NT_HID - 1, pend); }, np);
+      pend = np;
+    };
+    layer_f32<KS4_0, NT_HID, 0>(
+        st, ringlane, biaslane, [&](int kk) { return B0[kk]; }, [&](int to, f32x16& acc) { elu_into(X, to, acc); }, [] {}, pend);
+    static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
+    for (int l = 0; l < 4; l += 2) {
+      hidden(X, Y, l);
+      hidden(Y, X, l + 1);
     }
+    hidden(X, Y, 4);
     f32x16 fin;
-    layer_f32<S_KS4_H, 1, S_POS_LAST>(
-        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int kk) { return Bo[kk >> 4][kk & 15]; },
-        [&](int, f32x16& acc) { fin = acc; });
+    layer_f32<S_KS4_H, 1, POS_LAST>(
+        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int kk) { return Y[kk >> 4][kk & 15]; },
+        [&](int, f32x16&) {}, [&] { elu_into(Y, NT_HID - 1, pend); }, fin);
 #pragma unroll
-    for (int i = 0; i < S_SLOTS_PAD; ++i) st.begin();
+    for (int i = 0; i < SLOTS_PAD; ++i) st.begin();
 
     if (!FUSED) {
       if (valid) {
@@ -240,15 +258,16 @@ struct RefineArgs {
   float* y; const int* outmap; int head_act;        // module-level consumer
 };
 
-template <int NCB, bool FUSED>
-__global__ __launch_bounds__(TPB, 1) void refine_kernel(RefineArgs a) {
+template <int NCB, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
+  constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   constexpr int COLS = 32 * NCB;
-  WStream st;
+  WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
   const char* ringlane = smem + lane * 16;
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(TPB, 1) void refine_kernel(RefineArgs a) {
     bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID];
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
-      row[cb] = (int64_t)batch * (WAVES * COLS) + wave * COLS + cb * 32 + col;
+      row[cb] = (int64_t)batch * (NW * COLS) + wave * COLS + cb * 32 + col;
       valid[cb] = row[cb] < a.n;
       const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN + 8 * h;      // natural order: refine_in0()
 #pragma unroll
@@ -270,48 +289,47 @@ __global__ __launch_bounds__(TPB, 1) void refine_kernel(RefineArgs a) {
         Bo[cb][ks] = pack_bf16(v);
       }
     });
-    HiddenEpi<NCB, ACT_ELU> epi{Bn};
-    layer_bf16<NCB, R_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
+    // ping-pong: layer 0 Bo -> Bn, then Bn -> Bo, Bo -> Bn, ... (5 hidden layers end in Bo);
+    // `pend` = raw accumulators of the previous layer's last tile (its epilogue is deferred into the next layer)
+    f32x16 pend[NCB];
+    auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
+      f32x16 np[NCB];
+      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+                                               HiddenEpi<NCB, ACT_ELU>{out}, [&] { HiddenEpi<NCB, ACT_ELU>{in}(NT_HID - 1, pend); }, np);
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
-    for (int l = 0; l < R_NHID; ++l) {
-      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID,
-                                               [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+      for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+    };
+    layer_bf16<NCB, R_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU>{Bn}, [] {}, pend);
+    static_assert(R_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
+    for (int l = 0; l < 4; l += 2) {
+      hidden(Bn, Bo, l);
+      hidden(Bo, Bn, l + 1);
     }
+    hidden(Bn, Bo, 4);
     const float* blast = biaslane + (1 + R_NHID) * W_HID;
+    auto pre_last = [&] { HiddenEpi<NCB, ACT_ELU>{Bo}(NT_HID - 1, pend); };
+    f32x16 fin[NCB];
     if (!FUSED) {
-      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(
-          st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
-          [&](int to, f32x16(&acc)[NCB]) {
+      auto store_tile = [&](int to, f32x16(&acc)[NCB]) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-              if (valid[cb]) {
+        for (int cb = 0; cb < NCB; ++cb)
+          if (valid[cb]) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                  const int o = a.outmap[(to * 2 + h) * 16 + g];
-                  // head_act: refine = sigmoid(y[0:8]), offsets = tanh(y[8:32]), rgb = sigmoid(y[32:35]) (helpers:1536-1538)
-                  const float v = acc[cb][g];
-                  if (o >= 0) a.y[row[cb] * R_OUT + o] = !a.head_act ? v : ((o < 8 || o >= 32) ? sigmoid_f(v) : tanhf(v));
-                }
-              }
-          });
+            for (int g = 0; g < 16; ++g) {
+              const int o = a.outmap[(to * 2 + h) * 16 + g];
+              // head_act: refine = sigmoid(y[0:8]), offsets = tanh(y[8:32]), rgb = sigmoid(y[32:35]) (helpers:1536-1538)
+              const float v = acc[cb][g];
+              if (o >= 0) a.y[row[cb] * R_OUT + o] = !a.head_act ? v : ((o < 8 || o >= 32) ? sigmoid_f(v) : tanhf(v));
+            }
+          }
+      };
+      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, store_tile, pre_last, fin);
+      store_tile(R_NT_LAST - 1, fin);
 #pragma unroll
       for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
       continue;
     }
-    f32x16 fin[NCB];
-    layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(
-        st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
-        [&](int, f32x16(&acc)[NCB]) {
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) fin[cb] = acc[cb];
-        });
+    layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, f32x16(&)[NCB]) {}, pre_last, fin);
 #pragma unroll
     for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
 
@@ -362,8 +380,9 @@ struct NerfArgs {
   float* y; const int* outmap;                      // module-level consumer
 };
 
-template <int NCB, bool FUSED>
-__global__ __launch_bounds__(TPB, 1) void nerf_kernel(NerfArgs a) {
+template <int NCB, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
+  constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(TPB, 1) void nerf_kernel(NerfArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   constexpr int COLS = 32 * NCB;
   const int64_t nrows = FUSED ? a.n * 8 : a.n;
-  WStream st;
+  WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
   const char* ringlane = smem + lane * 16;
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(TPB, 1) void nerf_kernel(NerfArgs a) {
     bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID], Bx[NCB][N_KSX];
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
-      row[cb] = (int64_t)batch * (WAVES * COLS) + wave * COLS + cb * 32 + col;
+      row[cb] = (int64_t)batch * (NW * COLS) + wave * COLS + cb * 32 + col;
       valid[cb] = row[cb] < nrows;
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       if (FUSED) {
@@ -457,28 +476,27 @@ __global__ __launch_bounds__(TPB, 1) void nerf_kernel(NerfArgs a) {
         }
       }
     });
-    HiddenEpi<NCB, ACT_RELU> epi{Bn};
-    layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
+    // ping-pong: layer 0 Bo -> Bn, then Bn -> Bo, Bo -> Bn, ... (6 hidden layers end in Bn);
+    // `pend` = raw accumulators of the previous layer's last tile (its epilogue is deferred into the next layer)
+    f32x16 pend[NCB];
+    auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
+      f32x16 np[NCB];
+      layer_bf16<NCB, KS_HID, NT_HID, N_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+                                               HiddenEpi<NCB, ACT_RELU>{out}, [&] { HiddenEpi<NCB, ACT_RELU>{in}(NT_HID - 1, pend); }, np);
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
-    for (int l = 0; l < N_NHID; ++l) {
-      layer_bf16<NCB, KS_HID, NT_HID, N_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID,
-                                               [&](int cb, int ks) { return Bo[cb][ks]; }, epi);
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+      for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+    };
+    layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [] {}, pend);
+    static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
+    for (int l = 0; l < N_NHID; l += 2) {
+      hidden(Bn, Bo, l);
+      hidden(Bo, Bn, l + 1);
     }
     f32x16 fin[NCB];
     layer_bf16<NCB, N_KS_LAST, 1, N_POS_LAST>(
         st, ringlane, biaslane + (1 + N_NHID) * W_HID,
-        [&](int cb, int ks) { return ks < KS_HID ? Bo[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
-        [&](int, f32x16(&acc)[NCB]) {
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) fin[cb] = acc[cb];
-        });
+        [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
+        [&](int, f32x16(&)[NCB]) {}, [&] { HiddenEpi<NCB, ACT_RELU>{Bn}(NT_HID - 1, pend); }, fin);
 #pragma unroll
     for (int i = 0; i < N_SLOTS_PAD; ++i) st.begin();
 
@@ -543,18 +561,44 @@ int num_cu() {
   return g_num_cu;
 }
 
-template <class K>
-int prep_kernel(K kern, size_t lds) {
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// Tuning knobs (environment, read per call so that variants can be A/B-ed inside one process):
+// PNRF_SAMPLER_FOLD=0 disables the folded first sampler layer; PNRF_BF16_VARIANT = "1x8" (default:
+// 32 columns/wave, 8 waves, 2 waves/SIMD) or "2x4" (64 columns/wave, 4 waves, 1 wave/SIMD).
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+bool variant_1x8() {
+  const char* e = getenv("PNRF_BF16_VARIANT");
+  return !(e && e[0] == '2');          // default: 1x8 (two waves per SIMD)
+}
+bool sampler_fold() { return env_int("PNRF_SAMPLER_FOLD", 1) != 0; }
+
+template <class K, class A>
+int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream) {
+  // the ring + bias region exceeds the 64 KiB default dynamic-LDS limit: raise it once per kernel
+  static thread_local const void* done[16] = {};
+  static thread_local int ndone = 0;
+  bool seen = false;
+  for (int i = 0; i < ndone; ++i) seen |= (done[i] == (const void*)kern);
+  if (!seen) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RING_BYTES + 8192));
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    if (ndone < 16) done[ndone++] = (const void*)kern;
+  }
+  const int ncu = num_cu();
+  const int grid = nbatch < ncu ? nbatch : ncu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(tpb), lds, stream, a);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    set_error("hipFuncSetAttribute(max dynamic LDS=%zu) failed: %s", lds, hipGetErrorString(e));
+    set_error("kernel launch failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   return 0;
 }
-
-constexpr int NERF_NCB = 2;
-constexpr int REFINE_NCB = 2;
 
 }  // namespace
 
@@ -565,19 +609,17 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd: handle is not a sampler net");
   PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
   if (n == 0) return 0;
+  const bool fold = sampler_fold();
   SamplerArgs a = {};
-  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  a.blob = fold ? h->d_blob_fold : h->d_blob; a.nslots = fold ? h->nslots_fold : h->nslots;
+  a.bias = h->d_bias; a.nbias = h->nbias;
   a.n = n; a.nbatch = (int)((n + 127) / 128);
   a.rays = rays; a.tvals = h->d_tvals;
   a.depth_sorted = depth_sorted; a.add_sorted = add_sorted; a.mul_sorted = mul_sorted;
   a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  static int prepped = prep_kernel(sampler_kernel<true>, RING_BYTES + S_NBIAS * 4);
-  if (prepped) return prepped;
-  const int grid = a.nbatch < num_cu() ? a.nbatch : num_cu();
-  hipLaunchKernelGGL(sampler_kernel<true>, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a);
-  PNRF_LAUNCH_CHECK();
-  return 0;
+  return fold ? launch_mlp(sampler_kernel<2>, a, 256, lds, a.nbatch, (hipStream_t)stream)
+              : launch_mlp(sampler_kernel<1>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
@@ -587,16 +629,13 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   if (n == 0) return 0;
   RefineArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
-  constexpr int ROWS = WAVES * 32 * REFINE_NCB;
-  a.n = n; a.nbatch = (int)((n + ROWS - 1) / ROWS);
+  a.n = n;
   a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  static int prepped = prep_kernel(refine_kernel<REFINE_NCB, true>, RING_BYTES + R_NBIAS * 4);
-  if (prepped) return prepped;
-  const int grid = a.nbatch < num_cu() ? a.nbatch : num_cu();
-  hipLaunchKernelGGL((refine_kernel<REFINE_NCB, true>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a);
-  PNRF_LAUNCH_CHECK();
-  return 0;
+  const int rows = 256;            // both variants: 256 columns per workgroup batch
+  a.nbatch = (int)((n + rows - 1) / rows);
+  return variant_1x8() ? launch_mlp(refine_kernel<1, 8, true>, a, 512, lds, a.nbatch, (hipStream_t)stream)
+                       : launch_mlp(refine_kernel<2, 4, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
@@ -607,16 +646,13 @@ extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float*
   if (n == 0) return 0;
   NerfArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
-  constexpr int ROWS = WAVES * 32 * NERF_NCB;
-  a.n = n; a.nbatch = (int)((n * 8 + ROWS - 1) / ROWS);
+  a.n = n;
   a.pts = pts; a.rays = rays; a.z = z; a.add = add_sorted; a.mul = mul_sorted; a.rgbd = rgbd; a.raw = raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  static int prepped = prep_kernel(nerf_kernel<NERF_NCB, true>, RING_BYTES + N_NBIAS * 4);
-  if (prepped) return prepped;
-  const int grid = a.nbatch < num_cu() ? a.nbatch : num_cu();
-  hipLaunchKernelGGL((nerf_kernel<NERF_NCB, true>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a);
-  PNRF_LAUNCH_CHECK();
-  return 0;
+  const int rows = 256;
+  a.nbatch = (int)((n * 8 + rows - 1) / rows);
+  return variant_1x8() ? launch_mlp(nerf_kernel<1, 8, true>, a, 512, lds, a.nbatch, (hipStream_t)stream)
+                       : launch_mlp(nerf_kernel<2, 4, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, int head_act, void* stream) {
@@ -625,35 +661,23 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
   PNRF_REQUIRE(h->net != PNRF_NET_NERF || m == 0 || x_views, PNRF_E_ARG, "pnrf_mlp_fwd: the nerf net needs x_views [m,27]");
   if (m == 0) return 0;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  const int ncu = num_cu();
   if (h->net == PNRF_NET_SAMPLER) {
     SamplerArgs a = {};
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
     a.x = x; a.in0 = h->d_in0; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
-    static int prepped = prep_kernel(sampler_kernel<false>, RING_BYTES + S_NBIAS * 4);
-    if (prepped) return prepped;
-    hipLaunchKernelGGL(sampler_kernel<false>, dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
-  } else if (h->net == PNRF_NET_REFINE) {
+    return launch_mlp(sampler_kernel<0>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  }
+  if (h->net == PNRF_NET_REFINE) {
     RefineArgs a = {};
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
-    constexpr int ROWS = WAVES * 32;
-    a.n = m; a.nbatch = (int)((m + ROWS - 1) / ROWS);
+    a.n = m; a.nbatch = (int)((m + 127) / 128);
     a.x = x; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
-    static int prepped = prep_kernel(refine_kernel<1, false>, RING_BYTES + R_NBIAS * 4);
-    if (prepped) return prepped;
-    hipLaunchKernelGGL((refine_kernel<1, false>), dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
-  } else {
-    NerfArgs a = {};
-    a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
-    constexpr int ROWS = WAVES * 32;
-    a.n = m; a.nbatch = (int)((m + ROWS - 1) / ROWS);
-    a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out;
-    static int prepped = prep_kernel(nerf_kernel<1, false>, RING_BYTES + N_NBIAS * 4);
-    if (prepped) return prepped;
-    hipLaunchKernelGGL((nerf_kernel<1, false>), dim3(a.nbatch < ncu ? a.nbatch : ncu), dim3(TPB), lds, (hipStream_t)stream, a);
+    return launch_mlp(refine_kernel<1, 4, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
   }
-  PNRF_LAUNCH_CHECK();
-  return 0;
+  NerfArgs a = {};
+  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  a.n = m; a.nbatch = (int)((m + 127) / 128);
+  a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out;
+  return launch_mlp(nerf_kernel<1, 4, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
-

@@ -192,6 +192,30 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     bo += (size_t)L.nt * 32;
   }
 
+  // sampler: second stream with the folded first layer Wf[256x6] = sum_p W0[:, 6p:6p+6] (fp64 sum)
+  std::vector<char> blob_fold;
+  std::vector<float> wfold;
+  size_t slots_fold = 0;
+  if (net == PNRF_NET_SAMPLER) {
+    wfold.assign((size_t)W_HID * 6, 0.f);
+    for (int o = 0; o < W_HID; ++o)
+      for (int j = 0; j < 6; ++j) {
+        double acc = 0.0;
+        for (int pnt = 0; pnt < S_IN / 6; ++pnt) acc += (double)W[0][(size_t)o * S_IN + 6 * pnt + j];
+        wfold[(size_t)o * 6 + j] = (float)acc;
+      }
+    std::vector<Layer> Lf = Ls;
+    Layer& G = Lf[0];
+    G.W = wfold.data(); G.in_dim = 6; G.nk = 4 * SF_KS4_0; G.in_map.assign(G.nk * 2, -1);
+    for (int kk = 0; kk < 3; ++kk) for (int hh = 0; hh < 2; ++hh) G.in_map[kk * 2 + hh] = 2 * kk + hh;
+    for (auto& L : Lf) slots_fold += layer_slots(L, prec);
+    slots_fold += (NSLOTS - slots_fold % NSLOTS) % NSLOTS;
+    PNRF_REQUIRE(slots_fold == (size_t)SF_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (folded stream %zu slots, expected %d)", slots_fold, SF_NSLOTS);
+    blob_fold.assign(slots_fold * SLOT_BYTES, 0);
+    size_t sf = 0;
+    for (auto& L : Lf) { pack_layer(L, prec, blob_fold.data() + sf * SLOT_BYTES); sf += layer_slots(L, prec); }
+  }
+
   pnrf_mlp* h = new pnrf_mlp();
   memset(h, 0, sizeof(*h));
   h->net = net; h->prec = prec; h->in_dim = in0; h->in_dim_x = net == PNRF_NET_NERF ? N_INV : 0; h->out_dim = outN;
@@ -211,6 +235,11 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, out_map.size() * sizeof(int));
   if (e == hipSuccess) e = hipMemcpy(h->d_out, out_map.data(), out_map.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
+    h->nslots_fold = (uint32_t)slots_fold;
+    e = hipMalloc(&h->d_blob_fold, blob_fold.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_fold, blob_fold.data(), blob_fold.size(), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
     float tv[S_KS0 / 3];
     pnrf_linspace(0.f, 1.f, S_KS0 / 3, tv);
     e = hipMalloc((void**)&h->d_tvals, sizeof(tv));
@@ -228,6 +257,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
 extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
   if (!h) return 0;
   if (h->d_blob) (void)hipFree(h->d_blob);
+  if (h->d_blob_fold) (void)hipFree(h->d_blob_fold);
   if (h->d_bias) (void)hipFree(h->d_bias);
   if (h->d_in0) (void)hipFree(h->d_in0);
   if (h->d_inx) (void)hipFree(h->d_inx);

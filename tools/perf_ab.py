@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel variants in ONE process (cdna guide §5.4 rule 24).
+
+    python tools/perf_ab.py [--rounds 7]
+
+Variants are selected through the library's environment knobs, which are re-read on every call
+(PNRF_SAMPLER_FOLD, PNRF_BF16_VARIANT).  Reports median / min per stage kernel on the bench workload
+(one 1008x756 frame)."""
+import argparse
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pronerf_amd import ops, synthetic          # noqa: E402
+from pronerf_amd.render import Renderer         # noqa: E402
+
+H, W = 756, 1008
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--configs', default='fold=1,var=1x8;fold=1,var=2x4;fold=0,var=1x8')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    weights = synthetic.make_weights(0, 'trained')
+    scene = synthetic.make_scene(0, H=H, W=W, focal=815.13, rotate=True)
+    rend = Renderer(weights, max_rays=H * W, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W)
+    cfgs = [dict(kv.split('=') for kv in c.split(',')) for c in a.configs.split(';')]
+    res = {i: {'sampler': [], 'refine_in': [], 'refine': [], 'nerf': [], 'frame': []} for i in range(len(cfgs))}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for r in range(a.rounds + 1):
+        for i, c in enumerate(cfgs):
+            os.environ['PNRF_SAMPLER_FOLD'] = c.get('fold', '1')
+            os.environ['PNRF_BF16_VARIANT'] = c.get('var', '1x8')
+            e = [ev() for _ in range(5)]
+            e[0].record()
+            depth, _, add, mul, _, _ = ops.sampler_fwd(rend.sampler, rays, want_idx=False, want_rgb=False)
+            e[1].record()
+            rin = ops.refine_input(rays, or_rays, depth, rend.img4, rend.proj)
+            e[2].record()
+            z, pts = ops.refine_fwd(rend.refine, rin, rays, depth)
+            e[3].record()
+            rgbd, _ = ops.nerf_fwd(rend.nerf, pts, rays, z, add, mul)
+            e[4].record()
+            torch.cuda.synchronize()
+            if r == 0:
+                continue
+            t = [x.elapsed_time(y) for x, y in zip(e[:-1], e[1:])]
+            for k, v in zip(('sampler', 'refine_in', 'refine', 'nerf'), t):
+                res[i][k].append(v)
+            res[i]['frame'].append(sum(t))
+    for i, c in enumerate(cfgs):
+        line = ' '.join(f'{k}={statistics.median(v):.3f}/{min(v):.3f}' for k, v in res[i].items())
+        print(f'{c}: median/min ms  {line}')
+
+
+if __name__ == '__main__':
+    main()
