@@ -126,23 +126,35 @@ __device__ __forceinline__ float act_fast(float v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Layer loops.  Common structure (both precisions):
+//   * fragment f = to*KS + ks of the layer lives in slot f/16 (layer start is slot aligned);
+//     POS0 = ring position of the layer's first slot (compile-time, see pnrf_layout.h);
+//   * A fragments go through a rotating prefetch queue AHEAD deep, refilled from the head of a slot
+//     right behind its barrier (reads never cross a slot barrier);
+//   * the epilogue of a finished tile is DEFERRED and SPLIT: `epi1(to, piece, acc)` handles one
+//     piece of tile `to`'s accumulators and the pieces are issued one by one between the MFMA groups
+//     of tile to+1, each group fenced by sched_barrier(0).  With two waves per SIMD this keeps VALU
+//     work and MFMAs interleaved at instruction granularity instead of phase-locked behind the slot
+//     barrier.  The LAST tile's accumulators are returned in `last`; the caller passes their pieces
+//     as `pre1(piece)` of whatever layer comes next.
+//
 // One bf16 layer:  NT output tiles of 32 rows, KS k-steps of 16, NCB column blocks of 32.
 //   ringlane  = ring + lane*16            (LDS)
 //   biaslane  = bias_layer + h*16 floats  (LDS; packed [tile][h][16])
 //   Bi(cb,ks) = B operand of k-step ks for column block cb
-//   pre()     = runs right after the layer's first slot barrier (the caller's deferred work, e.g. the
-//               previous layer's last epilogue)
-//   epi(to, acc[NCB]) consumes finished tile `to` (accumulator holds W*x + b).  It is DEFERRED by one
-//               tile: it is issued at the head of tile to+1, behind that tile's slot barrier, so the
-//               scheduler can overlap its VALU work with tile to+1's MFMAs (slot barriers are
-//               scheduling boundaries).  The LAST tile is not passed to epi: its raw accumulators are
-//               returned in `last` and the caller defers them into whatever comes next.
-// Fragment f = to*KS + ks of the layer lives in slot f/16 (layer start is slot aligned);
-// POS0 = ring position of the layer's first slot (compile-time: see layout in pnrf_pack).
-template <int NCB, int KS, int NT, int POS0, class ST, class BFn, class Epi, class Pre>
-__device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const float* biaslane, BFn Bi, Epi epi, Pre pre,
+//   epi1(to, piece, acc[NCB]) / pre1(piece): piece = 0,1 = accumulator registers 8*piece..8*piece+7
+//               (= one packed bf16 B fragment of the next layer per column block).
+constexpr int BF16_PIECES = 2;
+template <int NCB, int KS, int NT, int POS0, class ST, class BFn, class Epi1, class Pre1>
+__device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const float* biaslane, BFn Bi, Epi1 epi1, Pre1 pre1,
                                            f32x16 (&last)[NCB]) {
+  constexpr int NF = KS * NT;
+  constexpr int AHEAD = KS < 8 ? KS : 8;
+  auto frag_ptr = [&](int g) {
+    return (const bf16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+  };
   f32x16 pend[NCB];
+  bf16x8 aq[AHEAD];
 #pragma unroll
   for (int to = 0; to < NT; ++to) {
     f32x16 acc[NCB];
@@ -158,15 +170,28 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int f = to * KS + ks;
-      if (f % SLOT_FRAGS == 0) st.begin();
-      if (ks == 0) {
-        if (to == 0) pre();
-        else epi(to - 1, pend);
+      if (f % SLOT_FRAGS == 0) {
+        st.begin();
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u)
+          if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+      } else if (ks == 0) {      // tile starts inside a slot (KS < 16): the queue is still being fed below
       }
-      const int pos = (POS0 + f / SLOT_FRAGS) % NSLOTS;
-      const bf16x8 a = *(const bf16x8*)(ringlane + pos * SLOT_BYTES + (f % SLOT_FRAGS) * FRAG_BYTES);
+      const bf16x8 a = aq[f % AHEAD];
+      if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
+        aq[f % AHEAD] = *frag_ptr(f + AHEAD);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
+      // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
+#pragma unroll
+      for (int pc = 0; pc < BF16_PIECES; ++pc) {
+        const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;       // k-step after which piece pc is issued
+        if (ks == (at < KS ? at : KS - 1)) {
+          if (to == 0) pre1(pc);
+          else epi1(to - 1, pc, pend);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) pend[cb] = acc[cb];
@@ -176,33 +201,51 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
 }
 template <int KS, int NT> constexpr int layer_slots_bf16() { return (KS * NT + SLOT_FRAGS - 1) / SLOT_FRAGS; }
 
-// One f32 layer (exact fp32 FMA chain, v_mfma_f32_32x32x2_f32), one column block of 32.
-//   KS4 = k-steps/4 = fragments per tile (a fragment carries the A values of 4 k-steps).
-//   Bf(kk) = B operand (one float per lane) of k-step kk.  pre / epi / last: as in layer_bf16.
-template <int KS4, int NT, int POS0, class ST, class BFn, class Epi, class Pre>
-__device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi epi, Pre pre, f32x16& last) {
-  f32x16 pend;
+// One f32 layer (exact fp32 FMA chain, v_mfma_f32_16x16x4_f32), one column block of 16 per wave.
+// 16 columns/wave keep two layers of fp32 activations in 64 + 64 registers, so the sampler runs two
+// waves per SIMD: one wave's VALU work overlaps the other wave's MFMAs, and the 40-cycle
+// dependent-accumulator latency of this instruction (issue 32) is hidden the same way.
+//   lane l: column l&15, quarter q = l>>4.  A[row l&15][k=q], B[k=q][col l&15]; D reg r = row 4q+r.
+//   NT  = output tiles of 16 rows; KS4 = k-steps/4 = fragments per tile (a fragment carries, per
+//         lane, the A values of 4 consecutive k-steps).
+//   Bf(kk) = B operand (one float per lane) of k-step kk.
+//   epi1(to, r, value) / pre1(r): piece r = accumulator register r (0..3) of the deferred tile.
+template <int KS4, int NT, int POS0, class ST, class BFn, class Epi1, class Pre1>
+__device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4& last) {
+  constexpr int NF = KS4 * NT;                 // fragments in the layer
+  constexpr int AHEAD = KS4 < 8 ? KS4 : 8;     // A fragments in flight ahead of the MFMAs
+  auto frag_ptr = [&](int g) {
+    return (const f32x4*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+  };
+  f32x4 pend;
+  f32x4 aq[AHEAD];                             // rotating prefetch queue (static indices after unrolling)
 #pragma unroll
   for (int to = 0; to < NT; ++to) {
-    f32x16 acc;
-    {
-      const f32x4* bp = (const f32x4*)(biaslane + to * 32);
-      f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
-    }
+    f32x4 acc = *(const f32x4*)(biaslane + to * 16);
 #pragma unroll
     for (int fr = 0; fr < KS4; ++fr) {
       const int f = to * KS4 + fr;
-      if (f % SLOT_FRAGS == 0) st.begin();
-      if (fr == 0) {
-        if (to == 0) pre();
-        else epi(to - 1, pend);
-      }
-      const int pos = (POS0 + f / SLOT_FRAGS) % NSLOTS;
-      const f32x4 a = *(const f32x4*)(ringlane + pos * SLOT_BYTES + (f % SLOT_FRAGS) * FRAG_BYTES);
+      if (f % SLOT_FRAGS == 0) {
+        st.begin();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], Bf(4 * fr + i), acc, 0, 0, 0);
+        for (int u = 0; u < AHEAD; ++u)
+          if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+      }
+      const f32x4 a = aq[f % AHEAD];
+      if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
+        aq[f % AHEAD] = *frag_ptr(f + AHEAD);   // keep the queue full
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], Bf(4 * fr + i), acc, 0, 0, 0);
+      // deferred epilogue: register r of the previous tile after MFMA group 1 + r*(KS4/4)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int at = KS4 >= 4 ? 1 + r * (KS4 / 4) : KS4 - 1;
+        if (fr == (at < KS4 ? at : KS4 - 1)) {
+          if (to == 0) pre1(r);
+          else epi1(to - 1, r, pend[r]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     pend = acc;
   }
@@ -216,7 +259,7 @@ __host__ __device__ constexpr int acc_row(int g, int h) { return (g & 3) + 8 * (
 // Feature (row of the 256-wide activation) that element j of half h supplies in bf16 k-step ks
 // when the B operand is the previous layer's packed accumulator (hidden layers).
 __host__ __device__ constexpr int hidden_feat_bf16(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
-// Same for the f32 engine: k-step kk of half h.
-__host__ __device__ constexpr int hidden_feat_f32(int kk, int h) { return 32 * (kk >> 4) + acc_row(kk & 15, h); }
+// Same for the f32 engine (16x16x4): k-step kk = 4t + r, quarter q supplies register r of tile t.
+__host__ __device__ constexpr int hidden_feat_f32(int kk, int q) { return 16 * (kk >> 2) + 4 * q + (kk & 3); }
 
 }  // namespace pnrf

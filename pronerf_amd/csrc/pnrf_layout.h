@@ -14,28 +14,30 @@ enum { NET_SAMPLER = 0, NET_REFINE = 1, NET_NERF = 2 };
 enum { PREC_F32 = 0, PREC_BF16 = 1 };
 
 constexpr int W_HID = 256;
-constexpr int NT_HID = 8;                 // 256 / 32 output tiles per hidden layer
+constexpr int NT_HID = 8;                 // bf16 engine: 256 / 32 output tiles per hidden layer
+constexpr int NT16_HID = 16;              // f32 engine: 256 / 16 output tiles per hidden layer
 
-// ---- sampler (f32): k-step = 2 features (one per lane half)
+// ---- sampler (f32, v_mfma_f32_16x16x4_f32): k-step = 4 features (one per lane quarter)
 constexpr int S_IN = 288, S_OUT = 27, S_NHID = 5;      // hidden 256->256 layers after layer 0
-constexpr int S_KS0 = S_IN / 2;                          // 144 k-steps
-constexpr int S_KS4_0 = S_KS0 / 4;                       // 36 fragments per tile
-constexpr int S_KS4_H = (W_HID / 2) / 4;                 // 32 fragments per tile
-constexpr int S_SLOTS_L0 = layer_slots_f32<S_KS4_0, NT_HID>();   // 18
-constexpr int S_SLOTS_H = layer_slots_f32<S_KS4_H, NT_HID>();    // 16
-constexpr int S_SLOTS_LAST = layer_slots_f32<S_KS4_H, 1>();      // 2
+constexpr int S_KS0 = S_IN / 4;                          // 72 k-steps
+constexpr int S_KS4_0 = S_KS0 / 4;                       // 18 fragments per tile
+constexpr int S_KS4_H = (W_HID / 4) / 4;                 // 16 fragments per tile (= one slot)
+constexpr int S_NT_LAST = 2;                             // 27 outputs in two 16-row tiles
+constexpr int S_SLOTS_L0 = layer_slots_f32<S_KS4_0, NT16_HID>();   // 18
+constexpr int S_SLOTS_H = layer_slots_f32<S_KS4_H, NT16_HID>();    // 16
+constexpr int S_SLOTS_LAST = layer_slots_f32<S_KS4_H, S_NT_LAST>();  // 2
 constexpr int S_POS_H = S_SLOTS_L0 % NSLOTS;
 constexpr int S_POS_LAST = (S_POS_H + S_NHID * S_SLOTS_H) % NSLOTS;
 constexpr int S_SLOTS_USED = S_SLOTS_L0 + S_NHID * S_SLOTS_H + S_SLOTS_LAST;
 constexpr int S_SLOTS_PAD = (NSLOTS - S_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int S_NSLOTS = S_SLOTS_USED + S_SLOTS_PAD;
-constexpr int S_NBIAS = (1 + S_NHID) * W_HID + 32;      // packed bias floats
+constexpr int S_NBIAS = (1 + S_NHID) * W_HID + 16 * S_NT_LAST;      // packed bias floats
 static_assert(S_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
 // folded layer 0 (fused path only): the 48 Pluecker 6-vectors of a ray are the same vector in exact
 // arithmetic (the moment (o+t d) x d^ does not depend on t), so W0[256x288] acts on them as
-// Wf[256x6] = sum_p W0[:, 6p:6p+6].  K = 6 padded to 8 = 4 k-steps = 1 fragment per tile.
+// Wf[256x6] = sum_p W0[:, 6p:6p+6].  K = 6 padded to 16 = 4 k-steps = 1 fragment per tile.
 constexpr int SF_KS4_0 = 1;
-constexpr int SF_SLOTS_L0 = layer_slots_f32<SF_KS4_0, NT_HID>();   // 1
+constexpr int SF_SLOTS_L0 = layer_slots_f32<SF_KS4_0, NT16_HID>();   // 1
 constexpr int SF_POS_H = SF_SLOTS_L0 % NSLOTS;
 constexpr int SF_POS_LAST = (SF_POS_H + S_NHID * S_SLOTS_H) % NSLOTS;
 constexpr int SF_SLOTS_USED = SF_SLOTS_L0 + S_NHID * S_SLOTS_H + S_SLOTS_LAST;
@@ -73,8 +75,8 @@ constexpr int N_NSLOTS = N_SLOTS_USED + N_SLOTS_PAD;
 constexpr int N_NBIAS = (1 + N_NHID) * W_HID + 32;
 
 // ---- input-feature maps of layer 0 (and of the NeRF view k-steps); -1 = zero padding.
-// sampler: k-step kk, half h  ->  mm_input feature (natural pairing)
-__host__ __device__ constexpr int sampler_in0(int kk, int h) { return 2 * kk + h; }
+// sampler: k-step kk, quarter q  ->  mm_input feature (natural order)
+__host__ __device__ constexpr int sampler_in0(int kk, int q) { return 4 * kk + q; }
 // refine: k-step ks, half h, element j -> refine_input feature (natural order)
 __host__ __device__ constexpr int refine_in0(int ks, int h, int j) { return 16 * ks + 8 * h + j; }
 // nerf layer 0: slot n = ks*8+j.  n<30: (freq k=n/3, coord c=n%3), half 0 = sin, half 1 = cos;
@@ -96,14 +98,13 @@ __host__ __device__ constexpr int nerf_inx(int e, int h, int j) {
 }
 
 // ---- output-row maps of the last layers: tile row -> network output index (-1 = unused).
-// sampler: half 0 holds depth[0..7] (regs 0-7) and add[0..7] (regs 8-15); half 1 holds
-// mul[0..7] (regs 0-7) and rgb[0..2] (regs 8-10).  Output order of the net:
-// [depth(8), add(8), mul(8), rgb(3)] (run_nerf_helpers.py:1502-1505).
-__host__ __device__ constexpr int sampler_out(int g, int h) {
-  if (h == 0) return g;                       // depth g | add g-8  == outputs 0..15
-  if (g < 8) return 16 + g;                   // mul
-  if (g < 11) return 24 + (g - 8);            // rgb
-  return -1;
+// sampler (two 16-row tiles tt = 0,1; lane quarter q; reg r): quarter 0 holds depth[4tt+r], quarter 1
+// add[4tt+r], quarter 2 mul[4tt+r], quarter 3 rgb[r] (tile 0 only) — each quarter ends up with all 8
+// values of "its" quantity for one ray.  Output order of the net: [depth(8), add(8), mul(8), rgb(3)]
+// (run_nerf_helpers.py:1502-1505).
+__host__ __device__ constexpr int sampler_out(int tt, int q, int r) {
+  if (q < 3) return 8 * q + 4 * tt + r;
+  return (tt == 0 && r < 3) ? 24 + r : -1;
 }
 // refine tile 0: half h, reg g=4a+b -> sample s=4h+a; b=0 refine logit, b=1..3 offset xyz.
 // Net output order: [refine(8), offsets(24 = s*3+c), rgb(3)] (run_nerf_helpers.py:1536-1538).

@@ -68,15 +68,20 @@ struct SamplerArgs {
   {                                                                                   \
     const bool sw = (dep[i] > dep[j]) || (dep[i] == dep[j] && idx[i] > idx[j]);       \
     const float td = sw ? dep[j] : dep[i]; dep[j] = sw ? dep[i] : dep[j]; dep[i] = td; \
-    const float ta = sw ? add[j] : add[i]; add[j] = sw ? add[i] : add[j]; add[i] = ta; \
     const int ti = sw ? idx[j] : idx[i]; idx[j] = sw ? idx[i] : idx[j]; idx[i] = ti;   \
   }
 
-// MODE 0: module-level (x -> y); 1: fused, full K=288 first layer; 2: fused, folded 6->256 first layer
+__device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
+  const float lo = q == 0 ? a : b, hi = q == 2 ? c : d;
+  return q < 2 ? lo : hi;
+}
+
+// MODE 0: module-level (x -> y); 1: fused, full K=288 first layer; 2: fused, folded 6->256 first layer.
+// 8 waves x 16 columns = 128 rays per workgroup batch, two waves per SIMD.
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void sampler_kernel(SamplerArgs a) {
+__global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
   constexpr bool FUSED = MODE != 0;
-  constexpr int TPB = 256;
+  constexpr int TPB = 512, NW = 8;
   constexpr int KS0 = MODE == 2 ? 4 * SF_KS4_0 : S_KS0;
   constexpr int KS4_0 = MODE == 2 ? SF_KS4_0 : S_KS4_0;
   constexpr int POS_H = MODE == 2 ? SF_POS_H : S_POS_H;
@@ -86,15 +91,15 @@ __global__ __launch_bounds__(256, 1) void sampler_kernel(SamplerArgs a) {
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
-  WStream<4> st;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+  WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
   const char* ringlane = smem + lane * 16;
-  const float* biaslane = bias_lds + h * 16;
+  const float* biaslane = bias_lds + 4 * q;
 
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
-    const int64_t row = (int64_t)batch * 128 + wave * 32 + col;
+    const int64_t row = (int64_t)batch * (NW * 16) + wave * 16 + col;
     const bool valid = row < a.n;
     const int64_t rr = valid ? row : a.n - 1;
     float B0[KS0];
@@ -108,73 +113,73 @@ __global__ __launch_bounds__(256, 1) void sampler_kernel(SamplerArgs a) {
       if (MODE == 2) {           // one Pluecker 6-vector (moment at t = 0) against the folded weights
         float m0, m1, m2;
         moment(ox, oy, oz, dx, dy, dz, 0.f, hx, hy, hz, m0, m1, m2);
-        B0[0] = h ? hy : hx; B0[1] = h ? m0 : hz; B0[2] = h ? m2 : m1; B0[3] = 0.f;
-      } else {
-#pragma unroll
-        for (int p = 0; p < S_KS0 / 3; ++p) {
+        B0[0] = sel4(q, hx, hy, hz, m0);
+        B0[1] = sel4(q, m1, m2, 0.f, 0.f);
+        B0[2] = 0.f; B0[3] = 0.f;
+      } else {                   // feature f = 6p + c of mm_input (trt.py:274-277); k-step kk holds f = 4kk + q
+        auto feat = [&](int f) {
+          const int pnt = f / 6, c = f % 6;
+          if (c == 0) return hx;
+          if (c == 1) return hy;
+          if (c == 2) return hz;
           float m0, m1, m2;
-          moment(ox, oy, oz, dx, dy, dz, a.tvals[p], hx, hy, hz, m0, m1, m2);
-          B0[(3 * p) % KS0] = h ? hy : hx;
-          B0[(3 * p + 1) % KS0] = h ? m0 : hz;
-          B0[(3 * p + 2) % KS0] = h ? m2 : m1;
-        }
+          moment(ox, oy, oz, dx, dy, dz, a.tvals[pnt], hx, hy, hz, m0, m1, m2);
+          return c == 3 ? m0 : (c == 4 ? m1 : m2);
+        };
+#pragma unroll
+        for (int kk = 0; kk < S_KS0; ++kk) B0[kk % KS0] = sel4(q, feat(4 * kk), feat(4 * kk + 1), feat(4 * kk + 2), feat(4 * kk + 3));
       }
     } else {
       const float* xr = a.x + rr * S_IN;
 #pragma unroll
-      for (int kk = 0; kk < KS0; ++kk) B0[kk] = xr[a.in0[kk * 2 + h]];
+      for (int kk = 0; kk < KS0; ++kk) B0[kk] = xr[a.in0[kk * 4 + q]];
     }
 
     // activations ping-pong between X and Y (fp32 accumulators are the next layer's B operand as they stand);
     // `pend` = raw accumulators of the previous layer's last tile, whose ELU is deferred into the next layer
-    f32x16 X[NT_HID], Y[NT_HID], pend;
-    auto elu_into = [&](f32x16(&dst)[NT_HID], int to, f32x16& acc) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) dst[to][g] = act_f32(acc[g], ACT_ELU);
-    };
-    auto hidden = [&](f32x16(&in)[NT_HID], f32x16(&out)[NT_HID], int l) {
-      f32x16 np;
-      layer_f32<S_KS4_H, NT_HID, POS_H>(
-          st, ringlane, biaslane + (1 + l) * W_HID, [&](int kk) { return in[kk >> 4][kk & 15]; },
-          [&](int to, f32x16& acc) { elu_into(out, to, acc); }, [&] { elu_into(in, NT_HID - 1, pend); }, np);
+    f32x4 X[NT16_HID], Y[NT16_HID], pend;
+    auto hidden = [&](f32x4(&in)[NT16_HID], f32x4(&out)[NT16_HID], int l) {
+      f32x4 np;
+      layer_f32<S_KS4_H, NT16_HID, POS_H>(
+          st, ringlane, biaslane + (1 + l) * W_HID, [&](int kk) { return in[kk >> 2][kk & 3]; },
+          [&](int to, int r, float v) { out[to][r] = act_f32(v, ACT_ELU); },
+          [&](int r) { in[NT16_HID - 1][r] = act_f32(pend[r], ACT_ELU); }, np);
       pend = np;
     };
-    layer_f32<KS4_0, NT_HID, 0>(
-        st, ringlane, biaslane, [&](int kk) { return B0[kk]; }, [&](int to, f32x16& acc) { elu_into(X, to, acc); }, [] {}, pend);
+    layer_f32<KS4_0, NT16_HID, 0>(
+        st, ringlane, biaslane, [&](int kk) { return B0[kk]; }, [&](int to, int r, float v) { X[to][r] = act_f32(v, ACT_ELU); }, [](int) {}, pend);
     static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
     for (int l = 0; l < 4; l += 2) {
       hidden(X, Y, l);
       hidden(Y, X, l + 1);
     }
     hidden(X, Y, 4);
-    f32x16 fin;
-    layer_f32<S_KS4_H, 1, POS_LAST>(
-        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int kk) { return Y[kk >> 4][kk & 15]; },
-        [&](int, f32x16&) {}, [&] { elu_into(Y, NT_HID - 1, pend); }, fin);
+    f32x4 fin0, fin1;
+    layer_f32<S_KS4_H, S_NT_LAST, POS_LAST>(
+        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int kk) { return Y[kk >> 2][kk & 3]; },
+        [&](int, int r, float v) { fin0[r] = v; }, [&](int r) { Y[NT16_HID - 1][r] = act_f32(pend[r], ACT_ELU); }, fin1);
 #pragma unroll
     for (int i = 0; i < SLOTS_PAD; ++i) st.begin();
+    const float vals[8] = {fin0[0], fin0[1], fin0[2], fin0[3], fin1[0], fin1[1], fin1[2], fin1[3]};
 
     if (!FUSED) {
       if (valid) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int o = a.outmap[h * 16 + g];
+        for (int i = 0; i < 8; ++i) {
+          const int o = a.outmap[(i >> 2) * 16 + 4 * q + (i & 3)];
           // head_act: depth = sigmoid(y[0:8]), rgb = sigmoid(y[24:27]) (helpers:1502-1505)
-          if (o >= 0) a.y[row * S_OUT + o] = (a.head_act && (o < 8 || o >= 24)) ? sigmoid_f(fin[g]) : fin[g];
+          if (o >= 0) a.y[row * S_OUT + o] = (a.head_act && (o < 8 || o >= 24)) ? sigmoid_f(vals[i]) : vals[i];
         }
       }
       continue;
     }
-    // ---- fused epilogue: half 0 holds depth logits (regs 0-7) + add (8-15); half 1 holds mul (0-7) + rgb (8-10)
-    float dep[8], add[8];
+    // ---- fused epilogue.  Quarter 0 of a column holds the 8 depth logits, quarter 1 add, quarter 2 mul,
+    // quarter 3 rgb (sampler_out).  Quarter 0 sorts; the permutation goes to the other quarters as a word.
+    float dep[8];
     int idx[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      dep[i] = sigmoid_f(fin[i]);
-      add[i] = fin[8 + i];
-      idx[i] = i;
-    }
-    if (h == 0 && valid && a.depth_raw) {
+    for (int i = 0; i < 8; ++i) { dep[i] = sigmoid_f(vals[i]); idx[i] = i; }
+    if (q == 0 && valid && a.depth_raw) {
       float4* p = (float4*)(a.depth_raw + row * 8);
       p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
       p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
@@ -193,39 +198,35 @@ __global__ __launch_bounds__(256, 1) void sampler_kernel(SamplerArgs a) {
     uint32_t word = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) word |= (uint32_t)idx[i] << (3 * i);
-    const uint32_t w0 = __shfl(word, col);      // half 0's permutation for this column, in both halves
-    if (h == 0) {
-      if (valid) {
+    const uint32_t w0 = __shfl(word, col);      // quarter 0's permutation for this column, in all quarters
+    float perm[8];                              // own values permuted like the depths (trt.py:634-635)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = (w0 >> (3 * i)) & 7;
+      float m = vals[0];
+#pragma unroll
+      for (int jj = 1; jj < 8; ++jj) m = (k == jj) ? vals[jj] : m;
+      perm[i] = m;
+    }
+    if (valid) {
+      if (q == 0) {
         float4* p = (float4*)(a.depth_sorted + row * 8);
         p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
         p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
-        float4* q = (float4*)(a.add_sorted + row * 8);
-        q[0] = make_float4(add[0], add[1], add[2], add[3]);
-        q[1] = make_float4(add[4], add[5], add[6], add[7]);
         if (a.sort_idx) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) a.sort_idx[row * 8 + i] = idx[i];
         }
-      }
-    } else {
-      float ms[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = (w0 >> (3 * i)) & 7;
-        float m = fin[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) m = (k == j) ? fin[j] : m;
-        ms[i] = m;
-      }
-      if (valid) {
-        float4* q = (float4*)(a.mul_sorted + row * 8);
-        q[0] = make_float4(ms[0], ms[1], ms[2], ms[3]);
-        q[1] = make_float4(ms[4], ms[5], ms[6], ms[7]);
+      } else if (q == 3) {
         if (a.mm_rgb) {
-          a.mm_rgb[row * 3 + 0] = sigmoid_f(fin[8]);
-          a.mm_rgb[row * 3 + 1] = sigmoid_f(fin[9]);
-          a.mm_rgb[row * 3 + 2] = sigmoid_f(fin[10]);
+          a.mm_rgb[row * 3 + 0] = sigmoid_f(vals[0]);
+          a.mm_rgb[row * 3 + 1] = sigmoid_f(vals[1]);
+          a.mm_rgb[row * 3 + 2] = sigmoid_f(vals[2]);
         }
+      } else {
+        float4* p = (float4*)((q == 1 ? a.add_sorted : a.mul_sorted) + row * 8);
+        p[0] = make_float4(perm[0], perm[1], perm[2], perm[3]);
+        p[1] = make_float4(perm[4], perm[5], perm[6], perm[7]);
       }
     }
   }
@@ -233,19 +234,19 @@ __global__ __launch_bounds__(256, 1) void sampler_kernel(SamplerArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ bf16 nets
+// Deferred hidden-layer epilogue, one piece at a time: piece pc = accumulator registers 8pc..8pc+7 of tile
+// `to` -> activation -> packed bf16 B fragment of k-step 2*to+pc of the next layer.
 template <int NCB, int ACT>
 struct HiddenEpi {
   bf16x8 (&Bn)[NCB][KS_HID];
-  __device__ __forceinline__ void operator()(int to, f32x16 (&acc)[NCB]) const {
+  __device__ __forceinline__ void operator()(int to, int pc, f32x16 (&acc)[NCB]) const {
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb) {
+      float v[8];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * s + j], ACT);
-        Bn[cb][2 * to + s] = pack_bf16(v);
-      }
+      for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * pc + j], ACT);
+      Bn[cb][2 * to + pc] = pack_bf16(v);
+    }
   }
 };
 
@@ -295,11 +296,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
     auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
       layer_bf16<NCB, KS_HID, NT_HID, R_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
-                                               HiddenEpi<NCB, ACT_ELU>{out}, [&] { HiddenEpi<NCB, ACT_ELU>{in}(NT_HID - 1, pend); }, np);
+                                               HiddenEpi<NCB, ACT_ELU>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
     };
-    layer_bf16<NCB, R_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU>{Bn}, [] {}, pend);
+    layer_bf16<NCB, R_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU>{Bn}, [](int) {}, pend);
     static_assert(R_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
     for (int l = 0; l < 4; l += 2) {
       hidden(Bn, Bo, l);
@@ -307,15 +308,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
     }
     hidden(Bn, Bo, 4);
     const float* blast = biaslane + (1 + R_NHID) * W_HID;
-    auto pre_last = [&] { HiddenEpi<NCB, ACT_ELU>{Bo}(NT_HID - 1, pend); };
+    auto pre_last = [&](int pc) { HiddenEpi<NCB, ACT_ELU>{Bo}(NT_HID - 1, pc, pend); };
     f32x16 fin[NCB];
     if (!FUSED) {
-      auto store_tile = [&](int to, f32x16(&acc)[NCB]) {
+      auto store_tile = [&](int to, int pc, f32x16(&acc)[NCB]) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
           if (valid[cb]) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
+            for (int g = 8 * pc; g < 8 * pc + 8; ++g) {
               const int o = a.outmap[(to * 2 + h) * 16 + g];
               // head_act: refine = sigmoid(y[0:8]), offsets = tanh(y[8:32]), rgb = sigmoid(y[32:35]) (helpers:1536-1538)
               const float v = acc[cb][g];
@@ -324,12 +325,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
           }
       };
       layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, store_tile, pre_last, fin);
-      store_tile(R_NT_LAST - 1, fin);
+      store_tile(R_NT_LAST - 1, 0, fin);
+      store_tile(R_NT_LAST - 1, 1, fin);
 #pragma unroll
       for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
       continue;
     }
-    layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, f32x16(&)[NCB]) {}, pre_last, fin);
+    layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
 #pragma unroll
     for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
 
@@ -482,11 +484,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
     auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
       layer_bf16<NCB, KS_HID, NT_HID, N_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
-                                               HiddenEpi<NCB, ACT_RELU>{out}, [&] { HiddenEpi<NCB, ACT_RELU>{in}(NT_HID - 1, pend); }, np);
+                                               HiddenEpi<NCB, ACT_RELU>{out}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
     };
-    layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [] {}, pend);
+    layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [](int) {}, pend);
     static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
     for (int l = 0; l < N_NHID; l += 2) {
       hidden(Bn, Bo, l);
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
     layer_bf16<NCB, N_KS_LAST, 1, N_POS_LAST>(
         st, ringlane, biaslane + (1 + N_NHID) * W_HID,
         [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
-        [&](int, f32x16(&)[NCB]) {}, [&] { HiddenEpi<NCB, ACT_RELU>{Bn}(NT_HID - 1, pend); }, fin);
+        [&](int, int, f32x16(&)[NCB]) {}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bn}(NT_HID - 1, pc, pend); }, fin);
 #pragma unroll
     for (int i = 0; i < N_SLOTS_PAD; ++i) st.begin();
 
@@ -618,8 +620,8 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   a.depth_sorted = depth_sorted; a.add_sorted = add_sorted; a.mul_sorted = mul_sorted;
   a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  return fold ? launch_mlp(sampler_kernel<2>, a, 256, lds, a.nbatch, (hipStream_t)stream)
-              : launch_mlp(sampler_kernel<1>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  return fold ? launch_mlp(sampler_kernel<2>, a, 512, lds, a.nbatch, (hipStream_t)stream)
+              : launch_mlp(sampler_kernel<1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
@@ -666,7 +668,7 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
     a.x = x; a.in0 = h->d_in0; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
-    return launch_mlp(sampler_kernel<0>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+    return launch_mlp(sampler_kernel<0>, a, 512, lds, a.nbatch, (hipStream_t)stream);
   }
   if (h->net == PNRF_NET_REFINE) {
     RefineArgs a = {};

@@ -30,10 +30,10 @@ struct Layer {
   const float* W;
   const float* b;
   int in_dim, out_dim;
-  int nt;                    // output tiles of 32 rows
-  int nk;                    // k-steps (bf16: 16 features each; f32: 2 features each, multiple of 4)
-  std::vector<int> in_map;   // bf16: [nk][2][8]; f32: [nk][2]   -> input feature or -1
-  std::vector<int> out_map;  // [nt][32] tile row -> output index or -1
+  int nt;                    // output tiles (bf16: 32 rows; f32: 16 rows)
+  int nk;                    // k-steps (bf16: 16 features each; f32: 4 features each, multiple of 4)
+  std::vector<int> in_map;   // bf16: [nk][2][8]; f32: [nk][4]   -> input feature or -1
+  std::vector<int> out_map;  // bf16: [nt][32], f32: [nt][16]  tile row -> output index or -1
 };
 
 static size_t layer_frags(const Layer& L, int prec) { return (size_t)L.nt * (prec == PREC_BF16 ? L.nk : L.nk / 4); }
@@ -52,21 +52,25 @@ static void pack_layer(const Layer& L, int prec, char* dst) {
           for (int j = 0; j < 8; ++j) frag[lane * 8 + j] = f2bf(wval(L, out, L.in_map[(ks * 2 + h) * 8 + j]));
         }
       }
-  } else {
+  } else {      // 16x16x4: lane = (row i = lane&15, quarter q = lane>>4); a fragment = 4 consecutive k-steps
     const int ks4 = L.nk / 4;
     for (int to = 0; to < L.nt; ++to)
       for (int fr = 0; fr < ks4; ++fr) {
         float* frag = (float*)(dst + ((size_t)to * ks4 + fr) * FRAG_BYTES);
         for (int lane = 0; lane < 64; ++lane) {
-          const int r = lane & 31, h = lane >> 5;
-          const int out = L.out_map[to * 32 + r];
-          for (int i = 0; i < 4; ++i) frag[lane * 4 + i] = wval(L, out, L.in_map[(4 * fr + i) * 2 + h]);
+          const int r = lane & 15, q = lane >> 4;
+          const int out = L.out_map[to * 16 + r];
+          for (int i = 0; i < 4; ++i) frag[lane * 4 + i] = wval(L, out, L.in_map[(4 * fr + i) * 4 + q]);
         }
       }
   }
 }
 
-static void pack_bias(const Layer& L, float* dst) {
+static void pack_bias(const Layer& L, int prec, float* dst) {
+  if (prec == PREC_F32) {      // [tile][16 rows] in tile-row order: lane quarter q reads rows 4q..4q+3
+    for (int i = 0; i < L.nt * 16; ++i) dst[i] = L.out_map[i] >= 0 ? L.b[L.out_map[i]] : 0.f;
+    return;
+  }
   for (int to = 0; to < L.nt; ++to)
     for (int h = 0; h < 2; ++h)
       for (int g = 0; g < 16; ++g) {
@@ -75,9 +79,9 @@ static void pack_bias(const Layer& L, float* dst) {
       }
 }
 
-static std::vector<int> identity_out(int nt) {
-  std::vector<int> m(nt * 32);
-  for (int i = 0; i < nt * 32; ++i) m[i] = i;
+static std::vector<int> identity_out(int rows) {
+  std::vector<int> m(rows);
+  for (int i = 0; i < rows; ++i) m[i] = i;
   return m;
 }
 static std::vector<int> hidden_in(int prec) {
@@ -88,9 +92,9 @@ static std::vector<int> hidden_in(int prec) {
       for (int h = 0; h < 2; ++h)
         for (int j = 0; j < 8; ++j) m[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
   } else {
-    m.resize((W_HID / 2) * 2);
-    for (int kk = 0; kk < W_HID / 2; ++kk)
-      for (int h = 0; h < 2; ++h) m[kk * 2 + h] = hidden_feat_f32(kk, h);
+    m.resize((W_HID / 4) * 4);
+    for (int kk = 0; kk < W_HID / 4; ++kk)
+      for (int q = 0; q < 4; ++q) m[kk * 4 + q] = hidden_feat_f32(kk, q);
   }
   return m;
 }
@@ -136,18 +140,18 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   for (int l = 0; l < n_layers; ++l) {
     Layer& L = Ls[l];
     L.W = W[l]; L.b = b[l]; L.in_dim = in_dim[l]; L.out_dim = out_dim[l];
-    L.nt = NT_HID; L.out_map = identity_out(NT_HID);
-    L.nk = prec == PREC_BF16 ? KS_HID : W_HID / 2;
+    L.nt = prec == PREC_BF16 ? NT_HID : NT16_HID; L.out_map = identity_out(W_HID);
+    L.nk = prec == PREC_BF16 ? KS_HID : W_HID / 4;
     L.in_map = hidden_in(prec);
   }
   std::vector<int> in0_map, inx_map, out_map;
   Layer& F = Ls[0];
   Layer& Z = Ls[n_layers - 1];
   if (net == PNRF_NET_SAMPLER) {
-    F.nk = S_KS0; F.in_map.assign(S_KS0 * 2, -1);
-    for (int kk = 0; kk < S_KS0; ++kk) for (int h = 0; h < 2; ++h) F.in_map[kk * 2 + h] = sampler_in0(kk, h);
-    Z.nt = 1; Z.out_map.assign(32, -1);
-    for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g) Z.out_map[acc_row(g, h)] = sampler_out(g, h);
+    F.nk = S_KS0; F.in_map.assign(S_KS0 * 4, -1);
+    for (int kk = 0; kk < S_KS0; ++kk) for (int q = 0; q < 4; ++q) F.in_map[kk * 4 + q] = sampler_in0(kk, q);
+    Z.nt = S_NT_LAST; Z.out_map.assign(16 * S_NT_LAST, -1);
+    for (int tt = 0; tt < S_NT_LAST; ++tt) for (int q = 0; q < 4; ++q) for (int r = 0; r < 4; ++r) Z.out_map[tt * 16 + 4 * q + r] = sampler_out(tt, q, r);
   } else if (net == PNRF_NET_REFINE) {
     F.nk = R_KS0; F.in_map.assign(R_KS0 * 16, -1);
     for (int ks = 0; ks < R_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) F.in_map[(ks * 2 + h) * 8 + j] = refine_in0(ks, h, j);
@@ -170,9 +174,13 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g) Z.out_map[acc_row(g, h)] = nerf_out(g, h);
   }
   in0_map = F.in_map;
-  out_map.assign(Z.nt * 32, -1);
-  for (int to = 0; to < Z.nt; ++to) for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g)
-    out_map[(to * 2 + h) * 16 + g] = Z.out_map[to * 32 + acc_row(g, h)];
+  if (prec == PREC_F32) {
+    out_map = Z.out_map;                       // [tile][16 rows]: lane quarter q, reg r -> [tile*16 + 4q + r]
+  } else {
+    out_map.assign(Z.nt * 32, -1);
+    for (int to = 0; to < Z.nt; ++to) for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g)
+      out_map[(to * 2 + h) * 16 + g] = Z.out_map[to * 32 + acc_row(g, h)];
+  }
 
   size_t slots = 0;
   for (auto& L : Ls) slots += layer_slots(L, prec);
@@ -181,15 +189,16 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   PNRF_REQUIRE(slots == expect, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (%zu slots, kernels expect %u)", slots, expect);
 
   std::vector<char> blob(slots * SLOT_BYTES, 0);
+  const int tile_rows = prec == PREC_BF16 ? 32 : 16;
   size_t nbias = 0;
-  for (auto& L : Ls) nbias += (size_t)L.nt * 32;
+  for (auto& L : Ls) nbias += (size_t)L.nt * tile_rows;
   std::vector<float> bias(nbias, 0.f);
   size_t so = 0, bo = 0;
   for (auto& L : Ls) {
     pack_layer(L, prec, blob.data() + so * SLOT_BYTES);
-    pack_bias(L, bias.data() + bo);
+    pack_bias(L, prec, bias.data() + bo);
     so += layer_slots(L, prec);
-    bo += (size_t)L.nt * 32;
+    bo += (size_t)L.nt * tile_rows;
   }
 
   // sampler: second stream with the folded first layer Wf[256x6] = sum_p W0[:, 6p:6p+6] (fp64 sum)
@@ -206,8 +215,8 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
       }
     std::vector<Layer> Lf = Ls;
     Layer& G = Lf[0];
-    G.W = wfold.data(); G.in_dim = 6; G.nk = 4 * SF_KS4_0; G.in_map.assign(G.nk * 2, -1);
-    for (int kk = 0; kk < 3; ++kk) for (int hh = 0; hh < 2; ++hh) G.in_map[kk * 2 + hh] = 2 * kk + hh;
+    G.W = wfold.data(); G.in_dim = 6; G.nk = 4 * SF_KS4_0; G.in_map.assign(G.nk * 4, -1);
+    for (int kk = 0; kk < 2; ++kk) for (int q = 0; q < 4; ++q) G.in_map[kk * 4 + q] = (4 * kk + q < 6) ? 4 * kk + q : -1;
     for (auto& L : Lf) slots_fold += layer_slots(L, prec);
     slots_fold += (NSLOTS - slots_fold % NSLOTS) % NSLOTS;
     PNRF_REQUIRE(slots_fold == (size_t)SF_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (folded stream %zu slots, expected %d)", slots_fold, SF_NSLOTS);
