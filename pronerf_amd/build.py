@@ -74,5 +74,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags=(), csrc: str = CSRC, include: str = INCLUDE) -> str:
+    """Build pronerf_amd/lib/libpronerf_hip_<name>.so with extra compiler flags (A/B timing, diagnostics)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, f'libpronerf_hip_{name}.so')
+    srcs = [os.path.join(csrc, s) for s in SOURCES]
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ['-shared', '-I', include, '-o', out] + srcs
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    if len(sys.argv) > 2 and sys.argv[1] == '--variant':
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build(force='--force' in sys.argv))

@@ -10,9 +10,9 @@
 //   * Weights are pre-packed on the host into 1 KiB "fragments" (64 lanes x 16 B) in exactly
 //     the order the kernel consumes them, so the global->LDS copy is a linear LDS-DMA
 //     (global_load_lds_dwordx4) and every ds_read_b128 is lane-linear (conflict free).
-//   * The packed blob is streamed through a ring of NSLOTS x 16 KiB LDS slots shared by the 4
-//     waves (one per SIMD) of the workgroup; PD slots are kept in flight behind a counted
-//     s_waitcnt vmcnt(N) + raw s_barrier (one barrier per 16 KiB slot).
+//   * The packed blob is streamed through a ring of NSLOTS x 16 KiB LDS slots shared by the
+//     waves of the workgroup; PD slots are kept in flight behind a counted s_waitcnt vmcnt(N) + raw
+//     s_barrier (one barrier per 16 KiB slot).
 //
 // This engine replaces the reference's chain of aten addmm + elu/relu launches
 // (run_nerf_helpers.py:1490-1497, 1526-1533, 1331-1343).
@@ -36,6 +36,17 @@ constexpr int RING_BYTES = NSLOTS * SLOT_BYTES;
 
 enum { ACT_RELU = 0, ACT_ELU = 1 };
 
+// Diagnostic build only (-DPNRF_DIAG, tools/diag_stamps.py): per-wave s_memtime shares.  No stamp executes in
+// the product build.
+#ifdef PNRF_DIAG
+__device__ unsigned long long g_pnrf_diag[4 * 8 * 1024];      // [block*NW + wave] x {total, vmcnt wait, barrier wait, n begin}
+__device__ __forceinline__ unsigned long long diag_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#endif
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -53,6 +64,9 @@ struct WStream {
   uint32_t dst_pos;    // next ring position
   uint32_t woff;       // per-lane byte offset inside a slot (source side)
   uint32_t wbase;      // wave-uniform byte offset inside a slot (LDS side)
+#ifdef PNRF_DIAG
+  unsigned long long t_vm = 0, t_bar = 0, n_begin = 0, t_start = 0;
+#endif
 
   __device__ __forceinline__ void init(const void* blob, uint32_t nslots_, char* ring_) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,20 +89,40 @@ struct WStream {
   __device__ __forceinline__ void prologue() {
 #pragma unroll
     for (int i = 0; i < PD; ++i) issue();
+#ifdef PNRF_DIAG
+    t_start = diag_now();
+#endif
   }
-  // Called before the first read of every slot, by every wave, in the same order.
-  //  vmcnt(N): my share of the slot about to be read has landed (N = younger slots in flight);
-  //  barrier : every wave's share has landed AND every wave has finished reading the previous
-  //            slot, whose ring position (== position of slot q+PD since NSLOTS == PD+1) is
-  //            then refilled.
+  // Called at the boundary between slot q-1 and slot q, by every wave, in the same order.
+  //  vmcnt(N): my share of slot q has landed (N = LOADS_PER_WAVE * (PD-1) younger loads may still be in
+  //            flight);
+  //  barrier : every wave's share has landed AND every wave has finished reading slot q-1, whose
+  //            ring position (== position of slot q+PD since NSLOTS == PD+1) is then refilled.
+  //  (Measured with tools/diag_stamps.py: the vmcnt wait is ~0; letting reads run one slot ahead across
+  //  the barrier with an 8-slot ring bought nothing, so reads stay inside their slot.)
   __device__ __forceinline__ void begin() {
+#ifdef PNRF_DIAG
+    const unsigned long long t0 = diag_now();
+#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD - 1)) : "memory");
+#ifdef PNRF_DIAG
+    const unsigned long long t1 = diag_now();
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef PNRF_DIAG
+    t_vm += t1 - t0; t_bar += diag_now() - t1; n_begin += 1;
+#endif
     issue();
   }
   // LDS-DMA still in flight at kernel end would land in another workgroup's LDS: drain.
   __device__ __forceinline__ void drain() {
+#ifdef PNRF_DIAG
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
+      const unsigned w = blockIdx.x * NW + (threadIdx.x >> 6);
+      g_pnrf_diag[4 * w + 0] = diag_now() - t_start; g_pnrf_diag[4 * w + 1] = t_vm; g_pnrf_diag[4 * w + 2] = t_bar; g_pnrf_diag[4 * w + 3] = n_begin;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -120,7 +154,8 @@ __device__ __forceinline__ float act_f32(float v, int act) {
 }
 __device__ __forceinline__ float act_fast(float v, int act) {
   // bf16 path: the result is rounded to 8 significant bits, v_exp_f32 is accurate enough.
-  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  // relu as a sign select: fmaxf() on an MFMA result costs an extra canonicalising v_max_f32 v,v,v
+  if (act == ACT_RELU) return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & ~(__builtin_bit_cast(int, v) >> 31));
   const float e = __expf(fminf(v, 0.f)) - 1.f;       // unconditional, see act_f32
   return fmaxf(v, 0.f) + e;
 }
@@ -171,15 +206,14 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
     for (int ks = 0; ks < KS; ++ks) {
       const int f = to * KS + ks;
       if (f % SLOT_FRAGS == 0) {
-        st.begin();
+        st.begin();              // the slot is readable now: (re)fill the queue from its head
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
           if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
-      } else if (ks == 0) {      // tile starts inside a slot (KS < 16): the queue is still being fed below
       }
       const bf16x8 a = aq[f % AHEAD];
       if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
-        aq[f % AHEAD] = *frag_ptr(f + AHEAD);
+        aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full inside the slot
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
       // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
@@ -226,14 +260,14 @@ __device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const fl
     for (int fr = 0; fr < KS4; ++fr) {
       const int f = to * KS4 + fr;
       if (f % SLOT_FRAGS == 0) {
-        st.begin();
+        st.begin();              // the slot is readable now: (re)fill the queue from its head
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
           if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
       }
       const f32x4 a = aq[f % AHEAD];
       if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
-        aq[f % AHEAD] = *frag_ptr(f + AHEAD);   // keep the queue full
+        aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full inside the slot
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], Bf(4 * fr + i), acc, 0, 0, 0);
       // deferred epilogue: register r of the previous tile after MFMA group 1 + r*(KS4/4)

@@ -15,6 +15,10 @@
 
 #include "pnrf_common.h"
 
+#ifndef PNRF_YOUNG_PRIO
+#define PNRF_YOUNG_PRIO 1
+#endif
+
 using namespace pnrf;
 
 namespace {
@@ -30,6 +34,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Two waves per SIMD: the second-dispatched half of the workgroup (waves NW/2..NW-1) loses every VALU/MFMA
+// arbitration to its older partner, finishes each tile late and makes the older half wait at the slot barrier
+// (tools/diag_stamps.py: 109 vs 600 cycles of barrier wait per tile).  One static s_setprio for that half
+// evens the pair out (cdna guide T5, static form).  The condition must be provably wave-uniform.
+template <int NW>
+__device__ __forceinline__ void young_half_priority() {
+  if (NW == 8 && PNRF_YOUNG_PRIO) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+  }
+}
 
 __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
   bf16x8 r;
@@ -95,6 +110,7 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
+  young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * q;
 
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
+  young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
 
@@ -395,6 +412,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
+  young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
 
@@ -683,3 +701,12 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
   a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out;
   return launch_mlp(nerf_kernel<1, 4, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
+
+#ifdef PNRF_DIAG
+// diagnostic build only: copy the stamp sums of the last MLP kernel launch to the host
+extern "C" int pnrf_diag_read(unsigned long long* out, int n) {
+  PNRF_HIP(hipDeviceSynchronize());
+  PNRF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pnrf::g_pnrf_diag), sizeof(unsigned long long) * n));
+  return 0;
+}
+#endif
