@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (rank 0, N=1)')
     ap.add_argument('--cpu-sample-rays', type=int, default=16384)
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
+                    'the multi-rank path with several ranks sharing one GPU)')
     return ap.parse_args()
 
 
@@ -132,6 +134,11 @@ def pmc_traffic():
         return None
 
 
+def dbg(msg):
+    if os.environ.get('PNRF_BENCH_DEBUG'):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -143,13 +150,20 @@ def main():
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and local_rank >= ndev:
+        raise SystemExit(f'LOCAL_RANK={local_rank} but only {ndev} GPU(s) are visible')
+    dev = torch.device('cuda', local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
+    dbg('process group up')
     from pronerf_amd import synthetic
     from pronerf_amd.render import Renderer, shard_range
 
@@ -178,14 +192,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dbg('renderer + inputs ready')
     for _ in range(args.warmup):
         step()
+    dbg('warm-up issued')
     fence()
+    dbg('warm-up done')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    dbg(f'timed region done: {dt:.3f}s')
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,6 +220,7 @@ def main():
             'ms_per_step': ms, 'ms_per_frame': ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'bf16 (refine+NeRF MLP, fp32 accumulate) + f32 (sampler MLP, exact f32 MFMA)',
             'data': 'synthetic',
+            'backend': (args.backend if world > 1 else None),
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, '
                                    '48 ray-encoding points, 1024-ray chunks (4x256-column workgroup batches), bf16 MLP',
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0],
