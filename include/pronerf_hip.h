@@ -34,6 +34,9 @@ extern "C" {
 #define PNRF_NET_SAMPLER 0   /* MinMaxRaySamplerTRT_Net / MinMaxRay_Net, 288->6x256->27, ELU  (run_nerf_helpers.py:1440-1507) */
 #define PNRF_NET_REFINE 1    /* MinMaxRayEpiSamplerTRT_Net, 144->6x256->35, ELU                 (run_nerf_helpers.py:1509-1540) */
 #define PNRF_NET_NERF 2      /* DoNeRFTRT(skip='auto'), 63->7x256->[256+27]->4, ReLU            (run_nerf_helpers.py:1186-1343) */
+#define PNRF_NET_NERFCLS 3   /* NeRF(D=8,W=256,skips=[4],use_viewdirs=True): the fine net stages 1/2 train and save
+                                (run_nerf_helpers.py:792-847).  12 Linear layers in the order pts_linears[0..7],
+                                feature_linear, alpha_linear, views_linears[0], rgb_linear; output [rgb(3), alpha]. */
 
 typedef struct pnrf_mlp pnrf_mlp_t;
 typedef struct pnrf_ctx pnrf_ctx_t;
@@ -54,8 +57,8 @@ int pnrf_mlp_free(pnrf_mlp_t* h);
  * (MinMaxRay_Net.forward, DoNeRFTRT.forward); head_act = 1: with the head activations of the TRT
  * wrapper classes applied in place of their slicing ops — sampler: sigmoid on y[0:8] and y[24:27];
  * refine: sigmoid on y[0:8] and y[32:35], tanh on y[8:32] (run_nerf_helpers.py:1502-1505, 1536-1538).
- * x: dev [m, in_dim]; x_views: dev [m, 27] (PNRF_NET_NERF only: the view embedding concatenated
- * before the last layer), else NULL.
+ * x: dev [m, in_dim]; x_views: dev [m, 27] (PNRF_NET_NERF / PNRF_NET_NERFCLS: the view embedding; x is then
+ * the 63-wide position embedding), else NULL.
  * Replaces <module>.forward (run_nerf_helpers.py:1490-1507, 1526-1540, 1331-1343). */
 int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m,
                  int head_act, void* stream);
@@ -118,7 +121,8 @@ int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* ra
                     const float* depth_sorted, float* z, float* pts, int64_t n, void* stream);
 /* NeRF: positional encoding of pts/viewdirs -> bf16 MLP -> alpha compositing with the sampler's
  * density modulation.  pts dev [n,8,3]; rays dev [n,11]; z, add_sorted, mul_sorted dev [n,8].
- * Outputs dev: rgbd[n,4] = (r,g,b,depth); raw[n,8,4] optional (NULL to skip).
+ * Outputs dev: rgbd[n,4] = (r,g,b,depth); raw[n,8,4] optional (NULL to skip).  h may be a PNRF_NET_NERF or a
+ * PNRF_NET_NERFCLS handle (the fine-net class mismatch of the released scripts).
  * (run_S_eS_eN_alter_trt.py:691-694; run_network :195-208) */
 int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
                   const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpronerf_hip.so')
 
-NET_SAMPLER, NET_REFINE, NET_NERF = 0, 1, 2
+NET_SAMPLER, NET_REFINE, NET_NERF, NET_NERFCLS = 0, 1, 2, 3
 ABI_VERSION = 1
 
 

@@ -34,7 +34,7 @@ constexpr int NSLOTS = 4;                          // ring slots (64 KiB of LDS)
 constexpr int PD = 3;                              // slots in flight ahead of the consumer
 constexpr int RING_BYTES = NSLOTS * SLOT_BYTES;
 
-enum { ACT_RELU = 0, ACT_ELU = 1 };
+enum { ACT_RELU = 0, ACT_ELU = 1, ACT_NONE = 2 };
 
 // Diagnostic build only (-DPNRF_DIAG, tools/diag_stamps.py): per-wave s_memtime shares.  No stamp executes in
 // the product build.
@@ -155,6 +155,7 @@ __device__ __forceinline__ float act_f32(float v, int act) {
 __device__ __forceinline__ float act_fast(float v, int act) {
   // bf16 path: the result is rounded to 8 significant bits, v_exp_f32 is accurate enough.
   // relu as a sign select: fmaxf() on an MFMA result costs an extra canonicalising v_max_f32 v,v,v
+  if (act == ACT_NONE) return v;
   if (act == ACT_RELU) return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & ~(__builtin_bit_cast(int, v) >> 31));
   const float e = __expf(fminf(v, 0.f)) - 1.f;       // unconditional, see act_f32
   return fmaxf(v, 0.f) + e;

@@ -399,7 +399,8 @@ struct NerfArgs {
   float* y; const int* outmap;                      // module-level consumer
 };
 
-template <int NCB, int NW, bool FUSED>
+// CLS = false: DoNeRFTRT; CLS = true: the NeRF class (skip-concat at layer 5, feature/alpha heads, view branch)
+template <int NCB, int NW, bool FUSED, bool CLS>
 __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
   constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -496,29 +497,85 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
         }
       }
     });
-    // ping-pong: layer 0 Bo -> Bn, then Bn -> Bo, Bo -> Bn, ... (6 hidden layers end in Bn);
-    // `pend` = raw accumulators of the previous layer's last tile (its epilogue is deferred into the next layer)
-    f32x16 pend[NCB];
-    auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
-      f32x16 np[NCB];
-      layer_bf16<NCB, KS_HID, NT_HID, N_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
-                                               HiddenEpi<NCB, ACT_RELU>{out}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{in}(NT_HID - 1, pc, pend); }, np);
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
-    };
-    layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [](int) {}, pend);
-    static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
-    for (int l = 0; l < N_NHID; l += 2) {
-      hidden(Bn, Bo, l);
-      hidden(Bo, Bn, l + 1);
-    }
     f32x16 fin[NCB];
-    layer_bf16<NCB, N_KS_LAST, 1, N_POS_LAST>(
-        st, ringlane, biaslane + (1 + N_NHID) * W_HID,
-        [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
-        [&](int, int, f32x16(&)[NCB]) {}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bn}(NT_HID - 1, pc, pend); }, fin);
+    f32x16 pend[NCB];      // raw accumulators of the previous layer's last tile (its epilogue is deferred into the next layer)
+    if constexpr (!CLS) {
+      // ping-pong: layer 0 Bo -> Bn, then Bn -> Bo, Bo -> Bn, ... (6 hidden layers end in Bn)
+      auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
+        f32x16 np[NCB];
+        layer_bf16<NCB, KS_HID, NT_HID, N_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+                                                 HiddenEpi<NCB, ACT_RELU>{out}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
-    for (int i = 0; i < N_SLOTS_PAD; ++i) st.begin();
+        for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+      };
+      layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [](int) {}, pend);
+      static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
+      for (int l = 0; l < N_NHID; l += 2) {
+        hidden(Bn, Bo, l);
+        hidden(Bo, Bn, l + 1);
+      }
+      layer_bf16<NCB, N_KS_LAST, 1, N_POS_LAST>(
+          st, ringlane, biaslane + (1 + N_NHID) * W_HID,
+          [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
+          [&](int, int, f32x16(&)[NCB]) {}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bn}(NT_HID - 1, pc, pend); }, fin);
+#pragma unroll
+      for (int i = 0; i < N_SLOTS_PAD; ++i) st.begin();
+    } else {
+      // NeRF class (helpers:824-847).  E0 Bo->Bn | E1..E4 ping-pong (ends in Bn) | E5 [Bn, P]->Bo | E6 Bo->Bn | E7 Bn->Bo |
+      // E8 Bo->Bn (feature, linear) + alpha | E9 [Bn, Bx]->Bo (128 wide) | E10 Bo -> rgb
+      bf16x8 P[NCB][N_KS0];                 // positional B fragments, needed again by the skip connection at layer 5
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int k = 0; k < N_KS0; ++k) P[cb][k] = Bo[cb][k];
+      auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l, auto posc) {
+        constexpr int POS = decltype(posc)::value;
+        f32x16 np[NCB];
+        layer_bf16<NCB, KS_HID, NT_HID, POS>(st, ringlane, biaslane + l * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+                                             HiddenEpi<NCB, ACT_RELU>{out}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{in}(NT_HID - 1, pc, pend); }, np);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+      };
+      layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [](int) {}, pend);
+      for (int l = 1; l < 5; l += 2) {        // E1..E4
+        hidden(Bn, Bo, l, std::integral_constant<int, C_POS_E1>{});
+        hidden(Bo, Bn, l + 1, std::integral_constant<int, C_POS_E1>{});
+      }
+      {                                       // E5: cat[pts, h] -> 256 (skip connection after layer 4)
+        f32x16 np[NCB];
+        layer_bf16<NCB, C_KS5, NT_HID, C_POS_E5>(
+            st, ringlane, biaslane + 5 * W_HID,
+            [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : P[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
+            HiddenEpi<NCB, ACT_RELU>{Bo}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bn}(NT_HID - 1, pc, pend); }, np);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+      }
+      hidden(Bo, Bn, 6, std::integral_constant<int, C_POS_E6>{});
+      hidden(Bn, Bo, 7, std::integral_constant<int, C_POS_E6>{});
+      float alpha[NCB];
+      {                                       // E8: feature (tiles 0-7, no activation) + alpha (tile 8, row 0)
+        f32x16 np[NCB];
+        layer_bf16<NCB, KS_HID, C_NT8, C_POS_E8>(st, ringlane, biaslane + C_BIAS_E8, [&](int cb, int ks) { return Bo[cb][ks]; },
+                                                 HiddenEpi<NCB, ACT_NONE>{Bn}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bo}(NT_HID - 1, pc, pend); }, np);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) alpha[cb] = np[cb][0];
+      }
+      {                                       // E9: views layer on cat[feature, view encoding] -> 128, ReLU
+        f32x16 np[NCB];
+        layer_bf16<NCB, C_KS9, C_NT9, C_POS_E9>(
+            st, ringlane, biaslane + C_BIAS_E9,
+            [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
+            HiddenEpi<NCB, ACT_RELU>{Bo}, [](int) {}, np);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+      }
+      layer_bf16<NCB, C_KS10, 1, C_POS_E10>(st, ringlane, biaslane + C_BIAS_E10, [&](int cb, int ks) { return Bo[cb][ks]; },
+                                            [&](int, int, f32x16(&)[NCB]) {}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bo}(C_NT9 - 1, pc, pend); }, fin);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) fin[cb][3] = alpha[cb];          // raw = [rgb, alpha] (helpers:851)
+#pragma unroll
+      for (int i = 0; i < C_SLOTS_PAD; ++i) st.begin();
+    }
 
     if (!FUSED) {
 #pragma unroll
@@ -661,7 +718,7 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
                              const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
                              int64_t n, void* stream) {
-  PNRF_REQUIRE(h && h->net == PNRF_NET_NERF, PNRF_E_ARG, "pnrf_nerf_fwd: handle is not a nerf net");
+  PNRF_REQUIRE(h && (h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS), PNRF_E_ARG, "pnrf_nerf_fwd: handle is not a nerf net");
   PNRF_REQUIRE(n >= 0 && (n == 0 || (pts && rays && z && add_sorted && mul_sorted && rgbd)), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer / negative n");
   if (n == 0) return 0;
   NerfArgs a = {};
@@ -671,14 +728,15 @@ extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float*
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * 8 + rows - 1) / rows);
-  return variant_1x8() ? launch_mlp(nerf_kernel<1, 8, true>, a, 512, lds, a.nbatch, (hipStream_t)stream)
-                       : launch_mlp(nerf_kernel<2, 4, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  return variant_1x8() ? launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream)
+                       : launch_mlp(nerf_kernel<2, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, int head_act, void* stream) {
   PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_fwd: null handle");
   PNRF_REQUIRE(m >= 0 && (m == 0 || (x && y)), PNRF_E_ARG, "pnrf_mlp_fwd: null pointer / negative m");
-  PNRF_REQUIRE(h->net != PNRF_NET_NERF || m == 0 || x_views, PNRF_E_ARG, "pnrf_mlp_fwd: the nerf net needs x_views [m,27]");
+  PNRF_REQUIRE((h->net != PNRF_NET_NERF && h->net != PNRF_NET_NERFCLS) || m == 0 || x_views, PNRF_E_ARG, "pnrf_mlp_fwd: the nerf nets need x_views [m,27]");
   if (m == 0) return 0;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   if (h->net == PNRF_NET_SAMPLER) {
@@ -699,7 +757,8 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = m; a.nbatch = (int)((m + 127) / 128);
   a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out;
-  return launch_mlp(nerf_kernel<1, 4, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 4, false, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  return launch_mlp(nerf_kernel<1, 4, false, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
 #ifdef PNRF_DIAG

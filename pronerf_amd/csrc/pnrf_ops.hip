@@ -419,8 +419,8 @@ static constexpr int WS_FLOATS_PER_RAY = 8 + 8 + 8 + 144 + 8 + 24;
 
 extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refine, const pnrf_mlp_t* nerf, int64_t max_rays, pnrf_ctx_t** out) {
   PNRF_REQUIRE(sampler && refine && nerf && out && max_rays > 0, PNRF_E_ARG, "pnrf_ctx_create: bad arguments");
-  PNRF_REQUIRE(sampler->net == PNRF_NET_SAMPLER && refine->net == PNRF_NET_REFINE && nerf->net == PNRF_NET_NERF, PNRF_E_ARG,
-               "pnrf_ctx_create: handles must be (sampler, refine, nerf)");
+  PNRF_REQUIRE(sampler->net == PNRF_NET_SAMPLER && refine->net == PNRF_NET_REFINE && (nerf->net == PNRF_NET_NERF || nerf->net == PNRF_NET_NERFCLS),
+               PNRF_E_ARG, "pnrf_ctx_create: handles must be (sampler, refine, nerf | nerf-class)");
   pnrf_ctx* c = new pnrf_ctx();
   c->sampler = sampler; c->refine = refine; c->nerf = nerf; c->max_rays = max_rays; c->ws = nullptr;
   hipError_t e = hipGetDevice(&c->device);

@@ -117,9 +117,113 @@ extern "C" int pnrf_linspace(float start, float end, int n, float* out) {
   return 0;
 }
 
+// NeRF-class fine net: 12 Linear modules -> 11 engine layers (feature + alpha share one layer).
+static int upload(pnrf_mlp* h, const std::vector<char>& blob, const std::vector<float>& bias, const std::vector<int>& in0,
+                  const std::vector<int>& inx, const std::vector<int>& outm);
+
+static int pack_nerfcls(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim, int n_layers, pnrf_mlp_t** out) {
+  PNRF_REQUIRE(n_layers == C_NLIN, PNRF_E_SHAPE, "pnrf_mlp_pack: the NeRF class expects %d Linear layers (pts0..7, feature, alpha, views, rgb), got %d", C_NLIN, n_layers);
+  const int ei[C_NLIN] = {N_IN, W_HID, W_HID, W_HID, W_HID, W_HID + N_IN, W_HID, W_HID, W_HID, W_HID, W_HID + N_INV, W_HID / 2};
+  const int eo[C_NLIN] = {W_HID, W_HID, W_HID, W_HID, W_HID, W_HID, W_HID, W_HID, W_HID, 1, W_HID / 2, 3};
+  for (int l = 0; l < C_NLIN; ++l) {
+    PNRF_REQUIRE(W[l] && b[l], PNRF_E_ARG, "pnrf_mlp_pack: null weight/bias at layer %d", l);
+    PNRF_REQUIRE(in_dim[l] == ei[l] && out_dim[l] == eo[l], PNRF_E_SHAPE, "pnrf_mlp_pack: NeRF-class layer %d is %dx%d, kernels are built for %dx%d",
+                 l, out_dim[l], in_dim[l], eo[l], ei[l]);
+  }
+  const std::vector<int> hid = hidden_in(PREC_BF16);
+  std::vector<Layer> Ls(11);
+  auto base = [&](Layer& L, int lin) {
+    L.W = W[lin]; L.b = b[lin]; L.in_dim = in_dim[lin]; L.out_dim = out_dim[lin];
+    L.nt = NT_HID; L.nk = KS_HID; L.in_map = hid; L.out_map = identity_out(W_HID);
+  };
+  for (int e = 0; e < 8; ++e) base(Ls[e], e);
+  // E0: positional k-steps (same slot order as the DoNeRFTRT first layer)
+  Ls[0].nk = N_KS0; Ls[0].in_map.assign(N_KS0 * 16, -1);
+  for (int ks = 0; ks < N_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) Ls[0].in_map[(ks * 2 + h) * 8 + j] = nerf_in0(ks, h, j);
+  // E5: input = cat[pts(63), h(256)] (helpers:838-839): 16 hidden k-steps on columns 63.., then the 4 positional k-steps on columns 0..62
+  Ls[5].nk = C_KS5; Ls[5].in_map.assign(C_KS5 * 16, -1);
+  for (int ks = 0; ks < KS_HID; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) Ls[5].in_map[(ks * 2 + h) * 8 + j] = N_IN + hidden_feat_bf16(ks, h, j);
+  for (int ks = 0; ks < N_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) Ls[5].in_map[((KS_HID + ks) * 2 + h) * 8 + j] = nerf_in0(ks, h, j);
+  // E8: feature (rows 0..255) + alpha (tile 8, row 0) from the same input (helpers:842-843)
+  std::vector<float> Wc((size_t)(W_HID + 1) * W_HID), bc(W_HID + 1);
+  memcpy(Wc.data(), W[8], sizeof(float) * W_HID * W_HID);
+  memcpy(Wc.data() + (size_t)W_HID * W_HID, W[9], sizeof(float) * W_HID);
+  memcpy(bc.data(), b[8], sizeof(float) * W_HID); bc[W_HID] = b[9][0];
+  Layer& E8 = Ls[8];
+  E8.W = Wc.data(); E8.b = bc.data(); E8.in_dim = W_HID; E8.out_dim = W_HID + 1; E8.nt = C_NT8; E8.nk = KS_HID; E8.in_map = hid;
+  E8.out_map.assign(32 * C_NT8, -1);
+  for (int i = 0; i < W_HID; ++i) E8.out_map[i] = i;
+  E8.out_map[W_HID] = W_HID;                       // alpha -> tile 8 row 0 = half 0, register 0
+  // E9: views layer on cat[feature(256), views(27)] (helpers:844-848)
+  Layer& E9 = Ls[9];
+  E9.W = W[10]; E9.b = b[10]; E9.in_dim = W_HID + N_INV; E9.out_dim = W_HID / 2; E9.nt = C_NT9; E9.nk = C_KS9;
+  E9.in_map.assign(C_KS9 * 16, -1);
+  std::vector<int> inx_map(N_KSX * 16, -1);
+  for (int ks = 0; ks < KS_HID; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) E9.in_map[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
+  for (int e = 0; e < N_KSX; ++e) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) {
+    const int v = nerf_inx(e, h, j);
+    inx_map[(e * 2 + h) * 8 + j] = v;
+    E9.in_map[((KS_HID + e) * 2 + h) * 8 + j] = v >= 0 ? W_HID + v : -1;
+  }
+  E9.out_map = identity_out(32 * C_NT9);
+  // E10: rgb (helpers:850)
+  Layer& E10 = Ls[10];
+  E10.W = W[11]; E10.b = b[11]; E10.in_dim = W_HID / 2; E10.out_dim = 3; E10.nt = 1; E10.nk = C_KS10;
+  E10.in_map.assign(C_KS10 * 16, -1);
+  for (int ks = 0; ks < C_KS10; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) E10.in_map[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
+  E10.out_map.assign(32, -1);
+  for (int g = 0; g < 3; ++g) E10.out_map[acc_row(g, 0)] = g;
+
+  size_t slots = 0, nbias = 0;
+  for (auto& L : Ls) { slots += layer_slots(L, PREC_BF16); nbias += (size_t)L.nt * 32; }
+  slots += (NSLOTS - slots % NSLOTS) % NSLOTS;
+  PNRF_REQUIRE(slots == (size_t)C_NSLOTS && nbias == (size_t)C_NBIAS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal NeRF-class layout mismatch (%zu slots, %zu bias floats)", slots, nbias);
+  std::vector<char> blob(slots * SLOT_BYTES, 0);
+  std::vector<float> bias(nbias, 0.f);
+  size_t so = 0, bo = 0;
+  for (auto& L : Ls) {
+    pack_layer(L, PREC_BF16, blob.data() + so * SLOT_BYTES);
+    pack_bias(L, PREC_BF16, bias.data() + bo);
+    so += layer_slots(L, PREC_BF16); bo += (size_t)L.nt * 32;
+  }
+  std::vector<int> outm(64, -1);                  // module-level store map: (half, reg) -> output index, rgb only (alpha handled by the kernel)
+  pnrf_mlp* h = new pnrf_mlp();
+  memset(h, 0, sizeof(*h));
+  h->net = PNRF_NET_NERFCLS; h->prec = PREC_BF16; h->in_dim = N_IN; h->in_dim_x = N_INV; h->out_dim = 4;
+  h->nslots = (uint32_t)slots; h->nbias = (int)nbias;
+  int rc = upload(h, blob, bias, Ls[0].in_map, inx_map, outm);
+  if (rc) { pnrf_mlp_free(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+static int upload(pnrf_mlp* h, const std::vector<char>& blob, const std::vector<float>& bias, const std::vector<int>& in0,
+                  const std::vector<int>& inx, const std::vector<int>& outm) {
+  h->n_in0 = (int)in0.size(); h->n_inx = (int)inx.size(); h->n_out = (int)outm.size();
+  hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipMalloc(&h->d_blob, blob.size());
+  if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, bias.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_in0, in0.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(h->d_in0, in0.data(), in0.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !inx.empty()) {
+    e = hipMalloc((void**)&h->d_inx, inx.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(h->d_inx, inx.data(), inx.size() * sizeof(int), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, outm.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(h->d_out, outm.data(), outm.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("pnrf_mlp_pack: device allocation/copy failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
 extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const* b, const int* in_dim,
                              const int* out_dim, int n_layers, pnrf_mlp_t** out) {
   PNRF_REQUIRE(W && b && in_dim && out_dim && out, PNRF_E_ARG, "pnrf_mlp_pack: null argument");
+  if (net == PNRF_NET_NERFCLS) return pack_nerfcls(W, b, in_dim, out_dim, n_layers, out);
   PNRF_REQUIRE(net == PNRF_NET_SAMPLER || net == PNRF_NET_REFINE || net == PNRF_NET_NERF, PNRF_E_ARG,
                "pnrf_mlp_pack: unknown net kind %d", net);
   const int prec = net == PNRF_NET_SAMPLER ? PREC_F32 : PREC_BF16;

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import NET_NERF, NET_REFINE, NET_SAMPLER, PnrfError, check
+from ._lib import NET_NERF, NET_NERFCLS, NET_REFINE, NET_SAMPLER, PnrfError, check
 
 f32 = torch.float32
 
@@ -51,7 +51,7 @@ class PackedMLP:
         self.handle = h
         self.net = net
         self.in_dim = ws[0].shape[1]
-        self.out_dim = ws[-1].shape[0]
+        self.out_dim = 4 if net == NET_NERFCLS else ws[-1].shape[0]      # NeRF class: [rgb(3), alpha]
 
     def __del__(self):
         try:

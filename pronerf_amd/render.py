@@ -57,7 +57,9 @@ class Renderer:
         with torch.cuda.device(self.device):
             self.sampler = ops.PackedMLP(ops.NET_SAMPLER, weights['sampler']['W'], weights['sampler']['b'])
             self.refine = ops.PackedMLP(ops.NET_REFINE, weights['refine']['W'], weights['refine']['b'])
-            self.nerf = ops.PackedMLP(ops.NET_NERF, weights['nerf']['W'], weights['nerf']['b'])
+            # 8 Linear layers = DoNeRFTRT; 12 = the NeRF class (pts0..7, feature, alpha, views, rgb)
+            nerf_kind = ops.NET_NERFCLS if len(weights['nerf']['W']) == 12 else ops.NET_NERF
+            self.nerf = ops.PackedMLP(nerf_kind, weights['nerf']['W'], weights['nerf']['b'])
             self.ctx = ops.RenderContext(self.sampler, self.refine, self.nerf, max_rays)
         self.img4 = None
         self.proj = None

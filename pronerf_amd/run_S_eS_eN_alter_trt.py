@@ -20,7 +20,7 @@ import torch
 from . import inverse_warp, ops
 from .ops import PnrfError
 from .render import Renderer, projection_matrices, select_neighbors
-from .run_nerf_helpers import (DoNeRFTRT, MinMaxRayEpiSamplerTRT_Net, MinMaxRaySamplerTRT_Net, Pluecker, get_embedder,  # noqa: F401
+from .run_nerf_helpers import (DoNeRFTRT, MinMaxRayEpiSamplerTRT_Net, MinMaxRaySamplerTRT_Net, NeRF, Pluecker, get_embedder,  # noqa: F401
                                get_rays, img2mse, mse2psnr, ndc_rays, to8b, weights_from_modules)
 
 
@@ -151,7 +151,11 @@ def create_nerf(args, device='cuda'):
         start = ckpt.get('global_step', 0)
         model_mmray.load_state_dict(ckpt['mmr_network_fn_state_dict'])
         model_refine.load_state_dict(ckpt['refine_net_state_dict'])
-        model_fine.load_state_dict(ckpt['network_fine_state_dict'])       # DoNeRFTRT keys; see weights_from_state_dicts
+        fine_sd = ckpt['network_fine_state_dict']
+        if any(k.startswith('pts_linears.') for k in fine_sd):            # saved from the NeRF class
+            model_fine = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=4,
+                              skips=[4], use_viewdirs=True).to(device)
+        model_fine.load_state_dict(fine_sd)
     network_query_fn = lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
                                                                         embeddirs_fn=embeddirs_fn, netchunk=getattr(args, 'netchunk', 1024 * 64))
     kw = {'network_query_fn': network_query_fn, 'perturb': False, 'N_importance': 0, 'network_fine': model_fine,

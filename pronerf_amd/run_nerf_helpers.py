@@ -9,6 +9,7 @@ Same names, argument meaning and error behaviour as the live subset of the refer
     MinMaxRaySamplerTRT_Net        helpers:1473-1507 -> pnrf_mlp_fwd (+ sigmoid heads)
     MinMaxRayEpiSamplerTRT_Net     helpers:1509-1540 -> pnrf_mlp_fwd (bf16 MFMA, sigmoid/tanh heads)
     DoNeRFTRT                      helpers:1186-1343 -> pnrf_mlp_fwd (bf16 MFMA)
+    NeRF                           helpers:792-847   -> pnrf_mlp_fwd (bf16 MFMA, skip + view branch)
     get_rays / ndc_rays            helpers:2705-2714, 2776-2793 -> pnrf_frame_rays_fwd / pnrf_ndc_rays_fwd
 
 The model classes keep the reference's ``state_dict`` keys (``fc_backbone.{i}.*``, ``fc_output.*``,
@@ -186,6 +187,37 @@ class DoNeRFTRT(_PackedNet):
         return self.packed().forward(input_pts, input_views)
 
 
+class NeRF(_PackedNet):
+    """The fine network stages 1/2 train and save (helpers:792-847): 8 pts layers with a skip-concat of the
+    position embedding after layer 4, alpha / feature heads, one view layer, rgb head.
+    ``forward(x[M, 63+27]) -> [M,4] = [rgb, alpha]``.  Same ``state_dict`` keys as the reference."""
+    _NET = ops.NET_NERFCLS
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = D, W, input_ch, input_ch_views, skips, use_viewdirs
+        self.pts_linears = nn.ModuleList([nn.Linear(input_ch, W)] +
+                                         [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + input_ch, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+        self._supported = (D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27 and list(skips) == [4] and use_viewdirs)
+
+    def _linears(self):
+        if not self._supported:
+            raise PnrfError('NeRF: the HIP kernels are built for D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True')
+        return list(self.pts_linears) + [self.feature_linear, self.alpha_linear, self.views_linears[0], self.rgb_linear]
+
+    def forward(self, x, input_views=None):
+        if input_views is None:
+            x, input_views = x[..., :self.input_ch].contiguous(), x[..., self.input_ch:self.input_ch + self.input_ch_views].contiguous()
+        return self.packed().forward(x, input_views)
+
+
 def weights_from_modules(min_max_ray_net, refine_net, network_fine):
     """{'sampler','refine','nerf'} weight dict for ``pronerf_amd.render.Renderer``."""
     return {'sampler': min_max_ray_net.weights(), 'refine': refine_net.weights(), 'nerf': network_fine.weights()}
@@ -193,17 +225,20 @@ def weights_from_modules(min_max_ray_net, refine_net, network_fine):
 
 def weights_from_state_dicts(mmr_sd, refine_sd, fine_sd):
     """Checkpoint state dicts (keys of run_S_eS_eN_alter_trt.py:476-481) -> weight dict.
-    ``fine_sd`` must carry DoNeRFTRT keys (``layers.{i}.*``); the ``NeRF``-class fine net that the
-    released stage-2 trainer saves is not handled by the kernels yet."""
+    ``fine_sd`` may carry DoNeRFTRT keys (``layers.{i}.*``) or the ``NeRF``-class keys (``pts_linears.*`` ...)
+    that the released stage-2 trainer actually saves; the kernel is chosen from them."""
     def stack(sd):
         n = len([k for k in sd if k.startswith('fc_backbone.') and k.endswith('.weight')])
         return {'W': [sd[f'fc_backbone.{i}.weight'] for i in range(n)] + [sd['fc_output.weight']],
                 'b': [sd[f'fc_backbone.{i}.bias'] for i in range(n)] + [sd['fc_output.bias']]}
-    if not any(k.startswith('layers.') for k in fine_sd):
-        raise PnrfError("fine-network state dict has no 'layers.*' keys: it was saved from the NeRF class "
-                        '(pts_linears.*), which the HIP kernels do not implement yet')
-    n = len([k for k in fine_sd if k.endswith('.weight')])
-    nerf = {'W': [fine_sd[f'layers.{i}.weight'] for i in range(n)], 'b': [fine_sd[f'layers.{i}.bias'] for i in range(n)]}
+    if any(k.startswith('pts_linears.') for k in fine_sd):        # NeRF class (what the released stage-2 trainer saves)
+        names = [f'pts_linears.{i}' for i in range(8)] + ['feature_linear', 'alpha_linear', 'views_linears.0', 'rgb_linear']
+        nerf = {'W': [fine_sd[f'{n}.weight'] for n in names], 'b': [fine_sd[f'{n}.bias'] for n in names]}
+    elif any(k.startswith('layers.') for k in fine_sd):           # DoNeRFTRT
+        n = len([k for k in fine_sd if k.endswith('.weight')])
+        nerf = {'W': [fine_sd[f'layers.{i}.weight'] for i in range(n)], 'b': [fine_sd[f'layers.{i}.bias'] for i in range(n)]}
+    else:
+        raise PnrfError("fine-network state dict has neither 'layers.*' (DoNeRFTRT) nor 'pts_linears.*' (NeRF) keys")
     return {'sampler': stack(mmr_sd), 'refine': stack(refine_sd), 'nerf': nerf}
 
 

@@ -106,8 +106,9 @@ def make_weights(seed: int = 0, kind: str = 'trained'):
     }
 
 
-def make_nerfcls_weights(seed: int = 0):
-    """Weights of the ``NeRF`` class fine net (default nn.Linear-style init, gain 2)."""
+def make_nerfcls_weights(seed: int = 0, head_scale: float = 1.0):
+    """Weights of the ``NeRF`` class fine net (default nn.Linear-style init, gain 2).  ``head_scale`` < 1
+    shrinks the rgb / alpha heads to trained-like magnitudes (logits of a few units)."""
     rs = np.random.RandomState(7919 * (seed + 1))
     t = nerfcls_layer_dims()
     out = {}
@@ -120,6 +121,10 @@ def make_nerfcls_weights(seed: int = 0):
     out['feature_linear'] = lin(*t['feature_linear'])
     out['alpha_linear'] = lin(*t['alpha_linear'])
     out['rgb_linear'] = lin(*t['rgb_linear'])
+    if head_scale != 1.0:
+        for k in ('alpha_linear', 'rgb_linear'):
+            W, b = out[k]
+            out[k] = ((W * head_scale).astype(np.float32), b)
     return out
 
 

@@ -222,3 +222,39 @@ def test_refine_and_nerf_stages(dev):
     r = orc.raw2outputs(raw.cpu(), o['z'], fr['rays'][:, 3:6], o['add_sorted'], o['mul_sorted'])
     np.testing.assert_allclose(rgbd[:, :3].cpu().numpy(), r[0].numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(rgbd[:, 3].cpu().numpy(), r[4].numpy(), rtol=0, atol=2e-6)
+
+
+def test_nerf_class_network(dev, golden_dir):
+    """The NeRF class (skip-concat, feature/alpha heads, view branch) — module-level forward against the oracle and
+    the reference-generated fixture, and the fused render path with it as the fine net."""
+    from pronerf_amd import ops
+    from pronerf_amd.render import Renderer
+    wc = synth.make_nerfcls_weights(0)
+    names = ['pts_linears'] * 8
+    Ws = [w for w, _ in wc['pts_linears']] + [wc['feature_linear'][0], wc['alpha_linear'][0], wc['views_linears'][0][0], wc['rgb_linear'][0]]
+    bs = [b for _, b in wc['pts_linears']] + [wc['feature_linear'][1], wc['alpha_linear'][1], wc['views_linears'][0][1], wc['rgb_linear'][1]]
+    mlp = ops.PackedMLP(ops.NET_NERFCLS, Ws, bs)
+    g = dict(np.load(os.path.join(golden_dir, 'operators.npz')))
+    x = torch.from_numpy(g['nc_x'])
+    got = mlp.forward(cu(x[:, :63], dev), cu(x[:, 63:], dev)).cpu()
+    assert relrms(got, torch.from_numpy(g['nc_y'])) < 2e-2, relrms(got, torch.from_numpy(g['nc_y']))
+    rs = np.random.RandomState(1)
+    for m in (1, 130, 517):
+        x = torch.from_numpy(rs.uniform(-1, 1, (m, 90)).astype(np.float32))
+        ref = orc.nerfcls_forward(wc, x)
+        got = mlp.forward(cu(x[:, :63], dev), cu(x[:, 63:], dev)).cpu()
+        assert relrms(got, ref) < 2e-2, (m, relrms(got, ref))
+    # fused render with the NeRF-class fine net (trained-like head magnitudes, as for the DoNeRFTRT 'trained' set)
+    wc = synth.make_nerfcls_weights(0, head_scale=0.3)
+    Ws = [w_ for w_, _ in wc['pts_linears']] + [wc['feature_linear'][0], wc['alpha_linear'][0], wc['views_linears'][0][0], wc['rgb_linear'][0]]
+    bs = [b_ for _, b_ in wc['pts_linears']] + [wc['feature_linear'][1], wc['alpha_linear'][1], wc['views_linears'][0][1], wc['rgb_linear'][1]]
+    w = synth.make_weights(0, 'trained')
+    scene = synth.make_scene(0, H=20, W=27, rotate=True)
+    fr = orc.frame_setup(scene)
+    o = orc.render_rays_infer({**w, 'nerfcls': wc}, fr['rays'], fr['or_rays'], fr['images'], fr['proj'], nerf='cls')
+    rend = Renderer({**w, 'nerf': {'W': Ws, 'b': bs}}, max_rays=20 * 27, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rgbd, idx = rend.render_rays(cu(fr['rays'], dev), cu(fr['or_rays'], dev), want_idx=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), o['sort_idx'].numpy())
+    assert orc.psnr(rgbd[:, :3].cpu(), o['rgb']) > 46.4
+    np.testing.assert_allclose(rgbd[:, 3].cpu().numpy(), o['depth'].numpy(), rtol=0, atol=2e-2)
