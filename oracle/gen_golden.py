@@ -219,9 +219,91 @@ def run_operator_cases(helpers, iw, trt):
     print('operators ->', os.path.getsize(path) // 1024, 'KiB')
 
 
+def load_stage2():
+    spec = importlib.util.spec_from_file_location('ref_s2', os.path.join(REF, 'run_S_eS_eN_alter_base_refine2.py'))
+    s2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(s2)
+    return s2
+
+
+def run_stage2_case(helpers, s2, name, seed, H, W, nv, randomize, white_bkgd, sigma_t=0.2):
+    """Stage-2 training-time render_rays of the reference (run_S_eS_eN_alter_base_refine2.py:525-680) on seeded inputs;
+    the random draws it makes (random.sample / random.random / torch.normal / torch.randn) are captured as inputs."""
+    import random as pyrandom
+    torch.manual_seed(3407); pyrandom.seed(3407 + seed)
+    S, NB, P = synth.N_SAMPLES, synth.NUM_NEIGHBOR, synth.N_POINT_RAY_ENC
+    w = synth.make_weights(seed, 'trained')
+    wc = synth.make_nerfcls_weights(seed, head_scale=0.3)
+    sd = synth.state_dicts(w)
+    sampler = helpers.MinMaxRay_Net(D=synth.MMNETDEPTH, W=synth.MMNETWIDTH, input_ch=6 * P, output_ch=3 * S + 3, skips=[10000])
+    refine = helpers.MinMaxRay_Net(D=synth.MMNETDEPTH, W=synth.MMNETWIDTH, input_ch=6 * S + 3 * NB * S, output_ch=4 * S + 3, skips=[10000])
+    fine = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    sampler.load_state_dict(sd['sampler']); refine.load_state_dict(sd['refine']); fine.load_state_dict(synth.nerfcls_state_dict(wc))
+    scene = synth.make_scene(seed, H=H, W=W, n_views=nv, sigma_t=sigma_t, rotate=True)
+    own = 2                                             # the rays come from training view `own`
+    K = torch.from_numpy(scene['K']); poses = torch.from_numpy(scene['poses']); c2w = poses[own]
+    rays_o, rays_d = helpers.get_rays(H, W, K, c2w)
+    viewdirs = (rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float()
+    or_o, or_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    N = or_o.shape[0]
+    or_rays = torch.cat([or_o, or_d, torch.ones(N, 1), 10 * torch.ones(N, 1), viewdirs], -1)
+    o, d = helpers.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    o, d = o.reshape(-1, 3).float(), d.reshape(-1, 3).float()
+    rays = torch.cat([o, d, 1e-6 * torch.ones(N, 1) * 0, torch.ones(N, 1), viewdirs], -1)     # near 0, far 1 (refine2.py:794-795 / fern_refine.txt)
+    embed_fn, _ = helpers.get_embedder(synth.MULTIRES, 0)
+    embeddirs_fn, _ = helpers.get_embedder(synth.MULTIRES_VIEWS, 0)
+    query = lambda inputs, vd, fn: s2.run_network(inputs, vd, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn)
+    cap = {}
+    o_sample, o_rand, o_normal, o_randn = pyrandom.sample, pyrandom.random, torch.normal, torch.randn
+
+    def p_sample(pop, k):
+        r = o_sample(pop, k); cap['order_idx'] = np.array(sorted(r), dtype=np.int64); return r
+
+    def p_random():
+        r = o_rand(); cap['coin'] = np.float64(r); return r
+
+    def p_normal(*a, **k):
+        r = o_normal(*a, **k); cap['normal'] = r.clone(); return r
+
+    def p_randn(*a, **k):
+        r = o_randn(*a, **k); cap['randn'] = r.clone(); return r
+
+    pyrandom.sample, pyrandom.random, torch.normal, torch.randn = p_sample, p_random, p_normal, p_randn
+    try:
+        with torch.no_grad():
+            ret = s2.render_rays(rays, or_rays, network_fn=None, network_query_fn=query, N_samples=S, network_fine=fine,
+                                 white_bkgd=white_bkgd, raw_noise_std=1.0, min_max_ray_net=sampler, refine_net=refine, N_point_ray_enc=P,
+                                 embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, randomize=randomize, embed_rays=helpers.Pluecker(),
+                                 images=torch.from_numpy(scene['images']), poses=poses, ref_K=K, num_neighbor=NB,
+                                 batch_rays_nearest_id=torch.full((N, 1), own, dtype=torch.int64), target_pose=c2w,
+                                 train_nerf=True, iter=1000)
+    finally:
+        pyrandom.sample, pyrandom.random, torch.normal, torch.randn = o_sample, o_rand, o_normal, o_randn
+    g = lambda t: t.detach().cpu().numpy()
+    out = dict(seed=np.int64(seed), H=np.int64(H), W=np.int64(W), nv=np.int64(nv), own=np.int64(own), randomize=np.bool_(randomize),
+               white_bkgd=np.bool_(white_bkgd), sigma_t=np.float32(sigma_t), rays=g(rays), or_rays=g(or_rays),
+               rgb_map0=g(ret['rgb_map0']), rgb_map1=g(ret['rgb_map1']), depth_map=g(ret['depth_map']), mm_rgb=g(ret['mm_rgb']),
+               z_vals=g(ret['z_vals']), z_vals0=g(ret['z_vals0']))
+    if randomize:
+        jit = torch.abs(cap['normal'] / 5).clamp(max=1 - 2e-6)
+        out.update(order_idx=cap['order_idx'], jitter=g(jit), jitter_dir=np.int64(1 if cap['coin'] > 0.5 else -1))
+    if 'randn' in cap:
+        out.update(raw_noise=g(cap['randn']))
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **out)
+    print(f'{name}: N={N} rgb mean={out["rgb_map1"].mean():.4f} -> {os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024} KiB')
+
+
 def main():
     helpers, iw, trt = load_reference()
+    s2 = load_stage2()
     os.makedirs(OUT, exist_ok=True)
+    if '--stage2-only' not in sys.argv:
+        main_infer(helpers, iw, trt)
+    run_stage2_case(helpers, s2, 'stage2_train_16x20', 0, 16, 20, 7, True, False)
+    run_stage2_case(helpers, s2, 'stage2_eval_white_12x18', 1, 12, 18, 6, False, True)
+
+
+def main_infer(helpers, iw, trt):
     run_operator_cases(helpers, iw, trt)
     # (name, seed, kind, H, W, Hf, Wf, rotate, sigma_t, take)
     run_infer_case(helpers, iw, trt, 'infer_trained_24x32', 0, 'trained', 24, 32)

@@ -307,6 +307,98 @@ def render_rays_infer(weights, rays, or_rays, images, proj, mm_input=None, n_sam
             'rgb': rgb, 'disp': disp, 'acc': acc, 'weights': wts, 'depth': dmap}
 
 
+# ----------------------------------------------------------------------------- stage-2 (training) forward
+def project_train(images_nchw, poses, K, or_o, or_d, depth_ndc, ref_nos, eps=1e-5):
+    """Training-variant neighbour projection with valid-mask mean fill.
+    inverse_warp.py:515-581 (inverse_warp_rod1_rt2_coords) + run_S_eS_eN_alter_base_refine2.py:570-626.
+
+    images_nchw [nv,3,Hf,Wf] (all training views); poses [nv,3,4] camera-to-world; K [3,3];
+    ref_nos [N,nb] per-ray indices of the source views; depth_ndc [N,S] sorted sampler depths.
+    c2 = R^T w - R^T t;  c2 /= (|c2.z| + 1e-8);  c2.z = 1;  c2.y = -c2.y;  p = K c2;  samples whose
+    normalised X or Y leaves [-1,1] give 0;  valid = (sum_c rgb > 0);  invalid (k,s) entries are replaced
+    by the mean over the valid neighbours of that sample.
+    Returns (epi [N, nb*S*3] with index (k*S+s)*3+c, margin [N]): margin = the smallest distance of any of the
+    ray's normalised coordinates to the in/out boundary |x| = 1 — the mask is discontinuous there, so
+    comparisons at fp32 round-off are only meaningful for rays with margin > ~1e-5."""
+    N, S = depth_ndc.shape
+    nb = ref_nos.shape[1]
+    _, _, Hf, Wf = images_nchw.shape
+    poses, K = _t(poses), _t(K)
+    z3d = 1.0 / (1.0 - depth_ndc - eps)                                         # refine2.py:570
+    Rt = poses[:, :, :3].transpose(1, 2)                                        # inverse_warp.py:530-533
+    tt = -torch.bmm(Rt, poses[:, :, 3:4])[:, :, 0]
+    vals = torch.zeros(N, nb, S, 3)
+    margin = torch.full((N,), float('inf'))
+    for k in range(nb):
+        v = ref_nos[:, k].long()
+        for s in range(S):
+            w = or_o + or_d * z3d[:, s:s + 1]                                   # inverse_warp.py:536
+            c2 = torch.einsum('nij,nj->ni', Rt[v], w) + tt[v]                   # :539
+            zz = c2[:, 2:3].abs()
+            c2n = c2 / (zz + 1e-8)                                              # :543-544
+            c2n = torch.stack([c2n[:, 0], -c2n[:, 1], torch.ones_like(c2n[:, 0])], -1)   # :545-546
+            p = c2n @ K.T                                                       # :547
+            X, Y = p[:, 0], p[:, 1]
+            xn = 2 * X / (Wf - 1) - 1; yn = 2 * Y / (Hf - 1) - 1                # :552-553
+            inside = (xn <= 1) & (xn >= -1) & (yn <= 1) & (yn >= -1)            # :558-562 (outside -> coordinate 2 -> zero)
+            margin = torch.minimum(margin, torch.minimum((xn.abs() - 1).abs(), (yn.abs() - 1).abs()))
+            out = torch.zeros(N, 3)
+            for vi in v.unique().tolist():
+                m = (v == vi) & inside
+                if m.any():
+                    out[m] = bilinear_zeros(images_nchw[vi], X[m], Y[m]).T
+            vals[:, k, s, :] = out
+    valid = (vals.sum(-1, keepdim=True) > 0).to(vals.dtype).expand(-1, -1, -1, 3)   # refine2.py:622
+    mean = (valid * vals).sum(1, keepdim=True) / (valid.sum(1, keepdim=True) + 1e-6)    # :623
+    vals = vals * valid + mean * (1 - valid)                                            # :624
+    return vals.reshape(N, nb * S * 3), margin                                          # :626
+
+
+def select_neighbors_train(target_poses, poses, num_neighbor, order_idx=None):
+    """Per-ray ranking of the training cameras by distance to the ray's own camera.
+    refine2.py:590-600: randomize -> drop rank 0 (self) and take the rank positions ``order_idx`` (a sorted random
+    subset drawn once per batch); evaluation (order_idx None) -> ranks 0..num_neighbor-1."""
+    d = ((target_poses[:, None, :, 3] - poses[None, :, :, 3]) ** 2).sum(2) ** 0.5
+    idx = torch.sort(d, dim=1, stable=True)[1]
+    if order_idx is None:
+        return idx[:, :num_neighbor]
+    return idx[:, 1:][:, torch.as_tensor(order_idx).long()]
+
+
+def render_rays_stage2(weights, rays, or_rays, images_nchw, poses, K, ref_nos, jitter=None, jitter_dir=1, raw_noise=None,
+                       white_bkgd=False, n_samples=8, n_pts=48, eps=1e-5):
+    """Stage-2 (refine) training-time ``render_rays`` forward with the random draws made explicit.
+    run_S_eS_eN_alter_base_refine2.py:525-680.  weights: 'sampler', 'refine' (stacks) and 'nerfcls' (NeRF class).
+    jitter [N,S] = min(|N(0,1)|/5, 1-2e-6) (refine2.py:649-653), jitter_dir +1 = toward the next sample / far,
+    -1 = toward the previous / near (the coin flip, :654-661); raw_noise [N,S] = randn*raw_noise_std (:497)."""
+    S = n_samples
+    N = rays.shape[0]
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    viewdirs = rays[:, -3:]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    mm_rgb, add, mul, depth = sampler_forward(weights['sampler'], mm_input_from_rays(o, d, n_pts), S)     # :551-563
+    depth_sorted, idx, add_s, mul_s = sort_gather(depth, add, mul, near, far)                               # :563-568
+    epi, margin = project_train(images_nchw, poses, K, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, ref_nos, eps)   # :570-626
+    pl = pluecker(o[:, None, :] + d[:, None, :] * depth_sorted[..., None], d[:, None, :].expand(-1, S, -1)).reshape(N, 6 * S)
+    refine_in = torch.cat([pl, epi], 1)                                                                      # :634
+    rdepth, refine_rgb, offs = refine_forward(weights['refine'], refine_in, S)                               # :635-638
+    z = interval_refine(depth_sorted, rdepth, near, far)                                                     # :640-643
+    if jitter is not None:                                                                                   # :646-662
+        if jitter_dir > 0:
+            diff = (z - torch.cat([z[:, 1:], far * torch.ones(N, 1)], 1)).abs()
+            z = z + jitter * diff
+        else:
+            diff = (z - torch.cat([near * torch.ones(N, 1), z[:, :-1]], 1)).abs()
+            z = z - jitter * diff
+    pts = o[:, None, :] + d[:, None, :] * z[..., None] + 1e-2 * offs.reshape(N, S, 3)                        # :666-668
+    emb = torch.cat([posenc(pts.reshape(-1, 3), 10), posenc(viewdirs[:, None, :].expand(-1, S, -1).reshape(-1, 3), 4)], -1)
+    raw = nerfcls_forward(weights['nerfcls'], emb).reshape(N, S, 4)                                          # :669
+    rgb, disp, acc, wts, dmap = raw2outputs(raw, z, d, add_s, mul_s, noise=raw_noise, white_bkgd=white_bkgd)  # :674
+    return {'rgb_map0': refine_rgb, 'rgb_map1': rgb, 'depth_map': dmap, 'mm_rgb': mm_rgb, 'z_vals': z.mean(-1),
+            'z_vals0': depth_sorted.mean(-1), 'depth_sorted': depth_sorted, 'sort_idx': idx, 'add_sorted': add_s, 'mul_sorted': mul_s,
+            'epi': epi, 'edge_margin': margin, 'refine_in': refine_in, 'z': z, 'pts': pts, 'raw': raw, 'acc': acc, 'weights': wts}
+
+
 def psnr(a, b, peak=1.0):
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float('inf') if mse == 0 else 10.0 * math.log10(peak * peak / mse)

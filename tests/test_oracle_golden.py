@@ -104,3 +104,28 @@ def test_operator_goldens(golden_dir):
     wc = synth.make_nerfcls_weights(0)
     y = orc.nerfcls_forward(wc, torch.from_numpy(g['nc_x']))
     np.testing.assert_allclose(y.numpy(), g['nc_y'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['stage2_train_16x20', 'stage2_eval_white_12x18'])
+def test_stage2_forward_matches_reference(golden_dir, name):
+    """Stage-2 training-time render_rays (refine2.py:525-680) with the reference's random draws replayed."""
+    g = load(golden_dir, name)
+    seed = int(g['seed'])
+    scene = synth.make_scene(seed, H=int(g['H']), W=int(g['W']), n_views=int(g['nv']), sigma_t=float(g['sigma_t']), rotate=True)
+    w = synth.make_weights(seed, 'trained')
+    w['nerfcls'] = synth.make_nerfcls_weights(seed, head_scale=0.3)
+    poses = torch.from_numpy(scene['poses'])
+    rays, or_rays = torch.from_numpy(g['rays']), torch.from_numpy(g['or_rays'])
+    N = rays.shape[0]
+    tp = poses[int(g['own'])][None].expand(N, -1, -1)
+    rand = bool(g['randomize'])
+    ref_nos = orc.select_neighbors_train(tp, poses, 4, g['order_idx'] if rand else None)
+    images = torch.from_numpy(scene['images']).permute(0, 3, 1, 2).contiguous()
+    out = orc.render_rays_stage2(w, rays, or_rays, images, poses, scene['K'], ref_nos,
+                                 jitter=torch.from_numpy(g['jitter']) if rand else None, jitter_dir=int(g['jitter_dir']) if rand else 1,
+                                 raw_noise=torch.from_numpy(g['raw_noise']), white_bkgd=bool(g['white_bkgd']))
+    m = (out['edge_margin'] > 1e-5).numpy()          # away from the in/out-of-image discontinuity of the projection mask
+    assert m.mean() > 0.5
+    for k in ('mm_rgb', 'z_vals0', 'z_vals', 'rgb_map0', 'depth_map', 'rgb_map1'):
+        np.testing.assert_allclose(out[k].numpy()[m], g[k][m], rtol=0, atol=3e-4, err_msg=k)
+    assert orc.psnr(out['rgb_map1'][torch.from_numpy(m)], torch.from_numpy(g['rgb_map1'][m])) > 75.0
