@@ -88,6 +88,13 @@ int pnrf_ndc_rays_fwd(const float* rays_o, const float* rays_d, int H, int W, fl
 int pnrf_warp_trt_fwd(const float* img, const float* depth, const float* ro1, const float* rd1,
                       int64_t ray_bstride, const float* w2c, float* out, int B, int Hf, int Wf,
                       int64_t n, void* stream);
+/* inverse_warp_rod1_rt2_coords (training variant): c2 = R^T w - R^T t, c2 /= |c2.z|+1e-8, c2.z = 1, c2.y = -c2.y,
+ * p = K c2; samples whose normalised X or Y leaves [-1,1] give 0.  img dev [B,3,Hf,Wf]; depth dev [B,n]; ro1, rd1 dev
+ * [3,n] per batch entry (batch stride ray_bstride floats, 0 = shared); c2w2 dev [B,3,4]; K dev [B,3,3]; out dev
+ * [B,3,n]  (inverse_warp.py:515-581). */
+int pnrf_warp_train_fwd(const float* img, const float* depth, const float* ro1, const float* rd1,
+                        int64_t ray_bstride, const float* c2w2, const float* K, float* out, int B, int Hf,
+                        int Wf, int64_t n, void* stream);
 /* Neighbour images [nv,3,Hf,Wf] -> texel-interleaved [nv,Hf,Wf,4] used by the fused projection
  * (replaces the x8 image replication of run_S_eS_eN_alter_trt.py:296-298). */
 int pnrf_images_pack(const float* img_nchw, float* out_nhwc4, int nv, int Hf, int Wf, void* stream);
@@ -97,6 +104,16 @@ int pnrf_images_pack(const float* img_nchw, float* out_nhwc4, int nv, int Hf, in
 int pnrf_refine_input_fwd(const float* rays, const float* or_rays, const float* depth_sorted,
                           const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
                           float* refine_in, int64_t n, void* stream);
+/* Training-time refine_in[n,144]: like pnrf_refine_input_fwd but with per-ray source views ref_nos dev [n,4] (int64,
+ * indices into the nv training views img4 dev [nv,Hf,Wf,4] / poses dev [nv,3,4] camera-to-world), the training
+ * projection (pnrf_warp_train_fwd) and the valid-mask mean fill: valid = (sum_c rgb > 0), invalid (view, sample)
+ * entries are replaced by the mean over the valid views of that sample.  K dev [3,3].  layout 0: epi index
+ * (k*8+s)*3+c (stage 2); 1: s*12+k*3+c (stage 1).
+ * (run_S_eS_eN_alter_base_refine2.py:570-634; run_S_eS_eN_alter_base.py:607-673) */
+int pnrf_refine_input_train_fwd(const float* rays, const float* or_rays, const float* depth_sorted,
+                                const float* img4, const float* poses, const float* K, const int64_t* ref_nos,
+                                int nv, int nb, int Hf, int Wf, float eps, int layout, float* refine_in,
+                                int64_t n, void* stream);
 /* raw2outputs (infer variant; clamp/noise/white_bkgd select the training variants):
  * raw dev [n,s,4]; z dev [n,s]; rays_d dev [n,3] with row stride d_stride floats; add,mul dev
  * [n,s] or NULL; noise dev [n,s] or NULL.  Outputs (any may be NULL): rgb[n,3], disp[n],
@@ -119,6 +136,13 @@ int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* d
  * Outputs dev: z[n,8], pts[n,8,3]  (run_S_eS_eN_alter_trt.py:668-681). */
 int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
                     const float* depth_sorted, float* z, float* pts, int64_t n, void* stream);
+/* Training-time refine stage (stage 2): as pnrf_refine_fwd, plus the depth jitter of refine2.py:646-662 —
+ * jitter dev [n,8] = min(|N(0,1)|/5, 1-2e-6) or NULL, jitter_dir +1 (toward the next refined sample / far) or -1 (toward
+ * the previous / near): z += dir * jitter * |z - neighbour| — and the refine rgb head rgb0 dev [n,3] =
+ * sigmoid(y[32:35]) (rgb_map0) or NULL.  (run_S_eS_eN_alter_base_refine2.py:635-668) */
+int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
+                          const float* depth_sorted, const float* jitter, int jitter_dir, float* z, float* pts,
+                          float* rgb0, int64_t n, void* stream);
 /* NeRF: positional encoding of pts/viewdirs -> bf16 MLP -> alpha compositing with the sampler's
  * density modulation.  pts dev [n,8,3]; rays dev [n,11]; z, add_sorted, mul_sorted dev [n,8].
  * Outputs dev: rgbd[n,4] = (r,g,b,depth); raw[n,8,4] optional (NULL to skip).  h may be a PNRF_NET_NERF or a
@@ -127,6 +151,13 @@ int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* ra
 int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
                   const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
                   int64_t n, void* stream);
+
+/* Training-time NeRF stage: as pnrf_nerf_fwd, plus noise dev [n,8] (= randn * raw_noise_std, added to sigma before
+ * the density modulation) or NULL, and white_bkgd (rgb += 1 - acc).
+ * (run_S_eS_eN_alter_base_refine2.py:497-520, 669-676) */
+int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
+                        const float* add_sorted, const float* mul_sorted, const float* noise, int white_bkgd,
+                        float* rgbd, float* raw, int64_t n, void* stream);
 
 /* ---- whole path: render_rays (inference) ----------------------------------------------------
  * A context owns the per-ray workspace for up to max_rays rays (allocated once). */

@@ -272,11 +272,14 @@ struct RefineArgs {
   const float* x;                                   // refine_in [n,144]
   const float* rays; const float* depth_sorted;     // fused consumer
   float* z; float* pts;
+  const float* jitter; int jitter_dir; float* rgb0;  // training mode: depth jitter [n,8] (>= 0), its direction, refine rgb head [n,3]
   float* y; const int* outmap; int head_act;        // module-level consumer
 };
 
-template <int NCB, int NW, bool FUSED>
+// MODE 0: module-level (x -> y); 1: fused inference epilogue; 2: fused training-time epilogue (depth jitter, refine rgb head)
+template <int NCB, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
+  constexpr bool FUSED = MODE != 0;
   constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
@@ -348,9 +351,33 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
       for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
       continue;
     }
-    layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
+    if constexpr (MODE == 1) {
+      layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
 #pragma unroll
-    for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
+      for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
+    } else {                   // training: tile 0 = refine + offsets, tile 1 = rgb head (rgb_map0, refine2.py:637)
+      f32x16 t1[NCB];
+      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(
+          st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
+          [&](int, int pc, f32x16(&acc)[NCB]) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) fin[cb][8 * pc + j] = acc[cb][8 * pc + j];
+          },
+          pre_last, t1);
+#pragma unroll
+      for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
+      if (a.rgb0 && h == 0) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          if (valid[cb]) {
+            a.rgb0[row[cb] * 3 + 0] = sigmoid_f(t1[cb][0]);
+            a.rgb0[row[cb] * 3 + 1] = sigmoid_f(t1[cb][1]);
+            a.rgb0[row[cb] * 3 + 2] = sigmoid_f(t1[cb][2]);
+          }
+      }
+    }
 
     // ---- fused epilogue: lane (ray, h) owns samples 4h..4h+3: reg 4a = refine logit, 4a+1..3 = offset
     static_for<NCB>([&](auto cbc) {
@@ -369,8 +396,31 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
         const float lower = __fmul_rn(0.5f, __fadd_rn(w[s4 + 1], w[s4]));       // trt.py:673-675
         const float upper = __fmul_rn(0.5f, __fadd_rn(w[s4 + 2], w[s4 + 1]));
         const float rf = sigmoid_f(fin[cb][4 * s4]);
-        const float zv = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), rf));   // :676
-        zz[s4] = zv;
+        zz[s4] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), rf));     // :676
+      }
+      if (MODE == 2) {           // depth jitter toward the next / previous refined sample (refine2.py:646-662)
+        const float o0 = __shfl_xor(zz[0], 32), o3 = __shfl_xor(zz[3], 32);     // the other half's first / last sample
+        if (a.jitter) {
+          const float4 jt = *(const float4*)(a.jitter + rr * 8 + 4 * h);
+          const float jv[4] = {jt.x, jt.y, jt.z, jt.w};
+          float zn[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            if (a.jitter_dir > 0) {
+              const float nxt = s4 < 3 ? zz[s4 < 3 ? s4 + 1 : 3] : (h == 0 ? o0 : far);
+              zn[s4] = __fadd_rn(zz[s4], __fmul_rn(jv[s4], fabsf(__fsub_rn(zz[s4], nxt))));
+            } else {
+              const float prv = s4 > 0 ? zz[s4 > 0 ? s4 - 1 : 0] : (h == 1 ? o3 : near);
+              zn[s4] = __fadd_rn(zz[s4], __fmul_rn(-jv[s4], fabsf(__fsub_rn(zz[s4], prv))));
+            }
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) zz[s4] = zn[s4];
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float zv = zz[s4];
         const float fx = tanhf(fin[cb][4 * s4 + 1]), fy = tanhf(fin[cb][4 * s4 + 2]), fz = tanhf(fin[cb][4 * s4 + 3]);
         pp[3 * s4 + 0] = __fadd_rn(__fadd_rn(ox, __fmul_rn(dx, zv)), __fmul_rn(1e-2f, fx));   // :679-681
         pp[3 * s4 + 1] = __fadd_rn(__fadd_rn(oy, __fmul_rn(dy, zv)), __fmul_rn(1e-2f, fy));
@@ -396,6 +446,7 @@ struct NerfArgs {
   const float* x; const float* xv; const int* in0; const int* inx;   // module-level producer
   const float* z; const float* add; const float* mul;                // fused consumer
   float* rgbd; float* raw;
+  const float* noise; int white_bkgd;                                // training-time compositing: sigma noise [n,8], white background
   float* y; const int* outmap;                      // module-level consumer
 };
 
@@ -599,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
       float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
       dist = __fmul_rn(dist, dn);                                                   // :583
       const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
-      const float sg = fmaxf(__fadd_rn(r3, ad), 0.f);
+      const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, a.noise[rr]) : r3, ad), 0.f);     // refine2.py:508
       float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
       alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                                     // :588
       const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
@@ -612,13 +663,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
       }
       const float wgt = __fmul_rn(alpha, T);
       const float c0 = __fmul_rn(wgt, cr), c1 = __fmul_rn(wgt, cg), c2 = __fmul_rn(wgt, cbv), c3 = __fmul_rn(wgt, zc);
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sa = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         s0 = __fadd_rn(s0, __shfl(c0, base + j));                                   // :591 sum over samples
         s1 = __fadd_rn(s1, __shfl(c1, base + j));
         s2 = __fadd_rn(s2, __shfl(c2, base + j));
         s3 = __fadd_rn(s3, __shfl(c3, base + j));                                   // :593 depth_map
+        sa = __fadd_rn(sa, __shfl(wgt, base + j));                                  // acc_map
+      }
+      if (a.white_bkgd) {                                                           // refine2.py:519-520
+        const float bg = __fsub_rn(1.f, sa);
+        s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg);
       }
       if (valid[cb] && h == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(s0, s1, s2, s3);
     });
@@ -699,6 +755,22 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
               : launch_mlp(sampler_kernel<1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 
+extern "C" int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays, const float* depth_sorted,
+                                     const float* jitter, int jitter_dir, float* z, float* pts, float* rgb0, int64_t n, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_REFINE, PNRF_E_ARG, "pnrf_refine_train_fwd: handle is not a refine net");
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (refine_in && rays && depth_sorted && z && pts)), PNRF_E_ARG, "pnrf_refine_train_fwd: null pointer / negative n");
+  PNRF_REQUIRE(!jitter || jitter_dir == 1 || jitter_dir == -1, PNRF_E_ARG, "pnrf_refine_train_fwd: jitter_dir must be +1 or -1");
+  if (n == 0) return 0;
+  RefineArgs a = {};
+  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  a.n = n;
+  a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
+  a.jitter = jitter; a.jitter_dir = jitter_dir; a.rgb0 = rgb0;
+  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  a.nbatch = (int)((n + 255) / 256);
+  return launch_mlp(refine_kernel<1, 8, 2>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+}
+
 extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
                                const float* depth_sorted, float* z, float* pts, int64_t n, void* stream) {
   PNRF_REQUIRE(h && h->net == PNRF_NET_REFINE, PNRF_E_ARG, "pnrf_refine_fwd: handle is not a refine net");
@@ -711,13 +783,19 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;            // both variants: 256 columns per workgroup batch
   a.nbatch = (int)((n + rows - 1) / rows);
-  return variant_1x8() ? launch_mlp(refine_kernel<1, 8, true>, a, 512, lds, a.nbatch, (hipStream_t)stream)
-                       : launch_mlp(refine_kernel<2, 4, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  return variant_1x8() ? launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream)
+                       : launch_mlp(refine_kernel<2, 4, 1>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
                              const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
                              int64_t n, void* stream) {
+  return pnrf_nerf_train_fwd(h, pts, rays, z, add_sorted, mul_sorted, nullptr, 0, rgbd, raw, n, stream);
+}
+
+extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
+                                   const float* add_sorted, const float* mul_sorted, const float* noise, int white_bkgd,
+                                   float* rgbd, float* raw, int64_t n, void* stream) {
   PNRF_REQUIRE(h && (h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS), PNRF_E_ARG, "pnrf_nerf_fwd: handle is not a nerf net");
   PNRF_REQUIRE(n >= 0 && (n == 0 || (pts && rays && z && add_sorted && mul_sorted && rgbd)), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer / negative n");
   if (n == 0) return 0;
@@ -725,6 +803,7 @@ extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float*
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = n;
   a.pts = pts; a.rays = rays; a.z = z; a.add = add_sorted; a.mul = mul_sorted; a.rgbd = rgbd; a.raw = raw;
+  a.noise = noise; a.white_bkgd = white_bkgd;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * 8 + rows - 1) / rows);
@@ -751,7 +830,7 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
     a.x = x; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
-    return launch_mlp(refine_kernel<1, 4, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+    return launch_mlp(refine_kernel<1, 4, 0>, a, 256, lds, a.nbatch, (hipStream_t)stream);
   }
   NerfArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;

@@ -246,6 +246,133 @@ __global__ void refine_input_kernel(const float* __restrict__ rays, const float*
   }
 }
 
+// ---------------------------------------------------------------- training-variant projection
+// inverse_warp_rod1_rt2_coords (inverse_warp.py:515-581): c2 = R^T w - R^T t; c2 /= |c2.z| + 1e-8; c2.z = 1; c2.y = -c2.y;
+// p = K c2; a sample whose normalised X or Y leaves [-1,1] yields 0; otherwise bilinear, zero padding, align_corners.
+__device__ __forceinline__ bool project_train(const float* __restrict__ pose /*3x4 c2w*/, const float* __restrict__ K /*3x3*/,
+                                              float w0, float w1, float w2, int Hf, int Wf, float& X, float& Y) {
+  // R2_ = R^T; t2_ = -(R^T t)  (bmm, K = 3)
+  float tt[3], c2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = pose[0 * 4 + i], r1 = pose[1 * 4 + i], r2 = pose[2 * 4 + i];       // row i of R^T = column i of R
+    tt[i] = -__fadd_rn(__fadd_rn(__fmul_rn(r0, pose[3]), __fmul_rn(r1, pose[7])), __fmul_rn(r2, pose[11]));
+    c2[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r0, w0), __fmul_rn(r1, w1)), __fmul_rn(r2, w2)), tt[i]);
+  }
+  const float z = __fadd_rn(fabsf(c2[2]), 1e-8f);
+  const float cx = __fdiv_rn(c2[0], z), cy = -__fdiv_rn(c2[1], z);
+  X = __fadd_rn(__fadd_rn(__fmul_rn(K[0], cx), __fmul_rn(K[1], cy)), K[2]);
+  Y = __fadd_rn(__fadd_rn(__fmul_rn(K[3], cx), __fmul_rn(K[4], cy)), K[5]);
+  const float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, X), (float)(Wf - 1)), 1.f);
+  const float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, Y), (float)(Hf - 1)), 1.f);
+  return xn <= 1.f && xn >= -1.f && yn <= 1.f && yn >= -1.f;
+}
+
+// stand-alone operator on planar images: one thread per (b, pixel)
+__global__ void warp_train_kernel(const float* __restrict__ img, const float* __restrict__ depth, const float* __restrict__ ro1,
+                                  const float* __restrict__ rd1, int64_t ray_bstride, const float* __restrict__ c2w2,
+                                  const float* __restrict__ Kmat, float* __restrict__ out, int B, int Hf, int Wf, int64_t n) {
+  const int64_t total = (int64_t)B * n;
+  const int64_t plane = (int64_t)Hf * Wf;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(q / n);
+    const int64_t i = q - (int64_t)b * n;
+    const float dep = depth[q];
+    const float* ro = ro1 + b * ray_bstride;
+    const float* rd = rd1 + b * ray_bstride;
+    const float w0 = __fadd_rn(ro[i], __fmul_rn(rd[i], dep)), w1 = __fadd_rn(ro[n + i], __fmul_rn(rd[n + i], dep)),
+                w2 = __fadd_rn(ro[2 * n + i], __fmul_rn(rd[2 * n + i], dep));
+    float X, Y;
+    const bool inside = project_train(c2w2 + b * 12, Kmat + b * 9, w0, w1, w2, Hf, Wf, X, Y);
+    int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
+    bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
+    const bool ok = inside && fin;
+    const bool okx0 = ok && x0 >= 0 && x0 < Wf, okx1 = ok && x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
+    const float* im = img + (int64_t)b * 3 * plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* pc = im + c * plane;
+      float acc = 0.f;
+      if (oky0 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0], __fmul_rn(wx0, wy0)));
+      if (oky0 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0 + 1], __fmul_rn(wx1, wy0)));
+      if (oky1 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0], __fmul_rn(wx0, wy1)));
+      if (oky1 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0 + 1], __fmul_rn(wx1, wy1)));
+      out[((int64_t)b * 3 + c) * n + i] = acc;
+    }
+  }
+}
+
+// Training refine_in: per-ray source views ref_nos[n,4], training projection, valid-mask mean fill
+// (refine2.py:570-634; base.py:607-673).  32 threads per ray, thread t = k*8+s; the 4 neighbours of a sample are the
+// lanes s, 8+s, 16+s, 24+s of the ray's 32-lane group.  layout 0: epi index (k*8+s)*3+c (stage 2 / inference);
+// layout 1: s*12+k*3+c (stage 1).
+__global__ void refine_input_train_kernel(const float* __restrict__ rays, const float* __restrict__ or_rays, const float* __restrict__ depth_sorted,
+                                          const float4* __restrict__ img4, const float* __restrict__ poses, const float* __restrict__ Kmat,
+                                          const int64_t* __restrict__ ref_nos, int nv, int Hf, int Wf, float eps, int layout,
+                                          float* __restrict__ out, int64_t n) {
+  const int64_t total = n * 32;
+  const int64_t plane = (int64_t)Hf * Wf;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (total + stride - 1) / stride;         // every lane runs every round: the shuffles below need full groups
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t q = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = q < total;
+    const int64_t ray = live ? q / 32 : n - 1;
+    const int t = (int)(q & 31);
+    const int k = t >> 3, s = t & 7;
+    const float dn = depth_sorted[ray * 8 + s];
+    const float* orr = or_rays + ray * 11;
+    const float z3d = __fdiv_rn(1.f, __fsub_rn(__fsub_rn(1.f, dn), eps));
+    const float w0 = __fadd_rn(orr[0], __fmul_rn(orr[3], z3d)), w1 = __fadd_rn(orr[1], __fmul_rn(orr[4], z3d)),
+                w2 = __fadd_rn(orr[2], __fmul_rn(orr[5], z3d));
+    int64_t view = ref_nos[ray * 4 + k];
+    view = view < 0 ? 0 : (view >= nv ? nv - 1 : view);
+    float X, Y;
+    const bool inside = project_train(poses + view * 12, Kmat, w0, w1, w2, Hf, Wf, X, Y);
+    int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
+    bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
+    const bool ok = inside && fin;
+    const bool okx0 = ok && x0 >= 0 && x0 < Wf, okx1 = ok && x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
+    const float4* im = img4 + view * plane;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 t00 = (oky0 && okx0) ? im[(int64_t)y0 * Wf + x0] : zero;
+    const float4 t01 = (oky0 && okx1) ? im[(int64_t)y0 * Wf + x0 + 1] : zero;
+    const float4 t10 = (oky1 && okx0) ? im[(int64_t)(y0 + 1) * Wf + x0] : zero;
+    const float4 t11 = (oky1 && okx1) ? im[(int64_t)(y0 + 1) * Wf + x0 + 1] : zero;
+    const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx1, wy0), a10 = __fmul_rn(wx0, wy1), a11 = __fmul_rn(wx1, wy1);
+    float v[3];
+    v[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.x, a00), __fmul_rn(t01.x, a01)), __fmul_rn(t10.x, a10)), __fmul_rn(t11.x, a11));
+    v[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.y, a00), __fmul_rn(t01.y, a01)), __fmul_rn(t10.y, a10)), __fmul_rn(t11.y, a11));
+    v[2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.z, a00), __fmul_rn(t01.z, a01)), __fmul_rn(t10.z, a10)), __fmul_rn(t11.z, a11));
+    // valid = (sum_c rgb > 0); mean over the valid neighbours of this sample, in k order (refine2.py:622-624)
+    const float valid = (__fadd_rn(__fadd_rn(v[0], v[1]), v[2]) > 0.f) ? 1.f : 0.f;
+    const int base = (threadIdx.x & 63 & 32) + s;
+    float cnt = 0.f, m[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float vk = __shfl(valid, base + kk * 8);
+      cnt = __fadd_rn(cnt, vk);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) m[c] = __fadd_rn(m[c], __fmul_rn(vk, __shfl(v[c], base + kk * 8)));
+    }
+    const float den = __fadd_rn(cnt, 1e-6f);
+    if (live) {
+      float* o = out + ray * 144 + 48 + (layout == 0 ? t * 3 : s * 12 + k * 3);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = __fadd_rn(__fmul_rn(v[c], valid), __fmul_rn(__fdiv_rn(m[c], den), __fsub_rn(1.f, valid)));
+      if (k == 0) {
+        const float* r = rays + ray * 11;
+        float hx, hy, hz, m0, m1, m2;
+        unit_dir(r[3], r[4], r[5], hx, hy, hz);
+        const float px = __fadd_rn(r[0], __fmul_rn(r[3], dn)), py = __fadd_rn(r[1], __fmul_rn(r[4], dn)), pz = __fadd_rn(r[2], __fmul_rn(r[5], dn));
+        cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
+        float* pl = out + ray * 144 + s * 6;
+        pl[0] = hx; pl[1] = hy; pl[2] = hz; pl[3] = m0; pl[4] = m1; pl[5] = m2;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- raw2outputs (trt.py:564-597; base.py:501-551; refine2.py:475-522)
 __global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
                                  const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
@@ -402,6 +529,30 @@ extern "C" int pnrf_composite_fwd(const float* raw, const float* z, const float*
   PNRF_REQUIRE(raw && z && rays_d, PNRF_E_ARG, "pnrf_composite_fwd: null pointer");
   hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise,
                      clampv, white_bkgd, rgb, disp, acc, weights, depth, n, s);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_warp_train_fwd(const float* img, const float* depth, const float* ro1, const float* rd1, int64_t ray_bstride,
+                                   const float* c2w2, const float* K, float* out, int B, int Hf, int Wf, int64_t n, void* stream) {
+  PNRF_REQUIRE(B >= 0 && n >= 0 && Hf >= 2 && Wf >= 2 && ray_bstride >= 0, PNRF_E_ARG, "pnrf_warp_train_fwd: bad sizes");
+  if (B == 0 || n == 0) return 0;
+  PNRF_REQUIRE(img && depth && ro1 && rd1 && c2w2 && K && out, PNRF_E_ARG, "pnrf_warp_train_fwd: null pointer");
+  hipLaunchKernelGGL(warp_train_kernel, dim3(grid_for((int64_t)B * n)), dim3(TPB), 0, (hipStream_t)stream, img, depth, ro1, rd1, ray_bstride, c2w2, K,
+                     out, B, Hf, Wf, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_refine_input_train_fwd(const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
+                                           const float* poses, const float* K, const int64_t* ref_nos, int nv, int nb, int Hf, int Wf,
+                                           float eps, int layout, float* refine_in, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && nb == 4 && nv >= 1 && Hf >= 2 && Wf >= 2 && (layout == 0 || layout == 1), PNRF_E_ARG,
+               "pnrf_refine_input_train_fwd: bad sizes (nb must be 4, got %d; layout 0|1, got %d)", nb, layout);
+  if (n == 0) return 0;
+  PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && poses && K && ref_nos && refine_in, PNRF_E_ARG, "pnrf_refine_input_train_fwd: null pointer");
+  hipLaunchKernelGGL(refine_input_train_kernel, dim3(grid_for(n * 32)), dim3(TPB), 0, (hipStream_t)stream, rays, or_rays, depth_sorted,
+                     (const float4*)img4, poses, K, ref_nos, nv, Hf, Wf, eps, layout, refine_in, n);
   PNRF_LAUNCH_CHECK();
   return 0;
 }

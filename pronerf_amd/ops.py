@@ -137,6 +137,57 @@ def warp_trt(img, depth, ro1, rd1, w2c):
     return out
 
 
+def warp_train(img, depth, ro1, rd1, c2w2, K):
+    """Training warp: img [B,3,Hf,Wf]; depth [B,n]; ro1, rd1 [3,n] (shared) or [B,3,n]; c2w2 [B,3,4]; K [B,3,3] -> [B,3,n]."""
+    img = _chk(img, 'img'); depth = _chk(depth, 'depth'); c2w2 = _chk(c2w2, 'c2w2', (3, 4)); K = _chk(K, 'intrinsics', (3, 3))
+    B, _, Hf, Wf = img.shape
+    n = depth.shape[-1]
+    if ro1.dim() == 3 and ro1.stride(0) == 0:
+        ro1, rd1 = ro1[0], rd1[0]
+    ro1 = _chk(ro1, 'ro1'); rd1 = _chk(rd1, 'rd1')
+    bstride = 3 * n if ro1.dim() == 3 else 0
+    out = torch.empty(B, 3, n, device=img.device, dtype=f32)
+    check(_lib.load().pnrf_warp_train_fwd(_ptr(img), _ptr(depth), _ptr(ro1), _ptr(rd1), bstride, _ptr(c2w2), _ptr(K), _ptr(out), B, Hf, Wf, n, _stream()),
+          'pnrf_warp_train_fwd')
+    return out
+
+
+def refine_input_train(rays, or_rays, depth_sorted, img4, poses, K, ref_nos, eps=1e-5, layout=0):
+    rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    img4 = _chk(img4, 'img4', (4,)); poses = _chk(poses, 'poses', (3, 4)); K = _chk(K, 'K', (3, 3))
+    if ref_nos.dtype != torch.int64 or not ref_nos.is_cuda or ref_nos.shape != (rays.shape[0], 4):
+        raise PnrfError(f'refine_input_train: ref_nos must be a GPU int64 tensor [n,4], got {ref_nos.dtype} {tuple(ref_nos.shape)}')
+    ref_nos = ref_nos.contiguous()
+    nv, Hf, Wf, _ = img4.shape
+    n = rays.shape[0]
+    out = torch.empty(n, 144, device=rays.device, dtype=f32)
+    check(_lib.load().pnrf_refine_input_train_fwd(_ptr(rays), _ptr(or_rays), _ptr(depth_sorted), _ptr(img4), _ptr(poses), _ptr(K), _ptr(ref_nos),
+                                                  nv, 4, Hf, Wf, eps, int(layout), _ptr(out), n, _stream()), 'pnrf_refine_input_train_fwd')
+    return out
+
+
+def refine_train_fwd(mlp, refine_in, rays, depth_sorted, jitter=None, jitter_dir=1, want_rgb0=True):
+    refine_in = _chk(refine_in, 'refine_in', (144,)); rays = _chk(rays, 'rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    jitter = None if jitter is None else _chk(jitter, 'jitter', (8,))
+    n, dev = rays.shape[0], rays.device
+    z = torch.empty(n, 8, device=dev, dtype=f32); pts = torch.empty(n, 8, 3, device=dev, dtype=f32)
+    rgb0 = torch.empty(n, 3, device=dev, dtype=f32) if want_rgb0 else None
+    check(_lib.load().pnrf_refine_train_fwd(mlp.handle, _ptr(refine_in), _ptr(rays), _ptr(depth_sorted), _ptr(jitter), int(jitter_dir),
+                                            _ptr(z), _ptr(pts), _ptr(rgb0), n, _stream()), 'pnrf_refine_train_fwd')
+    return z, pts, rgb0
+
+
+def nerf_train_fwd(mlp, pts, rays, z, add, mul, noise=None, white_bkgd=False, want_raw=False):
+    pts = _chk(pts, 'pts', (8, 3)); rays = _chk(rays, 'rays', (11,)); z = _chk(z, 'z', (8,)); add = _chk(add, 'add', (8,)); mul = _chk(mul, 'mul', (8,))
+    noise = None if noise is None else _chk(noise, 'noise', (8,))
+    n, dev = rays.shape[0], rays.device
+    rgbd = torch.empty(n, 4, device=dev, dtype=f32)
+    raw = torch.empty(n, 8, 4, device=dev, dtype=f32) if want_raw else None
+    check(_lib.load().pnrf_nerf_train_fwd(mlp.handle, _ptr(pts), _ptr(rays), _ptr(z), _ptr(add), _ptr(mul), _ptr(noise), int(bool(white_bkgd)),
+                                          _ptr(rgbd), _ptr(raw), n, _stream()), 'pnrf_nerf_train_fwd')
+    return rgbd, raw
+
+
 def images_pack(img_nchw):
     img = _chk(img_nchw, 'images')
     nv, c, Hf, Wf = img.shape
