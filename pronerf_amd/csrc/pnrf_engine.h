@@ -28,7 +28,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int FRAG_BYTES = 1024;                  // 64 lanes x 16 B
-constexpr int SLOT_FRAGS = 16;
+#ifndef PNRF_SLOT_FRAGS
+#define PNRF_SLOT_FRAGS 16
+#endif
+constexpr int SLOT_FRAGS = PNRF_SLOT_FRAGS;
 constexpr int SLOT_BYTES = SLOT_FRAGS * FRAG_BYTES;   // 16 KiB
 constexpr int NSLOTS = 4;                          // ring slots (64 KiB of LDS)
 constexpr int PD = 3;                              // slots in flight ahead of the consumer
@@ -149,7 +152,14 @@ __device__ __forceinline__ float act_f32(float v, int act) {
   // evaluated unconditionally: a source-level `v > 0 ? v : f(v)` is a real branch per value, which the
   // scheduler cannot interleave with MFMAs.  max(v,0) + expm1(min(v,0)) is exact in both cases.
   if (act == ACT_RELU) return fmaxf(v, 0.f);
-  const float e = expm1_neg(fminf(v, 0.f));
+#ifdef PNRF_EXACT_ELU
+  const float e = expm1_neg(fminf(v, 0.f));          // <= 1 ulp expm1, ~30 VALU per activation
+#else
+  // exp(x) - 1 through v_exp_f32: absolute error <= 6e-8 (one fp32 rounding of an O(1) activation) instead of expm1's
+  // relative 1e-7; measured on 61k rays x 5 weight sets: identical sort indices, max depth error 6.6e-7 vs 6.3e-7, and
+  // 13 % less sampler time (the ELU is ~30 VALU per activation otherwise, and VALU issue competes with the MFMAs).
+  const float e = __expf(fminf(v, 0.f)) - 1.f;
+#endif
   return fmaxf(v, 0.f) + e;
 }
 __device__ __forceinline__ float act_fast(float v, int act) {
