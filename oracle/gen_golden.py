@@ -293,14 +293,101 @@ def run_stage2_case(helpers, s2, name, seed, H, W, nv, randomize, white_bkgd, si
     print(f'{name}: N={N} rgb mean={out["rgb_map1"].mean():.4f} -> {os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024} KiB')
 
 
+def load_stage1():
+    spec = importlib.util.spec_from_file_location('ref_s1', os.path.join(REF, 'run_S_eS_eN_alter_base.py'))
+    s1 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(s1)
+    return s1
+
+
+def run_stage1_case(helpers, s1, name, seed, H, W, nv, train_sampler, pyseed, sigma_t=0.2):
+    """Stage-1 training-time render_rays of the reference (run_S_eS_eN_alter_base.py:554-761); odd steps
+    (train_sampler=False) take the exploration path.  Random draws are captured as inputs."""
+    import random as pyrandom
+    torch.manual_seed(3407); pyrandom.seed(pyseed)
+    S, NB, P = synth.N_SAMPLES, synth.NUM_NEIGHBOR, synth.N_POINT_RAY_ENC
+    w = synth.make_weights(seed, 'trained')
+    wc = synth.make_nerfcls_weights(seed, head_scale=0.3)
+    sd = synth.state_dicts(w)
+    sampler = helpers.MinMaxRay_Net(D=synth.MMNETDEPTH, W=synth.MMNETWIDTH, input_ch=6 * P, output_ch=3 * S + 3, skips=[10000])
+    refine = helpers.MinMaxRay_Net(D=synth.MMNETDEPTH, W=synth.MMNETWIDTH, input_ch=6 * S + 3 * NB * S, output_ch=4 * S + 3, skips=[10000])
+    fine = helpers.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    sampler.load_state_dict(sd['sampler']); refine.load_state_dict(sd['refine']); fine.load_state_dict(synth.nerfcls_state_dict(wc))
+    scene = synth.make_scene(seed, H=H, W=W, n_views=nv, sigma_t=sigma_t, rotate=True)
+    own = 1
+    K = torch.from_numpy(scene['K']); poses = torch.from_numpy(scene['poses']); c2w = poses[own]
+    rays_o, rays_d = helpers.get_rays(H, W, K, c2w)
+    viewdirs = (rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float()
+    or_o, or_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    N = or_o.shape[0]
+    or_rays = torch.cat([or_o, or_d, torch.ones(N, 1), 10 * torch.ones(N, 1), viewdirs], -1)
+    o, d = helpers.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    o, d = o.reshape(-1, 3).float(), d.reshape(-1, 3).float()
+    rays = torch.cat([o, d, 1e-6 * torch.ones(N, 1), torch.ones(N, 1), viewdirs], -1)          # near = 1e-6 (base.py:798)
+    embed_fn, _ = helpers.get_embedder(synth.MULTIRES, 0)
+    embeddirs_fn, _ = helpers.get_embedder(synth.MULTIRES_VIEWS, 0)
+    query = lambda inputs, vd, fn: s1.run_network(inputs, vd, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn)
+    cap = {'coins': [], 'normal': None, 'randn': None}
+    o_sample, o_rand, o_randint, o_normal, o_randn = pyrandom.sample, pyrandom.random, pyrandom.randint, torch.normal, torch.randn
+
+    def p_sample(pop, k):
+        r = o_sample(pop, k); cap['order_idx'] = np.array(sorted(r), dtype=np.int64); return r
+
+    def p_random():
+        r = o_rand(); cap['coins'].append(r); return r
+
+    def p_randint(a, b):
+        r = o_randint(a, b); cap['n_mult'] = r; return r
+
+    def p_normal(*a, **k):
+        r = o_normal(*a, **k); cap['normal'] = r.clone(); return r
+
+    def p_randn(*a, **k):
+        r = o_randn(*a, **k); cap['randn'] = r.clone(); return r
+
+    pyrandom.sample, pyrandom.random, pyrandom.randint, torch.normal, torch.randn = p_sample, p_random, p_randint, p_normal, p_randn
+    try:
+        with torch.no_grad():
+            ret = s1.render_rays(rays, or_rays, network_fn=fine, network_query_fn=query, N_samples=S, white_bkgd=False, raw_noise_std=1.0,
+                                 min_max_ray_net=sampler, refine_net=refine, N_point_ray_enc=P, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                                 randomize=True, embed_rays=helpers.Pluecker(), images=torch.from_numpy(scene['images']), poses=poses, ref_K=K,
+                                 num_neighbor=NB, batch_rays_nearest_id=torch.full((N, 1), own, dtype=torch.int64), target_pose=c2w,
+                                 train_nerf=True, train_sampler=train_sampler, epi_nerf=False, iter=1000)
+    finally:
+        pyrandom.sample, pyrandom.random, pyrandom.randint, torch.normal, torch.randn = o_sample, o_rand, o_randint, o_normal, o_randn
+    g = lambda t: t.detach().cpu().numpy()
+    out = dict(seed=np.int64(seed), H=np.int64(H), W=np.int64(W), nv=np.int64(nv), own=np.int64(own), train_sampler=np.bool_(train_sampler),
+               sigma_t=np.float32(sigma_t), rays=g(rays), or_rays=g(or_rays), order_idx=cap['order_idx'],
+               rgb_map0=g(ret['rgb_map0']), rgb_map1=g(ret['rgb_map1']), depth_map=g(ret['depth_map']), mm_rgb=g(ret['mm_rgb']),
+               depth_map0=g(ret['depth_map0']))
+    if train_sampler:
+        out.update(sigma1=g(ret['sigma1']))
+    else:
+        n_mult = cap['n_mult']
+        coins = cap['coins']
+        dir1 = (1 if coins[0] > 0.5 else -1) if n_mult > 1 else 1
+        dir2 = 1 if coins[-1] > 0.5 else -1
+        jit = torch.abs(cap['normal'] / 5).clamp(max=0.99)
+        out.update(n_mult=np.int64(n_mult), dir1=np.int64(dir1), dir2=np.int64(dir2), jitter=g(jit), raw_noise=g(cap['randn']))
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **out)
+    extra = '' if train_sampler else f' n_mult={out["n_mult"]} dir1={out["dir1"]} dir2={out["dir2"]}'
+    print(f'{name}: N={N} rgb mean={out["rgb_map1"].mean():.4f}{extra} -> {os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024} KiB')
+
+
 def main():
     helpers, iw, trt = load_reference()
     s2 = load_stage2()
     os.makedirs(OUT, exist_ok=True)
-    if '--stage2-only' not in sys.argv:
+    if '--stage2-only' not in sys.argv and '--stage1-only' not in sys.argv:
         main_infer(helpers, iw, trt)
-    run_stage2_case(helpers, s2, 'stage2_train_16x20', 0, 16, 20, 7, True, False)
-    run_stage2_case(helpers, s2, 'stage2_eval_white_12x18', 1, 12, 18, 6, False, True)
+    if '--stage1-only' not in sys.argv:
+        run_stage2_case(helpers, s2, 'stage2_train_16x20', 0, 16, 20, 7, True, False)
+        run_stage2_case(helpers, s2, 'stage2_eval_white_12x18', 1, 12, 18, 6, False, True)
+    s1 = load_stage1()
+    run_stage1_case(helpers, s1, 'stage1_joint_12x16', 0, 12, 16, 6, True, 11)
+    run_stage1_case(helpers, s1, 'stage1_explore_a_12x16', 1, 12, 16, 6, False, 5)
+    run_stage1_case(helpers, s1, 'stage1_explore_b_10x14', 2, 10, 14, 7, False, 8)
+    run_stage1_case(helpers, s1, 'stage1_explore_c_8x12', 3, 8, 12, 6, False, 4)        # n_mult = 8 (64 samples/ray), dir1 = -1
 
 
 def main_infer(helpers, iw, trt):

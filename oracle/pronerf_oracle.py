@@ -399,6 +399,65 @@ def render_rays_stage2(weights, rays, or_rays, images_nchw, poses, K, ref_nos, j
             'epi': epi, 'edge_margin': margin, 'refine_in': refine_in, 'z': z, 'pts': pts, 'raw': raw, 'acc': acc, 'weights': wts}
 
 
+def explore_samples(z, near, far, n_mult, dir1, jitter, dir2):
+    """Stage-1 exploration of the refined depths (run_S_eS_eN_alter_base.py:689-729) with its draws made explicit:
+    each of the 8 refined depths is replicated n_mult times toward the next (dir1 > 0) or previous (dir1 < 0) sample,
+    offsets linspace(0, 1-1/n_mult, n_mult) * |gap|, sorted; then z += dir2 * jitter * |z - neighbour| with
+    jitter [N, 8*n_mult] = min(|N(0,1)|/5, 0.99)."""
+    N = z.shape[0]
+    if n_mult > 1:
+        mults = torch.linspace(0, 1 - 1 / n_mult, n_mult)[None]
+        if dir1 > 0:
+            diff = (z - torch.cat([z[:, 1:], far * torch.ones(N, 1)], 1)).abs()
+            noise = mults[:, None, :] * diff[:, :, None]
+        else:
+            diff = (z - torch.cat([near * torch.ones(N, 1), z[:, :-1]], 1)).abs()
+            noise = -mults[:, None, :] * diff[:, :, None]
+        z = (z[:, :, None] + noise).reshape(N, -1)
+        z, _ = torch.sort(z, dim=-1)
+    if dir2 > 0:
+        diff = (z - torch.cat([z[:, 1:], far * torch.ones(N, 1)], 1)).abs()
+        return z + jitter * diff
+    diff = (z - torch.cat([near * torch.ones(N, 1), z[:, :-1]], 1)).abs()
+    return z - jitter * diff
+
+
+def render_rays_stage1(weights, rays, or_rays, images_nchw, poses, K, ref_nos, train_sampler, n_mult=1, dir1=1, jitter=None, dir2=1,
+                       raw_noise=None, white_bkgd=False, n_samples=8, n_pts=48):
+    """Stage-1 training-time ``render_rays`` forward (run_S_eS_eN_alter_base.py:554-761), random draws explicit.
+    train_sampler=True  (even steps): offsets added, compositing with the sampler's add/mul, no noise;
+    train_sampler=False (odd steps, randomize): exploration path (n_mult, dir1, jitter, dir2), no offsets, compositing
+    without add/mul and with sigma noise.  raw is clamped to +-10 (base.py:523); eps = 1e-6 (:607); epi is sample-major (:664-665)."""
+    S = n_samples
+    N = rays.shape[0]
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    viewdirs = rays[:, -3:]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    mm_rgb, add, mul, depth = sampler_forward(weights['sampler'], mm_input_from_rays(o, d, n_pts), S)
+    depth_sorted, idx, add_s, mul_s = sort_gather(depth, add, mul, near, far)
+    epi, margin = project_train(images_nchw, poses, K, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, ref_nos, 1e-6)
+    epi = epi.reshape(N, -1, S, 3).permute(0, 2, 1, 3).reshape(N, -1)                       # neighbour-major -> sample-major (:664-665)
+    pl = pluecker(o[:, None, :] + d[:, None, :] * depth_sorted[..., None], d[:, None, :].expand(-1, S, -1)).reshape(N, 6 * S)
+    refine_in = torch.cat([pl, epi], 1)
+    rdepth, refine_rgb, offs = refine_forward(weights['refine'], refine_in, S)
+    z = interval_refine(depth_sorted, rdepth, near, far)
+    if not train_sampler and jitter is not None:
+        z = explore_samples(z, near, far, n_mult, dir1, jitter, dir2)
+    Sx = z.shape[1]
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    if train_sampler:
+        pts = pts + 1e-2 * offs.reshape(N, S, 3)
+    emb = torch.cat([posenc(pts.reshape(-1, 3), 10), posenc(viewdirs[:, None, :].expand(-1, Sx, -1).reshape(-1, 3), 4)], -1)
+    raw = nerfcls_forward(weights['nerfcls'], emb).reshape(N, Sx, 4)
+    if train_sampler:
+        rgb, disp, acc, wts, dmap = raw2outputs(raw, z, d, add_s, mul_s, clamp=10.0, white_bkgd=white_bkgd)
+    else:
+        rgb, disp, acc, wts, dmap = raw2outputs(raw, z, d, noise=raw_noise, clamp=10.0, white_bkgd=white_bkgd)
+    return {'rgb_map0': refine_rgb, 'rgb_map1': rgb, 'depth_map': dmap, 'mm_rgb': mm_rgb, 'depth_map0': z.mean(-1), 'sigma1': raw[..., 3],
+            'depth_sorted': depth_sorted, 'sort_idx': idx, 'add_sorted': add_s, 'mul_sorted': mul_s, 'epi': epi, 'edge_margin': margin,
+            'refine_in': refine_in, 'z8': interval_refine(depth_sorted, rdepth, near, far), 'z': z, 'pts': pts, 'raw': raw}
+
+
 def psnr(a, b, peak=1.0):
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float('inf') if mse == 0 else 10.0 * math.log10(peak * peak / mse)

@@ -129,3 +129,29 @@ def test_stage2_forward_matches_reference(golden_dir, name):
     for k in ('mm_rgb', 'z_vals0', 'z_vals', 'rgb_map0', 'depth_map', 'rgb_map1'):
         np.testing.assert_allclose(out[k].numpy()[m], g[k][m], rtol=0, atol=3e-4, err_msg=k)
     assert orc.psnr(out['rgb_map1'][torch.from_numpy(m)], torch.from_numpy(g['rgb_map1'][m])) > 75.0
+
+
+@pytest.mark.parametrize('name', ['stage1_joint_12x16', 'stage1_explore_a_12x16', 'stage1_explore_b_10x14', 'stage1_explore_c_8x12'])
+def test_stage1_forward_matches_reference(golden_dir, name):
+    """Stage-1 training-time render_rays (base.py:554-761): joint step and the exploration path (8..64 samples per ray)."""
+    g = load(golden_dir, name)
+    seed, ts = int(g['seed']), bool(g['train_sampler'])
+    scene = synth.make_scene(seed, H=int(g['H']), W=int(g['W']), n_views=int(g['nv']), sigma_t=float(g['sigma_t']), rotate=True)
+    w = synth.make_weights(seed, 'trained')
+    w['nerfcls'] = synth.make_nerfcls_weights(seed, head_scale=0.3)
+    poses = torch.from_numpy(scene['poses'])
+    rays, or_rays = torch.from_numpy(g['rays']), torch.from_numpy(g['or_rays'])
+    N = rays.shape[0]
+    ref_nos = orc.select_neighbors_train(poses[int(g['own'])][None].expand(N, -1, -1), poses, 4, g['order_idx'])
+    images = torch.from_numpy(scene['images']).permute(0, 3, 1, 2).contiguous()
+    kw = {} if ts else dict(n_mult=int(g['n_mult']), dir1=int(g['dir1']), jitter=torch.from_numpy(g['jitter']), dir2=int(g['dir2']),
+                            raw_noise=torch.from_numpy(g['raw_noise']))
+    out = orc.render_rays_stage1(w, rays, or_rays, images, poses, scene['K'], ref_nos, ts, **kw)
+    if not ts:
+        assert out['z'].shape[1] == 8 * int(g['n_mult'])
+    m = (out['edge_margin'] > 1e-5).numpy()
+    assert m.mean() > 0.5
+    keys = ['mm_rgb', 'rgb_map0', 'depth_map0', 'depth_map', 'rgb_map1'] + (['sigma1'] if ts else [])
+    for k in keys:
+        np.testing.assert_allclose(out[k].numpy()[m], g[k][m], rtol=0, atol=5e-4, err_msg=k)
+    assert orc.psnr(out['rgb_map1'][torch.from_numpy(m)], torch.from_numpy(g['rgb_map1'][m])) > 70.0
