@@ -152,12 +152,22 @@ int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, cons
                   const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
                   int64_t n, void* stream);
 
-/* Training-time NeRF stage: as pnrf_nerf_fwd, plus noise dev [n,8] (= randn * raw_noise_std, added to sigma before
- * the density modulation) or NULL, and white_bkgd (rgb += 1 - acc).
- * (run_S_eS_eN_alter_base_refine2.py:497-520, 669-676) */
+/* Training-time NeRF stage: as pnrf_nerf_fwd, plus noise dev [n,S] (= randn * raw_noise_std, added to sigma before
+ * the density modulation) or NULL; clamp > 0 clamps raw to +-clamp first (stage 1: 10); white_bkgd (rgb += 1 - acc);
+ * add_sorted/mul_sorted may both be NULL (stage-1 odd steps composite without them); S samples per ray: pts dev
+ * [n,S,3].  S == 8: fused compositing into rgbd (raw optional).  S != 8 (stage-1 exploration, 16..256): rgbd must be
+ * NULL and raw dev [n,S,4] is written; composite it with pnrf_composite_fwd.
+ * (run_S_eS_eN_alter_base_refine2.py:497-520, 669-676; run_S_eS_eN_alter_base.py:523, 731-751) */
 int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
-                        const float* add_sorted, const float* mul_sorted, const float* noise, int white_bkgd,
-                        float* rgbd, float* raw, int64_t n, void* stream);
+                        const float* add_sorted, const float* mul_sorted, const float* noise, float clamp,
+                        int white_bkgd, int S, float* rgbd, float* raw, int64_t n, void* stream);
+/* Stage-1 exploration of the refined depths (run_S_eS_eN_alter_base.py:689-729): every one of the 8 depths z8 dev
+ * [n,8] is replicated n_mult times toward the next (dir1 = +1) or previous (-1) sample with offsets
+ * linspace(0, 1-1/n_mult, n_mult)*|gap|, the 8*n_mult values are sorted, then jittered: z += dir2 * jitter * |z -
+ * neighbour| with jitter dev [n, 8*n_mult] = min(|N(0,1)|/5, 0.99).  Outputs dev: z_out [n, 8*n_mult] and the query
+ * points pts_out [n, 8*n_mult, 3] = o + d*z (no learned offsets on these steps).  n_mult 1..32. */
+int pnrf_explore_fwd(const float* z8, const float* rays, const float* jitter, int n_mult, int dir1, int dir2,
+                     float* z_out, float* pts_out, int64_t n, void* stream);
 
 /* ---- whole path: render_rays (inference) ----------------------------------------------------
  * A context owns the per-ray workspace for up to max_rays rays (allocated once). */

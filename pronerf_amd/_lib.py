@@ -40,7 +40,8 @@ SIGNATURES = {
     'pnrf_warp_train_fwd': (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _i, _i, _i, _i64, _p]),
     'pnrf_refine_input_train_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _i64, _p]),
     'pnrf_refine_train_fwd': (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _p]),
-    'pnrf_nerf_train_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i64, _p]),
+    'pnrf_nerf_train_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p, _p, _i64, _p]),
+    'pnrf_explore_fwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _p]),
     'pnrf_images_pack': (_i, [_p, _p, _i, _i, _i, _p]),
     'pnrf_refine_input_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i64, _p]),
     'pnrf_composite_fwd': (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),

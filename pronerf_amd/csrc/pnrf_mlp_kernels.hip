@@ -447,6 +447,7 @@ struct NerfArgs {
   const float* z; const float* add; const float* mul;                // fused consumer
   float* rgbd; float* raw;
   const float* noise; int white_bkgd;                                // training-time compositing: sigma noise [n,8], white background
+  float clampv; int S;                                               // raw clamp (stage 1: 10), samples per ray (8; stage-1 exploration: 8..256)
   float* y; const int* outmap;                      // module-level consumer
 };
 
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   constexpr int COLS = 32 * NCB;
-  const int64_t nrows = FUSED ? a.n * 8 : a.n;
+  const int64_t nrows = FUSED ? a.n * a.S : a.n;
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
         // error (<= 2^k * 1e-7) is far below the bf16 rounding (2^-9) applied to the MLP input.
         const float* pp = a.pts + rr * 3;
         const float x3[3] = {pp[0], pp[1], pp[2]};
-        const float* vv = a.rays + (rr >> 3) * 11 + 8;
+        const float* vv = a.rays + (a.S == 8 ? (rr >> 3) : rr / a.S) * 11 + 8;
         const float v3[3] = {vv[0], vv[1], vv[2]};
         float f0[32], fx[16];
 #pragma unroll
@@ -634,25 +635,31 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
         if (valid[cb] && h == 0) *(float4*)(a.y + row[cb] * 4) = make_float4(fin[cb][0], fin[cb][1], fin[cb][2], fin[cb][3]);
       continue;
     }
-    // ---- fused epilogue: raw rgb-sigma of column `col` sits in regs 0-3 of half 0; the 8 samples of
-    // a ray are 8 adjacent lanes.  Compositing in the reference's sequential order (cumprod, sum).
+    // ---- fused epilogue: raw rgb-sigma of column `col` sits in regs 0-3 of half 0.  S != 8 (stage-1 exploration): only the
+    // raw output is written and pnrf_composite_fwd does the compositing.  S == 8: the 8 samples of a ray are 8 adjacent
+    // lanes; compositing in the reference's sequential order (cumprod, sum).
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
+      float r0 = fin[cb][0], r1 = fin[cb][1], r2 = fin[cb][2], r3 = fin[cb][3];
+      if (a.raw && valid[cb] && h == 0) *(float4*)(a.raw + row[cb] * 4) = make_float4(r0, r1, r2, r3);
+      if (a.S != 8 || !a.rgbd) return;
       const int64_t ray = rr >> 3;
       const int s = (int)(rr & 7);
       const float* r = a.rays + ray * 11;
       const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[3], r[3]), __fmul_rn(r[4], r[4])), __fmul_rn(r[5], r[5])));
-      const float zc = a.z[rr], ad = a.add[rr], mu = a.mul[rr];
-      const float r0 = fin[cb][0], r1 = fin[cb][1], r2 = fin[cb][2], r3 = fin[cb][3];
-      if (a.raw && valid[cb] && h == 0) *(float4*)(a.raw + row[cb] * 4) = make_float4(r0, r1, r2, r3);
+      const float zc = a.z[rr], ad = a.add ? a.add[rr] : 0.f, mu = a.mul ? a.mul[rr] : 1.f;
+      if (a.clampv > 0.f) {                                                         // base.py:523
+        r0 = fminf(fmaxf(r0, -a.clampv), a.clampv); r1 = fminf(fmaxf(r1, -a.clampv), a.clampv);
+        r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
+      }
       const float znext = __shfl_down(zc, 1);
       float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
       dist = __fmul_rn(dist, dn);                                                   // :583
       const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
       const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, a.noise[rr]) : r3, ad), 0.f);     // refine2.py:508
       float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
-      alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                                     // :588
+      if (a.mul) alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                          // :588
       const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
       const int base = lane & 0x38;
       float T = 1.f;
@@ -790,23 +797,27 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
                              const float* add_sorted, const float* mul_sorted, float* rgbd, float* raw,
                              int64_t n, void* stream) {
-  return pnrf_nerf_train_fwd(h, pts, rays, z, add_sorted, mul_sorted, nullptr, 0, rgbd, raw, n, stream);
+  PNRF_REQUIRE(n == 0 || (z && add_sorted && mul_sorted && rgbd), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer");
+  return pnrf_nerf_train_fwd(h, pts, rays, z, add_sorted, mul_sorted, nullptr, 0.f, 0, 8, rgbd, raw, n, stream);
 }
 
 extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
-                                   const float* add_sorted, const float* mul_sorted, const float* noise, int white_bkgd,
-                                   float* rgbd, float* raw, int64_t n, void* stream) {
+                                   const float* add_sorted, const float* mul_sorted, const float* noise, float clampv, int white_bkgd,
+                                   int S, float* rgbd, float* raw, int64_t n, void* stream) {
   PNRF_REQUIRE(h && (h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS), PNRF_E_ARG, "pnrf_nerf_fwd: handle is not a nerf net");
-  PNRF_REQUIRE(n >= 0 && (n == 0 || (pts && rays && z && add_sorted && mul_sorted && rgbd)), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer / negative n");
+  PNRF_REQUIRE(n >= 0 && S >= 1 && (n == 0 || (pts && rays)), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer / negative n / bad S");
+  PNRF_REQUIRE(n == 0 || (S == 8 ? ((rgbd && z) || raw) : (raw && !rgbd)), PNRF_E_ARG,
+               "pnrf_nerf_train_fwd: S == 8 needs rgbd (+z) or raw; S != 8 writes raw only (composite with pnrf_composite_fwd)");
+  PNRF_REQUIRE((add_sorted == nullptr) == (mul_sorted == nullptr), PNRF_E_ARG, "pnrf_nerf_train_fwd: add and mul go together");
   if (n == 0) return 0;
   NerfArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = n;
   a.pts = pts; a.rays = rays; a.z = z; a.add = add_sorted; a.mul = mul_sorted; a.rgbd = rgbd; a.raw = raw;
-  a.noise = noise; a.white_bkgd = white_bkgd;
+  a.noise = noise; a.white_bkgd = white_bkgd; a.clampv = clampv; a.S = S;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
-  a.nbatch = (int)((n * 8 + rows - 1) / rows);
+  a.nbatch = (int)((n * S + rows - 1) / rows);
   if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
   return variant_1x8() ? launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream)
                        : launch_mlp(nerf_kernel<2, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
@@ -835,7 +846,7 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
   NerfArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = m; a.nbatch = (int)((m + 127) / 128);
-  a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out;
+  a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out; a.S = 8;
   if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 4, false, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
   return launch_mlp(nerf_kernel<1, 4, false, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }

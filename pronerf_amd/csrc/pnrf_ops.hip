@@ -373,6 +373,55 @@ __global__ void refine_input_train_kernel(const float* __restrict__ rays, const 
   }
 }
 
+// ---------------------------------------------------------------- stage-1 exploration (base.py:689-729)
+struct ExploreArgs {
+  int n_mult, dir1, dir2, S;          // S = 8 * n_mult
+  float mults[32];                    // torch.linspace(0, 1 - 1/n_mult, n_mult)
+};
+// One thread per ray: replicate each of the 8 refined depths n_mult times toward the next (dir1 > 0) or previous sample,
+// sort, jitter toward the neighbour (dir2), and lift to query points o + d*z.  S <= 256 samples per ray.
+__global__ void explore_kernel(ExploreArgs a, const float* __restrict__ z8, const float* __restrict__ rays, const float* __restrict__ jitter,
+                               float* __restrict__ z_out, float* __restrict__ pts_out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* r = rays + i * 11;
+    const float near = r[6], far = r[7];
+    float zz[256];
+    float z[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) z[s] = z8[i * 8 + s];
+    const int S = a.S;
+    if (a.n_mult > 1) {
+      for (int s = 0; s < 8; ++s) {
+        const float nb = a.dir1 > 0 ? (s < 7 ? z[s + 1] : far) : (s > 0 ? z[s - 1] : near);
+        const float diff = fabsf(__fsub_rn(z[s], nb));
+        for (int j = 0; j < a.n_mult; ++j) {
+          const float m = a.dir1 > 0 ? a.mults[j] : -a.mults[j];
+          zz[s * a.n_mult + j] = __fadd_rn(z[s], __fmul_rn(m, diff));
+        }
+      }
+      for (int u = 1; u < S; ++u) {               // insertion sort (ascending), S <= 256
+        const float v = zz[u];
+        int w = u - 1;
+        while (w >= 0 && zz[w] > v) { zz[w + 1] = zz[w]; --w; }
+        zz[w + 1] = v;
+      }
+    } else {
+      for (int s = 0; s < 8; ++s) zz[s] = z[s];
+    }
+    float prev = near;                             // jitter uses the un-jittered neighbours (base.py:721-727)
+    for (int u = 0; u < S; ++u) {
+      const float cur = zz[u];
+      const float nb = a.dir2 > 0 ? (u + 1 < S ? zz[u + 1] : far) : prev;
+      const float jv = jitter[i * S + u];
+      const float zo = __fadd_rn(cur, __fmul_rn(a.dir2 > 0 ? jv : -jv, fabsf(__fsub_rn(cur, nb))));
+      prev = cur;
+      z_out[i * S + u] = zo;
+      float* p = pts_out + (i * S + u) * 3;
+      p[0] = __fadd_rn(r[0], __fmul_rn(r[3], zo)); p[1] = __fadd_rn(r[1], __fmul_rn(r[4], zo)); p[2] = __fadd_rn(r[2], __fmul_rn(r[5], zo));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- raw2outputs (trt.py:564-597; base.py:501-551; refine2.py:475-522)
 __global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
                                  const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
@@ -553,6 +602,20 @@ extern "C" int pnrf_refine_input_train_fwd(const float* rays, const float* or_ra
   PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && poses && K && ref_nos && refine_in, PNRF_E_ARG, "pnrf_refine_input_train_fwd: null pointer");
   hipLaunchKernelGGL(refine_input_train_kernel, dim3(grid_for(n * 32)), dim3(TPB), 0, (hipStream_t)stream, rays, or_rays, depth_sorted,
                      (const float4*)img4, poses, K, ref_nos, nv, Hf, Wf, eps, layout, refine_in, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_explore_fwd(const float* z8, const float* rays, const float* jitter, int n_mult, int dir1, int dir2,
+                                float* z_out, float* pts_out, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && n_mult >= 1 && n_mult <= 32 && (dir1 == 1 || dir1 == -1) && (dir2 == 1 || dir2 == -1), PNRF_E_ARG,
+               "pnrf_explore_fwd: bad arguments (n_mult 1..32, dir +-1)");
+  if (n == 0) return 0;
+  PNRF_REQUIRE(z8 && rays && jitter && z_out && pts_out, PNRF_E_ARG, "pnrf_explore_fwd: null pointer");
+  ExploreArgs a;
+  a.n_mult = n_mult; a.dir1 = dir1; a.dir2 = dir2; a.S = 8 * n_mult;
+  pnrf_linspace(0.f, (float)(1.0 - 1.0 / n_mult), n_mult, a.mults);
+  hipLaunchKernelGGL(explore_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, a, z8, rays, jitter, z_out, pts_out, n);
   PNRF_LAUNCH_CHECK();
   return 0;
 }

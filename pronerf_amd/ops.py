@@ -177,15 +177,30 @@ def refine_train_fwd(mlp, refine_in, rays, depth_sorted, jitter=None, jitter_dir
     return z, pts, rgb0
 
 
-def nerf_train_fwd(mlp, pts, rays, z, add, mul, noise=None, white_bkgd=False, want_raw=False):
-    pts = _chk(pts, 'pts', (8, 3)); rays = _chk(rays, 'rays', (11,)); z = _chk(z, 'z', (8,)); add = _chk(add, 'add', (8,)); mul = _chk(mul, 'mul', (8,))
-    noise = None if noise is None else _chk(noise, 'noise', (8,))
-    n, dev = rays.shape[0], rays.device
-    rgbd = torch.empty(n, 4, device=dev, dtype=f32)
-    raw = torch.empty(n, 8, 4, device=dev, dtype=f32) if want_raw else None
-    check(_lib.load().pnrf_nerf_train_fwd(mlp.handle, _ptr(pts), _ptr(rays), _ptr(z), _ptr(add), _ptr(mul), _ptr(noise), int(bool(white_bkgd)),
-                                          _ptr(rgbd), _ptr(raw), n, _stream()), 'pnrf_nerf_train_fwd')
+def nerf_train_fwd(mlp, pts, rays, z=None, add=None, mul=None, noise=None, clamp=0.0, white_bkgd=False, want_raw=False):
+    """pts [n,S,3].  S == 8: fused compositing -> (rgbd [n,4], raw|None).  S != 8: -> (None, raw [n,S,4])."""
+    pts = _chk(pts, 'pts', (3,)); rays = _chk(rays, 'rays', (11,))
+    n, S, dev = rays.shape[0], pts.shape[1], rays.device
+    if pts.shape[0] != n:
+        raise PnrfError(f'nerf_train_fwd: pts {tuple(pts.shape)} does not match {n} rays')
+    z = None if z is None else _chk(z, 'z'); add = None if add is None else _chk(add, 'add'); mul = None if mul is None else _chk(mul, 'mul')
+    noise = None if noise is None else _chk(noise, 'noise')
+    fused = S == 8
+    rgbd = torch.empty(n, 4, device=dev, dtype=f32) if fused else None
+    raw = torch.empty(n, S, 4, device=dev, dtype=f32) if (want_raw or not fused) else None
+    check(_lib.load().pnrf_nerf_train_fwd(mlp.handle, _ptr(pts), _ptr(rays), _ptr(z), _ptr(add), _ptr(mul), _ptr(noise), float(clamp),
+                                          int(bool(white_bkgd)), int(S), _ptr(rgbd), _ptr(raw), n, _stream()), 'pnrf_nerf_train_fwd')
     return rgbd, raw
+
+
+def explore(z8, rays, jitter, n_mult, dir1, dir2):
+    """Stage-1 exploration: z8 [n,8], jitter [n, 8*n_mult] -> (z [n, 8*n_mult], pts [n, 8*n_mult, 3])."""
+    z8 = _chk(z8, 'z8', (8,)); rays = _chk(rays, 'rays', (11,)); jitter = _chk(jitter, 'jitter', (8 * n_mult,))
+    n, dev = rays.shape[0], rays.device
+    z = torch.empty(n, 8 * n_mult, device=dev, dtype=f32); pts = torch.empty(n, 8 * n_mult, 3, device=dev, dtype=f32)
+    check(_lib.load().pnrf_explore_fwd(_ptr(z8), _ptr(rays), _ptr(jitter), int(n_mult), int(dir1), int(dir2), _ptr(z), _ptr(pts), n, _stream()),
+          'pnrf_explore_fwd')
+    return z, pts
 
 
 def images_pack(img_nchw):
