@@ -51,6 +51,8 @@ struct pnrf_mlp {
   uint32_t nslots;
   void* d_blob_fold;     // sampler only: stream with the folded 6->256 first layer (fused path)
   uint32_t nslots_fold;
+  void* d_blob_h16;      // sampler only: folded stream in split fp16 (hi / lo*2^11 planes) for layer_h16x2
+  uint32_t nslots_h16;
   float* d_bias;         // packed biases
   int nbias;
   int* d_in0;            // layer-0 input map   (device copy, for the module-level forward)

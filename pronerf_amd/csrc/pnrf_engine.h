@@ -23,6 +23,7 @@
 namespace pnrf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -297,6 +298,80 @@ __device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const fl
   last = pend;
 }
 template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + SLOT_FRAGS - 1) / SLOT_FRAGS; }
+
+// ------------------------------------------------------------------------------------------
+// Split-fp16 layer ("f16x2"): fp32-grade products from half-precision MFMAs.
+//   x = x_hi + x_lo, W = W_hi + W_lo with x_hi = fp16(x), x_lo = fp16((x - x_hi) * 2^11) (the low plane is stored
+//   scaled by 2^11 so that it stays a normal fp16 number), and   W.x ~= W_hi.x_hi + 2^-11 (W_hi.x_lo + W_lo.x_hi):
+//   22 significand bits per operand, the dropped W_lo.x_lo term is 2^-22 relative.  Three v_mfma_f32_16x16x32_f16
+//   per 32-deep k-step instead of eight v_mfma_f32_16x16x4_f32 of twice the duration: 3/16 of the MFMA cycles.
+//   Two fp32 accumulators per tile: `main` (hi.hi, initialised with the bias) and `cross` (the two mixed terms).
+//   Measured (oracle emulation and on the GPU, tools/idxcheck.py): depth error and sort indices indistinguishable from
+//   the exact-fp32 MFMA chain.
+// Geometry: 16 columns per wave (lane l: column l&15, group g = l>>4), output tiles of 16 rows handled in PAIRS — the
+//   pair (2tp, 2tp+1) is exactly the k-step tp (32 features) of the next layer: element j of group g = register j&3 of
+//   tile 2tp + (j>>2) = feature 32tp + 16(j>>2) + 4g + (j&3).
+//   Fragment order in the stream: (tp, ks, tile-in-pair, plane) -> 4 fragments per k-step; NTP tile pairs, KS k-steps.
+//   Bf(ks, plane) -> f16x8 B operand; epi1(tp, pc, main[2], cross[2]) / pre1(pc): piece pc = tile pc of the deferred pair.
+constexpr float H16_LO_SCALE = 2048.f;
+template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
+__device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1,
+                                            f32x4 (&last_main)[2], f32x4 (&last_cross)[2]) {
+  constexpr int NF = NTP * KS * 4;
+  constexpr int AHEAD = NF < 8 ? NF : 8;
+  auto frag_ptr = [&](int g) {
+    return (const f16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+  };
+  f32x4 pm[2], pc_[2];
+  f16x8 aq[AHEAD];
+#pragma unroll
+  for (int tp = 0; tp < NTP; ++tp) {
+    f32x4 mn[2], cr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { mn[t] = *(const f32x4*)(biaslane + (2 * tp + t) * 16); cr[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const int f = ((tp * KS + ks) * 2 + t) * 2 + pl;
+          if (f % SLOT_FRAGS == 0) {
+            st.begin();
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u)
+              if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+          }
+          const f16x8 a = aq[f % AHEAD];
+          if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
+            aq[f % AHEAD] = *frag_ptr(f + AHEAD);
+          if (pl == 0) {
+            mn[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bf(ks, 0), mn[t], 0, 0, 0);      // W_hi . x_hi
+            cr[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bf(ks, 1), cr[t], 0, 0, 0);      // W_hi . x_lo
+          } else {
+            cr[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bf(ks, 0), cr[t], 0, 0, 0);      // W_lo . x_hi
+          }
+        }
+      }
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;
+        if (ks == (at < KS ? at : KS - 1)) {
+          if (tp == 0) pre1(pc);
+          else epi1(tp - 1, pc, pm, pc_);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { pm[t] = mn[t]; pc_[t] = cr[t]; }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { last_main[t] = pm[t]; last_cross[t] = pc_[t]; }
+}
+template <int KS, int NTP> constexpr int layer_slots_h16x2() { return (KS * NTP * 4 + SLOT_FRAGS - 1) / SLOT_FRAGS; }
+// feature supplied by element j of lane group g in k-step ks when the B operand is the previous layer's tile pair
+__host__ __device__ constexpr int hidden_feat_h16(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
 
 // Row of a 32x32 accumulator tile held in register g of a lane in half h (cdna guide §3).
 __host__ __device__ constexpr int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }

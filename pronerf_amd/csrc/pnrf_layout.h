@@ -12,7 +12,7 @@
 namespace pnrf {
 
 enum { NET_SAMPLER = 0, NET_REFINE = 1, NET_NERF = 2, NET_NERFCLS = 3 };
-enum { PREC_F32 = 0, PREC_BF16 = 1 };
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_H16X2 = 2 };
 
 constexpr int W_HID = 256;
 constexpr int NT_HID = 8;                 // bf16 engine: 256 / 32 output tiles per hidden layer
@@ -44,6 +44,19 @@ constexpr int SF_POS_LAST = (SF_POS_H + S_NHID * S_SLOTS_H) % NSLOTS;
 constexpr int SF_SLOTS_USED = SF_SLOTS_L0 + S_NHID * S_SLOTS_H + S_SLOTS_LAST;
 constexpr int SF_SLOTS_PAD = (NSLOTS - SF_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int SF_NSLOTS = SF_SLOTS_USED + SF_SLOTS_PAD;
+
+// sampler in split-fp16 (layer_h16x2; fused path only, folded first layer): k-step = 32 features, tile pairs of 2x16 rows
+constexpr int SH_KS_H = W_HID / 32;                       // 8
+constexpr int SH_NTP_H = W_HID / 32;                      // 8 tile pairs
+constexpr int SH_SLOTS_L0 = layer_slots_h16x2<1, SH_NTP_H>();         // 2
+constexpr int SH_SLOTS_H = layer_slots_h16x2<SH_KS_H, SH_NTP_H>();    // 16
+constexpr int SH_SLOTS_LAST = layer_slots_h16x2<SH_KS_H, 1>();        // 2
+constexpr int SH_POS_H = SH_SLOTS_L0 % NSLOTS;
+constexpr int SH_POS_LAST = (SH_POS_H + S_NHID * SH_SLOTS_H) % NSLOTS;
+constexpr int SH_SLOTS_USED = SH_SLOTS_L0 + S_NHID * SH_SLOTS_H + SH_SLOTS_LAST;
+constexpr int SH_SLOTS_PAD = (NSLOTS - SH_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int SH_NSLOTS = SH_SLOTS_USED + SH_SLOTS_PAD;
+static_assert(SH_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
 
 // ---- refine (bf16): k-step = 16 features
 constexpr int R_IN = 144, R_OUT = 35, R_NHID = 5;

@@ -249,6 +249,149 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
   st.drain();
 }
 
+// Sampler in split fp16 (layer_h16x2): same producer geometry (16 columns per wave, lane quarter q), same fused epilogue;
+// the hidden activations live as two fp16 planes per 32-feature k-step (hi, lo*2^11).  Fused path, folded first layer only.
+__device__ __forceinline__ void split_h16(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)((v[j] - (float)h) * H16_LO_SCALE);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
+  constexpr int TPB = 512, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  young_half_priority<NW>();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + 4 * q;
+  constexpr float INV = 1.f / H16_LO_SCALE;
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    const int64_t row = (int64_t)batch * (NW * 16) + wave * 16 + col;
+    const bool valid = row < a.n;
+    const int64_t rr = valid ? row : a.n - 1;
+    const float* r = a.rays + rr * 11;
+    const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
+    const float near = r[6], far = r[7];
+    float hx, hy, hz, m0, m1, m2;
+    unit_dir(dx, dy, dz, hx, hy, hz);
+    moment(ox, oy, oz, dx, dy, dz, 0.f, hx, hy, hz, m0, m1, m2);
+    f16x8 P0h, P0l;                       // layer-0 B operand: group 0 holds the Pluecker 6-vector, groups 1-3 padding
+    {
+      const float z = 0.f;
+      const float v[8] = {q == 0 ? hx : z, q == 0 ? hy : z, q == 0 ? hz : z, q == 0 ? m0 : z, q == 0 ? m1 : z, q == 0 ? m2 : z, z, z};
+      split_h16(v, P0h, P0l);
+    }
+    // activations ping-pong between X and Y: per 32-feature k-step one hi and one lo plane
+    f16x8 Xh[SH_KS_H], Xl[SH_KS_H], Yh[SH_KS_H], Yl[SH_KS_H];
+    f32x4 pm[2], pc[2];                   // pending (deferred) tile pair of the previous layer
+    // piece pcx of tile pair tp -> elements 4*pcx..4*pcx+3 of k-step tp of the next layer's planes
+    auto store_piece = [&](f16x8(&dh)[SH_KS_H], f16x8(&dl)[SH_KS_H], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v = act_f32(fmaf(cr[pcx][g], INV, mn[pcx][g]), ACT_ELU);
+        const _Float16 h = (_Float16)v;
+        dh[tp][4 * pcx + g] = h;
+        dl[tp][4 * pcx + g] = (_Float16)((v - (float)h) * H16_LO_SCALE);
+      }
+    };
+    auto hidden = [&](f16x8(&ih)[SH_KS_H], f16x8(&il)[SH_KS_H], f16x8(&oh)[SH_KS_H], f16x8(&ol)[SH_KS_H], int l) {
+      f32x4 nm[2], nc[2];
+      layer_h16x2<SH_KS_H, SH_NTP_H, SH_POS_H>(
+          st, ringlane, biaslane + (1 + l) * W_HID, [&](int ks, int pl) { return pl == 0 ? ih[ks] : il[ks]; },
+          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { store_piece(oh, ol, tp, pcx, mn, cr); },
+          [&](int pcx) { store_piece(ih, il, SH_NTP_H - 1, pcx, pm, pc); }, nm, nc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
+    };
+    layer_h16x2<1, SH_NTP_H, 0>(
+        st, ringlane, biaslane, [&](int, int pl) { return pl == 0 ? P0h : P0l; },
+        [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { store_piece(Xh, Xl, tp, pcx, mn, cr); }, [](int) {}, pm, pc);
+    static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
+    for (int l = 0; l < 4; l += 2) {
+      hidden(Xh, Xl, Yh, Yl, l);
+      hidden(Yh, Yl, Xh, Xl, l + 1);
+    }
+    hidden(Xh, Xl, Yh, Yl, 4);
+    f32x4 fm[2], fc[2];
+    layer_h16x2<SH_KS_H, 1, SH_POS_LAST>(
+        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int ks, int pl) { return pl == 0 ? Yh[ks] : Yl[ks]; },
+        [&](int, int, f32x4(&)[2], f32x4(&)[2]) {}, [&](int pcx) { store_piece(Yh, Yl, SH_NTP_H - 1, pcx, pm, pc); }, fm, fc);
+#pragma unroll
+    for (int i = 0; i < SH_SLOTS_PAD; ++i) st.begin();
+    float vals[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vals[i] = fmaf(fc[i >> 2][i & 3], INV, fm[i >> 2][i & 3]);
+
+    // ---- fused epilogue.  Quarter 0 of a column holds the 8 depth logits, quarter 1 add, quarter 2 mul,
+    // quarter 3 rgb (sampler_out).  Quarter 0 sorts; the permutation goes to the other quarters as a word.
+    float dep[8];
+    int idx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dep[i] = sigmoid_f(vals[i]); idx[i] = i; }
+    if (q == 0 && valid && a.depth_raw) {
+      float4* p = (float4*)(a.depth_raw + row * 8);
+      p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
+      p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
+    }
+    const float span = __fsub_rn(far, near);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
+    // stable ascending sort (19-comparator network on (value, index) keys)          // trt.py:632-635
+    PNRF_CSWAP(0, 1) PNRF_CSWAP(2, 3) PNRF_CSWAP(4, 5) PNRF_CSWAP(6, 7)
+    PNRF_CSWAP(0, 2) PNRF_CSWAP(1, 3) PNRF_CSWAP(4, 6) PNRF_CSWAP(5, 7)
+    PNRF_CSWAP(1, 2) PNRF_CSWAP(5, 6) PNRF_CSWAP(0, 4) PNRF_CSWAP(3, 7)
+    PNRF_CSWAP(1, 5) PNRF_CSWAP(2, 6)
+    PNRF_CSWAP(1, 4) PNRF_CSWAP(3, 6)
+    PNRF_CSWAP(2, 4) PNRF_CSWAP(3, 5)
+    PNRF_CSWAP(3, 4)
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) word |= (uint32_t)idx[i] << (3 * i);
+    const uint32_t w0 = __shfl(word, col);      // quarter 0's permutation for this column, in all quarters
+    float perm[8];                              // own values permuted like the depths (trt.py:634-635)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = (w0 >> (3 * i)) & 7;
+      float m = vals[0];
+#pragma unroll
+      for (int jj = 1; jj < 8; ++jj) m = (k == jj) ? vals[jj] : m;
+      perm[i] = m;
+    }
+    if (valid) {
+      if (q == 0) {
+        float4* p = (float4*)(a.depth_sorted + row * 8);
+        p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
+        if (a.sort_idx) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a.sort_idx[row * 8 + i] = idx[i];
+        }
+      } else if (q == 3) {
+        if (a.mm_rgb) {
+          a.mm_rgb[row * 3 + 0] = sigmoid_f(vals[0]);
+          a.mm_rgb[row * 3 + 1] = sigmoid_f(vals[1]);
+          a.mm_rgb[row * 3 + 2] = sigmoid_f(vals[2]);
+        }
+      } else {
+        float4* p = (float4*)((q == 1 ? a.add_sorted : a.mul_sorted) + row * 8);
+        p[0] = make_float4(perm[0], perm[1], perm[2], perm[3]);
+        p[1] = make_float4(perm[4], perm[5], perm[6], perm[7]);
+      }
+    }
+  }
+  st.drain();
+}
+
 // ------------------------------------------------------------------------------------------ bf16 nets
 // Deferred hidden-layer epilogue, one piece at a time: piece pc = accumulator registers 8pc..8pc+7 of tile
 // `to` -> activation -> packed bf16 B fragment of k-step 2*to+pc of the next layer.
@@ -702,7 +845,8 @@ int num_cu() {
 }
 
 // Tuning knobs (environment, read per call so that variants can be A/B-ed inside one process):
-// PNRF_SAMPLER_FOLD=0 disables the folded first sampler layer; PNRF_BF16_VARIANT = "1x8" (default:
+// PNRF_SAMPLER_PREC=f32 runs the sampler on the exact-fp32 MFMA chain instead of split fp16 (layer_h16x2, the default);
+// PNRF_SAMPLER_FOLD=0 (with f32) disables the folded first sampler layer; PNRF_BF16_VARIANT = "1x8" (default:
 // 32 columns/wave, 8 waves, 2 waves/SIMD) or "2x4" (64 columns/wave, 4 waves, 1 wave/SIMD).
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -713,6 +857,10 @@ bool variant_1x8() {
   return !(e && e[0] == '2');          // default: 1x8 (two waves per SIMD)
 }
 bool sampler_fold() { return env_int("PNRF_SAMPLER_FOLD", 1) != 0; }
+bool sampler_f16x2() {
+  const char* e = getenv("PNRF_SAMPLER_PREC");
+  return !(e && e[0] == 'f' && e[1] == '3');       // default: split fp16 (f16x2); "f32" selects the exact-fp32 MFMA chain
+}
 
 template <class K, class A>
 int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream) {
@@ -750,6 +898,7 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
   if (n == 0) return 0;
   const bool fold = sampler_fold();
+  const bool h16 = sampler_f16x2();
   SamplerArgs a = {};
   a.blob = fold ? h->d_blob_fold : h->d_blob; a.nslots = fold ? h->nslots_fold : h->nslots;
   a.bias = h->d_bias; a.nbias = h->nbias;
@@ -758,6 +907,10 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   a.depth_sorted = depth_sorted; a.add_sorted = add_sorted; a.mul_sorted = mul_sorted;
   a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  if (h16) {
+    a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
+    return launch_mlp(sampler_h16_kernel, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  }
   return fold ? launch_mlp(sampler_kernel<2>, a, 512, lds, a.nbatch, (hipStream_t)stream)
               : launch_mlp(sampler_kernel<1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }

@@ -66,8 +66,31 @@ static void pack_layer(const Layer& L, int prec, char* dst) {
   }
 }
 
+// split-fp16 packing (layer_h16x2): in_map [nk][4][8], out_map [nt][16], fragments (tp, ks, tile-in-pair, plane)
+static inline uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+static void pack_layer_h16x2(const Layer& L, char* dst) {
+  const int ntp = L.nt / 2;
+  for (int tp = 0; tp < ntp; ++tp)
+    for (int ks = 0; ks < L.nk; ++ks)
+      for (int t = 0; t < 2; ++t) {
+        uint16_t* hi = (uint16_t*)(dst + ((((size_t)tp * L.nk + ks) * 2 + t) * 2 + 0) * FRAG_BYTES);
+        uint16_t* lo = (uint16_t*)(dst + ((((size_t)tp * L.nk + ks) * 2 + t) * 2 + 1) * FRAG_BYTES);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 15, g = lane >> 4;
+          const int out = L.out_map[(2 * tp + t) * 16 + r];
+          for (int j = 0; j < 8; ++j) {
+            const float w = wval(L, out, L.in_map[(ks * 4 + g) * 8 + j]);
+            const uint16_t h = f2h(w);
+            hi[lane * 8 + j] = h;
+            lo[lane * 8 + j] = f2h((w - h2f(h)) * H16_LO_SCALE);
+          }
+        }
+      }
+}
+
 static void pack_bias(const Layer& L, int prec, float* dst) {
-  if (prec == PREC_F32) {      // [tile][16 rows] in tile-row order: lane quarter q reads rows 4q..4q+3
+  if (prec == PREC_F32 || prec == PREC_H16X2) {      // [tile][16 rows] in tile-row order: lane quarter q reads rows 4q..4q+3
     for (int i = 0; i < L.nt * 16; ++i) dst[i] = L.out_map[i] >= 0 ? L.b[L.out_map[i]] : 0.f;
     return;
   }
@@ -329,6 +352,27 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (auto& L : Lf) { pack_layer(L, prec, blob_fold.data() + sf * SLOT_BYTES); sf += layer_slots(L, prec); }
   }
 
+  // sampler: third stream, folded first layer, split fp16 (hi / lo*2^11) for layer_h16x2
+  std::vector<char> blob_h16;
+  size_t slots_h16 = 0;
+  if (net == PNRF_NET_SAMPLER) {
+    std::vector<Layer> Lh = Ls;
+    for (auto& L : Lh) {                                       // hidden geometry of the 16x16x32 engine
+      L.nk = SH_KS_H; L.in_map.assign(SH_KS_H * 32, -1);
+      for (int ks = 0; ks < SH_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) L.in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+    }
+    Layer& G = Lh[0];
+    G.W = wfold.data(); G.in_dim = 6; G.nk = 1; G.in_map.assign(32, -1);
+    for (int j = 0; j < 6; ++j) G.in_map[j] = j;               // group 0 holds the 6 Pluecker features, the rest is padding
+    auto hs = [&](const Layer& L) { return ((size_t)(L.nt / 2) * L.nk * 4 + SLOT_FRAGS - 1) / SLOT_FRAGS; };
+    for (auto& L : Lh) slots_h16 += hs(L);
+    slots_h16 += (NSLOTS - slots_h16 % NSLOTS) % NSLOTS;
+    PNRF_REQUIRE(slots_h16 == (size_t)SH_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (f16x2 stream %zu slots, expected %d)", slots_h16, SH_NSLOTS);
+    blob_h16.assign(slots_h16 * SLOT_BYTES, 0);
+    size_t sh = 0;
+    for (auto& L : Lh) { pack_layer_h16x2(L, blob_h16.data() + sh * SLOT_BYTES); sh += hs(L); }
+  }
+
   pnrf_mlp* h = new pnrf_mlp();
   memset(h, 0, sizeof(*h));
   h->net = net; h->prec = prec; h->in_dim = in0; h->in_dim_x = net == PNRF_NET_NERF ? N_INV : 0; h->out_dim = outN;
@@ -353,6 +397,11 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_fold, blob_fold.data(), blob_fold.size(), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
+    h->nslots_h16 = (uint32_t)slots_h16;
+    e = hipMalloc(&h->d_blob_h16, blob_h16.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_h16, blob_h16.data(), blob_h16.size(), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
     float tv[S_KS0 / 3];
     pnrf_linspace(0.f, 1.f, S_KS0 / 3, tv);
     e = hipMalloc((void**)&h->d_tvals, sizeof(tv));
@@ -371,6 +420,7 @@ extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
   if (!h) return 0;
   if (h->d_blob) (void)hipFree(h->d_blob);
   if (h->d_blob_fold) (void)hipFree(h->d_blob_fold);
+  if (h->d_blob_h16) (void)hipFree(h->d_blob_h16);
   if (h->d_bias) (void)hipFree(h->d_bias);
   if (h->d_in0) (void)hipFree(h->d_in0);
   if (h->d_inx) (void)hipFree(h->d_inx);
