@@ -8,7 +8,7 @@
 Workload (BASELINE.json configs[1]): one 1008x756 LLFF-Fern-geometry frame =
 762 048 rays, 8 samples/ray, 4 neighbour views, 48 ray-encoding points; synthetic poses/images
 and seeded "trained-like" weights (no dataset/checkpoint ships).  A step = one pass of the hot
-path (sampler MLP fp32 -> neighbour projection -> refine MLP bf16 -> NeRF MLP bf16 -> alpha
+path (sampler MLP fp32-grade split fp16 -> neighbour projection -> refine MLP bf16 -> NeRF MLP bf16 -> alpha
 compositing) over one frame; the kernels tile the frame into 1024-ray chunks (4 workgroup
 batches of 256 columns) inside a single launch per stage.  Rays, images and weights are resident
 in HBM before the timed region, exactly like the reference's timed loop
@@ -123,13 +123,14 @@ def cpu_baseline(weights, scene, n_rays, budget_s=20.0):
                       f'best of {reps} passes of oracle.render_rays_infer (fp32 torch CPU)'}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary, if any."""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the latest committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 FETCH_SIZE x2 correction applied there), if any."""
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
     if not files:
         return None
     try:
-        return json.load(open(files[-1])).get('dominant_kernel_hbm_bytes_per_launch')
+        return json.load(open(files[-1]))['per_kernel'][kernel]['hbm_bytes_per_launch']
     except Exception:
         return None
 
@@ -210,6 +211,7 @@ def main():
         dt = float(t.item())
     finite = bool(torch.isfinite(out).all().item())
 
+    sampler_f32 = os.environ.get('PNRF_SAMPLER_PREC', '').startswith('f3')
     res = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -218,7 +220,9 @@ def main():
             'metric': 'rays/sec (and ms/1008x756 frame) LLFF Fern 8-sample infer',
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'ms_per_frame': ms, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'bf16 (refine+NeRF MLP, fp32 accumulate) + f32 (sampler MLP, exact f32 MFMA)',
+            'vs_baseline': None,
+            'dtype': 'bf16 (refine+NeRF MLP, fp32 accumulate) + ' + ('f32 (sampler MLP, exact f32 MFMA)' if sampler_f32 else
+                                                                  'f16x2 (sampler MLP: split fp16 hi+lo operands, fp32 accumulate, fp32-grade)'),
             'data': 'synthetic',
             'backend': (args.backend if world > 1 else None),
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, '
@@ -232,7 +236,8 @@ def main():
         if world == 1:
             prof = stage_profile(rend, rays, or_rays)
             flops = {'sampler_kernel': 2 * MAC_SAMPLER, 'refine_kernel': 2 * MAC_REFINE, 'nerf_kernel': 2 * MAC_NERF}
-            peaks = {'sampler_kernel': PEAK_F32, 'refine_kernel': PEAK_BF16, 'nerf_kernel': PEAK_BF16}
+            # the sampler's algorithmic FLOPs are priced against the peak of the MFMA dtype it runs on (f16 = bf16 rate)
+            peaks = {'sampler_kernel': PEAK_F32 if sampler_f32 else PEAK_BF16, 'refine_kernel': PEAK_BF16, 'nerf_kernel': PEAK_BF16}
             kern = {}
             for k, ms_k in prof.items():
                 kern[k] = {'ms': ms_k}
@@ -241,7 +246,7 @@ def main():
                     kern[k].update(achieved_tflops=ach, peak_tflops=peaks[k], frac=ach / peaks[k])
             dom = max(flops, key=lambda k: prof[k])
             res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
-                               'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': pmc_traffic(),
+                               'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': pmc_traffic(dom),
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total}
             res['kernels'] = kern
             if not args.no_cpu_baseline:

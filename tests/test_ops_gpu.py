@@ -156,9 +156,12 @@ def test_mlp_linearity_exact_integers(dev):
     np.testing.assert_array_equal(got.numpy(), h.numpy())
 
 
+@pytest.mark.parametrize('prec', ['h16', 'f32'])
 @pytest.mark.parametrize('kind,seed', [('trained', 0), ('spread', 2), ('default', 1)])
-def test_sampler_stage(dev, kind, seed):
+def test_sampler_stage(dev, kind, seed, prec, monkeypatch):
+    """Both sampler precisions: split fp16 (default; 22-bit operands, fp32 accumulate) and the exact-fp32 MFMA chain."""
     from pronerf_amd import ops
+    monkeypatch.setenv('PNRF_SAMPLER_PREC', prec)
     w, mlps = _packed(dev, seed, kind)
     scene = synth.make_scene(seed, H=40, W=52, rotate=True)
     fr = orc.frame_setup(scene)
