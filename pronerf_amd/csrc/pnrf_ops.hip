@@ -194,55 +194,73 @@ __global__ void images_pack_kernel(const float* __restrict__ in, float4* __restr
 }
 
 // Projection + sample Pluecker -> refine_in[n,144]   (trt.py:637-661)
-// 32 threads per ray: thread t = k*8+s projects sample s into neighbour k (4 taps x 16 B);
-// threads 0..7 additionally write the Pluecker 6-vector of sample s.
-__global__ void refine_input_kernel(const float* __restrict__ rays, const float* __restrict__ or_rays, const float* __restrict__ depth_sorted,
+// Workgroup = 64 consecutive rays x 4 neighbours: lane = ray, wave = neighbour view, loop over the 8 samples.  Consecutive rays
+// are consecutive pixels, so for a fixed (view, sample) the 64 lanes of a wave fetch adjacent texels (coalesced 16-byte taps, each
+// cache line fetched once) — with one thread per (ray, view, sample) in ray-major order a wave touched 256 unrelated lines and
+// the L2 hit rate was 63 %.  The [64 rays][144] tile is transposed through LDS and written out as one contiguous 36 KiB block.
+constexpr int RI_TILE = 64;
+__global__ __launch_bounds__(256) void refine_input_kernel(const float* __restrict__ rays, const float* __restrict__ or_rays, const float* __restrict__ depth_sorted,
                                     const float4* __restrict__ img4, const float* __restrict__ proj, int nb, int Hf, int Wf, float eps,
                                     float* __restrict__ out, int64_t n) {
-  __shared__ float sM[8 * 12];
-  if (threadIdx.x < nb * 12) sM[threadIdx.x] = proj[threadIdx.x];
-  __syncthreads();
-  const int per_ray = nb * 8;                   // 32 for nb = 4
-  const int64_t total = n * per_ray;
+  __shared__ float sM[4 * 12];
+  __shared__ float sT[144 * (RI_TILE + 1)];          // [feature][ray] (+1: conflict-free column writes)
+  if (threadIdx.x < 48) sM[threadIdx.x] = proj[threadIdx.x];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
   const int64_t plane = (int64_t)Hf * Wf;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t ray = q / per_ray;
-    const int t = (int)(q - ray * per_ray);
-    const int k = t >> 3, s = t & 7;
-    const float dn = depth_sorted[ray * 8 + s];
+  const int64_t ntiles = (n + RI_TILE - 1) / RI_TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                  // sM ready / previous tile's sT fully written out
+    const int64_t ray0 = tile * RI_TILE;
+    const int64_t ray = ray0 + lane < n ? ray0 + lane : n - 1;
     const float* orr = or_rays + ray * 11;
-    const float z3d = __fdiv_rn(1.f, __fsub_rn(__fsub_rn(1.f, dn), eps));                    // trt.py:637
-    const float w0 = __fadd_rn(orr[0], __fmul_rn(orr[3], z3d)), w1 = __fadd_rn(orr[1], __fmul_rn(orr[4], z3d)),
-                w2 = __fadd_rn(orr[2], __fmul_rn(orr[5], z3d));                              // inverse_warp.py:600 (w3 = 1)
+    const float o0 = orr[0], o1 = orr[1], o2 = orr[2], e0 = orr[3], e1 = orr[4], e2 = orr[5];
+    const float4 da = *(const float4*)(depth_sorted + ray * 8), db = *(const float4*)(depth_sorted + ray * 8 + 4);
+    const float dn8[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
     const float* M = sM + k * 12;
-    float p[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[r * 4], w0), __fmul_rn(M[r * 4 + 1], w1)), __fmul_rn(M[r * 4 + 2], w2)), M[r * 4 + 3]);
-    const float X = __fdiv_rn(p[0], p[2]), Y = __fdiv_rn(p[1], p[2]);
-    int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
-    bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
-    const bool okx0 = x0 >= 0 && x0 < Wf, okx1 = x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
     const float4* im = img4 + (int64_t)k * plane;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 t00 = (oky0 && okx0) ? im[(int64_t)y0 * Wf + x0] : zero;
-    const float4 t01 = (oky0 && okx1) ? im[(int64_t)y0 * Wf + x0 + 1] : zero;
-    const float4 t10 = (oky1 && okx0) ? im[(int64_t)(y0 + 1) * Wf + x0] : zero;
-    const float4 t11 = (oky1 && okx1) ? im[(int64_t)(y0 + 1) * Wf + x0 + 1] : zero;
-    const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx1, wy0), a10 = __fmul_rn(wx0, wy1), a11 = __fmul_rn(wx1, wy1);
-    float* o = out + ray * 144 + 48 + t * 3;                                                  // epi index (k*8+s)*3+c
-    o[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.x, a00), __fmul_rn(t01.x, a01)), __fmul_rn(t10.x, a10)), __fmul_rn(t11.x, a11));
-    o[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.y, a00), __fmul_rn(t01.y, a01)), __fmul_rn(t10.y, a10)), __fmul_rn(t11.y, a11));
-    o[2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.z, a00), __fmul_rn(t01.z, a01)), __fmul_rn(t10.z, a10)), __fmul_rn(t11.z, a11));
-    if (k == 0) {                                                                             // trt.py:656-658
-      const float* r = rays + ray * 11;
-      float hx, hy, hz, m0, m1, m2;
-      unit_dir(r[3], r[4], r[5], hx, hy, hz);
-      const float px = __fadd_rn(r[0], __fmul_rn(r[3], dn)), py = __fadd_rn(r[1], __fmul_rn(r[4], dn)), pz = __fadd_rn(r[2], __fmul_rn(r[5], dn));
-      cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
-      float* pl = out + ray * 144 + s * 6;
-      pl[0] = hx; pl[1] = hy; pl[2] = hz; pl[3] = m0; pl[4] = m1; pl[5] = m2;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float z3d = __fdiv_rn(1.f, __fsub_rn(__fsub_rn(1.f, dn8[s]), eps));                 // trt.py:637
+      const float w0 = __fadd_rn(o0, __fmul_rn(e0, z3d)), w1 = __fadd_rn(o1, __fmul_rn(e1, z3d)), w2 = __fadd_rn(o2, __fmul_rn(e2, z3d));   // inverse_warp.py:600
+      float p[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[r * 4], w0), __fmul_rn(M[r * 4 + 1], w1)), __fmul_rn(M[r * 4 + 2], w2)), M[r * 4 + 3]);
+      const float X = __fdiv_rn(p[0], p[2]), Y = __fdiv_rn(p[1], p[2]);
+      int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
+      bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
+      const bool okx0 = x0 >= 0 && x0 < Wf, okx1 = x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 t00 = (oky0 && okx0) ? im[(int64_t)y0 * Wf + x0] : zero;
+      const float4 t01 = (oky0 && okx1) ? im[(int64_t)y0 * Wf + x0 + 1] : zero;
+      const float4 t10 = (oky1 && okx0) ? im[(int64_t)(y0 + 1) * Wf + x0] : zero;
+      const float4 t11 = (oky1 && okx1) ? im[(int64_t)(y0 + 1) * Wf + x0 + 1] : zero;
+      const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx1, wy0), a10 = __fmul_rn(wx0, wy1), a11 = __fmul_rn(wx1, wy1);
+      const int f = 48 + (k * 8 + s) * 3;                                                        // epi index (k*8+s)*3+c
+      sT[(f + 0) * (RI_TILE + 1) + lane] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.x, a00), __fmul_rn(t01.x, a01)), __fmul_rn(t10.x, a10)), __fmul_rn(t11.x, a11));
+      sT[(f + 1) * (RI_TILE + 1) + lane] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.y, a00), __fmul_rn(t01.y, a01)), __fmul_rn(t10.y, a10)), __fmul_rn(t11.y, a11));
+      sT[(f + 2) * (RI_TILE + 1) + lane] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.z, a00), __fmul_rn(t01.z, a01)), __fmul_rn(t10.z, a10)), __fmul_rn(t11.z, a11));
     }
+    {                                                                                            // trt.py:656-658: wave k encodes samples 2k, 2k+1
+      const float* r = rays + ray * 11;
+      float hx, hy, hz;
+      unit_dir(r[3], r[4], r[5], hx, hy, hz);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = 2 * k + u;
+        const float dn = s < 4 ? (s == 0 ? da.x : s == 1 ? da.y : s == 2 ? da.z : da.w) : (s == 4 ? db.x : s == 5 ? db.y : s == 6 ? db.z : db.w);
+        float m0, m1, m2;
+        const float px = __fadd_rn(r[0], __fmul_rn(r[3], dn)), py = __fadd_rn(r[1], __fmul_rn(r[4], dn)), pz = __fadd_rn(r[2], __fmul_rn(r[5], dn));
+        cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
+        float* q = sT + (s * 6) * (RI_TILE + 1) + lane;
+        q[0] = hx; q[RI_TILE + 1] = hy; q[2 * (RI_TILE + 1)] = hz; q[3 * (RI_TILE + 1)] = m0; q[4 * (RI_TILE + 1)] = m1; q[5 * (RI_TILE + 1)] = m2;
+      }
+    }
+    __syncthreads();
+    const int64_t nvalid = (n - ray0 < RI_TILE ? n - ray0 : RI_TILE) * 144;                       // contiguous block of the output
+    float* dst = out + ray0 * 144;
+    for (int e = threadIdx.x; e < RI_TILE * 144; e += 256)
+      if (e < nvalid) dst[e] = sT[(e % 144) * (RI_TILE + 1) + e / 144];
   }
 }
 
@@ -564,7 +582,7 @@ extern "C" int pnrf_refine_input_fwd(const float* rays, const float* or_rays, co
   PNRF_REQUIRE(n >= 0 && nb == 4 && Hf >= 2 && Wf >= 2, PNRF_E_ARG, "pnrf_refine_input_fwd: bad sizes (nb must be 4, got %d)", nb);
   if (n == 0) return 0;
   PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && proj && refine_in, PNRF_E_ARG, "pnrf_refine_input_fwd: null pointer");
-  hipLaunchKernelGGL(refine_input_kernel, dim3(grid_for(n * nb * 8)), dim3(TPB), 0, (hipStream_t)stream, rays, or_rays, depth_sorted,
+  hipLaunchKernelGGL(refine_input_kernel, dim3(grid_for((n + RI_TILE - 1) / RI_TILE, 1)), dim3(256), 0, (hipStream_t)stream, rays, or_rays, depth_sorted,
                      (const float4*)img4, proj, nb, Hf, Wf, eps, refine_in, n);
   PNRF_LAUNCH_CHECK();
   return 0;

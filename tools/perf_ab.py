@@ -58,7 +58,7 @@ def main():
             rend = rends[c.get('lib', '')]
             os.environ['PNRF_SAMPLER_FOLD'] = c.get('fold', '1')
             os.environ['PNRF_BF16_VARIANT'] = c.get('var', '1x8')
-            os.environ['PNRF_SAMPLER_PREC'] = c.get('prec', 'f32')
+            os.environ['PNRF_SAMPLER_PREC'] = c.get('prec', 'h16')
             e = [ev() for _ in range(5)]
             e[0].record()
             depth, _, add, mul, _, _ = ops.sampler_fwd(rend.sampler, rays, want_idx=False, want_rgb=False)
