@@ -44,6 +44,8 @@ enum { ACT_RELU = 0, ACT_ELU = 1, ACT_NONE = 2 };
 // the product build.
 #ifdef PNRF_DIAG
 __device__ unsigned long long g_pnrf_diag[4 * 8 * 1024];      // [block*NW + wave] x {total, vmcnt wait, barrier wait, n begin}
+__device__ unsigned long long g_pnrf_tl[16 * 8 * 64];            // timeline stamps of two steady-state tiles, first 64 workgroups
+#define PNRF_TL(i) asm volatile("s_memtime %0" : "=s"(tlv[i]))
 __device__ __forceinline__ unsigned long long diag_now() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -58,6 +60,23 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Weight stream: global blob -> LDS ring by LDS-DMA.  All members are wave-uniform except woff.
 // NW = waves per workgroup (4 = one per SIMD, 8 = two per SIMD); every wave issues 16/NW of the
 // sixteen 1 KiB LDS-DMA instructions of a slot.
+// A-fragment queue policy.  XSLOT = 1: at the barrier that opens slot q the slots q AND q+1 have landed (wait_slot's
+// vmcnt leaves one slot in flight instead of two), so the queue keeps refilling across the slot boundary and the first
+// MFMAs behind a barrier find their fragments in registers.  Measured with the timeline stamps (tools/diag_stamps.py):
+// filled from scratch behind every barrier, each tile opened with ~200 idle cycles on every SIMD (LDS round trip of the
+// 8 waves' fills) on top of the ~150 cycles from last arrival to release.  The queue is filled from scratch only at a
+// layer's first fragment.  XSLOT = 0: reads stay inside their slot.
+#ifndef PNRF_XSLOT
+#define PNRF_XSLOT 1
+#endif
+constexpr int XSLOT = PNRF_XSLOT;
+constexpr int AHEAD_MAX = 8;               // deepest A-fragment queue of the layer engines
+__host__ __device__ constexpr bool queue_fill(int f, int u, int nf) {        // at a slot head: load fragment f+u now?
+  return f + u < nf && (XSLOT ? f == 0 : (f + u) / SLOT_FRAGS == f / SLOT_FRAGS);
+}
+__host__ __device__ constexpr bool queue_refill(int f, int ahead, int nf) {  // after consuming f: load fragment f+ahead?
+  return f + ahead < nf && (XSLOT ? true : ((f + ahead) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + ahead < SLOT_FRAGS));
+}
 template <int NW>
 struct WStream {
   static constexpr int LOADS_PER_WAVE = SLOT_FRAGS / NW;
@@ -80,14 +99,40 @@ struct WStream {
     wbase = wave * (LOADS_PER_WAVE * FRAG_BYTES);
     woff = wbase + lane * 16;
   }
-  __device__ __forceinline__ void issue() {
-    const char* src = g + (size_t)src_slot * SLOT_BYTES + woff;
-    char* dst = ring + dst_pos * SLOT_BYTES + wbase;
+  // The LDS-DMA pieces go out through inline asm, not __builtin_amdgcn_global_load_lds: hipcc books the builtin as a FLAT
+  // access that may touch LDS, and from then on waits lgkmcnt(0) before every MFMA that consumes a ds_read — behind each
+  // barrier a wave then sits out its whole 8-9 fragment queue fill (all 8 waves': 72 KiB through the 256 B/clk LDS)
+  // before its first MFMA.  Hidden from the compiler the reads keep their counted lgkmcnt(N).  Completion is counted by
+  // wait_slot()'s own vmcnt; M0 (compiler-reserved) is saved and restored inside the statement.
+  __device__ __forceinline__ void issue_loads() {
+#ifndef PNRF_PROBE_NODMA
+    const uint64_t src = (uint64_t)(uintptr_t)g + (uint64_t)src_slot * SLOT_BYTES;                 // wave-uniform
+    const uint32_t dst = (uint32_t)(uintptr_t)(lptr_t)ring + dst_pos * SLOT_BYTES + wbase;       // wave-uniform LDS byte address
 #pragma unroll
-    for (int i = 0; i < LOADS_PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + i * FRAG_BYTES), (lptr_t)(dst + i * FRAG_BYTES), 16, 0, 0);
+    for (int i = 0; i < LOADS_PER_WAVE; ++i) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %2\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(woff), "s"(src + (uint64_t)(i * FRAG_BYTES)), "s"(dst + (uint32_t)(i * FRAG_BYTES))
+          : "memory");
+    }
+#endif
+  }
+  __device__ __forceinline__ void advance() {
     src_slot = (src_slot + 1 == nslots) ? 0u : src_slot + 1;
     dst_pos = (dst_pos + 1) & (NSLOTS - 1);
+  }
+  __device__ __forceinline__ void issue() { issue_loads(); advance(); }
+  // Refill of the ring position freed by wait_slot(); the layers call it after the first MFMA of every slot, so that the
+  // MFMA pipe is already busy while this wave pays the DMA issue.  (Moving the issue further into the slot, or staggering
+  // it between the two waves of a SIMD, was measured and is slower: 3.92 -> 3.96..4.11 ms for the NeRF kernel.)
+  __device__ __forceinline__ void slot_issue(int fpos) {
+    if (fpos == 0) issue();
   }
   // Fill the pipeline: PD slots in flight.
   __device__ __forceinline__ void prologue() {
@@ -104,20 +149,22 @@ struct WStream {
   //            ring position (== position of slot q+PD since NSLOTS == PD+1) is then refilled.
   //  (Measured with tools/diag_stamps.py: the vmcnt wait is ~0; letting reads run one slot ahead across
   //  the barrier with an 8-slot ring bought nothing, so reads stay inside their slot.)
-  __device__ __forceinline__ void begin() {
+  __device__ __forceinline__ void begin() { wait_slot(); issue(); }
+  __device__ __forceinline__ void wait_slot() {
 #ifdef PNRF_DIAG
     const unsigned long long t0 = diag_now();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD - 1 - XSLOT)) : "memory");
 #ifdef PNRF_DIAG
     const unsigned long long t1 = diag_now();
 #endif
+#ifndef PNRF_PROBE_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
 #ifdef PNRF_DIAG
     t_vm += t1 - t0; t_bar += diag_now() - t1; n_begin += 1;
 #endif
-    issue();
   }
   // LDS-DMA still in flight at kernel end would land in another workgroup's LDS: drain.
   __device__ __forceinline__ void drain() {
@@ -132,6 +179,7 @@ struct WStream {
   }
 };
 static_assert(NSLOTS == PD + 1, "ring protocol assumes one free slot");
+static_assert(PD - 1 - XSLOT >= 1 && AHEAD_MAX <= SLOT_FRAGS, "queue reads at most one slot ahead");
 
 // expm1(x) for x <= 0, branch-free (ocml's expm1f compiles to divergent branch blocks that cannot be
 // interleaved with MFMAs).  x > -0.5: degree-8 Taylor polynomial in Horner form; else expf(x) - 1.
@@ -167,7 +215,15 @@ __device__ __forceinline__ float act_fast(float v, int act) {
   // bf16 path: the result is rounded to 8 significant bits, v_exp_f32 is accurate enough.
   // relu as a sign select: fmaxf() on an MFMA result costs an extra canonicalising v_max_f32 v,v,v
   if (act == ACT_NONE) return v;
+#ifdef PNRF_RELU_SELECT
   if (act == ACT_RELU) return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & ~(__builtin_bit_cast(int, v) >> 31));
+#else
+  if (act == ACT_RELU) {      // one v_max_f32; written in asm because fmaxf() on an MFMA result adds a canonicalising v_max v,v,v
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+  }
+#endif
   const float e = __expf(fminf(v, 0.f)) - 1.f;       // unconditional, see act_f32
   return fmaxf(v, 0.f) + e;
 }
@@ -202,41 +258,76 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
   };
   f32x16 pend[NCB];
   bf16x8 aq[AHEAD];
+#ifdef PNRF_DIAG
+  constexpr bool TL = KS == 16 && NT == 8;      // timeline of tiles 4 and 5 of a full hidden layer (tools/diag_stamps.py)
+  unsigned long long tlv[13];
+#endif
+  // the bias of tile to+1 is read from LDS at the head of tile `to` (software pipelined): read in place, the first MFMA of
+  // every tile would wait a full LDS round trip for its accumulator with both waves of the SIMD phase-locked behind the barrier
+  f32x4 nb0, nb1, nb2, nb3;
+  { const f32x4* bp = (const f32x4*)biaslane; nb0 = bp[0]; nb1 = bp[1]; nb2 = bp[2]; nb3 = bp[3]; }
 #pragma unroll
   for (int to = 0; to < NT; ++to) {
     f32x16 acc[NCB];
     {
-      const f32x4* bp = (const f32x4*)(biaslane + to * 32);
-      f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      const f32x4 b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[cb][i] = b0[i]; acc[cb][4 + i] = b1[i]; acc[cb][8 + i] = b2[i]; acc[cb][12 + i] = b3[i]; }
       }
+      if (to + 1 < NT) { const f32x4* bp = (const f32x4*)(biaslane + (to + 1) * 32); nb0 = bp[0]; nb1 = bp[1]; nb2 = bp[2]; nb3 = bp[3]; }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int f = to * KS + ks;
       if (f % SLOT_FRAGS == 0) {
-        st.begin();              // the slot is readable now: (re)fill the queue from its head
+#ifdef PNRF_DIAG
+        if (TL && to == 4) PNRF_TL(0);
+        if (TL && to == 5) PNRF_TL(6);
+        if (TL && to == 6) PNRF_TL(12);
+#endif
+        st.wait_slot();          // the slot is readable now: (re)fill the queue from its head
+#ifdef PNRF_DIAG
+        if (TL && to == 4) PNRF_TL(1);
+        if (TL && to == 5) PNRF_TL(7);
+#endif
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
-          if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+          if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
       }
       const bf16x8 a = aq[f % AHEAD];
-      if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
-        aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full inside the slot
+      if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
       // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
 #pragma unroll
       for (int pc = 0; pc < BF16_PIECES; ++pc) {
         const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;       // k-step after which piece pc is issued
+#ifndef PNRF_PROBE_NOEPI
         if (ks == (at < KS ? at : KS - 1)) {
           if (to == 0) pre1(pc);
           else epi1(to - 1, pc, pend);
         }
+#endif
       }
+      st.slot_issue(f % SLOT_FRAGS);
+#ifdef PNRF_DIAG
+      if (TL && (to == 4 || to == 5)) {
+        const int b = (to - 4) * 6;
+        if (ks == 0) PNRF_TL(b + 2);
+        if (ks == 1) PNRF_TL(b + 3);
+        if (ks == 8) PNRF_TL(b + 4);
+        if (ks == 15) PNRF_TL(b + 5);
+      }
+      if (TL && to == 6 && ks == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) g_pnrf_tl[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + i] = tlv[i];
+        }
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -265,21 +356,22 @@ __device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const fl
   };
   f32x4 pend;
   f32x4 aq[AHEAD];                             // rotating prefetch queue (static indices after unrolling)
+  f32x4 nbias = *(const f32x4*)biaslane;        // bias of the next tile, read one tile ahead (see layer_bf16)
 #pragma unroll
   for (int to = 0; to < NT; ++to) {
-    f32x4 acc = *(const f32x4*)(biaslane + to * 16);
+    f32x4 acc = nbias;
+    if (to + 1 < NT) nbias = *(const f32x4*)(biaslane + (to + 1) * 16);
 #pragma unroll
     for (int fr = 0; fr < KS4; ++fr) {
       const int f = to * KS4 + fr;
       if (f % SLOT_FRAGS == 0) {
-        st.begin();              // the slot is readable now: (re)fill the queue from its head
+        st.wait_slot();          // the slot is readable now: (re)fill the queue from its head
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
-          if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+          if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
       }
       const f32x4 a = aq[f % AHEAD];
-      if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
-        aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full inside the slot
+      if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], Bf(4 * fr + i), acc, 0, 0, 0);
       // deferred epilogue: register r of the previous tile after MFMA group 1 + r*(KS4/4)
@@ -291,6 +383,7 @@ __device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const fl
           else epi1(to - 1, r, pend[r]);
         }
       }
+      st.slot_issue(f % SLOT_FRAGS);
       __builtin_amdgcn_sched_barrier(0);
     }
     pend = acc;
@@ -324,11 +417,16 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
   };
   f32x4 pm[2], pc_[2];
   f16x8 aq[AHEAD];
+  f32x4 nbias[2] = {*(const f32x4*)biaslane, *(const f32x4*)(biaslane + 16)};     // bias of the next tile pair, one pair ahead
 #pragma unroll
   for (int tp = 0; tp < NTP; ++tp) {
     f32x4 mn[2], cr[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { mn[t] = *(const f32x4*)(biaslane + (2 * tp + t) * 16); cr[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 2; ++t) { mn[t] = nbias[t]; cr[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (tp + 1 < NTP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) nbias[t] = *(const f32x4*)(biaslane + (2 * (tp + 1) + t) * 16);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -337,20 +435,20 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
         for (int pl = 0; pl < 2; ++pl) {
           const int f = ((tp * KS + ks) * 2 + t) * 2 + pl;
           if (f % SLOT_FRAGS == 0) {
-            st.begin();
+            st.wait_slot();
 #pragma unroll
             for (int u = 0; u < AHEAD; ++u)
-              if (f + u < NF && (f + u) / SLOT_FRAGS == f / SLOT_FRAGS) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+              if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
           }
           const f16x8 a = aq[f % AHEAD];
-          if (f + AHEAD < NF && (f + AHEAD) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + AHEAD < SLOT_FRAGS)
-            aq[f % AHEAD] = *frag_ptr(f + AHEAD);
+          if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);
           if (pl == 0) {
             mn[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bf(ks, 0), mn[t], 0, 0, 0);      // W_hi . x_hi
             cr[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bf(ks, 1), cr[t], 0, 0, 0);      // W_hi . x_lo
           } else {
             cr[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bf(ks, 0), cr[t], 0, 0, 0);      // W_lo . x_hi
           }
+          st.slot_issue(f % SLOT_FRAGS);
         }
       }
 #pragma unroll

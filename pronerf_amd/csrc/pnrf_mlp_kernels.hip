@@ -421,7 +421,7 @@ struct RefineArgs {
 
 // MODE 0: module-level (x -> y); 1: fused inference epilogue; 2: fused training-time epilogue (depth jitter, refine rgb head)
 template <int NCB, int NW, int MODE>
-__global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
+__global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(RefineArgs a) {
   constexpr bool FUSED = MODE != 0;
   constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -441,10 +441,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
     int64_t row[NCB];
     bool valid[NCB];
     bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID];
+    float e_ray[NCB][8];         // inputs of the fused epilogue, fetched with the batch's features (see nerf_kernel's RawIn)
+    float4 e_d0[NCB], e_d1[NCB];
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
       row[cb] = (int64_t)batch * (NW * COLS) + wave * COLS + cb * 32 + col;
       valid[cb] = row[cb] < a.n;
+      if (MODE != 0) {
+        const int64_t rr = valid[cb] ? row[cb] : a.n - 1;
+        const float* r = a.rays + rr * 11;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e_ray[cb][i] = r[i];
+        e_d0[cb] = *(const float4*)(a.depth_sorted + rr * 8); e_d1[cb] = *(const float4*)(a.depth_sorted + rr * 8 + 4);
+      }
       const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN + 8 * h;      // natural order: refine_in0()
 #pragma unroll
       for (int ks = 0; ks < R_KS0; ++ks) {
@@ -526,9 +535,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void refine_kernel(RefineArgs a) {
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
       const int64_t rr = valid[cb] ? row[cb] : a.n - 1;
-      const float* r = a.rays + rr * 11;
+      const float* r = e_ray[cb];
       const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5], near = r[6], far = r[7];
-      const float4 d0 = *(const float4*)(a.depth_sorted + rr * 8), d1 = *(const float4*)(a.depth_sorted + rr * 8 + 4);
+      const float4 d0 = e_d0[cb], d1 = e_d1[cb];
       // e = [near, d0..d7, far]; window w[i] = e[4h+i], i=0..5
       float w[6];
       w[0] = h ? d0.w : near; w[1] = h ? d1.x : d0.x; w[2] = h ? d1.y : d0.y;
@@ -596,7 +605,7 @@ struct NerfArgs {
 
 // CLS = false: DoNeRFTRT; CLS = true: the NeRF class (skip-concat at layer 5, feature/alpha heads, view branch)
 template <int NCB, int NW, bool FUSED, bool CLS>
-__global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
+__global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArgs a) {
   constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
@@ -612,23 +621,54 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
 
+  // Raw per-column inputs of a batch (fused path): sample position, view direction, and what the compositing epilogue
+  // needs — all fetched at the head of the batch: loaded where it is used, the epilogue's share costs a second exposed HBM
+  // round trip with all 8 waves of the workgroup waiting behind the last layer (3.74 -> 3.66 ms per frame).  Fetching
+  // one batch ahead from inside the last hidden layer was measured too and is a loss (3.73 ms): 13 more live registers
+  // spill, and the loads sit in the same in-order vmcnt queue as the weight stream.
+  struct RawIn { float x[3], v[3], d[3], z, add, mul, noise; };
+  const bool composite = FUSED && a.S == 8 && a.rgbd;
+  auto fetch = [&](int b, RawIn(&R)[NCB]) {
+    static_for<NCB>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      const int64_t r0 = (int64_t)b * (NW * COLS) + wave * COLS + cb * 32 + col;
+      const int64_t rr = r0 < nrows ? r0 : nrows - 1;
+      const float* pp = a.pts + rr * 3;
+      const float* ry = a.rays + (a.S == 8 ? (rr >> 3) : rr / a.S) * 11;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { R[cb].x[c] = pp[c]; R[cb].v[c] = ry[8 + c]; }
+      if (composite) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[cb].d[c] = ry[3 + c];
+        R[cb].z = a.z[rr]; R[cb].add = a.add ? a.add[rr] : 0.f; R[cb].mul = a.mul ? a.mul[rr] : 1.f;
+        R[cb].noise = a.noise ? a.noise[rr] : 0.f;
+      }
+    });
+  };
+  RawIn raw[NCB];
+
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
     int64_t row[NCB];
     bool valid[NCB];
     bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID], Bx[NCB][N_KSX];
+    float e_dn[NCB], e_z[NCB], e_add[NCB], e_mul[NCB], e_noise[NCB];
+    if constexpr (FUSED) fetch(batch, raw);
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
       row[cb] = (int64_t)batch * (NW * COLS) + wave * COLS + cb * 32 + col;
       valid[cb] = row[cb] < nrows;
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
+      if (FUSED && composite) {
+        const float* r = raw[cb].d;
+        e_dn[cb] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[0], r[0]), __fmul_rn(r[1], r[1])), __fmul_rn(r[2], r[2])));
+        e_z[cb] = raw[cb].z; e_add[cb] = raw[cb].add; e_mul[cb] = raw[cb].mul; e_noise[cb] = raw[cb].noise;
+      }
       if (FUSED) {
         // positional encoding in B-fragment order (nerf_in0 / nerf_inx): half 0 = sin, half 1 = cos.
         // sin/cos(2^k x): one accurate sincosf at k=0, then the exact double-angle recurrence; its
         // error (<= 2^k * 1e-7) is far below the bf16 rounding (2^-9) applied to the MLP input.
-        const float* pp = a.pts + rr * 3;
-        const float x3[3] = {pp[0], pp[1], pp[2]};
-        const float* vv = a.rays + (a.S == 8 ? (rr >> 3) : rr / a.S) * 11 + 8;
-        const float v3[3] = {vv[0], vv[1], vv[2]};
+        const float x3[3] = {raw[cb].x[0], raw[cb].x[1], raw[cb].x[2]};
+        const float v3[3] = {raw[cb].v[0], raw[cb].v[1], raw[cb].v[2]};
         float f0[32], fx[16];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -786,12 +826,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       float r0 = fin[cb][0], r1 = fin[cb][1], r2 = fin[cb][2], r3 = fin[cb][3];
       if (a.raw && valid[cb] && h == 0) *(float4*)(a.raw + row[cb] * 4) = make_float4(r0, r1, r2, r3);
-      if (a.S != 8 || !a.rgbd) return;
+      if (!composite) return;
       const int64_t ray = rr >> 3;
       const int s = (int)(rr & 7);
-      const float* r = a.rays + ray * 11;
-      const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[3], r[3]), __fmul_rn(r[4], r[4])), __fmul_rn(r[5], r[5])));
-      const float zc = a.z[rr], ad = a.add ? a.add[rr] : 0.f, mu = a.mul ? a.mul[rr] : 1.f;
+      const float dn = e_dn[cb], zc = e_z[cb], ad = e_add[cb], mu = e_mul[cb];
       if (a.clampv > 0.f) {                                                         // base.py:523
         r0 = fminf(fmaxf(r0, -a.clampv), a.clampv); r1 = fminf(fmaxf(r1, -a.clampv), a.clampv);
         r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
@@ -800,7 +838,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void nerf_kernel(NerfArgs a) {
       float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
       dist = __fmul_rn(dist, dn);                                                   // :583
       const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
-      const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, a.noise[rr]) : r3, ad), 0.f);     // refine2.py:508
+      const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
       float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
       if (a.mul) alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                          // :588
       const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
@@ -856,6 +894,10 @@ bool variant_1x8() {
   const char* e = getenv("PNRF_BF16_VARIANT");
   return !(e && e[0] == '2');          // default: 1x8 (two waves per SIMD)
 }
+bool variant_1x4() {                   // "1x4": two independent 4-wave workgroups per CU (one wave per SIMD each)
+  const char* e = getenv("PNRF_BF16_VARIANT");
+  return e && e[0] == '1' && e[1] == 'x' && e[2] == '4';
+}
 bool sampler_fold() { return env_int("PNRF_SAMPLER_FOLD", 1) != 0; }
 bool sampler_f16x2() {
   const char* e = getenv("PNRF_SAMPLER_PREC");
@@ -863,7 +905,7 @@ bool sampler_f16x2() {
 }
 
 template <class K, class A>
-int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream) {
+int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream, int wg_per_cu = 1) {
   // the ring + bias region exceeds the 64 KiB default dynamic-LDS limit: raise it once per kernel
   static thread_local const void* done[16] = {};
   static thread_local int ndone = 0;
@@ -877,7 +919,7 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
     }
     if (ndone < 16) done[ndone++] = (const void*)kern;
   }
-  const int ncu = num_cu();
+  const int ncu = num_cu() * wg_per_cu;
   const int grid = nbatch < ncu ? nbatch : ncu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(tpb), lds, stream, a);
   hipError_t e = hipGetLastError();
@@ -941,6 +983,10 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   a.n = n;
   a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  if (variant_1x4()) {
+    a.nbatch = (int)((n + 127) / 128);
+    return launch_mlp(refine_kernel<1, 4, 1>, a, 256, lds, a.nbatch, (hipStream_t)stream, 2);
+  }
   const int rows = 256;            // both variants: 256 columns per workgroup batch
   a.nbatch = (int)((n + rows - 1) / rows);
   return variant_1x8() ? launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream)
@@ -972,6 +1018,10 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);
   if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (variant_1x4()) {
+    a.nbatch = (int)((n * S + 127) / 128);
+    return launch_mlp(nerf_kernel<1, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream, 2);
+  }
   return variant_1x8() ? launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream)
                        : launch_mlp(nerf_kernel<2, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
@@ -1009,6 +1059,11 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
 extern "C" int pnrf_diag_read(unsigned long long* out, int n) {
   PNRF_HIP(hipDeviceSynchronize());
   PNRF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pnrf::g_pnrf_diag), sizeof(unsigned long long) * n));
+  return 0;
+}
+extern "C" int pnrf_diag_read_timeline(unsigned long long* out, int n) {
+  PNRF_HIP(hipDeviceSynchronize());
+  PNRF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pnrf::g_pnrf_tl), sizeof(unsigned long long) * n));
   return 0;
 }
 #endif

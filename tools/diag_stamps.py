@@ -57,3 +57,28 @@ for var, nw in (('1x8', 8), ('2x4', 4)):
     for _ in range(2):
         rgbd, _ = ops.nerf_fwd(rend.nerf, pts, rays, z, add, mul)
     print(f'nerf {var}:', read(nw))
+
+
+def timeline(nwg=8):
+    """Stamps of tiles 4 and 5 of the last full hidden layer (layer_bf16, -DPNRF_DIAG), per wave, in cycles after the
+    workgroup's first stamp: arrive | barrier released | after MFMA 0 | 1 | 8 | 15 issued | (tile 5 likewise) | arrive at tile 6."""
+    n = 64 * 8 * 16
+    buf = (C.c_ulonglong * n)()
+    lib.pnrf_diag_read_timeline.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    assert lib.pnrf_diag_read_timeline(buf, n) == 0
+    a = np.array(buf[:], dtype=np.int64).reshape(64, 8, 16)[:, :, :13]
+    names = ['arr4', 'rel4', 'm0', 'm1', 'm8', 'm15', 'arr5', 'rel5', 'm0', 'm1', 'm8', 'm15', 'arr6']
+    print('      ' + ' '.join(f'{x:>6s}' for x in names))
+    for wg in range(nwg):
+        t0 = a[wg].min()
+        for w in range(8):
+            print(f'wg{wg} w{w} ' + ' '.join(f'{int(v - t0):6d}' for v in a[wg, w]))
+    rel = a - a[:, :, :1].min(axis=1, keepdims=True)
+    print('mean  ' + ' '.join(f'{v:6.0f}' for v in rel.reshape(-1, 13).mean(0)))
+
+
+os.environ['PNRF_BF16_VARIANT'] = '1x8'
+for _ in range(2):
+    rgbd, _ = ops.nerf_fwd(rend.nerf, pts, rays, z, add, mul)
+print('nerf 1x8 timeline (cycles):')
+timeline()
