@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Fold the rocprofv3 --pmc passes of one round into profiles/<tag>_pmc_summary.json.
+
+    python tools/pmc_summary.py <tag> <dir with one sub-directory per pass>
+
+Each pass directory holds rocprofv3's *_counter_collection.csv (one counter set per pass, collected with
+--kernel-trace only, as MI355X_MICROARCH.md prescribes).  Per kernel (mean over its launches, copy kernels
+dropped):  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB  — gfx950 reports half of a wide coalesced
+read stream in FETCH_SIZE;  clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration;  mfma_busy_frac =
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8).  bench.py reads hbm_bytes_per_launch as
+roofline.traffic.  The raw CSVs are copied next to the summary."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+tag, src = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(ROOT, 'profiles')
+
+
+def short(name):
+    for k in ('nerf_kernel', 'refine_input_kernel', 'refine_kernel', 'sampler_h16_kernel', 'sampler_kernel', 'frame_rays_kernel',
+              'images_pack_kernel'):
+        if k in name:
+            return 'sampler_kernel' if k == 'sampler_h16_kernel' else k
+    return None
+
+
+acc = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True)):
+    names = set()
+    disp = {}
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            k = short(r['Kernel_Name'])
+            if not k:
+                continue
+            names.add(r['Counter_Name'])
+            acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+            disp[(k, r['Dispatch_Id'])] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    for (k, _), d in disp.items():
+        acc[k]['dur_ns@' + '+'.join(sorted(names))].append(d)
+    shutil.copy(f, os.path.join(out_dir, f'{tag}_pmc_' + '_'.join(sorted(names))[:60] + '_counter_collection.csv'))
+
+per = {}
+for k, c in acc.items():
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    e = {n: round(v, 1) for n, v in m.items() if not n.startswith('dur_ns@')}
+    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+        e['hbm_bytes_per_launch'] = int((2 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024)
+    durs = [v for n, v in m.items() if n.startswith('dur_ns@') and 'GRBM_GUI_ACTIVE' in n]
+    if durs and 'GRBM_GUI_ACTIVE' in m:
+        e['dur_ns_in_clock_pass'] = round(durs[0], 1)
+        cyc = m['GRBM_GUI_ACTIVE'] / 8
+        e['clock_GHz'] = round(cyc / durs[0], 3)
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
+            e['mfma_busy_frac'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc), 3)
+    per[k] = e
+summary = {
+    'round': tag,
+    'command': 'rocprofv3 --pmc <C> --kernel-trace --output-format csv -d <pass dir> -- python3 bench.py --steps 3 --warmup 1 '
+               '--no-cpu-baseline   (tools/profile_round.sh: one pass per counter set)',
+    'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over launches); see tools/pmc_summary.py for the derived fields',
+    'per_kernel': per,
+}
+path = os.path.join(out_dir, f'{tag}_pmc_summary.json')
+json.dump(summary, open(path, 'w'), indent=1)
+print(path)
+print(json.dumps({k: {n: v for n, v in e.items() if n in ('hbm_bytes_per_launch', 'clock_GHz', 'mfma_busy_frac')} for k, e in per.items()}, indent=1))
