@@ -86,6 +86,17 @@ struct SamplerArgs {
     const int ti = sw ? idx[j] : idx[i]; idx[j] = sw ? idx[i] : idx[j]; idx[i] = ti;   \
   }
 
+// stable ascending sort of dep[8] with idx[8]: 19-comparator network on (value, index) keys, used by both sampler kernels
+// (tests/test_abi_cpu.py checks this exact list exhaustively on 0/1 inputs and for stability)
+#define PNRF_SORT8                                                       \
+  PNRF_CSWAP(0, 1) PNRF_CSWAP(2, 3) PNRF_CSWAP(4, 5) PNRF_CSWAP(6, 7)  \
+  PNRF_CSWAP(0, 2) PNRF_CSWAP(1, 3) PNRF_CSWAP(4, 6) PNRF_CSWAP(5, 7)  \
+  PNRF_CSWAP(1, 2) PNRF_CSWAP(5, 6) PNRF_CSWAP(0, 4) PNRF_CSWAP(3, 7)  \
+  PNRF_CSWAP(1, 5) PNRF_CSWAP(2, 6)                                     \
+  PNRF_CSWAP(1, 4) PNRF_CSWAP(3, 6)                                     \
+  PNRF_CSWAP(2, 4) PNRF_CSWAP(3, 5)                                     \
+  PNRF_CSWAP(3, 4)
+
 __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
   const float lo = q == 0 ? a : b, hi = q == 2 ? c : d;
   return q < 2 ? lo : hi;
@@ -204,13 +215,7 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
     // stable ascending sort (19-comparator network on (value, index) keys)          // trt.py:632-635
-    PNRF_CSWAP(0, 1) PNRF_CSWAP(2, 3) PNRF_CSWAP(4, 5) PNRF_CSWAP(6, 7)
-    PNRF_CSWAP(0, 2) PNRF_CSWAP(1, 3) PNRF_CSWAP(4, 6) PNRF_CSWAP(5, 7)
-    PNRF_CSWAP(1, 2) PNRF_CSWAP(5, 6) PNRF_CSWAP(0, 4) PNRF_CSWAP(3, 7)
-    PNRF_CSWAP(1, 5) PNRF_CSWAP(2, 6)
-    PNRF_CSWAP(1, 4) PNRF_CSWAP(3, 6)
-    PNRF_CSWAP(2, 4) PNRF_CSWAP(3, 5)
-    PNRF_CSWAP(3, 4)
+    PNRF_SORT8
     uint32_t word = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) word |= (uint32_t)idx[i] << (3 * i);
@@ -347,13 +352,7 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
     // stable ascending sort (19-comparator network on (value, index) keys)          // trt.py:632-635
-    PNRF_CSWAP(0, 1) PNRF_CSWAP(2, 3) PNRF_CSWAP(4, 5) PNRF_CSWAP(6, 7)
-    PNRF_CSWAP(0, 2) PNRF_CSWAP(1, 3) PNRF_CSWAP(4, 6) PNRF_CSWAP(5, 7)
-    PNRF_CSWAP(1, 2) PNRF_CSWAP(5, 6) PNRF_CSWAP(0, 4) PNRF_CSWAP(3, 7)
-    PNRF_CSWAP(1, 5) PNRF_CSWAP(2, 6)
-    PNRF_CSWAP(1, 4) PNRF_CSWAP(3, 6)
-    PNRF_CSWAP(2, 4) PNRF_CSWAP(3, 5)
-    PNRF_CSWAP(3, 4)
+    PNRF_SORT8
     uint32_t word = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) word |= (uint32_t)idx[i] << (3 * i);
