@@ -239,3 +239,58 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         print(f'Mean Test PSNR {float(sum(psnrs) / len(psnrs))}')
     render_kwargs['psnrs'] = [float(p) for p in psnrs]
     return np.stack(rgbs0, 0), np.stack(rgbs1, 0), np.stack(depths, 0), np.stack(depths, 0)
+
+
+# ------------------------------------------------------------------------------------ frame driver
+def config_parser():
+    """Options of the inference script (run_S_eS_eN_alter_trt.py:44-183); see ``pronerf_amd.config``."""
+    from .config import config_parser as _cp
+    return _cp('trt')
+
+
+def train(argv=None, device='cuda'):
+    """The inference driver (run_S_eS_eN_alter_trt.py:699-800 — the reference calls it ``train`` too): load the LLFF scene,
+    pick the reference views, load the stage-2 checkpoint, render the hold-out views (``--render_test``) or the spiral path,
+    write PNGs + PSNR.  Returns the ``render_kwargs`` dict (per-frame milliseconds in ``render_ms``, PSNRs in ``psnrs``).
+
+    Deviations, all from SURVEY.md Appendix B: ``load_llff_data_infer`` gets ``num_neighbor=None`` like the reference's call
+    (B-2), which here ranks all training views instead of raising; no ONNX export side effect (B-4); ``--use_trt`` raises."""
+    from .load_llff import load_llff_data_infer
+    args = config_parser().parse_args(argv)
+    if args.dataset_type != 'llff':
+        raise ValueError('only dataset_type=llff is supported (as in the reference release)')
+    if args.use_trt:
+        raise PnrfError('--use_trt: TensorRT does not exist on ROCm; the fused HIP path is the engine')
+    images, poses, bds, render_poses, i_test, i_ref = load_llff_data_infer(args.datadir, args.factor, recenter=True, bd_factor=.75,
+                                                                            spherify=args.spherify)
+    hwf = poses[0, :3, -1]
+    poses = poses[:, :3, :4]
+    render_poses = render_poses[:, :3, :4]
+    if args.llffhold > 0:
+        i_test = np.arange(images.shape[0])[::args.llffhold]                                 # :722-724
+    near, far = (float(bds.min()) * .9, float(bds.max())) if args.no_ndc else (0., 1.)    # :731-738
+    H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)  # :746-751
+    out_root = os.path.join(args.basedir, args.expname or 'pronerf')
+    os.makedirs(out_root, exist_ok=True)
+    with open(os.path.join(out_root, 'args.txt'), 'w') as f:                                 # :757-761
+        for k in sorted(vars(args)):
+            f.write('{} = {}\n'.format(k, getattr(args, k)))
+    kw, start = create_nerf(args, device=device)
+    kw.update({'near': near, 'far': far, 'images': images[i_ref], 'poses': poses[i_ref], 'ref_K': K})   # :773-787
+    if args.max_images is not None:
+        i_test = i_test[:args.max_images]
+    if args.render_test:
+        targets, gt = poses[i_test], images[i_test]
+    else:
+        targets, gt = render_poses, None
+    savedir = os.path.join(out_root, 'renderonly_{}_{:06d}'.format('test' if args.render_test else 'path', start))
+    with torch.no_grad():
+        render_path(targets, [H, W, focal], K, args.chunk, kw, gt_imgs=gt, savedir=savedir, render_factor=args.render_factor,
+                    near=near, far=far)
+    print('Saved test set' if args.render_test else 'Saved render path', savedir)
+    return kw
+
+
+if __name__ == '__main__':
+    train()

@@ -1,0 +1,64 @@
+"""Config-file / CLI surface (pronerf_amd.config): the reference's own Fern configs must parse, command line wins."""
+import glob
+import os
+
+import pytest
+
+from pronerf_amd.config import config_parser, read_config_file
+
+FERN_TRT = """expname = fern_8samples_trtinfer
+ft_path = logs_minmax/fern_refine_8samples/370000.tar
+datadir = data/nerf_llff_data/fern
+dataset_type = llff
+factor = 4
+llffhold = 8
+N_rand = 4096
+N_samples = 8
+use_viewdirs = True
+raw_noise_std = 1e0
+lrate = 5e-4
+mmnetdepth = 6
+mmnetskips = [10000]
+N_point_ray_enc = 48
+mm_emb = False
+weight_decay = 5e-8
+num_neighbor = 4
+use_trt = False
+"""
+
+
+def test_config_file_then_command_line(tmp_path):
+    p = tmp_path / 'fern_trt.txt'
+    p.write_text(FERN_TRT)
+    a = config_parser('trt').parse_args(['--config', str(p)])
+    assert a.expname == 'fern_8samples_trtinfer' and a.factor == 4 and a.N_samples == 8 and a.N_point_ray_enc == 48
+    assert a.mmnetskips == [10000] and a.use_viewdirs is True and a.mm_emb is False and a.use_trt is False
+    assert a.raw_noise_std == 1.0 and a.weight_decay == 5e-8 and a.netdepth == 8 and a.basedir == './logs_trt/'
+    b = config_parser('trt').parse_args(['--config', str(p), '--factor', '8', '--render_test', '--max_images', '2'])
+    assert b.factor == 8 and b.render_test is True and b.max_images == 2 and b.N_samples == 8
+
+
+def test_unknown_option_in_file_is_an_error(tmp_path):
+    p = tmp_path / 'bad.txt'
+    p.write_text('no_such_option = 3\n')
+    with pytest.raises(SystemExit):
+        config_parser('trt').parse_args(['--config', str(p)])
+
+
+@pytest.mark.parametrize('variant', ['trt', 'refine2', 'base'])
+def test_defaults(variant):
+    a = config_parser(variant).parse_args([])
+    assert a.N_samples == 64 and a.N_point_ray_enc == 32 and a.lrate_decay == 250 and a.num_neighbor == 4
+    assert a.basedir == ('./logs_trt/' if variant == 'trt' else './logs_epi_RR/')
+    assert hasattr(a, 'max_images') == (variant == 'trt') and hasattr(a, 'pretrain_path') == (variant == 'refine2')
+
+
+def test_reference_configs_parse_if_present():
+    """In the development container the reference's shipped configs are parsed as they are (skipped on the GPU box)."""
+    files = glob.glob('/root/reference/configs/llff/fern/*.txt')
+    if not files:
+        pytest.skip('reference not present')
+    for f in files:
+        variant = 'trt' if f.endswith('_trt.txt') else ('refine2' if f.endswith('_refine.txt') else 'base')
+        a = config_parser(variant).parse_args(['--config', f])
+        assert a.N_samples == 8 and set(read_config_file(f)) <= set(vars(a))

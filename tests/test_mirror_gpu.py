@@ -161,3 +161,40 @@ def test_nerf_class_module_and_checkpoint_dispatch(dev, golden_dir, tmp_path):
     torch.save({'global_step': 2, 'mmr_network_fn_state_dict': sds['sampler'], 'refine_net_state_dict': sds['refine'], 'network_fine_state_dict': sds['nerf']}, ck)
     kw, start = trt.create_nerf(a, device=dev)
     assert start == 2 and isinstance(kw['network_fine'], h.DoNeRFTRT)
+
+
+def test_frame_driver_on_an_llff_directory(dev, tmp_path):
+    """train() of the inference mirror end to end: LLFF directory + COLMAP model + .tar checkpoint with the reference's keys
+    -> hold-out renders, PNGs, PSNR; frame 0 is compared with the oracle's rendering of the same pose / reference views."""
+    import llff_synth
+    from pronerf_amd import load_llff as L
+    from pronerf_amd import run_S_eS_eN_alter_trt as trt
+    root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=1, n=10, H=24, W=32, factor=4)
+    w = synth.make_weights(0, 'trained')
+    sds = synth.state_dicts(w)
+    ck = str(tmp_path / '000123.tar')
+    torch.save({'global_step': 123, 'mmr_network_fn_state_dict': sds['sampler'], 'refine_net_state_dict': sds['refine'],
+                'network_fine_state_dict': sds['nerf']}, ck)
+    cfg = tmp_path / 'cfg.txt'
+    cfg.write_text(f'expname = drv\nbasedir = {tmp_path}/logs\ndatadir = {root}\nft_path = {ck}\nfactor = 4\nllffhold = 8\nN_samples = 8\n'
+                   'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\n')
+    kw = trt.train(['--config', str(cfg), '--render_test'], device=dev)
+    out = tmp_path / 'logs' / 'drv' / 'renderonly_test_000123'
+    assert sorted(os.listdir(out)) == ['000.png', '001.png', 'depth_000.png', 'depth_001.png']
+    assert (tmp_path / 'logs' / 'drv' / 'args.txt').read_text().count('\n') > 50
+    assert len(kw['psnrs']) == 2 and len(kw['render_ms']) == 2
+    # checker: same scene through the loader + oracle
+    images, poses, bds, _, i_test, i_ref = L.load_llff_data_infer(root, factor=4)
+    H, W, focal = int(poses[0, 0, 4]), int(poses[0, 1, 4]), float(poses[0, 2, 4])
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+    scene = {'H': H, 'W': W, 'K': K, 'c2w': poses[i_test[0], :3, :4], 'poses': poses[i_ref][:, :3, :4], 'images': images[i_ref]}
+    fr = orc.frame_setup(scene)
+    ref = orc.render_rays_infer(w, fr['rays'], fr['or_rays'], fr['images'], fr['proj'])
+    got = _read_png(str(out / '000.png')).astype(np.float32) / 255.
+    want = np.clip(ref['rgb'].reshape(H, W, 3).numpy(), 0, 1)
+    assert orc.psnr(torch.from_numpy(got), torch.from_numpy(want)) > 40.0        # 8-bit PNG (quantisation floor ~59 dB) vs the oracle's frame
+
+
+def _read_png(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))
