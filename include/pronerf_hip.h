@@ -40,6 +40,7 @@ extern "C" {
 
 typedef struct pnrf_mlp pnrf_mlp_t;
 typedef struct pnrf_ctx pnrf_ctx_t;
+typedef struct pnrf_trainer pnrf_trainer_t;
 
 int pnrf_abi_version(void);
 const char* pnrf_last_error(void);
@@ -180,6 +181,78 @@ int pnrf_ctx_free(pnrf_ctx_t* ctx);
 int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_rays,
                          const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
                          float* rgbd, int64_t* sort_idx, int64_t n, void* stream);
+
+/* ---- stage-2 training step --------------------------------------------------
+ * fp32 throughout, like the reference's training.  Layer products are rocBLAS GEMMs inside the library; every other
+ * stage (heads, sort, interval refinement, jitter, encodings, compositing, losses, Adam) is a kernel of this library. */
+
+/* Operator-level backward passes (each mirrors what torch.autograd derives for the forward it names). */
+/* raw2outputs backward for d rgb_map [n,3]: arguments as pnrf_composite_fwd; outputs d_raw dev [n,s,4], d_z dev [n,s] (NULL to
+ * skip), d_add / d_mul dev [n,s] (NULL to skip).  s <= 64.  (run_S_eS_eN_alter_base_refine2.py:475-522) */
+int pnrf_composite_bwd(const float* raw, const float* z, const float* rays_d, int d_stride, const float* add,
+                       const float* mul, const float* noise, float clamp, int white_bkgd, const float* d_rgb,
+                       float* d_raw, float* d_z, float* d_add, float* d_mul, int64_t n, int s, void* stream);
+/* Embedder.embed backward: d_x[n,3] from d_out[n, 3+6*n_freq] (run_nerf_helpers.py:666-671). */
+int pnrf_posenc_bwd(const float* x, const float* d_out, float* d_x, int64_t n, int n_freq, void* stream);
+/* Sampler head on the raw output y dev [n,27] of MinMaxRay_Net: depth = sigmoid(y[0:8]) (far-near)+near, stable ascending
+ * sort, add / mul gathered by the sort indices, mm_rgb = sigmoid(y[24:27]) (NULL to skip)
+ * (run_S_eS_eN_alter_base_refine2.py:557-568); the backward scatters through sort_idx. */
+int pnrf_sampler_head_fwd(const float* y, const float* rays, float* depth_sorted, int64_t* sort_idx, float* add_sorted,
+                          float* mul_sorted, float* mm_rgb, int64_t n, void* stream);
+int pnrf_sampler_head_bwd(const float* y, const float* rays, const int64_t* sort_idx, const float* d_depth_sorted,
+                          const float* d_add_sorted, const float* d_mul_sorted, const float* d_mm_rgb, float* d_y,
+                          int64_t n, void* stream);
+/* Refine head on the raw output y dev [n,35]: refine = sigmoid(y[0:8]), offsets = tanh(y[8:32]), rgb0 = sigmoid(y[32:35])
+ * (NULL to skip); interval refinement, depth jitter (jitter dev [n,8] or NULL, jitter_dir +-1), query points
+ * pts dev [n,8,3] = o + d z + 0.01 offsets; z_pre dev [n,8] = depths before the jitter (input of the backward)
+ * (run_S_eS_eN_alter_base_refine2.py:635-668).  Backward: d_pts dev [n,8,3], d_z dev [n,8] or NULL, d_rgb0 dev [n,3] or
+ * NULL -> d_y dev [n,35], d_depth_sorted dev [n,8]. */
+int pnrf_refine_head_fwd(const float* y, const float* rays, const float* depth_sorted, const float* jitter,
+                         int jitter_dir, float* z_pre, float* z, float* pts, float* rgb0, int64_t n, void* stream);
+int pnrf_refine_head_bwd(const float* y, const float* rays, const float* depth_sorted, const float* z_pre,
+                         const float* jitter, int jitter_dir, const float* d_pts, const float* d_z,
+                         const float* d_rgb0, float* d_y, float* d_depth_sorted, int64_t n, void* stream);
+
+/* Trainer: fp32 parameters, gradients, Adam moments and workspaces of the three networks for batches of up to max_rays
+ * rays.  26 Linear layers in this order: sampler fc_backbone.0..5, fc_output (MinMaxRay_Net, 288 -> 27); refine net
+ * likewise (144 -> 35); fine net of class NeRF: pts_linears.0..7, feature_linear, alpha_linear, views_linears.0, rgb_linear.
+ * W[i]: [out_dim[i], in_dim[i]] row-major (torch layout), host or device.
+ * Replaces create_nerf's modules + torch.optim.Adam (run_S_eS_eN_alter_base_refine2.py:337-395). */
+int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim,
+                        int n_layers, int64_t max_rays, pnrf_trainer_t** out);
+int pnrf_trainer_free(pnrf_trainer_t* t);
+/* kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment; W, b: host or device (NULL to skip). */
+int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, float* W, float* b, void* stream);
+int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const float* W, const float* b, void* stream);
+int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step);
+
+typedef struct pnrf_train_batch {
+  const float* rays;       /* dev [n,11] NDC ray batch (o, d, near, far, viewdir) */
+  const float* or_rays;    /* dev [n,11] world-space rays */
+  const float* target;     /* dev [n,3] ground-truth colours */
+  const float* img4;       /* dev [nv,Hf,Wf,4] training views (pnrf_images_pack) */
+  const float* poses;      /* dev [nv,3,4] camera-to-world */
+  const float* K;          /* dev [3,3] */
+  const int64_t* ref_nos;  /* dev [n,4] source views of each ray (the reference's random neighbour draw, made explicit) */
+  const float* jitter;     /* dev [n,8] = min(|N(0,1)|/5, 1-2e-6) or NULL */
+  const float* raw_noise;  /* dev [n,8] = randn * raw_noise_std or NULL */
+  int64_t n;
+  int nv, Hf, Wf;
+  int jitter_dir;          /* +1 toward the next sample / far, -1 toward the previous / near */
+  int white_bkgd;
+  float eps;               /* NDC -> metric epsilon: 1e-5 */
+  float a_mmrgb;           /* weight of mse(rgb_map0) + mse(mm_rgb) in the loss (0 in fern_refine.txt) */
+} pnrf_train_batch_t;
+
+/* render_rays (training) + img2mse + loss.backward(): leaves the gradients of all 26 layers in the trainer.
+ * loss dev [4] = {total, mse(rgb_map1), mse(rgb_map0), mse(mm_rgb)}; rgb_map1 dev [n,3] or NULL.
+ * (run_S_eS_eN_alter_base_refine2.py:525-680, 858-868) */
+int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* batch, float* loss, float* rgb_map1,
+                              void* stream);
+/* optimizer.step() of torch.optim.Adam (L2 weight decay added to the gradient) over all parameters
+ * (run_S_eS_eN_alter_base_refine2.py:394, 869). */
+int pnrf_trainer_adam_step(pnrf_trainer_t* t, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           void* stream);
 
 /* Host helper: torch.linspace(start,end,n) in fp32, as used for the 48 ray points
  * (run_S_eS_eN_alter_trt.py:556-557).  out: HOST [n]. */

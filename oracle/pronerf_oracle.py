@@ -378,7 +378,8 @@ def render_rays_stage2(weights, rays, or_rays, images_nchw, poses, K, ref_nos, j
     near, far = rays[:, 6:7], rays[:, 7:8]
     mm_rgb, add, mul, depth = sampler_forward(weights['sampler'], mm_input_from_rays(o, d, n_pts), S)     # :551-563
     depth_sorted, idx, add_s, mul_s = sort_gather(depth, add, mul, near, far)                               # :563-568
-    epi, margin = project_train(images_nchw, poses, K, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, ref_nos, eps)   # :570-626
+    with torch.no_grad():                      # the reference builds the epipolar features under torch.no_grad() (:576-626)
+        epi, margin = project_train(images_nchw, poses, K, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, ref_nos, eps)   # :570-626
     pl = pluecker(o[:, None, :] + d[:, None, :] * depth_sorted[..., None], d[:, None, :].expand(-1, S, -1)).reshape(N, 6 * S)
     refine_in = torch.cat([pl, epi], 1)                                                                      # :634
     rdepth, refine_rgb, offs = refine_forward(weights['refine'], refine_in, S)                               # :635-638
@@ -461,3 +462,35 @@ def render_rays_stage1(weights, rays, or_rays, images_nchw, poses, K, ref_nos, t
 def psnr(a, b, peak=1.0):
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float('inf') if mse == 0 else 10.0 * math.log10(peak * peak / mse)
+
+
+# ----------------------------------------------------------------------------- stage-2 training step
+def trainer_layers(weights):
+    """The 26 (W, b) pairs of the stage-2 optimizer in the trainer's order: sampler fc_backbone.0..5 + fc_output, refine net
+    likewise, fine net (class NeRF) pts_linears.0..7, feature_linear, alpha_linear, views_linears.0, rgb_linear
+    (run_S_eS_eN_alter_base_refine2.py:358-392).  ``weights``: 'sampler', 'refine' stacks and 'nerfcls'."""
+    wc = weights['nerfcls']
+    out = list(zip(weights['sampler']['W'], weights['sampler']['b'])) + list(zip(weights['refine']['W'], weights['refine']['b']))
+    out += list(wc['pts_linears']) + [wc['feature_linear'], wc['alpha_linear'], wc['views_linears'][0], wc['rgb_linear']]
+    return out
+
+
+def weights_from_layers(layers):
+    """Inverse of ``trainer_layers`` (entries may be tensors that require grad)."""
+    L = list(layers)
+    return {'sampler': {'W': [w for w, _ in L[0:7]], 'b': [b for _, b in L[0:7]]},
+            'refine': {'W': [w for w, _ in L[7:14]], 'b': [b for _, b in L[7:14]]},
+            'nerfcls': {'pts_linears': L[14:22], 'feature_linear': L[22], 'alpha_linear': L[23], 'views_linears': [L[24]], 'rgb_linear': L[25]}}
+
+
+def stage2_loss(layers, rays, or_rays, target, images_nchw, poses, K, ref_nos, jitter=None, jitter_dir=1, raw_noise=None, white_bkgd=False,
+                a_mmrgb=0.0):
+    """loss of one stage-2 iteration (run_S_eS_eN_alter_base_refine2.py:855-866): img2mse(rgb_map1, target)
+    [+ a_mmrgb (img2mse(rgb_map0) + img2mse(mm_rgb))].  Returns (loss, img_loss, outputs)."""
+    o = render_rays_stage2(weights_from_layers(layers), rays, or_rays, images_nchw, poses, K, ref_nos, jitter=jitter, jitter_dir=jitter_dir,
+                           raw_noise=raw_noise, white_bkgd=white_bkgd)
+    img_loss = torch.mean((o['rgb_map1'] - target) ** 2)
+    loss = img_loss
+    if a_mmrgb > 0:
+        loss = loss + a_mmrgb * (torch.mean((o['rgb_map0'] - target) ** 2) + torch.mean((o['mm_rgb'] - target) ** 2))
+    return loss, img_loss, o

@@ -19,7 +19,8 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libpronerf_hip.so')
-SOURCES = ['pnrf_pack.hip', 'pnrf_ops.hip', 'pnrf_mlp_kernels.hip']
+SOURCES = ['pnrf_pack.hip', 'pnrf_ops.hip', 'pnrf_mlp_kernels.hip', 'pnrf_train.hip']
+LINK = ['-lrocblas']          # layer products of the training step (plain library GEMMs)
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
 
@@ -64,7 +65,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f'hipcc failed on {s}:\n{out}')
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs + LINK
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -79,7 +80,7 @@ def build_variant(name: str, extra_flags=(), csrc: str = CSRC, include: str = IN
     os.makedirs(LIBDIR, exist_ok=True)
     out = os.path.join(LIBDIR, f'libpronerf_hip_{name}.so')
     srcs = [os.path.join(csrc, s) for s in SOURCES]
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ['-shared', '-I', include, '-o', out] + srcs
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ['-shared', '-I', include, '-o', out] + srcs + LINK
     subprocess.run(cmd, check=True)
     return out
 

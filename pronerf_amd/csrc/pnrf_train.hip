@@ -1,0 +1,777 @@
+// pnrf_train.hip — stage-2 training step: forward with saved activations, backward, Adam.
+//
+// Reference: run_S_eS_eN_alter_base_refine2.py — render_rays :525-680 (forward), loss / backward / optimizer.step :858-869,
+// create_nerf :337-395 (one Adam over fine net + sampler + refine net, betas (0.9, 0.999), eps 1e-8, L2 weight decay).
+//
+// Everything is fp32, like the reference's training.  The layer products (Y = X W^T, dX = dY W, dW = dY^T X) are plain
+// library GEMMs (rocBLAS); every other stage is a hand-written kernel here: bias + activation and its backward with the
+// bias-gradient column sums, the sampler head (sigmoid, depth affine, stable 8-sort, gathers) and its scatter backward,
+// the refine head (interval refinement, depth jitter, query points) and its backward, positional-encoding forward /
+// backward, alpha-compositing backward (suffix products, no division by the transmittance factors), the MSE losses and
+// Adam.  The projection into the training views carries no gradient in the reference (`torch.no_grad`, :576) and the
+// Pluecker moment does not depend on the depth along the ray, so no gradient reaches refine_in or mm_input and the first
+// layers of the sampler / refine nets need no dX.  A trainer owns parameters, gradients, Adam moments and workspaces;
+// nothing is allocated per step and every launch goes to the caller's stream.
+#include <rocblas/rocblas.h>
+
+#include "pnrf_common.h"
+
+using namespace pnrf;
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(int64_t work, int per_block = TPB) {
+  int64_t g = (work + per_block - 1) / per_block;
+  const int64_t cap = 256 * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+enum { T_ACT_NONE = 0, T_ACT_RELU = 1, T_ACT_ELU = 2 };
+
+// ------------------------------------------------------------------------------------------ dense-layer pieces
+// Y[r, j] = act(Y[r, j] + b[j]) in place; Y has row stride ld.
+__global__ void bias_act_kernel(float* __restrict__ Y, int ld, const float* __restrict__ b, int64_t R, int out, int act) {
+  const int64_t total = R * out;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / out;
+    const int j = (int)(i - r * out);
+    float v = Y[r * ld + j] + b[j];
+    if (act == T_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == T_ACT_ELU) v = v > 0.f ? v : expm1f(v);           // F.elu, alpha = 1
+    Y[r * ld + j] = v;
+  }
+}
+
+// dZ = dH * act'(H) in place (H = saved post-activation output) and partial column sums for the bias gradient.
+// grid (ceil(out/64), NCHUNK); block 256 = 64 columns x 4 row lanes.  part[chunk][out].
+constexpr int DB_CHUNKS = 64;
+__global__ void act_bwd_colsum_kernel(float* __restrict__ dH, int ldd, const float* __restrict__ H, int ldh, int64_t R, int out, int act,
+                                      float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int64_t rows_per = (R + DB_CHUNKS - 1) / DB_CHUNKS;
+  const int64_t r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
+  float s = 0.f;
+  if (j < out) {
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      float g = dH[r * ldd + j];
+      if (act != T_ACT_NONE) {
+        const float h = H[r * ldh + j];
+        if (act == T_ACT_RELU) g = h > 0.f ? g : 0.f;
+        else g = h > 0.f ? g : g * (h + 1.f);                            // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
+        dH[r * ldd + j] = g;
+      }
+      s += g;
+    }
+  }
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && j < out) part[blockIdx.y * out + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int out, float* __restrict__ db) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= out) return;
+  float s = 0.f;
+  for (int k = 0; k < DB_CHUNKS; ++k) s += part[k * out + j];
+  db[j] = s;
+}
+
+// ------------------------------------------------------------------------------------------ positional encoding
+// out[row, col_off + ...] = [x, sin(2^k x), cos(2^k x)]_k with row stride ld; the input row is row / rep (view directions are
+// shared by the `rep` samples of a ray), x has row stride xs.   (run_nerf_helpers.py:666-671)
+__global__ void posenc_strided_kernel(const float* __restrict__ x, int xs, int rep, float* __restrict__ out, int ld, int col_off, int64_t rows,
+                                      int n_freq) {
+  const int64_t total = rows * 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / 3;
+    const int c = (int)(i - row * 3);
+    const float v = x[(row / rep) * xs + c];
+    float* o = out + row * ld + col_off;
+    o[c] = v;
+    for (int k = 0; k < n_freq; ++k) {
+      const float arg = v * (float)(1u << k);
+      o[3 + 6 * k + c] = sinf(arg);
+      o[3 + 6 * k + 3 + c] = cosf(arg);
+    }
+  }
+}
+// dx[row, c] = sum over the two gradient sources (either may be NULL) of  dE[c] + sum_k 2^k (cos(2^k x) dE[sin_k] - sin(2^k x) dE[cos_k])
+__global__ void posenc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dA, int lda, const float* __restrict__ dB, int ldb,
+                                  float* __restrict__ dx, int64_t rows, int n_freq) {
+  const int64_t total = rows * 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / 3;
+    const int c = (int)(i - row * 3);
+    const float v = x[i];
+    float g = 0.f;
+    for (int src = 0; src < 2; ++src) {
+      const float* d = src == 0 ? dA : dB;
+      if (!d) continue;
+      const float* e = d + row * (src == 0 ? lda : ldb);
+      g += e[c];
+      for (int k = 0; k < n_freq; ++k) {
+        const float f = (float)(1u << k), arg = v * f;
+        g += f * (cosf(arg) * e[3 + 6 * k + c] - sinf(arg) * e[3 + 6 * k + 3 + c]);
+      }
+    }
+    dx[i] = g;
+  }
+}
+// copy a column block: dst[r, dcol + j] = src[r, scol + j], j < w
+__global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, int scol, float* __restrict__ dst, int ldd, int dcol, int64_t R, int w) {
+  const int64_t total = R * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / w;
+    const int j = (int)(i - r * w);
+    dst[r * ldd + dcol + j] = src[r * lds_ + scol + j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ sampler head
+// y[n,27] -> depth = sigmoid(y[0:8]) (far-near)+near, stable ascending sort, add/mul gathered by the sort indices,
+// mm_rgb = sigmoid(y[24:27])  (refine2.py:551-568).  One thread per ray.
+__global__ void sampler_head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ rays, float* __restrict__ depth_sorted,
+                                        int64_t* __restrict__ idx_out, float* __restrict__ add_s, float* __restrict__ mul_s, float* __restrict__ mm_rgb,
+                                        int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* yr = y + i * 27;
+    const float near = rays[i * 11 + 6], far = rays[i * 11 + 7];
+    const float span = __fsub_rn(far, near);
+    float dep[8];
+    int idx[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { dep[s] = __fadd_rn(__fmul_rn(sigmoid_f(yr[s]), span), near); idx[s] = s; }
+    // insertion sort on (value, index): stable, 8 elements
+#pragma unroll
+    for (int a = 1; a < 8; ++a) {
+#pragma unroll
+      for (int b = a; b > 0; --b) {
+        const bool sw = dep[b - 1] > dep[b];
+        const float tv = sw ? dep[b - 1] : dep[b]; dep[b - 1] = sw ? dep[b] : dep[b - 1]; dep[b] = tv;
+        const int ti = sw ? idx[b - 1] : idx[b]; idx[b - 1] = sw ? idx[b] : idx[b - 1]; idx[b] = ti;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      depth_sorted[i * 8 + s] = dep[s];
+      idx_out[i * 8 + s] = idx[s];
+      float a = yr[8], m = yr[16];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) { a = idx[s] == k ? yr[8 + k] : a; m = idx[s] == k ? yr[16 + k] : m; }
+      add_s[i * 8 + s] = a; mul_s[i * 8 + s] = m;
+    }
+    if (mm_rgb) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) mm_rgb[i * 3 + c] = sigmoid_f(yr[24 + c]);
+    }
+  }
+}
+// dy[n,27] from d depth_sorted, d add_sorted, d mul_sorted (scatter through the sort indices) and d mm_rgb (may be NULL).
+__global__ void sampler_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ rays, const int64_t* __restrict__ idx,
+                                        const float* __restrict__ d_depth, const float* __restrict__ d_add, const float* __restrict__ d_mul,
+                                        const float* __restrict__ d_rgb, float* __restrict__ dy, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* yr = y + i * 27;
+    const float span = rays[i * 11 + 7] - rays[i * 11 + 6];
+    float g[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) g[k] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = (int)idx[i * 8 + s];
+      const float gd = d_depth[i * 8 + s], ga = d_add[i * 8 + s], gm = d_mul[i * 8 + s];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q == k) { g[q] += gd; g[8 + q] += ga; g[16 + q] += gm; }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float sg = sigmoid_f(yr[s]);
+      g[s] = g[s] * span * sg * (1.f - sg);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sg = sigmoid_f(yr[24 + c]);
+      g[24 + c] = d_rgb ? d_rgb[i * 3 + c] * sg * (1.f - sg) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) dy[i * 27 + k] = g[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ refine head
+// y[n,35] -> refine = sigmoid(y[0:8]), offsets = tanh(y[8:32]), rgb0 = sigmoid(y[32:35]); interval refinement over the sorted
+// depths, depth jitter toward the next (dir > 0) / previous (dir < 0) sample, query points o + d z + 0.01 offsets
+// (refine2.py:635-668).  z_pre = refined depths before the jitter (saved for the backward).
+__global__ void refine_head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ rays, const float* __restrict__ depth_sorted,
+                                       const float* __restrict__ jitter, int jitter_dir, float* __restrict__ z_pre, float* __restrict__ z,
+                                       float* __restrict__ pts, float* __restrict__ rgb0, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* yr = y + i * 35;
+    const float* r = rays + i * 11;
+    const float near = r[6], far = r[7];
+    float D[8], zz[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) D[s] = depth_sorted[i * 8 + s];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float lower = s == 0 ? __fmul_rn(0.5f, __fadd_rn(near, D[0])) : __fmul_rn(0.5f, __fadd_rn(D[s], D[s - 1]));
+      const float upper = s == 7 ? __fmul_rn(0.5f, __fadd_rn(far, D[7])) : __fmul_rn(0.5f, __fadd_rn(D[s + 1], D[s]));
+      zz[s] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), sigmoid_f(yr[s])));
+      z_pre[i * 8 + s] = zz[s];
+    }
+    if (jitter) {
+      float zn[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float j = jitter[i * 8 + s];
+        if (jitter_dir > 0) zn[s] = __fadd_rn(zz[s], __fmul_rn(j, fabsf(__fsub_rn(zz[s], s < 7 ? zz[s < 7 ? s + 1 : 7] : far))));
+        else zn[s] = __fsub_rn(zz[s], __fmul_rn(j, fabsf(__fsub_rn(zz[s], s > 0 ? zz[s > 0 ? s - 1 : 0] : near))));
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) zz[s] = zn[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      z[i * 8 + s] = zz[s];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        pts[(i * 8 + s) * 3 + c] = __fadd_rn(__fadd_rn(r[c], __fmul_rn(r[3 + c], zz[s])), __fmul_rn(1e-2f, tanhf(yr[8 + 3 * s + c])));
+    }
+    if (rgb0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb0[i * 3 + c] = sigmoid_f(yr[32 + c]);
+    }
+  }
+}
+// Backward of the refine head.  Inputs: d pts [n,8,3], d z [n,8] (from the compositing), d rgb0 [n,3] or NULL.
+// Outputs: dy [n,35], d depth_sorted [n,8].
+__global__ void refine_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ rays, const float* __restrict__ depth_sorted,
+                                       const float* __restrict__ z_pre, const float* __restrict__ jitter, int jitter_dir,
+                                       const float* __restrict__ d_pts, const float* __restrict__ d_z, const float* __restrict__ d_rgb0,
+                                       float* __restrict__ dy, float* __restrict__ d_depth, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* yr = y + i * 35;
+    const float* r = rays + i * 11;
+    const float near = r[6], far = r[7];
+    float gz[8], zp[8], D[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      zp[s] = z_pre[i * 8 + s]; D[s] = depth_sorted[i * 8 + s];
+      float g = d_z ? d_z[i * 8 + s] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float gp = d_pts[(i * 8 + s) * 3 + c];
+        g += gp * r[3 + c];                                                   // pts = o + d z + 0.01 offs
+        const float t = tanhf(yr[8 + 3 * s + c]);
+        dy[i * 35 + 8 + 3 * s + c] = 1e-2f * gp * (1.f - t * t);
+      }
+      gz[s] = g;
+    }
+    if (jitter) {        // z' = z +- j |z - neighbour|
+      float gp[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) gp[s] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float j = jitter[i * 8 + s];
+        if (jitter_dir > 0) {
+          const float nb = s < 7 ? zp[s < 7 ? s + 1 : 7] : far;
+          const float u = zp[s] - nb;
+          const float sg = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+          gp[s] += gz[s] * (1.f + j * sg);
+          if (s < 7) gp[s < 7 ? s + 1 : 7] += gz[s] * (-j * sg);
+        } else {
+          const float nb = s > 0 ? zp[s > 0 ? s - 1 : 0] : near;
+          const float u = zp[s] - nb;
+          const float sg = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+          gp[s] += gz[s] * (1.f - j * sg);
+          if (s > 0) gp[s > 0 ? s - 1 : 0] += gz[s] * (j * sg);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) gz[s] = gp[s];
+    }
+    // z = lower + (upper - lower) refine
+    float gD[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) gD[s] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float lower = s == 0 ? 0.5f * (near + D[0]) : 0.5f * (D[s] + D[s - 1]);
+      const float upper = s == 7 ? 0.5f * (far + D[7]) : 0.5f * (D[s + 1] + D[s]);
+      const float rf = sigmoid_f(yr[s]);
+      dy[i * 35 + s] = gz[s] * (upper - lower) * rf * (1.f - rf);
+      const float gl = gz[s] * (1.f - rf), gu = gz[s] * rf;
+      if (s == 0) gD[0] += 0.5f * gl; else { gD[s] += 0.5f * gl; gD[s - 1] += 0.5f * gl; }
+      if (s == 7) gD[7] += 0.5f * gu; else { gD[s + 1] += 0.5f * gu; gD[s] += 0.5f * gu; }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) d_depth[i * 8 + s] = gD[s];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sg = sigmoid_f(yr[32 + c]);
+      dy[i * 35 + 32 + c] = d_rgb0 ? d_rgb0[i * 3 + c] * sg * (1.f - sg) : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ compositing backward
+// raw2outputs (refine2.py:475-522) backward for d rgb_map [n,3]: d raw [n,S,4], d z [n,S], d add / d mul [n,S] (NULL to skip).
+// The derivative of the transmittance products is accumulated with explicit suffix products (S <= 64), never dividing by
+// a factor 1 - alpha + 1e-10 that can be 1e-10.
+constexpr int CB_MAXS = 64;
+__global__ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
+                                     const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
+                                     int white_bkgd, const float* __restrict__ d_rgb, float* __restrict__ d_raw, float* __restrict__ d_z,
+                                     float* __restrict__ d_add, float* __restrict__ d_mul, int64_t n, int S) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* d = rays_d + i * d_stride;
+    const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float g0 = d_rgb[i * 3], g1 = d_rgb[i * 3 + 1], g2 = d_rgb[i * 3 + 2];
+    float x[CB_MAXS], al[CB_MAXS], dw[CB_MAXS];
+    // pass 1: forward quantities
+    float T = 1.f;
+    for (int s = 0; s < S; ++s) {
+      const int64_t e = i * S + s;
+      float r0 = raw[e * 4], r1 = raw[e * 4 + 1], r2 = raw[e * 4 + 2], r3 = raw[e * 4 + 3];
+      if (clampv > 0.f) { r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv); r2 = fminf(fmaxf(r2, -clampv), clampv); r3 = fminf(fmaxf(r3, -clampv), clampv); }
+      const float dist = ((s + 1 < S) ? (z[e + 1] - z[e]) : 1e10f) * dn;
+      float sg = r3;
+      if (noise) sg += noise[e];
+      if (add) sg += add[e];
+      const float a = 1.f - expf(-fmaxf(sg, 0.f) * dist);
+      al[s] = mul ? a * fmaxf(mul[e], 0.f) : a;
+      x[s] = 1.f - al[s] + 1e-10f;
+      const float w = al[s] * T;
+      T *= x[s];
+      const float c0 = sigmoid_f(r0), c1 = sigmoid_f(r1), c2 = sigmoid_f(r2);
+      dw[s] = g0 * c0 + g1 * c1 + g2 * c2 - (white_bkgd ? (g0 + g1 + g2) : 0.f);     // rgb_map += 1 - sum_s w_s
+      const bool in0 = !(clampv > 0.f) || fabsf(raw[e * 4]) <= clampv, in1 = !(clampv > 0.f) || fabsf(raw[e * 4 + 1]) <= clampv,
+                 in2 = !(clampv > 0.f) || fabsf(raw[e * 4 + 2]) <= clampv;
+      d_raw[e * 4] = in0 ? g0 * w * c0 * (1.f - c0) : 0.f;
+      d_raw[e * 4 + 1] = in1 ? g1 * w * c1 * (1.f - c1) : 0.f;
+      d_raw[e * 4 + 2] = in2 ? g2 * w * c2 * (1.f - c2) : 0.f;
+    }
+    // pass 2: d alpha_s = dw_s T_s - sum_{j>s} dw_j alpha_j prod_{k<j, k!=s} x_k
+    float gz_next = 0.f;       // contribution of dist_{s} to z_{s+1}, carried backwards is awkward: do it forwards below
+    float Tpre = 1.f;          // prod_{k<s} x_k
+    float carry = 0.f;         // d z contribution from the previous interval (d dist_{s-1} * dn)
+    for (int s = 0; s < S; ++s) {
+      const int64_t e = i * S + s;
+      float tail = 0.f, P = Tpre;                                       // P = prod_{k<j, k != s} x_k, starts at j = s+1 with prod_{k<s}
+      for (int j = s + 1; j < S; ++j) {
+        tail += dw[j] * al[j] * P;
+        P *= x[j];
+      }
+      const float dal = dw[s] * Tpre - tail;
+      Tpre *= x[s];
+      // alpha = a * relu(mul); a = 1 - exp(-relu(sig) dist)
+      float r3 = raw[e * 4 + 3];
+      const bool in3 = !(clampv > 0.f) || fabsf(r3) <= clampv;
+      if (clampv > 0.f) r3 = fminf(fmaxf(r3, -clampv), clampv);
+      float sg = r3;
+      if (noise) sg += noise[e];
+      if (add) sg += add[e];
+      const float dist = ((s + 1 < S) ? (z[e + 1] - z[e]) : 1e10f) * dn;
+      const float ee = fmaxf(sg, 0.f);
+      const float ex = expf(-ee * dist);
+      const float a = 1.f - ex;
+      const float m = mul ? mul[e] : 1.f;
+      const float da = mul ? dal * fmaxf(m, 0.f) : dal;
+      if (d_mul) d_mul[e] = (mul && m > 0.f) ? dal * a : 0.f;
+      const float dsg = sg > 0.f ? da * dist * ex : 0.f;
+      d_raw[e * 4 + 3] = in3 ? dsg : 0.f;
+      if (d_add) d_add[e] = add ? dsg : 0.f;
+      const float ddist = (s + 1 < S) ? da * ee * ex * dn : 0.f;          // the last interval (1e10) does not depend on z
+      if (d_z) d_z[e] = carry - ddist;
+      carry = ddist;
+    }
+    (void)gz_next;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ losses, Adam
+// loss[k] = mean((pred - target)^2), d_pred = scale * 2 (pred - target) / numel.  One block (deterministic).
+__global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t numel, float scale,
+                                   float* __restrict__ loss_out, float* __restrict__ d_pred) {
+  __shared__ float red[1024];
+  float s = 0.f;
+  const float inv = 1.f / (float)numel;
+  for (int64_t i = threadIdx.x; i < numel; i += blockDim.x) {
+    const float e = pred[i] - target[i];
+    s += e * e;
+    if (d_pred) d_pred[i] = scale * 2.f * e * inv;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss_out = red[0] * inv;
+}
+__global__ void total_loss_kernel(float* loss, float a_mmrgb) { loss[0] = loss[1] + a_mmrgb * (loss[2] + loss[3]); }
+
+// torch.optim.Adam (no amsgrad): g += wd p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);                   // lerp, as torch's single-tensor Adam
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ trainer object
+struct TLin { int in, out; size_t w, b; };       // offsets into the flat parameter array
+
+struct pnrf_trainer {
+  int device = 0;
+  int64_t max_rays = 0;
+  std::vector<TLin> L;                           // 0..6 sampler, 7..13 refine, 14..25 fine net (pts0..7, feature, alpha, views, rgb)
+  size_t nparam = 0;
+  float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+  int64_t step = 0;
+  rocblas_handle blas = nullptr;
+  std::vector<void*> allocs;
+  // workspaces
+  float *mm_input, *s_h[6], *s_y, *depth_sorted, *add_s, *mul_s, *mm_rgb;
+  int64_t* sort_idx;
+  float *refine_in, *r_h[6], *r_y, *z_pre, *z, *pts, *rgb0;
+  float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
+  float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
+      *d_h0, *d_h1, *part, *loss;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(pnrf_trainer* t, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) { set_error("pnrf_trainer: hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); return (int)e; }
+  t->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+#define T_ALLOC(ptr, count) do { int rc_ = dev_alloc(t, &(ptr), (size_t)(count)); if (rc_) return rc_; } while (0)
+#define T_BLAS(expr)                                                                                   \
+  do {                                                                                                 \
+    rocblas_status st_ = (expr);                                                                       \
+    if (st_ != rocblas_status_success) { set_error("%s failed: rocblas status %d", #expr, (int)st_); return 1000 + (int)st_; } \
+  } while (0)
+
+// Y[R,out] (row stride ldy) = X[R,in] (row stride ldx) W^T, W row-major [out,in]
+int gemm_fwd(pnrf_trainer* t, const float* X, int ldx, const float* W, int in, int out, float* Y, int ldy, int64_t R) {
+  const float one = 1.f, zero = 0.f;
+  T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, out, (int)R, in, &one, W, in, X, ldx, &zero, Y, ldy));
+  return 0;
+}
+// dX[R,in] = beta dX + dY[R,out] W
+int gemm_dx(pnrf_trainer* t, const float* dY, int ldy, const float* W, int in, int out, float* dX, int ldx, int64_t R, float beta) {
+  const float one = 1.f;
+  T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, in, (int)R, out, &one, W, in, dY, ldy, &beta, dX, ldx));
+  return 0;
+}
+// dW[out,in] = dY^T X
+int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R) {
+  const float one = 1.f, zero = 0.f;
+  T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_transpose, in, out, (int)R, &one, X, ldx, dY, ldy, &zero, dW, in));
+  return 0;
+}
+
+int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, hipStream_t s) {
+  const TLin& l = t->L[li];
+  int rc = gemm_fwd(t, X, ldx, t->P + l.w, l.in, l.out, Y, ldy, R);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for(R * l.out)), dim3(TPB), 0, s, Y, ldy, t->P + l.b, R, l.out, act);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+// dH (row stride ldd) holds dL/dH on entry and dL/dZ on exit; H = saved output of the layer; X = saved input.
+// dX == nullptr: no input gradient wanted.
+int layer_bwd(pnrf_trainer* t, int li, float* dH, int ldd, const float* H, int ldh, const float* X, int ldx, float* dX, int lddx, float beta,
+              int64_t R, int act, hipStream_t s) {
+  const TLin& l = t->L[li];
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((l.out + 63) / 64, DB_CHUNKS), dim3(256), 0, s, dH, ldd, H, ldh, R, l.out, act, t->part);
+  PNRF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((l.out + 255) / 256), dim3(256), 0, s, t->part, l.out, t->G + l.b);
+  PNRF_LAUNCH_CHECK();
+  int rc = gemm_dw(t, X, ldx, dH, ldd, t->G + l.w, l.in, l.out, R);
+  if (rc) return rc;
+  if (dX) rc = gemm_dx(t, dH, ldd, t->P + l.w, l.in, l.out, dX, lddx, R, beta);
+  return rc;
+}
+
+constexpr int L_S = 0, L_R = 7, L_N = 14, L_FEAT = 22, L_ALPHA = 23, L_VIEWS = 24, L_RGB = 25, N_LAYERS = 26;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI: operators
+extern "C" int pnrf_composite_bwd(const float* raw, const float* z, const float* rays_d, int d_stride, const float* add, const float* mul,
+                                  const float* noise, float clampv, int white_bkgd, const float* d_rgb, float* d_raw, float* d_z, float* d_add,
+                                  float* d_mul, int64_t n, int s, void* stream) {
+  PNRF_REQUIRE(n >= 0 && s >= 1 && s <= CB_MAXS && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_bwd: bad sizes (1 <= s <= %d)", CB_MAXS);
+  if (n == 0) return 0;
+  PNRF_REQUIRE(raw && z && rays_d && d_rgb && d_raw, PNRF_E_ARG, "pnrf_composite_bwd: null pointer");
+  PNRF_REQUIRE((add == nullptr) == (mul == nullptr), PNRF_E_ARG, "pnrf_composite_bwd: add and mul go together");
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise, clampv,
+                     white_bkgd, d_rgb, d_raw, d_z, d_add, d_mul, n, s);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_posenc_bwd(const float* x, const float* d_out, float* d_x, int64_t n, int n_freq, void* stream) {
+  PNRF_REQUIRE(n >= 0 && n_freq >= 0 && n_freq <= 16 && (n == 0 || (x && d_out && d_x)), PNRF_E_ARG, "pnrf_posenc_bwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(n * 3)), dim3(TPB), 0, (hipStream_t)stream, x, d_out, 3 + 6 * n_freq, (const float*)nullptr, 0,
+                     d_x, n, n_freq);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pnrf_sampler_head_fwd(const float* y, const float* rays, float* depth_sorted, int64_t* sort_idx, float* add_sorted, float* mul_sorted,
+                                     float* mm_rgb, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (y && rays && depth_sorted && sort_idx && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_head_fwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sampler_head_fwd_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, y, rays, depth_sorted, sort_idx, add_sorted,
+                     mul_sorted, mm_rgb, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pnrf_sampler_head_bwd(const float* y, const float* rays, const int64_t* sort_idx, const float* d_depth_sorted, const float* d_add_sorted,
+                                     const float* d_mul_sorted, const float* d_mm_rgb, float* d_y, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (y && rays && sort_idx && d_depth_sorted && d_add_sorted && d_mul_sorted && d_y)), PNRF_E_ARG,
+               "pnrf_sampler_head_bwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sampler_head_bwd_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, y, rays, sort_idx, d_depth_sorted, d_add_sorted,
+                     d_mul_sorted, d_mm_rgb, d_y, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pnrf_refine_head_fwd(const float* y, const float* rays, const float* depth_sorted, const float* jitter, int jitter_dir, float* z_pre,
+                                    float* z, float* pts, float* rgb0, int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (y && rays && depth_sorted && z_pre && z && pts)), PNRF_E_ARG, "pnrf_refine_head_fwd: bad arguments");
+  PNRF_REQUIRE(!jitter || jitter_dir == 1 || jitter_dir == -1, PNRF_E_ARG, "pnrf_refine_head_fwd: jitter_dir must be +1 or -1");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(refine_head_fwd_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, y, rays, depth_sorted, jitter, jitter_dir, z_pre, z,
+                     pts, rgb0, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pnrf_refine_head_bwd(const float* y, const float* rays, const float* depth_sorted, const float* z_pre, const float* jitter,
+                                    int jitter_dir, const float* d_pts, const float* d_z, const float* d_rgb0, float* d_y, float* d_depth_sorted,
+                                    int64_t n, void* stream) {
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (y && rays && depth_sorted && z_pre && d_pts && d_y && d_depth_sorted)), PNRF_E_ARG, "pnrf_refine_head_bwd: bad arguments");
+  PNRF_REQUIRE(!jitter || jitter_dir == 1 || jitter_dir == -1, PNRF_E_ARG, "pnrf_refine_head_bwd: jitter_dir must be +1 or -1");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(refine_head_bwd_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, y, rays, depth_sorted, z_pre, jitter, jitter_dir,
+                     d_pts, d_z, d_rgb0, d_y, d_depth_sorted, n);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: trainer
+extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim, int n_layers,
+                                   int64_t max_rays, pnrf_trainer_t** out) {
+  PNRF_REQUIRE(W && b && in_dim && out_dim && out && max_rays >= 1, PNRF_E_ARG, "pnrf_trainer_create: null pointer / max_rays < 1");
+  PNRF_REQUIRE(n_layers == N_LAYERS, PNRF_E_ARG, "pnrf_trainer_create: expected %d Linear layers (7 sampler, 7 refine, 12 NeRF class), got %d", N_LAYERS, n_layers);
+  static const int want_in[N_LAYERS] = {288, 256, 256, 256, 256, 256, 256, 144, 256, 256, 256, 256, 256, 256,
+                                        63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
+  static const int want_out[N_LAYERS] = {256, 256, 256, 256, 256, 256, 27, 256, 256, 256, 256, 256, 256, 35,
+                                         256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 128, 3};
+  for (int i = 0; i < N_LAYERS; ++i)
+    PNRF_REQUIRE(in_dim[i] == want_in[i] && out_dim[i] == want_out[i], PNRF_E_ARG, "pnrf_trainer_create: layer %d is %dx%d, expected %dx%d", i, out_dim[i],
+                 in_dim[i], want_out[i], want_in[i]);
+  pnrf_trainer* t = new pnrf_trainer();
+  PNRF_HIP(hipGetDevice(&t->device));
+  t->max_rays = max_rays;
+  size_t off = 0;
+  for (int i = 0; i < N_LAYERS; ++i) {
+    TLin l; l.in = in_dim[i]; l.out = out_dim[i]; l.w = off; off += (size_t)l.in * l.out; l.b = off; off += l.out;
+    off = (off + 3) & ~(size_t)3;
+    t->L.push_back(l);
+  }
+  t->nparam = off;
+  T_ALLOC(t->P, off); T_ALLOC(t->G, off); T_ALLOC(t->M, off); T_ALLOC(t->V, off);
+  PNRF_HIP(hipMemset(t->P, 0, off * 4)); PNRF_HIP(hipMemset(t->G, 0, off * 4)); PNRF_HIP(hipMemset(t->M, 0, off * 4)); PNRF_HIP(hipMemset(t->V, 0, off * 4));
+  for (int i = 0; i < N_LAYERS; ++i) {
+    PNRF_HIP(hipMemcpy(t->P + t->L[i].w, W[i], (size_t)t->L[i].in * t->L[i].out * 4, hipMemcpyDefault));
+    PNRF_HIP(hipMemcpy(t->P + t->L[i].b, b[i], (size_t)t->L[i].out * 4, hipMemcpyDefault));
+  }
+  if (rocblas_create_handle(&t->blas) != rocblas_status_success) { set_error("pnrf_trainer_create: rocblas_create_handle failed"); return 1; }
+  rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
+  const int64_t N = max_rays, R = 8 * max_rays;
+  T_ALLOC(t->mm_input, N * 288);
+  for (int k = 0; k < 6; ++k) { T_ALLOC(t->s_h[k], N * 256); T_ALLOC(t->r_h[k], N * 256); }
+  T_ALLOC(t->s_y, N * 27); T_ALLOC(t->depth_sorted, N * 8); T_ALLOC(t->add_s, N * 8); T_ALLOC(t->mul_s, N * 8); T_ALLOC(t->mm_rgb, N * 3);
+  T_ALLOC(t->sort_idx, N * 8);
+  T_ALLOC(t->refine_in, N * 144); T_ALLOC(t->r_y, N * 35); T_ALLOC(t->z_pre, N * 8); T_ALLOC(t->z, N * 8); T_ALLOC(t->pts, N * 24); T_ALLOC(t->rgb0, N * 3);
+  T_ALLOC(t->emb, R * 90);
+  for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], R * 256);
+  T_ALLOC(t->n_c5, R * 319); T_ALLOC(t->n_a5, R * 256); T_ALLOC(t->n_a6, R * 256); T_ALLOC(t->n_a7, R * 256);
+  T_ALLOC(t->n_cv, R * 283); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, N * 8);
+  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * 283); T_ALLOC(t->d_a, R * 256);
+  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, R * 63); T_ALLOC(t->d_pts, R * 3); T_ALLOC(t->d_z, N * 8);
+  T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
+  T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
+  T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->loss, 4);
+  *out = t;
+  return 0;
+}
+
+extern "C" int pnrf_trainer_free(pnrf_trainer_t* t) {
+  if (!t) return 0;
+  for (void* p : t->allocs) hipFree(p);
+  if (t->blas) rocblas_destroy_handle(t->blas);
+  delete t;
+  return 0;
+}
+
+// kind 0 parameters, 1 gradients, 2 Adam first moment, 3 Adam second moment; W / b: host or device destinations (either may be NULL)
+extern "C" int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, float* W, float* b, void* stream) {
+  PNRF_REQUIRE(t && kind >= 0 && kind <= 3 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_read: bad kind / layer");
+  const float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : t->V;
+  const TLin& l = t->L[layer];
+  PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (W) PNRF_HIP(hipMemcpy(W, base + l.w, (size_t)l.in * l.out * 4, hipMemcpyDefault));
+  if (b) PNRF_HIP(hipMemcpy(b, base + l.b, (size_t)l.out * 4, hipMemcpyDefault));
+  return 0;
+}
+extern "C" int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const float* W, const float* b, void* stream) {
+  PNRF_REQUIRE(t && kind >= 0 && kind <= 3 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_write: bad kind / layer");
+  float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : t->V;
+  const TLin& l = t->L[layer];
+  PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (W) PNRF_HIP(hipMemcpy(base + l.w, W, (size_t)l.in * l.out * 4, hipMemcpyDefault));
+  if (b) PNRF_HIP(hipMemcpy(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault));
+  return 0;
+}
+extern "C" int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step) {
+  PNRF_REQUIRE(t && step >= 0, PNRF_E_ARG, "pnrf_trainer_set_step: bad arguments");
+  t->step = step;
+  return 0;
+}
+
+extern "C" int pnrf_trainer_adam_step(pnrf_trainer_t* t, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  PNRF_REQUIRE(t && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, PNRF_E_ARG, "pnrf_trainer_adam_step: bad hyper-parameters");
+  t->step += 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t->step), bc2 = 1.0 - pow((double)beta2, (double)t->step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, (hipStream_t)stream, t->P, t->G, t->M, t->V, (int64_t)t->nparam, lr, beta1,
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+
+// One stage-2 forward + backward over a batch of rays (refine2.py:525-680, :858-868).  Gradients of all 26 layers are left in the
+// trainer (pnrf_trainer_read kind 1); loss dev [4] = {total, mse(rgb_map1), mse(rgb_map0), mse(mm_rgb)}; rgb_out dev [n,3] or NULL.
+extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, float* loss, float* rgb_out, void* stream) {
+  PNRF_REQUIRE(t && bt && loss, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: null pointer");
+  const int64_t N = bt->n, R = 8 * bt->n;
+  PNRF_REQUIRE(N >= 1 && N <= t->max_rays, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: n = %lld outside [1, max_rays = %lld]", (long long)N, (long long)t->max_rays);
+  PNRF_REQUIRE(bt->rays && bt->or_rays && bt->target && bt->img4 && bt->poses && bt->K && bt->ref_nos, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: null batch pointer");
+  PNRF_REQUIRE(!bt->jitter || bt->jitter_dir == 1 || bt->jitter_dir == -1, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: jitter_dir must be +1 or -1");
+  hipStream_t s = (hipStream_t)stream;
+  T_BLAS(rocblas_set_stream(t->blas, s));
+  int rc;
+#define T_RC(expr) do { rc = (expr); if (rc) return rc; } while (0)
+  // ---------------- forward
+  T_RC(pnrf_ray_encode_fwd(bt->rays, t->mm_input, N, 48, stream));                                                    // :551-556
+  {
+    const float* x = t->mm_input; int ldx = 288;
+    for (int k = 0; k < 6; ++k) { T_RC(layer_fwd(t, L_S + k, x, ldx, t->s_h[k], 256, N, T_ACT_ELU, s)); x = t->s_h[k]; ldx = 256; }
+    T_RC(layer_fwd(t, L_S + 6, x, 256, t->s_y, 27, N, T_ACT_NONE, s));
+  }
+  T_RC(pnrf_sampler_head_fwd(t->s_y, bt->rays, t->depth_sorted, t->sort_idx, t->add_s, t->mul_s, t->mm_rgb, N, stream));     // :557-568
+  T_RC(pnrf_refine_input_train_fwd(bt->rays, bt->or_rays, t->depth_sorted, bt->img4, bt->poses, bt->K, bt->ref_nos, bt->nv, 4, bt->Hf, bt->Wf, bt->eps, 0,
+                                   t->refine_in, N, stream));                                                         // :570-634
+  {
+    const float* x = t->refine_in; int ldx = 144;
+    for (int k = 0; k < 6; ++k) { T_RC(layer_fwd(t, L_R + k, x, ldx, t->r_h[k], 256, N, T_ACT_ELU, s)); x = t->r_h[k]; ldx = 256; }
+    T_RC(layer_fwd(t, L_R + 6, x, 256, t->r_y, 35, N, T_ACT_NONE, s));
+  }
+  T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, bt->jitter, bt->jitter_dir, t->z_pre, t->z, t->pts, t->rgb0, N, stream));   // :635-668
+  hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, 3, 1, t->emb, 90, 0, R, 10);
+  hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, bt->rays + 8, 11, 8, t->emb, 90, 63, R, 4);
+  PNRF_LAUNCH_CHECK();
+  // NeRF class (run_nerf_helpers.py:824-847)
+  T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
+  for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + 63, 319, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 63)), dim3(TPB), 0, s, t->emb, 90, 0, t->n_c5, 319, 0, R, 63);
+  PNRF_LAUNCH_CHECK();
+  T_RC(layer_fwd(t, L_N + 5, t->n_c5, 319, t->n_a5, 256, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_N + 6, t->n_a5, 256, t->n_a6, 256, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_N + 7, t->n_a6, 256, t->n_a7, 256, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
+  T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, 283, R, T_ACT_NONE, s));
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 27)), dim3(TPB), 0, s, t->emb, 90, 63, t->n_cv, 283, 256, R, 27);
+  PNRF_LAUNCH_CHECK();
+  T_RC(layer_fwd(t, L_VIEWS, t->n_cv, 283, t->n_hv, 128, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
+  T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, 0.f, bt->white_bkgd, t->rgb_map, nullptr, nullptr, t->wts,
+                          nullptr, N, 8, stream));                                                                     // :674
+  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
+  // ---------------- losses (:861-866)
+  const bool aux = bt->a_mmrgb > 0.f;
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, bt->a_mmrgb, t->loss + 2, aux ? t->d_rgb0 : (float*)nullptr);
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, bt->a_mmrgb, t->loss + 3, aux ? t->d_mmrgb : (float*)nullptr);
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, aux ? bt->a_mmrgb : 0.f);
+  PNRF_LAUNCH_CHECK();
+  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
+  // ---------------- backward
+  T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, 0.f, bt->white_bkgd, t->d_rgb_map, t->d_raw, t->d_z, t->d_add,
+                          t->d_mul, N, 8, stream));
+  // rgb head: d_raw[:, 0:3] -> d_hv ; views layer -> d_cv ; feature -> d_a7 (beta 0) ; alpha: d_raw[:, 3] -> d_a7 (beta 1)
+  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, nullptr, 0, t->n_hv, 128, t->d_hv, 128, 0.f, R, T_ACT_NONE, s));
+  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, t->n_hv, 128, t->n_cv, 283, t->d_cv, 283, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, nullptr, 0, t->n_a7, 256, t->d_a, 256, 0.f, R, T_ACT_NONE, s));
+  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, nullptr, 0, t->n_a7, 256, t->d_a, 256, 1.f, R, T_ACT_NONE, s));
+  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, t->n_a7, 256, t->n_a6, 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, t->n_a6, 256, t->n_a5, 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, t->n_a5, 256, t->n_c5, 319, t->d_c5, 319, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + 63, 319, t->n_c5 + 63, 319, t->n_a[3], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, t->n_a[3], 256, t->n_a[2], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, t->n_a[2], 256, t->n_a[1], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, t->n_a[1], 256, t->n_a[0], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, t->n_a[0], 256, t->emb, 90, t->d_e0, 63, 0.f, R, T_ACT_RELU, s));
+  hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, 319, t->d_pts, R, 10);
+  PNRF_LAUNCH_CHECK();
+  T_RC(pnrf_refine_head_bwd(t->r_y, bt->rays, t->depth_sorted, t->z_pre, bt->jitter, bt->jitter_dir, t->d_pts, t->d_z, aux ? t->d_rgb0 : nullptr, t->d_ry,
+                            t->d_depth, N, stream));
+  {   // refine net: no gradient reaches refine_in (Pluecker moment is depth-independent; the projection is under no_grad)
+    float* dcur = t->d_ry; int ldd = 35;
+    T_RC(layer_bwd(t, L_R + 6, dcur, ldd, nullptr, 0, t->r_h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_NONE, s));
+    float* dA = t->d_h0; float* dB = t->d_h1;
+    for (int k = 5; k >= 1; --k) {
+      T_RC(layer_bwd(t, L_R + k, dA, 256, t->r_h[k], 256, t->r_h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, s));
+      float* tmp = dA; dA = dB; dB = tmp;
+    }
+    T_RC(layer_bwd(t, L_R + 0, dA, 256, t->r_h[0], 256, t->refine_in, 144, nullptr, 0, 0.f, N, T_ACT_ELU, s));
+  }
+  T_RC(pnrf_sampler_head_bwd(t->s_y, bt->rays, t->sort_idx, t->d_depth, t->d_add, t->d_mul, aux ? t->d_mmrgb : nullptr, t->d_sy, N, stream));
+  {
+    T_RC(layer_bwd(t, L_S + 6, t->d_sy, 27, nullptr, 0, t->s_h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_NONE, s));
+    float* dA = t->d_h0; float* dB = t->d_h1;
+    for (int k = 5; k >= 1; --k) {
+      T_RC(layer_bwd(t, L_S + k, dA, 256, t->s_h[k], 256, t->s_h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, s));
+      float* tmp = dA; dA = dB; dB = tmp;
+    }
+    T_RC(layer_bwd(t, L_S + 0, dA, 256, t->s_h[0], 256, t->mm_input, 288, nullptr, 0, 0.f, N, T_ACT_ELU, s));
+  }
+#undef T_RC
+  return 0;
+}

@@ -302,3 +302,143 @@ def linspace(start, end, n):
     out = (C.c_float * n)()
     check(_lib.load().pnrf_linspace(start, end, n, out), 'pnrf_linspace')
     return np.array(out[:], dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------------------ stage-2 training step
+def composite_bwd(raw, z, rays_d, d_rgb, add=None, mul=None, noise=None, clamp=0.0, white_bkgd=False):
+    """raw2outputs backward for d rgb_map -> (d_raw, d_z, d_add, d_mul); d_add / d_mul are None without add / mul."""
+    raw = _chk(raw, 'raw', (4,)); z = _chk(z, 'z_vals'); rays_d = _chk(rays_d, 'rays_d', (3,)); d_rgb = _chk(d_rgb, 'd_rgb', (3,))
+    n, s = z.shape
+    add = None if add is None else _chk(add, 'mm_density_add')
+    mul = None if mul is None else _chk(mul, 'mm_density_mul')
+    noise = None if noise is None else _chk(noise, 'noise')
+    d_raw = torch.empty_like(raw); d_z = torch.empty_like(z)
+    d_add = None if add is None else torch.empty_like(z)
+    d_mul = None if mul is None else torch.empty_like(z)
+    check(_lib.load().pnrf_composite_bwd(_ptr(raw), _ptr(z), _ptr(rays_d), 3, _ptr(add), _ptr(mul), _ptr(noise), float(clamp), int(bool(white_bkgd)),
+                                         _ptr(d_rgb), _ptr(d_raw), _ptr(d_z), _ptr(d_add), _ptr(d_mul), n, s, _stream()), 'pnrf_composite_bwd')
+    return d_raw, d_z, d_add, d_mul
+
+
+def posenc_bwd(x, d_out, n_freq):
+    x = _chk(x, 'x', (3,)); d_out = _chk(d_out, 'd_out', (3 + 6 * n_freq,))
+    d_x = torch.empty_like(x)
+    check(_lib.load().pnrf_posenc_bwd(_ptr(x), _ptr(d_out), _ptr(d_x), x.numel() // 3, n_freq, _stream()), 'pnrf_posenc_bwd')
+    return d_x
+
+
+def sampler_head_fwd(y, rays):
+    y = _chk(y, 'y', (27,)); rays = _chk(rays, 'rays', (11,))
+    n, dev = y.shape[0], y.device
+    depth = torch.empty(n, 8, device=dev, dtype=f32); add = torch.empty_like(depth); mul = torch.empty_like(depth)
+    idx = torch.empty(n, 8, device=dev, dtype=torch.int64); rgb = torch.empty(n, 3, device=dev, dtype=f32)
+    check(_lib.load().pnrf_sampler_head_fwd(_ptr(y), _ptr(rays), _ptr(depth), _ptr(idx), _ptr(add), _ptr(mul), _ptr(rgb), n, _stream()), 'pnrf_sampler_head_fwd')
+    return depth, idx, add, mul, rgb
+
+
+def sampler_head_bwd(y, rays, idx, d_depth, d_add, d_mul, d_rgb=None):
+    y = _chk(y, 'y', (27,)); rays = _chk(rays, 'rays', (11,))
+    d_y = torch.empty_like(y)
+    check(_lib.load().pnrf_sampler_head_bwd(_ptr(y), _ptr(rays), _ptr(idx.contiguous()), _ptr(_chk(d_depth, 'd_depth', (8,))), _ptr(_chk(d_add, 'd_add', (8,))),
+                                            _ptr(_chk(d_mul, 'd_mul', (8,))), _ptr(d_rgb), _ptr(d_y), y.shape[0], _stream()), 'pnrf_sampler_head_bwd')
+    return d_y
+
+
+def refine_head_fwd(y, rays, depth_sorted, jitter=None, jitter_dir=1):
+    y = _chk(y, 'y', (35,)); rays = _chk(rays, 'rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    n, dev = y.shape[0], y.device
+    z_pre = torch.empty(n, 8, device=dev, dtype=f32); z = torch.empty_like(z_pre)
+    pts = torch.empty(n, 8, 3, device=dev, dtype=f32); rgb0 = torch.empty(n, 3, device=dev, dtype=f32)
+    jitter = None if jitter is None else _chk(jitter, 'jitter', (8,))
+    check(_lib.load().pnrf_refine_head_fwd(_ptr(y), _ptr(rays), _ptr(depth_sorted), _ptr(jitter), int(jitter_dir), _ptr(z_pre), _ptr(z), _ptr(pts), _ptr(rgb0),
+                                           n, _stream()), 'pnrf_refine_head_fwd')
+    return z_pre, z, pts, rgb0
+
+
+def refine_head_bwd(y, rays, depth_sorted, z_pre, d_pts, d_z=None, d_rgb0=None, jitter=None, jitter_dir=1):
+    y = _chk(y, 'y', (35,)); rays = _chk(rays, 'rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    d_y = torch.empty_like(y); d_depth = torch.empty_like(depth_sorted)
+    jitter = None if jitter is None else _chk(jitter, 'jitter', (8,))
+    check(_lib.load().pnrf_refine_head_bwd(_ptr(y), _ptr(rays), _ptr(depth_sorted), _ptr(_chk(z_pre, 'z_pre', (8,))), _ptr(jitter), int(jitter_dir),
+                                           _ptr(_chk(d_pts, 'd_pts', (3,))), _ptr(d_z), _ptr(d_rgb0), _ptr(d_y), _ptr(d_depth), y.shape[0], _stream()),
+          'pnrf_refine_head_bwd')
+    return d_y, d_depth
+
+
+TRAINER_LAYERS = 26          # 7 sampler + 7 refine + 12 NeRF class (pts_linears.0..7, feature, alpha, views, rgb)
+
+
+class Trainer:
+    """fp32 parameters, gradients, Adam state and workspaces of the stage-2 training step (pnrf_trainer_*).
+
+    weights / biases: 26 arrays in the order of ``TRAINER_LAYERS`` (torch layout ``W[out, in]``)."""
+
+    def __init__(self, weights, biases, max_rays, device='cuda:0'):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise PnrfError('Trainer needs a GPU device (pronerf_amd has no CPU path)')
+        n = len(weights)
+        ws = [np.ascontiguousarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b, dtype=np.float32) for b in biases]
+        self.shapes = [w.shape for w in ws]
+        Wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws]); bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        ind = (C.c_int * n)(*[w.shape[1] for w in ws]); outd = (C.c_int * n)(*[w.shape[0] for w in ws])
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.pnrf_trainer_create(Wp, bp, ind, outd, n, int(max_rays), C.byref(h)), 'pnrf_trainer_create')
+        self.handle = h
+        self.max_rays = int(max_rays)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.load().pnrf_trainer_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def read(self, kind, layer):
+        """kind: 'param' | 'grad' | 'm' | 'v' -> (W, b) as new device tensors."""
+        k = {'param': 0, 'grad': 1, 'm': 2, 'v': 3}[kind]
+        out_d, in_d = self.shapes[layer]
+        W = torch.empty(out_d, in_d, device=self.device, dtype=f32); b = torch.empty(out_d, device=self.device, dtype=f32)
+        with torch.cuda.device(self.device):
+            check(_lib.load().pnrf_trainer_read(self.handle, k, layer, _ptr(W), _ptr(b), _stream()), 'pnrf_trainer_read')
+        return W, b
+
+    def write(self, kind, layer, W=None, b=None):
+        k = {'param': 0, 'grad': 1, 'm': 2, 'v': 3}[kind]
+        W = None if W is None else torch.as_tensor(W, dtype=f32).contiguous()
+        b = None if b is None else torch.as_tensor(b, dtype=f32).contiguous()
+        with torch.cuda.device(self.device):
+            check(_lib.load().pnrf_trainer_write(self.handle, k, layer, _ptr(W), _ptr(b), _stream()), 'pnrf_trainer_write')
+
+    def set_step(self, step):
+        check(_lib.load().pnrf_trainer_set_step(self.handle, int(step)), 'pnrf_trainer_set_step')
+
+    def fwd_bwd(self, rays, or_rays, target, img4, poses, K, ref_nos, jitter=None, jitter_dir=1, raw_noise=None, white_bkgd=False, eps=1e-5,
+                a_mmrgb=0.0, want_rgb=True):
+        """One forward + backward; returns (loss[4] device tensor = total, img, rgb0, mm_rgb; rgb_map1 [n,3] or None)."""
+        rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); target = _chk(target, 'target', (3,))
+        img4 = _chk(img4, 'img4', (4,)); poses = _chk(poses, 'poses', (3, 4)); K = _chk(K, 'K', (3, 3))
+        if ref_nos.dtype != torch.int64 or not ref_nos.is_cuda or tuple(ref_nos.shape) != (rays.shape[0], 4):
+            raise PnrfError('ref_nos: expected an int64 GPU tensor [n, 4]')
+        ref_nos = ref_nos.contiguous()
+        jitter = None if jitter is None else _chk(jitter, 'jitter', (8,))
+        raw_noise = None if raw_noise is None else _chk(raw_noise, 'raw_noise', (8,))
+        n = rays.shape[0]
+        loss = torch.empty(4, device=rays.device, dtype=f32)
+        rgb = torch.empty(n, 3, device=rays.device, dtype=f32) if want_rgb else None
+        bt = _lib.TrainBatch(rays=rays.data_ptr(), or_rays=or_rays.data_ptr(), target=target.data_ptr(), img4=img4.data_ptr(), poses=poses.data_ptr(),
+                             K=K.data_ptr(), ref_nos=ref_nos.data_ptr(), jitter=None if jitter is None else jitter.data_ptr(),
+                             raw_noise=None if raw_noise is None else raw_noise.data_ptr(), n=n, nv=img4.shape[0], Hf=img4.shape[1], Wf=img4.shape[2],
+                             jitter_dir=int(jitter_dir), white_bkgd=int(bool(white_bkgd)), eps=float(eps), a_mmrgb=float(a_mmrgb))
+        with torch.cuda.device(rays.device):
+            check(_lib.load().pnrf_train_stage2_fwd_bwd(self.handle, C.byref(bt), _ptr(loss), _ptr(rgb), _stream()), 'pnrf_train_stage2_fwd_bwd')
+        return loss, rgb
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        with torch.cuda.device(self.device):
+            check(_lib.load().pnrf_trainer_adam_step(self.handle, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _stream()),
+                  'pnrf_trainer_adam_step')
