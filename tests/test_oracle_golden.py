@@ -155,3 +155,36 @@ def test_stage1_forward_matches_reference(golden_dir, name):
     for k in keys:
         np.testing.assert_allclose(out[k].numpy()[m], g[k][m], rtol=0, atol=5e-4, err_msg=k)
     assert orc.psnr(out['rgb_map1'][torch.from_numpy(m)], torch.from_numpy(g['rgb_map1'][m])) > 70.0
+
+
+# ------------------------------------------------------------------------------------------ stage-2 training iteration
+@pytest.mark.parametrize('name', ['stage2_step_12x16', 'stage2_step_white_mmrgb_10x14'])
+def test_oracle_training_iteration_matches_reference_fp64(golden_dir, name):
+    """loss and loss.backward() of the oracle, run in float64, against the reference's own iteration run in float64
+    (oracle/gen_golden_train.py): pins the oracle's differentiable structure (what is and is not under no_grad, detach points,
+    the order of the 26 parameter tensors) to ~1e-9.  Two fp32 runs of this chain only agree to 1e-4 .. 2e-2 (2^9 positional
+    frequencies, 1e10 last interval), which would hide such differences."""
+    import train_golden_util as U
+    g, b = U.load_case(golden_dir, name + '_f64')
+    loss, img_loss, o, layers = U.oracle_grads(b, torch.float64)
+    assert abs(loss - float(g['loss'])) < 1e-12 and abs(img_loss - float(g['img_loss'])) < 1e-12
+    np.testing.assert_allclose(o['rgb_map1'].detach().numpy(), g['rgb_map1'], rtol=0, atol=1e-12)
+    U.check_against_golden(g, [(W.grad, x.grad) for W, x in layers], None, tol_grad=1e-8, tol_norm=1e-8)
+
+
+@pytest.mark.parametrize('name', ['stage2_step_12x16', 'stage2_step_white_mmrgb_10x14'])
+def test_oracle_training_iteration_matches_reference_fp32(golden_dir, name):
+    """The fp32 iteration (what the reference actually runs): loss and image to 1e-6, gradients to the fp32 noise of the chain,
+    parameters after the reference's optimizer.step()."""
+    import train_golden_util as U
+    g, b = U.load_case(golden_dir, name)
+    layers = [(torch.tensor(W, requires_grad=True), torch.tensor(x, requires_grad=True)) for W, x in orc.trainer_layers(b['w'])]
+    opt = torch.optim.Adam([p for pair in layers for p in pair], lr=b['lr'], betas=(0.9, 0.999), weight_decay=b['wd'])
+    loss, img_loss, o = orc.stage2_loss(layers, b['rays'], b['or_rays'], b['target'], b['images'], b['poses'], b['K'], b['ref_nos'], jitter=b['jitter'],
+                                        jitter_dir=b['jdir'], raw_noise=b['noise'], white_bkgd=b['white'], a_mmrgb=b['a_mmrgb'])
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-6 and abs(float(img_loss.detach()) - float(g['img_loss'])) < 1e-6
+    np.testing.assert_allclose(o['rgb_map1'].detach().numpy(), g['rgb_map1'], rtol=0, atol=2e-6)
+    loss.backward()
+    grads = [(W.grad, x.grad) for W, x in layers]
+    opt.step()
+    U.check_against_golden(g, grads, [(W.detach(), x.detach()) for W, x in layers], tol_grad=5e-2, tol_norm=2e-2)
