@@ -79,6 +79,89 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int out, flo
   db[j] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
+// dW[out, in] = dZ^T[out, R] X[R, in] with R = rays or ray-samples (4096 .. 32768) and out, in <= 319: a tiny output with a
+// very long contraction.  rocBLAS runs the 256x256 cases as four 128x128 macro-tiles without splitting K (4 workgroups on
+// 256 CUs, 0.45 ms each, 4.0 of 6.8 ms per training iteration), hence this kernel: grid = (64x64 output tiles) x (K
+// splits), each workgroup reduces its slice of rows with v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) and
+// writes a partial tile; dw_reduce_kernel adds the partials in a fixed order (deterministic, no atomics).
+//   workgroup = 4 waves, wave w owns the 32x32 quadrant (w>>1, w&1) of the tile = 2x2 MFMA tiles;
+//   MFMA operands: A[m][k] = dZ[row k][out m], B[k][n] = X[row k][in n]; lane l supplies (m or n) = l&15, k = l>>4;
+//   rows are staged 32 at a time through LDS with a row stride of 80 floats: the 4 k-rows a wave reads per MFMA then fall
+//   into disjoint bank groups (ds_read_b32: 32 banks, conflicts within each 32-lane half).
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+constexpr int DW_TILE = 64, DW_ROWS = 32, DW_LDS_STRIDE = 80, DW_MAX_SPLITS = 64;
+__global__ __launch_bounds__(256) void dw_splitk_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
+                                                        float* __restrict__ part, int out, int in, int64_t R, int64_t rows_per_split) {
+  __shared__ float sA[DW_ROWS * DW_LDS_STRIDE];
+  __shared__ float sB[DW_ROWS * DW_LDS_STRIDE];
+  const int tiles_n = (in + DW_TILE - 1) / DW_TILE;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, q = lane >> 4;
+  const int64_t r_begin = blockIdx.y * rows_per_split;
+  const int64_t r_end = (r_begin + rows_per_split < R) ? r_begin + rows_per_split : R;
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int lc = threadIdx.x & 63, lr = threadIdx.x >> 6;          // loader: column 0..63, rows lr, lr+4, ...
+  const int gm = tm * DW_TILE + lc, gn = tn * DW_TILE + lc;
+  // the next 32-row block is fetched into registers while the MFMAs of the current one run (its global-load latency would
+  // otherwise be exposed once per block: 32 times per workgroup)
+  float pa[DW_ROWS / 4], pb[DW_ROWS / 4];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int k = 0; k < DW_ROWS / 4; ++k) {
+      const int64_t r = r0 + lr + 4 * k;
+      const bool ok = r < r_end;
+      pa[k] = (ok && gm < out) ? dZ[r * ldz + gm] : 0.f;
+      pb[k] = (ok && gn < in) ? X[r * ldx + gn] : 0.f;
+    }
+  };
+  fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += DW_ROWS) {
+#pragma unroll
+    for (int k = 0; k < DW_ROWS / 4; ++k) {
+      sA[(lr + 4 * k) * DW_LDS_STRIDE + lc] = pa[k];
+      sB[(lr + 4 * k) * DW_LDS_STRIDE + lc] = pb[k];
+    }
+    __syncthreads();
+    if (r0 + DW_ROWS < r_end) fetch(r0 + DW_ROWS);
+#pragma unroll
+    for (int kk = 0; kk < DW_ROWS / 4; ++kk) {
+      const int row = (4 * kk + q) * DW_LDS_STRIDE;
+      const float a0 = sA[row + wm * 32 + c16], a1 = sA[row + wm * 32 + 16 + c16];
+      const float b0 = sB[row + wn * 32 + c16], b1 = sB[row + wn * 32 + 16 + c16];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* p = part + (size_t)blockIdx.y * out * in;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = tm * DW_TILE + wm * 32 + 16 * i + 4 * q + e, n = tn * DW_TILE + wn * 32 + 16 * j + c16;      // D reg e = row 4q+e, col l&15
+        if (m < out && n < in) p[(size_t)m * in + n] = acc[i][j][e];
+      }
+}
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int64_t numel, float* __restrict__ dW) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * numel + i];
+    dW[i] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ positional encoding
 // out[row, col_off + ...] = [x, sin(2^k x), cos(2^k x)]_k with row stride ld; the input row is row / rep (view directions are
 // shared by the `rep` samples of a ray), x has row stride xs.   (run_nerf_helpers.py:666-671)
@@ -452,7 +535,7 @@ struct pnrf_trainer {
   float *refine_in, *r_h[6], *r_y, *z_pre, *z, *pts, *rgb0;
   float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
   float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
-      *d_h0, *d_h1, *part, *loss;
+      *d_h0, *d_h1, *part, *dw_part, *loss;
 };
 
 namespace {
@@ -485,10 +568,23 @@ int gemm_dx(pnrf_trainer* t, const float* dY, int ldy, const float* W, int in, i
   T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, in, (int)R, out, &one, W, in, dY, ldy, &beta, dX, ldx));
   return 0;
 }
-// dW[out,in] = dY^T X
-int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R) {
-  const float one = 1.f, zero = 0.f;
-  T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_transpose, in, out, (int)R, &one, X, ldx, dY, ldy, &zero, dW, in));
+// dW[out,in] = dY^T X  (dw_splitk_kernel + dw_reduce_kernel)
+int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R, hipStream_t s) {
+  const int tiles = ((out + DW_TILE - 1) / DW_TILE) * ((in + DW_TILE - 1) / DW_TILE);
+  // enough workgroups for 4 per CU (they hide each other's load latency), at least 128 rows per split, at most DW_MAX_SPLITS partials
+  int64_t splits = (1024 + tiles - 1) / tiles;
+  const int64_t by_rows = (R + 127) / 128;
+  if (splits > by_rows) splits = by_rows;
+  if (splits > DW_MAX_SPLITS) splits = DW_MAX_SPLITS;
+  if (splits < 1) splits = 1;
+  int64_t rows_per = (R + splits - 1) / splits;
+  rows_per = (rows_per + DW_ROWS - 1) / DW_ROWS * DW_ROWS;
+  splits = (R + rows_per - 1) / rows_per;
+  hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dY, ldy, X, ldx, t->dw_part, out, in, R, rows_per);
+  PNRF_LAUNCH_CHECK();
+  const int64_t numel = (int64_t)out * in;
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel)), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW);
+  PNRF_LAUNCH_CHECK();
   return 0;
 }
 
@@ -509,7 +605,7 @@ int layer_bwd(pnrf_trainer* t, int li, float* dH, int ldd, const float* H, int l
   PNRF_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3((l.out + 255) / 256), dim3(256), 0, s, t->part, l.out, t->G + l.b);
   PNRF_LAUNCH_CHECK();
-  int rc = gemm_dw(t, X, ldx, dH, ldd, t->G + l.w, l.in, l.out, R);
+  int rc = gemm_dw(t, X, ldx, dH, ldd, t->G + l.w, l.in, l.out, R, s);
   if (rc) return rc;
   if (dX) rc = gemm_dx(t, dH, ldd, t->P + l.w, l.in, l.out, dX, lddx, R, beta);
   return rc;
@@ -627,7 +723,7 @@ extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b,
   T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, R * 63); T_ALLOC(t->d_pts, R * 3); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
-  T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->loss, 4);
+  T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->dw_part, (size_t)DW_MAX_SPLITS * 256 * 320); T_ALLOC(t->loss, 4);
   *out = t;
   return 0;
 }
