@@ -1,17 +1,14 @@
-"""Host-side mirror of the reference's stage-2 (refine) trainer functions for the FORWARD of the path
-(run_S_eS_eN_alter_base_refine2.py): ``render_rays`` (:525-680) and ``raw2outputs`` (:475-522).
+"""Host-side mirror of the reference's stage-2 (refine) trainer (run_S_eS_eN_alter_base_refine2.py): ``render_rays`` (:525-680),
+``raw2outputs`` (:475-522) and the training driver ``train`` (:683-1000).
 
-Same signature, kwargs and returned dict as the reference.  The per-ray work runs in HIP kernels:
-sampler MLP + sort (pnrf_sampler_fwd), training projection with valid-mask mean fill
-(pnrf_refine_input_train_fwd), refine MLP + depth jitter + query points (pnrf_refine_train_fwd), NeRF-class
-MLP + compositing with sigma noise / white background (pnrf_nerf_train_fwd).  The random draws of the
-reference (one ``random.sample`` of neighbour ranks and one coin flip per batch, |N(0,1)|/5 jitter, N(0,1)
-sigma noise) are made here with the same generators (``random``, ``torch.normal``, ``torch.randn``) and handed to
-the kernels as inputs.
+``render_rays`` / ``raw2outputs``: same signature, kwargs and returned dict as the reference; inference-precision forward
+through the fused kernels (pnrf_sampler_fwd, pnrf_refine_input_train_fwd, pnrf_refine_train_fwd, pnrf_nerf_train_fwd) without
+an autograd graph — what the periodic test-set renders of a training run need.
 
-Forward only: the outputs carry no autograd graph.  The fused backward of the three MLPs and the optimizer
-step are the next row of SURVEY.md §8(f); until then this serves evaluation during training (i_testset renders,
-refine2.py:981-994 style) and the parity of the training graph's forward.
+``train``: the optimisation loop runs on ``ops.Trainer`` (pnrf_train_stage2_fwd_bwd + pnrf_trainer_adam_step: fp32 forward with
+saved activations, full backward, Adam — pronerf_amd/csrc/pnrf_train.hip), not on torch.autograd.  The random draws of the
+reference (one ``random.sample`` of neighbour ranks and one coin flip per batch, |N(0,1)|/5 jitter, N(0,1) sigma noise) are
+made here with the same generators and handed to the kernels as inputs.
 """
 from __future__ import annotations
 
@@ -109,3 +106,121 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
     rgbd, _ = ops.nerf_train_fwd(fine, pts, ray_batch, z, add, mul, noise=noise, white_bkgd=white_bkgd)         # :669-676
     return {'rgb_map0': rgb0, 'rgb_map1': rgbd[:, :3], 'depth_map': rgbd[:, 3], 'mm_rgb': mm_rgb,
             'z_vals': z.mean(dim=-1), 'z_vals0': depth.mean(dim=-1)}
+
+
+# ------------------------------------------------------------------------------------ training loop
+_MM_KEYS = [f'fc_backbone.{i}' for i in range(6)] + ['fc_output']
+_FINE_KEYS = [f'pts_linears.{i}' for i in range(8)] + ['feature_linear', 'alpha_linear', 'views_linears.0', 'rgb_linear']
+
+
+def trainer_layer_list(sampler_sd, refine_sd, fine_sd):
+    """The 26 (W, b) pairs in the order of ``ops.Trainer`` from the three reference-keyed state dicts (MinMaxRay_Net x2, NeRF)."""
+    out = []
+    for sd, keys in ((sampler_sd, _MM_KEYS), (refine_sd, _MM_KEYS), (fine_sd, _FINE_KEYS)):
+        for k in keys:
+            out.append((sd[k + '.weight'].detach().float().cpu().numpy(), sd[k + '.bias'].detach().float().cpu().numpy()))
+    return out
+
+
+def state_dicts_from_trainer(tr):
+    """Inverse of ``trainer_layer_list``: (sampler_sd, refine_sd, fine_sd) with the reference's keys, CPU tensors."""
+    sds = ({}, {}, {})
+    li = 0
+    for sd, keys in zip(sds, (_MM_KEYS, _MM_KEYS, _FINE_KEYS)):
+        for k in keys:
+            W, b = tr.read('param', li)
+            sd[k + '.weight'], sd[k + '.bias'] = W.cpu(), b.cpu()
+            li += 1
+    return sds
+
+
+def save_checkpoint(path, tr, global_step):
+    """``torch.save`` of a dict with the reference's keys (refine2.py:884-893).  'network_fn_state_dict' carries the fine net as
+    well: the next stage / a restart reads the NeRF from that key (refine2.py:365).  The optimizer state is this trainer's Adam
+    moments ('pnrf_adam_m' / 'pnrf_adam_v', one [W, b] pair per layer) instead of torch.optim state dicts."""
+    s_sd, r_sd, f_sd = state_dicts_from_trainer(tr)
+    adam = {k: [[t.cpu() for t in tr.read(k, li)] for li in range(ops.TRAINER_LAYERS)] for k in ('m', 'v')}
+    torch.save({'global_step': int(global_step), 'network_fn_state_dict': f_sd, 'network_fine_state_dict': f_sd, 'mmr_network_fn_state_dict': s_sd,
+                'refine_net_state_dict': r_sd, 'pnrf_adam_m': adam['m'], 'pnrf_adam_v': adam['v']}, path)
+
+
+def config_parser():
+    """Options of the stage-2 script (run_S_eS_eN_alter_base_refine2.py:27-160); see ``pronerf_amd.config``."""
+    from .config import config_parser as _cp
+    return _cp('refine2')
+
+
+def train(argv=None, device='cuda'):
+    """Stage-2 training driver (run_S_eS_eN_alter_base_refine2.py:683-1000): LLFF scene, stage-1 checkpoint (--pretrain_path),
+    pre-shuffled ray batches of all training views, one ``Trainer.fwd_bwd`` + ``adam_step`` per iteration with the reference's
+    per-batch random draws and learning-rate decay, checkpoints with the reference's keys every ``i_weights``.
+    Returns (trainer, list of (iteration, loss, psnr))."""
+    import os
+    from .load_llff import load_llff_data
+    from .render import N_SAMPLES
+    args = config_parser().parse_args(argv)
+    if args.dataset_type != 'llff':
+        raise ValueError('only dataset_type=llff is supported (as in the reference release)')
+    if not args.pretrain_path:
+        raise ValueError('Stage 2 refinement requires --pretrain_path with a stage 1 checkpoint.')
+    if args.N_samples != N_SAMPLES or args.num_neighbor != 4 or args.N_point_ray_enc != 48 or args.mmnetdepth != 6:
+        raise PnrfError('the HIP trainer is built for N_samples=8, num_neighbor=4, N_point_ray_enc=48, mmnetdepth=6 (fern_refine.txt)')
+    dev = torch.device(device)
+    images, poses, bds, _, i_test = load_llff_data(args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
+    hwf = poses[0, :3, -1]
+    poses = poses[:, :3, :4]
+    i_test = np.arange(images.shape[0])[::args.llffhold] if args.llffhold > 0 else np.atleast_1d(i_test)          # :703-706
+    i_train = np.array([i for i in np.arange(int(images.shape[0])) if i not in i_test])
+    H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+    out_root = os.path.join(args.basedir, args.expname or 'pronerf_stage2')
+    os.makedirs(out_root, exist_ok=True)
+    with open(os.path.join(out_root, 'args.txt'), 'w') as f:
+        for k in sorted(vars(args)):
+            f.write('{} = {}\n'.format(k, getattr(args, k)))
+    ck = torch.load(args.pretrain_path, map_location='cpu')
+    start = 0
+    tr = ops.Trainer(*zip(*trainer_layer_list(ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], ck['network_fn_state_dict'])),
+                     max_rays=args.N_rand, device=dev)
+    # rays of all training views, as render() prepares them (:206-279): NDC batch + world-space batch, [n_train*H*W, 11] each
+    with torch.cuda.device(dev):
+        pr = [ops.frame_rays(K, poses[i], H, W, near=0., far=1., device=dev) for i in i_train]
+        rays_all = torch.cat([p[0] for p in pr], 0); or_rays_all = torch.cat([p[1] for p in pr], 0)
+        del pr
+        target_all = torch.as_tensor(images[i_train], dtype=torch.float32).reshape(-1, 3).to(dev)
+        own_all = torch.arange(len(i_train), device=dev).repeat_interleave(H * W)
+        img4, poses_t, K_t, rank = _train_views(images[i_train], poses[i_train], K, dev)
+    n_total = rays_all.shape[0]
+    perm = torch.randperm(n_total, device=dev)                                                                 # :796-799
+    i_batch, global_step, log = 0, start, []
+    n_iters = 500000 + 1 if args.max_steps is None else start + args.max_steps + 1                              # :808-810
+    lr = args.lrate
+    nv = len(i_train)
+    for i in range(start + 1, n_iters):
+        idx = perm[i_batch:i_batch + args.N_rand]
+        i_batch += args.N_rand
+        if i_batch >= n_total:                                                                                  # :840-844
+            perm = torch.randperm(n_total, device=dev); i_batch = 0
+        if idx.shape[0] < args.N_rand:
+            continue
+        # the per-batch draws of render_rays (:594-600, :649-661, raw2outputs :497)
+        order = torch.as_tensor(sorted(random.sample(range(nv - 1), 4)), device=dev)
+        ref_nos = rank[own_all[idx]][:, 1:][:, order].contiguous()
+        jitter = torch.abs(torch.normal(0.0, 1.0, size=(idx.shape[0], 8), device=dev) / 5).clamp(max=1 - 2e-6)
+        jdir = 1 if random.random() > 0.5 else -1
+        noise = torch.randn(idx.shape[0], 8, device=dev) * args.raw_noise_std if args.raw_noise_std > 0 else None
+        loss, _ = tr.fwd_bwd(rays_all[idx], or_rays_all[idx], target_all[idx], img4, poses_t, K_t, ref_nos, jitter=jitter, jitter_dir=jdir,
+                             raw_noise=noise, white_bkgd=args.white_bkgd, a_mmrgb=args.a_mmrgb, want_rgb=False)
+        tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay)
+        lr = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1000)))                                   # :872-878
+        if i % args.i_weights == 0 or i == n_iters - 1:
+            path = os.path.join(out_root, '{:06d}.tar'.format(i))
+            save_checkpoint(path, tr, global_step)
+            print('Saved checkpoints at', path)
+        if i % args.i_print == 0 or i == n_iters - 1:
+            lh = loss.cpu().numpy()
+            psnr = float(-10.0 * np.log10(max(float(lh[1]), 1e-12)))
+            log.append((i, float(lh[0]), psnr))
+            print(f'[TRAIN] Iter: {i} Loss: {float(lh[0])}  PSNR: {psnr}')
+        global_step += 1
+    return tr, log

@@ -264,3 +264,35 @@ def test_stage2_step_vs_reference_golden(dev, golden_dir, name):
         else:
             tr.adam_step(b['lr'], weight_decay=b['wd'])
             U.check_against_golden(g, grads, [tr.read('param', i) for i in range(26)], tol_grad=1e-1, tol_norm=5e-2)
+
+
+def test_stage2_train_driver_end_to_end(dev, tmp_path):
+    """train() of the stage-2 mirror on an LLFF directory: stage-1 checkpoint in, a few iterations, checkpoint with the
+    reference's keys out — which the inference driver then loads and renders."""
+    import llff_synth
+    from pronerf_amd import run_S_eS_eN_alter_base_refine2 as s2
+    from pronerf_amd import run_S_eS_eN_alter_trt as trt
+    root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=2, n=10, H=24, W=32, factor=4)
+    w = synth.make_weights(0, 'trained'); wc = synth.make_nerfcls_weights(0, head_scale=0.3)
+    sds = synth.state_dicts(w)
+    pre = str(tmp_path / 'stage1.tar')
+    torch.save({'global_step': 7, 'network_fn_state_dict': synth.nerfcls_state_dict(wc), 'mmr_network_fn_state_dict': sds['sampler'],
+                'refine_net_state_dict': sds['refine']}, pre)
+    cfg = tmp_path / 'refine.txt'
+    cfg.write_text(f'expname = s2\nbasedir = {tmp_path}/logs\ndatadir = {root}\npretrain_path = {pre}\nfactor = 4\nllffhold = 8\nN_rand = 512\nN_samples = 8\n'
+                   'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\nraw_noise_std = 1e0\nlrate = 5e-4\n'
+                   'weight_decay = 5e-8\ni_print = 5\ni_weights = 1000\n')
+    tr, log = s2.train(['--config', str(cfg), '--max_steps', '20'], device=dev)
+    assert [e[0] for e in log] == [5, 10, 15, 20] and all(np.isfinite(e[1]) for e in log)
+    assert log[-1][1] < log[0][1]                                     # the loss goes down on this small scene
+    ck_path = tmp_path / 'logs' / 's2' / '000020.tar'
+    ck = torch.load(str(ck_path), map_location='cpu')
+    assert sorted(ck['network_fine_state_dict']) == sorted(synth.nerfcls_state_dict(wc))
+    assert sorted(ck['mmr_network_fn_state_dict']) == sorted(sds['sampler']) and ck['global_step'] == 19
+    moved = float((ck['refine_net_state_dict']['fc_output.weight'] - sds['refine']['fc_output.weight']).abs().max())
+    assert 0 < moved <= 20 * 5e-4 * 1.01                              # Adam moves a weight by at most lr per step
+    icfg = tmp_path / 'infer.txt'
+    icfg.write_text(f'expname = inf\nbasedir = {tmp_path}/logs\ndatadir = {root}\nft_path = {ck_path}\nfactor = 4\nllffhold = 8\nN_samples = 8\n'
+                    'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\n')
+    kw = trt.train(['--config', str(icfg), '--render_test', '--max_images', '1'], device=dev)
+    assert len(kw['psnrs']) == 1 and np.isfinite(kw['psnrs'][0])
