@@ -216,15 +216,17 @@ int pnrf_refine_head_bwd(const float* y, const float* rays, const float* depth_s
 /* Trainer: fp32 parameters, gradients, Adam moments and workspaces of the three networks for batches of up to max_rays
  * rays.  26 Linear layers in this order: sampler fc_backbone.0..5, fc_output (MinMaxRay_Net, 288 -> 27); refine net
  * likewise (144 -> 35); fine net of class NeRF: pts_linears.0..7, feature_linear, alpha_linear, views_linears.0, rgb_linear.
- * W[i]: [out_dim[i], in_dim[i]] row-major (torch layout), host or device.
+ * W[i]: [out_dim[i], in_dim[i]] row-major (torch layout), host or device.  max_samples: samples per ray the NeRF-side
+ * workspaces are sized for (8; stage-1 exploration: up to 64).
  * Replaces create_nerf's modules + torch.optim.Adam (run_S_eS_eN_alter_base_refine2.py:337-395). */
 int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim,
-                        int n_layers, int64_t max_rays, pnrf_trainer_t** out);
+                        int n_layers, int64_t max_rays, int max_samples, pnrf_trainer_t** out);
 int pnrf_trainer_free(pnrf_trainer_t* t);
-/* kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment; W, b: host or device (NULL to skip). */
+/* kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment of the joint optimizer, 4 / 5 those of the NeRF-only
+ * optimizer; W, b: host or device (NULL to skip). */
 int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, float* W, float* b, void* stream);
 int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const float* W, const float* b, void* stream);
-int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step);
+int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step, int64_t step_nerf);
 
 typedef struct pnrf_train_batch {
   const float* rays;       /* dev [n,11] NDC ray batch (o, d, near, far, viewdir) */
@@ -241,18 +243,28 @@ typedef struct pnrf_train_batch {
   int jitter_dir;          /* +1 toward the next sample / far, -1 toward the previous / near */
   int white_bkgd;
   float eps;               /* NDC -> metric epsilon: 1e-5 */
-  float a_mmrgb;           /* weight of mse(rgb_map0) + mse(mm_rgb) in the loss (0 in fern_refine.txt) */
+  float a_mmrgb;           /* weight of mse(rgb_map0) + mse(mm_rgb) in the loss (0 in fern_refine.txt; 1 on stage-1 even iterations) */
+  float clamp;             /* raw clamp before compositing: 0 = none (stage 2), 10 (stage 1, base.py:523) */
+  int layout;              /* epi feature layout: 0 neighbour-major (stage 2), 1 sample-major (stage 1) */
 } pnrf_train_batch_t;
 
-/* render_rays (training) + img2mse + loss.backward(): leaves the gradients of all 26 layers in the trainer.
- * loss dev [4] = {total, mse(rgb_map1), mse(rgb_map0), mse(mm_rgb)}; rgb_map1 dev [n,3] or NULL.
- * (run_S_eS_eN_alter_base_refine2.py:525-680, 858-868) */
+/* Joint iteration: render_rays (training) + img2mse [+ a_mmrgb (...)] + loss.backward(): leaves the gradients of all 26
+ * layers in the trainer.  loss dev [4] = {total, mse(rgb_map1), mse(rgb_map0), mse(mm_rgb)}; rgb_map1 dev [n,3] or NULL.
+ * Stage 2 (run_S_eS_eN_alter_base_refine2.py:525-680, 858-868) and, with layout 1 / eps 1e-6 / clamp 10 / a_mmrgb 1 / no
+ * jitter and noise, the even iterations of stage 1 (run_S_eS_eN_alter_base.py:554-761, 941-958). */
 int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* batch, float* loss, float* rgb_map1,
                               void* stream);
-/* optimizer.step() of torch.optim.Adam (L2 weight decay added to the gradient) over all parameters
- * (run_S_eS_eN_alter_base_refine2.py:394, 869). */
-int pnrf_trainer_adam_step(pnrf_trainer_t* t, float lr, float beta1, float beta2, float eps, float weight_decay,
-                           void* stream);
+/* Odd iterations of stage 1 (run_S_eS_eN_alter_base.py:929-940, exploration :689-729): sampler / refine nets without
+ * gradient, refined depths explored into 8 n_mult samples (replicated toward dir1, jittered toward batch->jitter_dir with
+ * batch->jitter dev [n, 8 n_mult]), no offsets, compositing without add / mul with batch->raw_noise dev [n, 8 n_mult];
+ * loss = img2mse(rgb_map1); gradients for the 12 NeRF layers only. */
+int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* batch, int n_mult, int dir1, float* loss,
+                               float* rgb_map1, void* stream);
+/* optimizer.step() of torch.optim.Adam (L2 weight decay added to the gradient).  which 0: the joint optimizer over all
+ * parameters (run_S_eS_eN_alter_base_refine2.py:394, 869; stage 1 s_optimizer); which 1: the NeRF-only optimizer of stage 1
+ * (run_S_eS_eN_alter_base.py:398-421, 940) with its own moments and step count. */
+int pnrf_trainer_adam_step(pnrf_trainer_t* t, int which, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, void* stream);
 
 /* Host helper: torch.linspace(start,end,n) in fp32, as used for the 48 ray points
  * (run_S_eS_eN_alter_trt.py:556-557).  out: HOST [n]. */

@@ -434,13 +434,18 @@ def render_rays_stage1(weights, rays, or_rays, images_nchw, poses, K, ref_nos, t
     o, d = rays[:, 0:3], rays[:, 3:6]
     viewdirs = rays[:, -3:]
     near, far = rays[:, 6:7], rays[:, 7:8]
-    mm_rgb, add, mul, depth = sampler_forward(weights['sampler'], mm_input_from_rays(o, d, n_pts), S)
+    import contextlib
+    frozen = contextlib.nullcontext if train_sampler else torch.no_grad      # odd steps: sampler / refine nets under no_grad (base.py:592-596, 675-679)
+    with frozen():
+        mm_rgb, add, mul, depth = sampler_forward(weights['sampler'], mm_input_from_rays(o, d, n_pts), S)
     depth_sorted, idx, add_s, mul_s = sort_gather(depth, add, mul, near, far)
-    epi, margin = project_train(images_nchw, poses, K, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, ref_nos, 1e-6)
-    epi = epi.reshape(N, -1, S, 3).permute(0, 2, 1, 3).reshape(N, -1)                       # neighbour-major -> sample-major (:664-665)
+    with torch.no_grad():                                                    # epipolar features: always under no_grad (base.py:612-665)
+        epi, margin = project_train(images_nchw, poses, K, or_rays[:, 0:3], or_rays[:, 3:6], depth_sorted, ref_nos, 1e-6)
+        epi = epi.reshape(N, -1, S, 3).permute(0, 2, 1, 3).reshape(N, -1)                   # neighbour-major -> sample-major (:664-665)
     pl = pluecker(o[:, None, :] + d[:, None, :] * depth_sorted[..., None], d[:, None, :].expand(-1, S, -1)).reshape(N, 6 * S)
     refine_in = torch.cat([pl, epi], 1)
-    rdepth, refine_rgb, offs = refine_forward(weights['refine'], refine_in, S)
+    with frozen():
+        rdepth, refine_rgb, offs = refine_forward(weights['refine'], refine_in, S)
     z = interval_refine(depth_sorted, rdepth, near, far)
     if not train_sampler and jitter is not None:
         z = explore_samples(z, near, far, n_mult, dir1, jitter, dir2)
@@ -493,4 +498,17 @@ def stage2_loss(layers, rays, or_rays, target, images_nchw, poses, K, ref_nos, j
     loss = img_loss
     if a_mmrgb > 0:
         loss = loss + a_mmrgb * (torch.mean((o['rgb_map0'] - target) ** 2) + torch.mean((o['mm_rgb'] - target) ** 2))
+    return loss, img_loss, o
+
+
+def stage1_loss(layers, rays, or_rays, target, images_nchw, poses, K, ref_nos, train_sampler, n_mult=1, dir1=1, jitter=None, dir2=1, raw_noise=None,
+                white_bkgd=False):
+    """loss of one stage-1 iteration (run_S_eS_eN_alter_base.py:929-958): odd (train_sampler False) img2mse(rgb_map1) on the
+    explored samples; even img2mse(rgb_map1) + img2mse(rgb_map0) + img2mse(mm_rgb).  Returns (loss, img_loss, outputs)."""
+    o = render_rays_stage1(weights_from_layers(layers), rays, or_rays, images_nchw, poses, K, ref_nos, train_sampler, n_mult=n_mult, dir1=dir1,
+                           jitter=jitter, dir2=dir2, raw_noise=raw_noise, white_bkgd=white_bkgd)
+    img_loss = torch.mean((o['rgb_map1'] - target) ** 2)
+    loss = img_loss
+    if train_sampler:
+        loss = loss + torch.mean((o['rgb_map0'] - target) ** 2) + torch.mean((o['mm_rgb'] - target) ** 2)
     return loss, img_loss, o

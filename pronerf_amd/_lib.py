@@ -59,13 +59,14 @@ SIGNATURES = {
     'pnrf_sampler_head_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     'pnrf_refine_head_fwd': (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i64, _p]),
     'pnrf_refine_head_bwd': (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i64, _p]),
-    'pnrf_trainer_create': (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, _i64, C.POINTER(_p)]),
+    'pnrf_trainer_create': (_i, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, _i64, _i, C.POINTER(_p)]),
     'pnrf_trainer_free': (_i, [_p]),
     'pnrf_trainer_read': (_i, [_p, _i, _i, _p, _p, _p]),
     'pnrf_trainer_write': (_i, [_p, _i, _i, _p, _p, _p]),
-    'pnrf_trainer_set_step': (_i, [_p, _i64]),
+    'pnrf_trainer_set_step': (_i, [_p, _i64, _i64]),
     'pnrf_train_stage2_fwd_bwd': (_i, [_p, _p, _p, _p, _p]),
-    'pnrf_trainer_adam_step': (_i, [_p, _f, _f, _f, _f, _f, _p]),
+    'pnrf_train_explore_fwd_bwd': (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    'pnrf_trainer_adam_step': (_i, [_p, _i, _f, _f, _f, _f, _f, _p]),
 }
 
 
@@ -73,7 +74,7 @@ class TrainBatch(C.Structure):
     """pnrf_train_batch_t (include/pronerf_hip.h)."""
     _fields_ = [('rays', _p), ('or_rays', _p), ('target', _p), ('img4', _p), ('poses', _p), ('K', _p), ('ref_nos', _p), ('jitter', _p),
                 ('raw_noise', _p), ('n', _i64), ('nv', _i), ('Hf', _i), ('Wf', _i), ('jitter_dir', _i), ('white_bkgd', _i), ('eps', _f),
-                ('a_mmrgb', _f)]
+                ('a_mmrgb', _f), ('clamp', _f), ('layout', _i)]
 
 _lib = None
 

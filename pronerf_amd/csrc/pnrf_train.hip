@@ -523,10 +523,12 @@ struct TLin { int in, out; size_t w, b; };       // offsets into the flat parame
 struct pnrf_trainer {
   int device = 0;
   int64_t max_rays = 0;
+  int max_samples = 8;                          // samples per ray the NeRF-side workspaces are sized for (stage-1 exploration: up to 64)
   std::vector<TLin> L;                           // 0..6 sampler, 7..13 refine, 14..25 fine net (pts0..7, feature, alpha, views, rgb)
   size_t nparam = 0;
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
-  int64_t step = 0;
+  float *M2 = nullptr, *V2 = nullptr;            // second Adam state over the NeRF layers only (stage 1: `optimizer` next to `s_optimizer`)
+  int64_t step = 0, step2 = 0;
   rocblas_handle blas = nullptr;
   std::vector<void*> allocs;
   // workspaces
@@ -681,8 +683,9 @@ extern "C" int pnrf_refine_head_bwd(const float* y, const float* rays, const flo
 
 // ------------------------------------------------------------------------------------------ C ABI: trainer
 extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim, int n_layers,
-                                   int64_t max_rays, pnrf_trainer_t** out) {
+                                   int64_t max_rays, int max_samples, pnrf_trainer_t** out) {
   PNRF_REQUIRE(W && b && in_dim && out_dim && out && max_rays >= 1, PNRF_E_ARG, "pnrf_trainer_create: null pointer / max_rays < 1");
+  PNRF_REQUIRE(max_samples >= 8 && max_samples <= 256 && max_samples % 8 == 0, PNRF_E_ARG, "pnrf_trainer_create: max_samples must be a multiple of 8 in [8, 256]");
   PNRF_REQUIRE(n_layers == N_LAYERS, PNRF_E_ARG, "pnrf_trainer_create: expected %d Linear layers (7 sampler, 7 refine, 12 NeRF class), got %d", N_LAYERS, n_layers);
   static const int want_in[N_LAYERS] = {288, 256, 256, 256, 256, 256, 256, 144, 256, 256, 256, 256, 256, 256,
                                         63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
@@ -694,6 +697,7 @@ extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b,
   pnrf_trainer* t = new pnrf_trainer();
   PNRF_HIP(hipGetDevice(&t->device));
   t->max_rays = max_rays;
+  t->max_samples = max_samples;
   size_t off = 0;
   for (int i = 0; i < N_LAYERS; ++i) {
     TLin l; l.in = in_dim[i]; l.out = out_dim[i]; l.w = off; off += (size_t)l.in * l.out; l.b = off; off += l.out;
@@ -701,26 +705,27 @@ extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b,
     t->L.push_back(l);
   }
   t->nparam = off;
-  T_ALLOC(t->P, off); T_ALLOC(t->G, off); T_ALLOC(t->M, off); T_ALLOC(t->V, off);
+  T_ALLOC(t->P, off); T_ALLOC(t->G, off); T_ALLOC(t->M, off); T_ALLOC(t->V, off); T_ALLOC(t->M2, off); T_ALLOC(t->V2, off);
   PNRF_HIP(hipMemset(t->P, 0, off * 4)); PNRF_HIP(hipMemset(t->G, 0, off * 4)); PNRF_HIP(hipMemset(t->M, 0, off * 4)); PNRF_HIP(hipMemset(t->V, 0, off * 4));
+  PNRF_HIP(hipMemset(t->M2, 0, off * 4)); PNRF_HIP(hipMemset(t->V2, 0, off * 4));
   for (int i = 0; i < N_LAYERS; ++i) {
     PNRF_HIP(hipMemcpy(t->P + t->L[i].w, W[i], (size_t)t->L[i].in * t->L[i].out * 4, hipMemcpyDefault));
     PNRF_HIP(hipMemcpy(t->P + t->L[i].b, b[i], (size_t)t->L[i].out * 4, hipMemcpyDefault));
   }
   if (rocblas_create_handle(&t->blas) != rocblas_status_success) { set_error("pnrf_trainer_create: rocblas_create_handle failed"); return 1; }
   rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
-  const int64_t N = max_rays, R = 8 * max_rays;
+  const int64_t N = max_rays, R = (int64_t)max_samples * max_rays;
   T_ALLOC(t->mm_input, N * 288);
   for (int k = 0; k < 6; ++k) { T_ALLOC(t->s_h[k], N * 256); T_ALLOC(t->r_h[k], N * 256); }
   T_ALLOC(t->s_y, N * 27); T_ALLOC(t->depth_sorted, N * 8); T_ALLOC(t->add_s, N * 8); T_ALLOC(t->mul_s, N * 8); T_ALLOC(t->mm_rgb, N * 3);
   T_ALLOC(t->sort_idx, N * 8);
-  T_ALLOC(t->refine_in, N * 144); T_ALLOC(t->r_y, N * 35); T_ALLOC(t->z_pre, N * 8); T_ALLOC(t->z, N * 8); T_ALLOC(t->pts, N * 24); T_ALLOC(t->rgb0, N * 3);
+  T_ALLOC(t->refine_in, N * 144); T_ALLOC(t->r_y, N * 35); T_ALLOC(t->z_pre, N * 8); T_ALLOC(t->z, R); T_ALLOC(t->pts, R * 3); T_ALLOC(t->rgb0, N * 3);
   T_ALLOC(t->emb, R * 90);
   for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], R * 256);
   T_ALLOC(t->n_c5, R * 319); T_ALLOC(t->n_a5, R * 256); T_ALLOC(t->n_a6, R * 256); T_ALLOC(t->n_a7, R * 256);
-  T_ALLOC(t->n_cv, R * 283); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, N * 8);
+  T_ALLOC(t->n_cv, R * 283); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
   T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * 283); T_ALLOC(t->d_a, R * 256);
-  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, R * 63); T_ALLOC(t->d_pts, R * 3); T_ALLOC(t->d_z, N * 8);
+  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
   T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->dw_part, (size_t)DW_MAX_SPLITS * 256 * 320); T_ALLOC(t->loss, 4);
@@ -736,10 +741,11 @@ extern "C" int pnrf_trainer_free(pnrf_trainer_t* t) {
   return 0;
 }
 
-// kind 0 parameters, 1 gradients, 2 Adam first moment, 3 Adam second moment; W / b: host or device destinations (either may be NULL)
+// kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment (joint optimizer), 4 / 5 those of the NeRF-only optimizer;
+// W / b: host or device destinations (either may be NULL)
 extern "C" int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, float* W, float* b, void* stream) {
-  PNRF_REQUIRE(t && kind >= 0 && kind <= 3 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_read: bad kind / layer");
-  const float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : t->V;
+  PNRF_REQUIRE(t && kind >= 0 && kind <= 5 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_read: bad kind / layer");
+  const float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   const TLin& l = t->L[layer];
   PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (W) PNRF_HIP(hipMemcpy(W, base + l.w, (size_t)l.in * l.out * 4, hipMemcpyDefault));
@@ -747,62 +753,67 @@ extern "C" int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, f
   return 0;
 }
 extern "C" int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const float* W, const float* b, void* stream) {
-  PNRF_REQUIRE(t && kind >= 0 && kind <= 3 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_write: bad kind / layer");
-  float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : t->V;
+  PNRF_REQUIRE(t && kind >= 0 && kind <= 5 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_write: bad kind / layer");
+  float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   const TLin& l = t->L[layer];
   PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (W) PNRF_HIP(hipMemcpy(base + l.w, W, (size_t)l.in * l.out * 4, hipMemcpyDefault));
   if (b) PNRF_HIP(hipMemcpy(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault));
   return 0;
 }
-extern "C" int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step) {
-  PNRF_REQUIRE(t && step >= 0, PNRF_E_ARG, "pnrf_trainer_set_step: bad arguments");
-  t->step = step;
+extern "C" int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step, int64_t step_nerf) {
+  PNRF_REQUIRE(t && step >= 0 && step_nerf >= 0, PNRF_E_ARG, "pnrf_trainer_set_step: bad arguments");
+  t->step = step; t->step2 = step_nerf;
   return 0;
 }
 
-extern "C" int pnrf_trainer_adam_step(pnrf_trainer_t* t, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
-  PNRF_REQUIRE(t && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, PNRF_E_ARG, "pnrf_trainer_adam_step: bad hyper-parameters");
-  t->step += 1;
-  const double bc1 = 1.0 - pow((double)beta1, (double)t->step), bc2 = 1.0 - pow((double)beta2, (double)t->step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, (hipStream_t)stream, t->P, t->G, t->M, t->V, (int64_t)t->nparam, lr, beta1,
-                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+// which = 0: the joint optimizer over all 26 layers (stage 2 `optimizer`, stage 1 `s_optimizer`); which = 1: the NeRF-only
+// optimizer of stage 1 (`optimizer`, base.py:398-421) with its own moments and step count.
+extern "C" int pnrf_trainer_adam_step(pnrf_trainer_t* t, int which, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  PNRF_REQUIRE(t && (which == 0 || which == 1) && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, PNRF_E_ARG,
+               "pnrf_trainer_adam_step: bad arguments");
+  int64_t& st = which == 0 ? t->step : t->step2;
+  st += 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)st), bc2 = 1.0 - pow((double)beta2, (double)st);
+  const size_t first = which == 0 ? 0 : t->L[L_N].w;
+  const int64_t count = (int64_t)(t->nparam - first);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(TPB), 0, (hipStream_t)stream, t->P + first, t->G + first, (which == 0 ? t->M : t->M2) + first,
+                     (which == 0 ? t->V : t->V2) + first, count, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   PNRF_LAUNCH_CHECK();
   return 0;
 }
 
-// One stage-2 forward + backward over a batch of rays (refine2.py:525-680, :858-868).  Gradients of all 26 layers are left in the
-// trainer (pnrf_trainer_read kind 1); loss dev [4] = {total, mse(rgb_map1), mse(rgb_map0), mse(mm_rgb)}; rgb_out dev [n,3] or NULL.
-extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, float* loss, float* rgb_out, void* stream) {
-  PNRF_REQUIRE(t && bt && loss, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: null pointer");
-  const int64_t N = bt->n, R = 8 * bt->n;
-  PNRF_REQUIRE(N >= 1 && N <= t->max_rays, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: n = %lld outside [1, max_rays = %lld]", (long long)N, (long long)t->max_rays);
-  PNRF_REQUIRE(bt->rays && bt->or_rays && bt->target && bt->img4 && bt->poses && bt->K && bt->ref_nos, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: null batch pointer");
-  PNRF_REQUIRE(!bt->jitter || bt->jitter_dir == 1 || bt->jitter_dir == -1, PNRF_E_ARG, "pnrf_train_stage2_fwd_bwd: jitter_dir must be +1 or -1");
-  hipStream_t s = (hipStream_t)stream;
-  T_BLAS(rocblas_set_stream(t->blas, s));
-  int rc;
-#define T_RC(expr) do { rc = (expr); if (rc) return rc; } while (0)
-  // ---------------- forward
-  T_RC(pnrf_ray_encode_fwd(bt->rays, t->mm_input, N, 48, stream));                                                    // :551-556
+namespace {
+
+#define T_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+// rays -> sampler MLP -> head/sort -> projection -> refine MLP (activations saved in the trainer)
+int sampler_refine_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, hipStream_t s) {
+  void* stream = (void*)s;
+  const int64_t N = bt->n;
+  T_RC(pnrf_ray_encode_fwd(bt->rays, t->mm_input, N, 48, stream));                                                    // refine2.py:551-556
   {
     const float* x = t->mm_input; int ldx = 288;
     for (int k = 0; k < 6; ++k) { T_RC(layer_fwd(t, L_S + k, x, ldx, t->s_h[k], 256, N, T_ACT_ELU, s)); x = t->s_h[k]; ldx = 256; }
     T_RC(layer_fwd(t, L_S + 6, x, 256, t->s_y, 27, N, T_ACT_NONE, s));
   }
   T_RC(pnrf_sampler_head_fwd(t->s_y, bt->rays, t->depth_sorted, t->sort_idx, t->add_s, t->mul_s, t->mm_rgb, N, stream));     // :557-568
-  T_RC(pnrf_refine_input_train_fwd(bt->rays, bt->or_rays, t->depth_sorted, bt->img4, bt->poses, bt->K, bt->ref_nos, bt->nv, 4, bt->Hf, bt->Wf, bt->eps, 0,
-                                   t->refine_in, N, stream));                                                         // :570-634
+  T_RC(pnrf_refine_input_train_fwd(bt->rays, bt->or_rays, t->depth_sorted, bt->img4, bt->poses, bt->K, bt->ref_nos, bt->nv, 4, bt->Hf, bt->Wf, bt->eps,
+                                   bt->layout, t->refine_in, N, stream));                                             // :570-634
   {
     const float* x = t->refine_in; int ldx = 144;
     for (int k = 0; k < 6; ++k) { T_RC(layer_fwd(t, L_R + k, x, ldx, t->r_h[k], 256, N, T_ACT_ELU, s)); x = t->r_h[k]; ldx = 256; }
     T_RC(layer_fwd(t, L_R + 6, x, 256, t->r_y, 35, N, T_ACT_NONE, s));
   }
-  T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, bt->jitter, bt->jitter_dir, t->z_pre, t->z, t->pts, t->rgb0, N, stream));   // :635-668
+  return 0;
+}
+
+// query points t->pts [N*S,3] + view directions -> raw [N*S,4]  (NeRF class, run_nerf_helpers.py:824-847)
+int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream_t s) {
+  const int64_t R = bt->n * S;
   hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, 3, 1, t->emb, 90, 0, R, 10);
-  hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, bt->rays + 8, 11, 8, t->emb, 90, 63, R, 4);
+  hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, bt->rays + 8, 11, S, t->emb, 90, 63, R, 4);
   PNRF_LAUNCH_CHECK();
-  // NeRF class (run_nerf_helpers.py:824-847)
   T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
   for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + 63, 319, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
@@ -817,21 +828,12 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
   PNRF_LAUNCH_CHECK();
   T_RC(layer_fwd(t, L_VIEWS, t->n_cv, 283, t->n_hv, 128, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
-  T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, 0.f, bt->white_bkgd, t->rgb_map, nullptr, nullptr, t->wts,
-                          nullptr, N, 8, stream));                                                                     // :674
-  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
-  // ---------------- losses (:861-866)
-  const bool aux = bt->a_mmrgb > 0.f;
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, bt->a_mmrgb, t->loss + 2, aux ? t->d_rgb0 : (float*)nullptr);
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, bt->a_mmrgb, t->loss + 3, aux ? t->d_mmrgb : (float*)nullptr);
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, aux ? bt->a_mmrgb : 0.f);
-  PNRF_LAUNCH_CHECK();
-  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
-  // ---------------- backward
-  T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, 0.f, bt->white_bkgd, t->d_rgb_map, t->d_raw, t->d_z, t->d_add,
-                          t->d_mul, N, 8, stream));
-  // rgb head: d_raw[:, 0:3] -> d_hv ; views layer -> d_cv ; feature -> d_a7 (beta 0) ; alpha: d_raw[:, 3] -> d_a7 (beta 1)
+  return 0;
+}
+
+// t->d_raw [R,4] -> gradients of the 12 NeRF layers; want_dpts: also d pts [R,3] into t->d_pts
+int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
+  // rgb head: d_raw[:, 0:3] -> d_hv ; views layer -> d_cv ; feature -> d_a (beta 0) ; alpha: d_raw[:, 3] -> d_a (beta 1)
   T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, nullptr, 0, t->n_hv, 128, t->d_hv, 128, 0.f, R, T_ACT_NONE, s));
   T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, t->n_hv, 128, t->n_cv, 283, t->d_cv, 283, 0.f, R, T_ACT_RELU, s));
   T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, nullptr, 0, t->n_a7, 256, t->d_a, 256, 0.f, R, T_ACT_NONE, s));
@@ -843,14 +845,60 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
   T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, t->n_a[3], 256, t->n_a[2], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
   T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, t->n_a[2], 256, t->n_a[1], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
   T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, t->n_a[1], 256, t->n_a[0], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, t->n_a[0], 256, t->emb, 90, t->d_e0, 63, 0.f, R, T_ACT_RELU, s));
-  hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, 319, t->d_pts, R, 10);
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, t->n_a[0], 256, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, 0.f, R, T_ACT_RELU, s));
+  if (want_dpts) {
+    hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, 319, t->d_pts, R, 10);
+    PNRF_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int check_batch(const pnrf_trainer* t, const pnrf_train_batch_t* bt, const float* loss, int S, const char* who) {
+  PNRF_REQUIRE(t && bt && loss, PNRF_E_ARG, "%s: null pointer", who);
+  PNRF_REQUIRE(bt->n >= 1 && bt->n <= t->max_rays, PNRF_E_ARG, "%s: n = %lld outside [1, max_rays = %lld]", who, (long long)bt->n, (long long)t->max_rays);
+  PNRF_REQUIRE(S >= 8 && S <= t->max_samples && S % 8 == 0, PNRF_E_ARG, "%s: %d samples per ray outside [8, max_samples = %d] / not a multiple of 8", who, S, t->max_samples);
+  PNRF_REQUIRE(bt->rays && bt->or_rays && bt->target && bt->img4 && bt->poses && bt->K && bt->ref_nos, PNRF_E_ARG, "%s: null batch pointer", who);
+  PNRF_REQUIRE(!bt->jitter || bt->jitter_dir == 1 || bt->jitter_dir == -1, PNRF_E_ARG, "%s: jitter_dir must be +1 or -1", who);
+  PNRF_REQUIRE(bt->layout == 0 || bt->layout == 1, PNRF_E_ARG, "%s: layout must be 0 (neighbour-major) or 1 (sample-major)", who);
+  PNRF_REQUIRE(bt->clamp >= 0.f, PNRF_E_ARG, "%s: clamp must be >= 0", who);
+  return 0;
+}
+
+}  // namespace
+
+// Joint iteration: render_rays (training) + img2mse [+ a_mmrgb (img2mse(rgb_map0) + img2mse(mm_rgb))] + loss.backward() for all
+// three networks.  Stage 2 (refine2.py:525-680, 858-868): layout 0, eps 1e-5, clamp 0, jitter + sigma noise.  Stage-1 even
+// iterations (base.py:554-761 with train_sampler=True, :941-958): layout 1, eps 1e-6, clamp 10, no jitter / noise, a_mmrgb 1.
+// Gradients of all 26 layers are left in the trainer (pnrf_trainer_read kind 1); loss dev [4] = {total, mse(rgb_map1),
+// mse(rgb_map0), mse(mm_rgb)}; rgb_out dev [n,3] or NULL.
+extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, float* loss, float* rgb_out, void* stream) {
+  T_RC(check_batch(t, bt, loss, 8, "pnrf_train_stage2_fwd_bwd"));
+  const int64_t N = bt->n, R = 8 * bt->n;
+  hipStream_t s = (hipStream_t)stream;
+  T_BLAS(rocblas_set_stream(t->blas, s));
+  // ---------------- forward
+  T_RC(sampler_refine_forward(t, bt, s));
+  T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, bt->jitter, bt->jitter_dir, t->z_pre, t->z, t->pts, t->rgb0, N, stream));   // :635-668
+  T_RC(nerf_forward(t, bt, 8, s));
+  T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, bt->clamp, bt->white_bkgd, t->rgb_map, nullptr, nullptr,
+                          t->wts, nullptr, N, 8, stream));                                                            // :674
+  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
+  // ---------------- losses (:861-866)
+  const bool aux = bt->a_mmrgb > 0.f;
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, bt->a_mmrgb, t->loss + 2, aux ? t->d_rgb0 : (float*)nullptr);
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, bt->a_mmrgb, t->loss + 3, aux ? t->d_mmrgb : (float*)nullptr);
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, aux ? bt->a_mmrgb : 0.f);
   PNRF_LAUNCH_CHECK();
+  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
+  // ---------------- backward
+  T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, bt->clamp, bt->white_bkgd, t->d_rgb_map, t->d_raw, t->d_z,
+                          t->d_add, t->d_mul, N, 8, stream));
+  T_RC(nerf_backward(t, R, true, s));
   T_RC(pnrf_refine_head_bwd(t->r_y, bt->rays, t->depth_sorted, t->z_pre, bt->jitter, bt->jitter_dir, t->d_pts, t->d_z, aux ? t->d_rgb0 : nullptr, t->d_ry,
                             t->d_depth, N, stream));
   {   // refine net: no gradient reaches refine_in (Pluecker moment is depth-independent; the projection is under no_grad)
-    float* dcur = t->d_ry; int ldd = 35;
-    T_RC(layer_bwd(t, L_R + 6, dcur, ldd, nullptr, 0, t->r_h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_NONE, s));
+    T_RC(layer_bwd(t, L_R + 6, t->d_ry, 35, nullptr, 0, t->r_h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_NONE, s));
     float* dA = t->d_h0; float* dB = t->d_h1;
     for (int k = 5; k >= 1; --k) {
       T_RC(layer_bwd(t, L_R + k, dA, 256, t->r_h[k], 256, t->r_h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, s));
@@ -868,6 +916,38 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
     }
     T_RC(layer_bwd(t, L_S + 0, dA, 256, t->s_h[0], 256, t->mm_input, 288, nullptr, 0, 0.f, N, T_ACT_ELU, s));
   }
-#undef T_RC
   return 0;
 }
+
+// Stage-1 odd iteration (base.py:554-761 with train_sampler=False, :929-940): sampler and refine nets run without gradient,
+// the refined depths are explored into S = 8 n_mult samples (pnrf_explore_fwd: replicate toward dir1, sort, jitter toward
+// jitter_dir with batch->jitter dev [n, S]), query points carry no learned offsets, compositing without add / mul and with
+// batch->raw_noise dev [n, S]; loss = img2mse(rgb_map1); only the 12 NeRF layers get gradients (the others are left untouched).
+extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int n_mult, int dir1, float* loss, float* rgb_out,
+                                          void* stream) {
+  PNRF_REQUIRE(n_mult >= 1 && n_mult <= 32 && (dir1 == 1 || dir1 == -1), PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: n_mult 1..32, dir1 +-1");
+  const int S = 8 * n_mult;
+  T_RC(check_batch(t, bt, loss, S, "pnrf_train_explore_fwd_bwd"));
+  PNRF_REQUIRE(bt->jitter, PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: the exploration jitter [n, 8 n_mult] is required");
+  const int64_t N = bt->n, R = (int64_t)S * bt->n;
+  hipStream_t s = (hipStream_t)stream;
+  T_BLAS(rocblas_set_stream(t->blas, s));
+  T_RC(sampler_refine_forward(t, bt, s));
+  T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, nullptr, 1, t->z_pre, t->z, t->pts, t->rgb0, N, stream));     // z_pre = refined depths
+  T_RC(pnrf_explore_fwd(t->z_pre, bt->rays, bt->jitter, n_mult, dir1, bt->jitter_dir, t->z, t->pts, N, stream));            // base.py:689-729
+  T_RC(nerf_forward(t, bt, S, s));
+  T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, nullptr, nullptr, bt->raw_noise, bt->clamp, bt->white_bkgd, t->rgb_map, nullptr, nullptr, t->wts,
+                          nullptr, N, S, stream));
+  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, 0.f, t->loss + 2, (float*)nullptr);
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, 0.f, t->loss + 3, (float*)nullptr);
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, 0.f);
+  PNRF_LAUNCH_CHECK();
+  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
+  T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, nullptr, nullptr, bt->raw_noise, bt->clamp, bt->white_bkgd, t->d_rgb_map, t->d_raw, nullptr, nullptr,
+                          nullptr, N, S, stream));
+  T_RC(nerf_backward(t, R, false, s));
+  return 0;
+}
+#undef T_RC

@@ -373,7 +373,7 @@ class Trainer:
 
     weights / biases: 26 arrays in the order of ``TRAINER_LAYERS`` (torch layout ``W[out, in]``)."""
 
-    def __init__(self, weights, biases, max_rays, device='cuda:0'):
+    def __init__(self, weights, biases, max_rays, device='cuda:0', max_samples=8):
         lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -386,9 +386,10 @@ class Trainer:
         ind = (C.c_int * n)(*[w.shape[1] for w in ws]); outd = (C.c_int * n)(*[w.shape[0] for w in ws])
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            check(lib.pnrf_trainer_create(Wp, bp, ind, outd, n, int(max_rays), C.byref(h)), 'pnrf_trainer_create')
+            check(lib.pnrf_trainer_create(Wp, bp, ind, outd, n, int(max_rays), int(max_samples), C.byref(h)), 'pnrf_trainer_create')
         self.handle = h
         self.max_rays = int(max_rays)
+        self.max_samples = int(max_samples)
 
     def __del__(self):
         try:
@@ -399,8 +400,8 @@ class Trainer:
             pass
 
     def read(self, kind, layer):
-        """kind: 'param' | 'grad' | 'm' | 'v' -> (W, b) as new device tensors."""
-        k = {'param': 0, 'grad': 1, 'm': 2, 'v': 3}[kind]
+        """kind: 'param' | 'grad' | 'm' | 'v' (joint Adam) | 'm_nerf' | 'v_nerf' (NeRF-only Adam) -> (W, b) as new device tensors."""
+        k = self._KINDS[kind]
         out_d, in_d = self.shapes[layer]
         W = torch.empty(out_d, in_d, device=self.device, dtype=f32); b = torch.empty(out_d, device=self.device, dtype=f32)
         with torch.cuda.device(self.device):
@@ -408,37 +409,59 @@ class Trainer:
         return W, b
 
     def write(self, kind, layer, W=None, b=None):
-        k = {'param': 0, 'grad': 1, 'm': 2, 'v': 3}[kind]
+        k = self._KINDS[kind]
         W = None if W is None else torch.as_tensor(W, dtype=f32).contiguous()
         b = None if b is None else torch.as_tensor(b, dtype=f32).contiguous()
         with torch.cuda.device(self.device):
             check(_lib.load().pnrf_trainer_write(self.handle, k, layer, _ptr(W), _ptr(b), _stream()), 'pnrf_trainer_write')
 
-    def set_step(self, step):
-        check(_lib.load().pnrf_trainer_set_step(self.handle, int(step)), 'pnrf_trainer_set_step')
+    _KINDS = {'param': 0, 'grad': 1, 'm': 2, 'v': 3, 'm_nerf': 4, 'v_nerf': 5}
 
-    def fwd_bwd(self, rays, or_rays, target, img4, poses, K, ref_nos, jitter=None, jitter_dir=1, raw_noise=None, white_bkgd=False, eps=1e-5,
-                a_mmrgb=0.0, want_rgb=True):
-        """One forward + backward; returns (loss[4] device tensor = total, img, rgb0, mm_rgb; rgb_map1 [n,3] or None)."""
+    def set_step(self, step, step_nerf=0):
+        check(_lib.load().pnrf_trainer_set_step(self.handle, int(step), int(step_nerf)), 'pnrf_trainer_set_step')
+
+    def _batch(self, rays, or_rays, target, img4, poses, K, ref_nos, jitter, jitter_dir, raw_noise, white_bkgd, eps, a_mmrgb, clamp, layout, S):
         rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); target = _chk(target, 'target', (3,))
         img4 = _chk(img4, 'img4', (4,)); poses = _chk(poses, 'poses', (3, 4)); K = _chk(K, 'K', (3, 3))
         if ref_nos.dtype != torch.int64 or not ref_nos.is_cuda or tuple(ref_nos.shape) != (rays.shape[0], 4):
             raise PnrfError('ref_nos: expected an int64 GPU tensor [n, 4]')
         ref_nos = ref_nos.contiguous()
-        jitter = None if jitter is None else _chk(jitter, 'jitter', (8,))
-        raw_noise = None if raw_noise is None else _chk(raw_noise, 'raw_noise', (8,))
-        n = rays.shape[0]
-        loss = torch.empty(4, device=rays.device, dtype=f32)
-        rgb = torch.empty(n, 3, device=rays.device, dtype=f32) if want_rgb else None
+        jitter = None if jitter is None else _chk(jitter, 'jitter', (S,))
+        raw_noise = None if raw_noise is None else _chk(raw_noise, 'raw_noise', (S,))
+        keep = (rays, or_rays, target, img4, poses, K, ref_nos, jitter, raw_noise)          # alive until the call returns
         bt = _lib.TrainBatch(rays=rays.data_ptr(), or_rays=or_rays.data_ptr(), target=target.data_ptr(), img4=img4.data_ptr(), poses=poses.data_ptr(),
                              K=K.data_ptr(), ref_nos=ref_nos.data_ptr(), jitter=None if jitter is None else jitter.data_ptr(),
-                             raw_noise=None if raw_noise is None else raw_noise.data_ptr(), n=n, nv=img4.shape[0], Hf=img4.shape[1], Wf=img4.shape[2],
-                             jitter_dir=int(jitter_dir), white_bkgd=int(bool(white_bkgd)), eps=float(eps), a_mmrgb=float(a_mmrgb))
-        with torch.cuda.device(rays.device):
+                             raw_noise=None if raw_noise is None else raw_noise.data_ptr(), n=rays.shape[0], nv=img4.shape[0], Hf=img4.shape[1],
+                             Wf=img4.shape[2], jitter_dir=int(jitter_dir), white_bkgd=int(bool(white_bkgd)), eps=float(eps), a_mmrgb=float(a_mmrgb),
+                             clamp=float(clamp), layout=int(layout))
+        return bt, keep
+
+    def fwd_bwd(self, rays, or_rays, target, img4, poses, K, ref_nos, jitter=None, jitter_dir=1, raw_noise=None, white_bkgd=False, eps=1e-5,
+                a_mmrgb=0.0, want_rgb=True, clamp=0.0, layout=0):
+        """One joint forward + backward (stage 2; stage-1 even iterations with clamp=10, layout=1, eps=1e-6, a_mmrgb=1);
+        returns (loss[4] device tensor = total, img, rgb0, mm_rgb; rgb_map1 [n,3] or None)."""
+        bt, keep = self._batch(rays, or_rays, target, img4, poses, K, ref_nos, jitter, jitter_dir, raw_noise, white_bkgd, eps, a_mmrgb, clamp, layout, 8)
+        dev = keep[0].device
+        loss = torch.empty(4, device=dev, dtype=f32)
+        rgb = torch.empty(keep[0].shape[0], 3, device=dev, dtype=f32) if want_rgb else None
+        with torch.cuda.device(dev):
             check(_lib.load().pnrf_train_stage2_fwd_bwd(self.handle, C.byref(bt), _ptr(loss), _ptr(rgb), _stream()), 'pnrf_train_stage2_fwd_bwd')
         return loss, rgb
 
-    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def explore_fwd_bwd(self, rays, or_rays, target, img4, poses, K, ref_nos, n_mult, dir1, jitter, dir2, raw_noise=None, white_bkgd=False, eps=1e-6,
+                        clamp=10.0, layout=1, want_rgb=True):
+        """Stage-1 odd iteration: NeRF-only forward + backward on 8*n_mult explored samples per ray (jitter, raw_noise: [n, 8*n_mult])."""
+        bt, keep = self._batch(rays, or_rays, target, img4, poses, K, ref_nos, jitter, dir2, raw_noise, white_bkgd, eps, 0.0, clamp, layout, 8 * int(n_mult))
+        dev = keep[0].device
+        loss = torch.empty(4, device=dev, dtype=f32)
+        rgb = torch.empty(keep[0].shape[0], 3, device=dev, dtype=f32) if want_rgb else None
+        with torch.cuda.device(dev):
+            check(_lib.load().pnrf_train_explore_fwd_bwd(self.handle, C.byref(bt), int(n_mult), int(dir1), _ptr(loss), _ptr(rgb), _stream()),
+                  'pnrf_train_explore_fwd_bwd')
+        return loss, rgb
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, nerf_only=False):
+        """optimizer.step(); nerf_only: the stage-1 NeRF-only optimizer (own moments / step count) instead of the joint one."""
         with torch.cuda.device(self.device):
-            check(_lib.load().pnrf_trainer_adam_step(self.handle, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _stream()),
-                  'pnrf_trainer_adam_step')
+            check(_lib.load().pnrf_trainer_adam_step(self.handle, int(bool(nerf_only)), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                     float(weight_decay), _stream()), 'pnrf_trainer_adam_step')

@@ -188,3 +188,19 @@ def test_oracle_training_iteration_matches_reference_fp32(golden_dir, name):
     grads = [(W.grad, x.grad) for W, x in layers]
     opt.step()
     U.check_against_golden(g, grads, [(W.detach(), x.detach()) for W, x in layers], tol_grad=5e-2, tol_norm=2e-2)
+
+
+@pytest.mark.parametrize('name', ['stage1_step_joint_12x16', 'stage1_step_explore_10x14'])
+def test_oracle_stage1_iteration_matches_reference_fp64(golden_dir, name):
+    """Stage-1 iterations (even: joint, three MSE terms; odd: exploration, NeRF only) of the oracle in float64 against the
+    reference's own (run_S_eS_eN_alter_base.py:929-958).  On odd iterations the sampler / refine nets get no gradient at all."""
+    import train_golden_util as U
+    g, b = U.load_case(golden_dir, name + '_f64')
+    loss, img_loss, o, layers = U.oracle_grads(b, torch.float64)
+    assert abs(loss - float(g['loss'])) < 1e-12 and abs(img_loss - float(g['img_loss'])) < 1e-12
+    np.testing.assert_allclose(o['rgb_map1'].detach().numpy(), g['rgb_map1'], rtol=0, atol=1e-12)
+    if b['train_sampler']:
+        U.check_against_golden(g, [(W.grad, x.grad) for W, x in layers], None, tol_grad=1e-8, tol_norm=1e-8)
+    else:
+        assert all(W.grad is None and x.grad is None for W, x in layers[:14]) and all(float(g[f'gW_norm_{i}']) == 0 for i in range(14))
+        U.check_against_golden(g, [(W.grad, x.grad) for W, x in layers], None, tol_grad=1e-8, tol_norm=1e-8, layers=range(14, 26))

@@ -296,3 +296,52 @@ def test_stage2_train_driver_end_to_end(dev, tmp_path):
                     'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\n')
     kw = trt.train(['--config', str(icfg), '--render_test', '--max_images', '1'], device=dev)
     assert len(kw['psnrs']) == 1 and np.isfinite(kw['psnrs'][0])
+
+
+@pytest.mark.parametrize('name', ['stage1_step_joint_12x16', 'stage1_step_explore_10x14'])
+def test_stage1_iterations_vs_reference_golden(dev, golden_dir, name):
+    """Stage-1 alternation on the HIP trainer against the reference's own iterations (run_S_eS_eN_alter_base.py:929-958): even
+    = joint step (sample-major epi, eps 1e-6, clamp 10, three MSE terms, joint Adam); odd = exploration to 8*n_mult samples,
+    NeRF-only gradients, the NeRF-only Adam.  Same criteria as the stage-2 golden test."""
+    import train_golden_util as U
+    from pronerf_amd import ops
+    g64, b64 = U.load_case(golden_dir, name + '_f64')
+    _, _, _, l32 = U.oracle_grads(b64, torch.float32)
+    st = int(g64['stride'])
+    joint = bool(b64['train_sampler'])
+    active = range(26) if joint else range(14, 26)
+    for gname, (g, b) in (('f64', (g64, b64)), ('f32', U.load_case(golden_dir, name))):
+        layers = orc.trainer_layers(b['w'])
+        tr = ops.Trainer([W for W, _ in layers], [x for _, x in layers], max_rays=b['N'], device=dev, max_samples=8 if joint else 8 * b['n_mult'])
+        img4 = ops.images_pack(cu(b['images'], dev))
+        args = (cu(b['rays'], dev), cu(b['or_rays'], dev), cu(b['target'], dev), img4, cu(b['poses'], dev), cu(b['K'], dev), b['ref_nos'].to(dev).contiguous())
+        if joint:
+            L, rgb = tr.fwd_bwd(*args, eps=1e-6, a_mmrgb=1.0, clamp=10.0, layout=1)
+        else:
+            for li in range(14):                      # must stay untouched by the NeRF-only backward
+                tr.write('grad', li, torch.full(layers[li][0].shape, 7.0).to(dev), torch.full(layers[li][1].shape, 7.0).to(dev))
+            L, rgb = tr.explore_fwd_bwd(*args, n_mult=b['n_mult'], dir1=b['dir1'], jitter=cu(b['jitter'], dev), dir2=b['dir2'], raw_noise=cu(b['noise'], dev))
+        Lh = L.cpu().numpy()
+        assert abs(Lh[0] - float(g['loss'])) < 3e-5 and abs(Lh[1] - float(g['img_loss'])) < 3e-5
+        np.testing.assert_allclose(rgb.cpu().numpy(), g['rgb_map1'], rtol=0, atol=2e-4)
+        grads = [tr.read('grad', i) for i in range(26)]
+        if not joint:
+            assert all(float(grads[i][0].min()) == 7.0 and float(grads[i][1].max()) == 7.0 for i in range(14))
+        if gname == 'f64':
+            ratios = []
+            for i in active:
+                for k, (mine, cpu32) in enumerate(((grads[i][0].reshape(-1)[::st], l32[i][0].grad.reshape(-1)[::st]), (grads[i][1], l32[i][1].grad))):
+                    want = g[('gW_%d' if k == 0 else 'gb_%d') % i]
+                    e, n = U.rel(mine, want), U.rel(cpu32, want)
+                    assert e < 6 * n + 1e-3 and e < 0.1, (i, k, e, n)
+                    ratios.append(e / (n + 1e-7))
+            assert float(np.median(ratios)) < 3.0, float(np.median(ratios))
+        else:
+            before = [tr.read('param', i) for i in range(14)]
+            tr.adam_step(b['lr'], weight_decay=b['wd'], nerf_only=not joint)
+            after = [tr.read('param', i) for i in range(26)]
+            U.check_against_golden(g, grads, after, tol_grad=1e-1, tol_norm=5e-2, layers=active)
+            if not joint:                                 # the NeRF-only optimizer leaves the sampler / refine nets alone
+                assert all(torch.equal(before[i][0], after[i][0]) and torch.equal(before[i][1], after[i][1]) for i in range(14))
+                mW, _ = tr.read('m_nerf', 20); jW, _ = tr.read('m', 20)
+                assert float(mW.abs().max()) > 0 and float(jW.abs().max()) == 0

@@ -12,6 +12,8 @@ CASES = ['stage2_step_12x16', 'stage2_step_white_mmrgb_10x14']          # each a
 
 def load_case(golden_dir, name):
     g = dict(np.load(os.path.join(golden_dir, name + '.npz')))
+    if name.startswith('stage1'):
+        return g, _load_stage1(g)
     seed = int(g['seed'])
     scene = synth.make_scene(seed, H=int(g['H']), W=int(g['W']), n_views=int(g['nv']), sigma_t=0.2, rotate=True)
     w = synth.make_weights(seed, 'trained'); w['nerfcls'] = synth.make_nerfcls_weights(seed, head_scale=0.3)
@@ -23,6 +25,22 @@ def load_case(golden_dir, name):
              ref_nos=ref_nos, jitter=torch.from_numpy(g['jitter']), noise=torch.from_numpy(g['raw_noise']), N=N, jdir=int(g['jitter_dir']),
              white=bool(g['white_bkgd']), a_mmrgb=float(g['a_mmrgb']), lr=float(g['lr']), wd=float(g['weight_decay']))
     return g, b
+
+
+def _load_stage1(g):
+    seed = int(g['seed'])
+    scene = synth.make_scene(seed, H=int(g['H']), W=int(g['W']), n_views=int(g['nv']), sigma_t=0.2, rotate=True)
+    w = synth.make_weights(seed, 'trained'); w['nerfcls'] = synth.make_nerfcls_weights(seed, head_scale=0.3)
+    poses = torch.from_numpy(scene['poses']); images = torch.from_numpy(scene['images']).permute(0, 3, 1, 2).contiguous()
+    rays, or_rays = torch.from_numpy(g['rays']), torch.from_numpy(g['or_rays'])
+    N = rays.shape[0]
+    ref_nos = orc.select_neighbors_train(poses[int(g['own'])][None].expand(N, -1, -1), poses, 4, g['order_idx'])
+    ts = bool(g['train_sampler'])
+    b = dict(w=w, rays=rays, or_rays=or_rays, target=torch.from_numpy(g['target']), images=images, poses=poses, K=torch.from_numpy(scene['K']),
+             ref_nos=ref_nos, N=N, white=False, lr=float(g['lr']), wd=float(g['weight_decay']), stage=1, train_sampler=ts, jitter=None, noise=None)
+    if not ts:
+        b.update(n_mult=int(g['n_mult']), dir1=int(g['dir1']), dir2=int(g['dir2']), jitter=torch.from_numpy(g['jitter']), noise=torch.from_numpy(g['raw_noise']))
+    return b
 
 
 def rel(a, b):
@@ -37,18 +55,23 @@ def oracle_grads(b, dtype):
     try:
         c = lambda v: v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v
         layers = [(torch.tensor(W, dtype=dtype, requires_grad=True), torch.tensor(x, dtype=dtype, requires_grad=True)) for W, x in orc.trainer_layers(b['w'])]
-        loss, img_loss, o = orc.stage2_loss(layers, c(b['rays']), c(b['or_rays']), c(b['target']), c(b['images']), c(b['poses']), c(b['K']), b['ref_nos'],
-                                            jitter=c(b['jitter']), jitter_dir=b['jdir'], raw_noise=c(b['noise']), white_bkgd=b['white'], a_mmrgb=b['a_mmrgb'])
+        if b.get('stage', 2) == 1:
+            loss, img_loss, o = orc.stage1_loss(layers, c(b['rays']), c(b['or_rays']), c(b['target']), c(b['images']), c(b['poses']), c(b['K']), b['ref_nos'],
+                                                b['train_sampler'], n_mult=b.get('n_mult', 1), dir1=b.get('dir1', 1), jitter=c(b['jitter']), dir2=b.get('dir2', 1),
+                                                raw_noise=c(b['noise']))
+        else:
+            loss, img_loss, o = orc.stage2_loss(layers, c(b['rays']), c(b['or_rays']), c(b['target']), c(b['images']), c(b['poses']), c(b['K']), b['ref_nos'],
+                                                jitter=c(b['jitter']), jitter_dir=b['jdir'], raw_noise=c(b['noise']), white_bkgd=b['white'], a_mmrgb=b['a_mmrgb'])
         loss.backward()
     finally:
         torch.set_default_dtype(old)
     return float(loss.detach()), float(img_loss.detach()), o, layers
 
 
-def check_against_golden(g, grads, params_after, tol_grad, tol_norm):
+def check_against_golden(g, grads, params_after, tol_grad, tol_norm, layers=range(26)):
     """grads / params_after: 26 (W, b) pairs.  Subsampled gradient entries, gradient norms and post-Adam parameters."""
     st = int(g['stride'])
-    for i in range(26):
+    for i in layers:
         gW, gb = grads[i]
         assert rel(gW.reshape(-1)[::st], g[f'gW_{i}']) < tol_grad and rel(gb, g[f'gb_{i}']) < tol_grad, (i, rel(gW.reshape(-1)[::st], g[f'gW_{i}']), rel(gb, g[f'gb_{i}']))
         assert abs(float(torch.as_tensor(gW).double().norm()) - float(g[f'gW_norm_{i}'])) < tol_norm * float(g[f'gW_norm_{i}'])
