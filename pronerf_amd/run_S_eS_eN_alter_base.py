@@ -6,7 +6,9 @@ Stage-1 specifics relative to stage 2 (SURVEY.md §3.4): NDC->metric uses 1e-6; 
 compositing uses the sampler's add/mul; on odd steps (``train_sampler=False`` with ``randomize``) the *exploration
 path* replicates each refined depth ``n_mult = randint(1, 64/8)`` times (8..64 samples per ray), jitters them, and
 composites without add/mul but with sigma noise.  The random draws are made here with the reference's generators
-and handed to the kernels.  Forward only (see run_S_eS_eN_alter_base_refine2.py in this package).
+and handed to the kernels.  ``render_rays`` is forward only; ``train`` (:764-1000) runs the alternating optimisation on
+``ops.Trainer`` (pnrf_train_explore_fwd_bwd on odd iterations with the NeRF-only Adam, pnrf_train_stage2_fwd_bwd on even
+iterations with the joint Adam).
 """
 from __future__ import annotations
 
@@ -88,3 +90,98 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
     if train_sampler:
         ret['sigma1'] = raw[..., 3]
     return ret
+
+
+# ------------------------------------------------------------------------------------ training loop
+def config_parser():
+    """Options of the stage-1 script (run_S_eS_eN_alter_base.py:31-164); see ``pronerf_amd.config``."""
+    from .config import config_parser as _cp
+    return _cp('base')
+
+
+def train(argv=None, device='cuda'):
+    """Stage-1 training driver (run_S_eS_eN_alter_base.py:764-1000): networks from their default initialisation (or --ft_path),
+    odd iterations = NeRF alone on the explored samples (`optimizer`), even iterations = NeRF + sampler + refine net with
+    img2mse(rgb1) + img2mse(rgb0) + img2mse(mm_rgb) (`s_optimizer`), learning rate decayed on global_step/2 (:961-967),
+    checkpoints with the reference's keys.  Returns (trainer, list of (iteration, loss, psnr))."""
+    import os
+    from .load_llff import load_llff_data
+    from .run_S_eS_eN_alter_base_refine2 import save_checkpoint, trainer_layer_list
+    args = config_parser().parse_args(argv)
+    if args.dataset_type != 'llff':
+        raise ValueError('only dataset_type=llff is supported (as in the reference release)')
+    if args.epi_nerf:
+        raise PnrfError('--epi_nerf references a class the reference does not define (SURVEY.md Appendix B-7)')
+    if args.N_samples != 8 or args.num_neighbor != 4 or args.N_point_ray_enc != 48 or args.mmnetdepth != 6:
+        raise PnrfError('the HIP trainer is built for N_samples=8, num_neighbor=4, N_point_ray_enc=48, mmnetdepth=6 (fern_epi.txt)')
+    dev = torch.device(device)
+    images, poses, bds, _, i_test = load_llff_data(args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
+    hwf = poses[0, :3, -1]
+    poses = poses[:, :3, :4]
+    i_test = np.arange(images.shape[0])[::args.llffhold] if args.llffhold > 0 else np.atleast_1d(i_test)
+    i_train = np.array([i for i in np.arange(int(images.shape[0])) if i not in i_test])
+    H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+    out_root = os.path.join(args.basedir, args.expname or 'pronerf_stage1')
+    os.makedirs(out_root, exist_ok=True)
+    with open(os.path.join(out_root, 'args.txt'), 'w') as f:
+        for k in sorted(vars(args)):
+            f.write('{} = {}\n'.format(k, getattr(args, k)))
+    start = 0
+    if args.ft_path is not None and args.ft_path != 'None':
+        ck = torch.load(args.ft_path, map_location='cpu')
+        start = int(ck.get('global_step', 0))
+        sds = (ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], ck['network_fn_state_dict'])
+    else:                                                # create_nerf (:337-380): torch's default nn.Linear initialisation
+        sds = (MinMaxRay_Net(D=6, W=256, input_ch=288, output_ch=27, skips=[10000]).state_dict(),
+               MinMaxRay_Net(D=6, W=256, input_ch=144, output_ch=35, skips=[10000]).state_dict(),
+               NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True).state_dict())
+    max_mult = 64 // 8                                                                                        # :690
+    tr = ops.Trainer(*zip(*trainer_layer_list(*sds)), max_rays=args.N_rand, device=dev, max_samples=8 * max_mult)
+    with torch.cuda.device(dev):
+        pr = [ops.frame_rays(K, poses[i], H, W, near=1e-6, far=1., device=dev) for i in i_train]               # near = 1e-6 (:798)
+        rays_all = torch.cat([p[0] for p in pr], 0); or_rays_all = torch.cat([p[1] for p in pr], 0)
+        del pr
+        target_all = torch.as_tensor(images[i_train], dtype=torch.float32).reshape(-1, 3).to(dev)
+        own_all = torch.arange(len(i_train), device=dev).repeat_interleave(H * W)
+        img4, poses_t, K_t, rank = _train_views(images[i_train], poses[i_train], K, dev)
+    n_total = rays_all.shape[0]
+    perm = torch.randperm(n_total, device=dev)
+    i_batch, global_step, log = 0, start, []
+    n_iters = 500000 + 1 if args.max_steps is None else start + args.max_steps + 1
+    lr, nv = args.lrate, len(i_train)
+    for i in range(start + 1, n_iters):
+        idx = perm[i_batch:i_batch + args.N_rand]
+        i_batch += args.N_rand
+        if i_batch >= n_total:
+            perm = torch.randperm(n_total, device=dev); i_batch = 0
+        if idx.shape[0] < args.N_rand:
+            continue
+        n = idx.shape[0]
+        order = torch.as_tensor(sorted(random.sample(range(nv - 1), 4)), device=dev)                           # :629-634
+        ref_nos = rank[own_all[idx]][:, 1:][:, order].contiguous()
+        batch = (rays_all[idx], or_rays_all[idx], target_all[idx], img4, poses_t, K_t, ref_nos)
+        if i % 2 != 0:                                                                                         # :929-940
+            n_mult = random.randint(1, max_mult)                                                               # :690-691
+            dir1 = (1 if random.random() > 0.5 else -1) if n_mult > 1 else 1
+            jitter = torch.abs(torch.normal(0.0, 1.0, size=(n, 8 * n_mult), device=dev) / 5).clamp(max=0.99)   # :715-719
+            dir2 = 1 if random.random() > 0.5 else -1
+            noise = torch.randn(n, 8 * n_mult, device=dev) * args.raw_noise_std if args.raw_noise_std > 0 else None
+            loss, _ = tr.explore_fwd_bwd(*batch, n_mult=n_mult, dir1=dir1, jitter=jitter, dir2=dir2, raw_noise=noise, white_bkgd=args.white_bkgd,
+                                         want_rgb=False)
+            tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay, nerf_only=True)
+        else:                                                                                                  # :941-958
+            loss, _ = tr.fwd_bwd(*batch, white_bkgd=args.white_bkgd, eps=1e-6, a_mmrgb=1.0, clamp=10.0, layout=1, want_rgb=False)
+            tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay)
+        lr = args.lrate * (0.1 ** ((global_step / 2) / (args.lrate_decay * 1000)))                            # :961-967
+        if i % args.i_weights == 0 or i == n_iters - 1:
+            path = os.path.join(out_root, '{:06d}.tar'.format(i))
+            save_checkpoint(path, tr, global_step)
+            print('Saved checkpoints at', path)
+        if i % args.i_print == 0 or i == n_iters - 1:
+            lh = loss.cpu().numpy()
+            psnr = float(-10.0 * np.log10(max(float(lh[1]), 1e-12)))
+            log.append((i, float(lh[0]), psnr))
+            print(f'[TRAIN] Iter: {i} Loss: {float(lh[0])}  PSNR: {psnr}')
+        global_step += 1
+    return tr, log

@@ -139,9 +139,10 @@ def save_checkpoint(path, tr, global_step):
     well: the next stage / a restart reads the NeRF from that key (refine2.py:365).  The optimizer state is this trainer's Adam
     moments ('pnrf_adam_m' / 'pnrf_adam_v', one [W, b] pair per layer) instead of torch.optim state dicts."""
     s_sd, r_sd, f_sd = state_dicts_from_trainer(tr)
-    adam = {k: [[t.cpu() for t in tr.read(k, li)] for li in range(ops.TRAINER_LAYERS)] for k in ('m', 'v')}
+    adam = {k: [[t.cpu() for t in tr.read(k, li)] for li in range(ops.TRAINER_LAYERS)] for k in ('m', 'v', 'm_nerf', 'v_nerf')}
     torch.save({'global_step': int(global_step), 'network_fn_state_dict': f_sd, 'network_fine_state_dict': f_sd, 'mmr_network_fn_state_dict': s_sd,
-                'refine_net_state_dict': r_sd, 'pnrf_adam_m': adam['m'], 'pnrf_adam_v': adam['v']}, path)
+                'refine_net_state_dict': r_sd, 'pnrf_adam_m': adam['m'], 'pnrf_adam_v': adam['v'], 'pnrf_adam_m_nerf': adam['m_nerf'],
+                'pnrf_adam_v_nerf': adam['v_nerf']}, path)
 
 
 def config_parser():

@@ -345,3 +345,30 @@ def test_stage1_iterations_vs_reference_golden(dev, golden_dir, name):
                 assert all(torch.equal(before[i][0], after[i][0]) and torch.equal(before[i][1], after[i][1]) for i in range(14))
                 mW, _ = tr.read('m_nerf', 20); jW, _ = tr.read('m', 20)
                 assert float(mW.abs().max()) > 0 and float(jW.abs().max()) == 0
+
+
+def test_stage1_then_stage2_then_inference_chain(dev, tmp_path):
+    """The reference's three-script workflow on an LLFF directory, all on the HIP path: stage-1 train() from scratch ->
+    checkpoint -> stage-2 train() (--pretrain_path) -> checkpoint -> inference train() (--ft_path) renders a hold-out view."""
+    import llff_synth
+    from pronerf_amd import run_S_eS_eN_alter_base as s1
+    from pronerf_amd import run_S_eS_eN_alter_base_refine2 as s2
+    from pronerf_amd import run_S_eS_eN_alter_trt as trt
+    root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=3, n=10, H=24, W=32, factor=4)
+    common = (f'basedir = {tmp_path}/logs\ndatadir = {root}\nfactor = 4\nllffhold = 8\nN_rand = 512\nN_samples = 8\nN_point_ray_enc = 48\nmmnetdepth = 6\n'
+              'mmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\nraw_noise_std = 1e0\nlrate = 5e-4\nweight_decay = 5e-8\ni_print = 4\ni_weights = 1000\n')
+    (tmp_path / 'epi.txt').write_text('expname = s1\n' + common)
+    torch.manual_seed(0)
+    tr1, log1 = s1.train(['--config', str(tmp_path / 'epi.txt'), '--max_steps', '24'], device=dev)
+    assert [e[0] for e in log1] == [4, 8, 12, 16, 20, 24] and all(np.isfinite(e[1]) for e in log1)
+    assert log1[-1][1] < log1[0][1]                                   # even iterations' joint loss goes down from the random initialisation
+    ck1 = tmp_path / 'logs' / 's1' / '000024.tar'
+    c = torch.load(str(ck1), map_location='cpu')
+    assert {'global_step', 'network_fn_state_dict', 'mmr_network_fn_state_dict', 'refine_net_state_dict'} <= set(c)
+    assert float(c['pnrf_adam_m_nerf'][20][0].abs().max()) > 0 and float(c['pnrf_adam_m'][3][0].abs().max()) > 0     # both optimizers stepped
+    (tmp_path / 'refine.txt').write_text(f'expname = s2\npretrain_path = {ck1}\n' + common)
+    tr2, log2 = s2.train(['--config', str(tmp_path / 'refine.txt'), '--max_steps', '8'], device=dev)
+    ck2 = tmp_path / 'logs' / 's2' / '000008.tar'
+    (tmp_path / 'infer.txt').write_text(f'expname = inf\nft_path = {ck2}\n' + common)
+    kw = trt.train(['--config', str(tmp_path / 'infer.txt'), '--render_test', '--max_images', '1'], device=dev)
+    assert len(kw['psnrs']) == 1 and np.isfinite(kw['psnrs'][0])
