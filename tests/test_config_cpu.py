@@ -62,3 +62,24 @@ def test_reference_configs_parse_if_present():
         variant = 'trt' if f.endswith('_trt.txt') else ('refine2' if f.endswith('_refine.txt') else 'base')
         a = config_parser(variant).parse_args(['--config', f])
         assert a.N_samples == 8 and set(read_config_file(f)) <= set(vars(a))
+
+
+def test_cli_subcommands_map_to_driver_arguments():
+    """pronerf_amd.cli: the reference CLI's sub-commands / options (pronerf/cli.py:170-219) -> the drivers' argv."""
+    from pronerf_amd import cli
+    p = cli.build_parser()
+    ns = p.parse_args(['train-stage1', '--config', 'a.txt', '--max-steps', '5', '--', '--N_rand', '1024'])
+    assert cli.stage1_argv(ns) == ['--config', 'a.txt', '--max_steps', '5', '--N_rand', '1024']
+    ns = p.parse_args(['train-stage2', '--config', 'b.txt', '--pretrain-path', 'x.tar', '--no-reload'])
+    assert cli.stage2_argv(ns) == ['--config', 'b.txt', '--pretrain_path', 'x.tar', '--no_reload']
+    ns = p.parse_args(['infer', '--config', 'c.txt', '--checkpoint', 'y.tar', '--render-test', '--max-images', '2'])
+    assert cli.infer_argv(ns) == ['--config', 'c.txt', '--ft_path', 'y.tar', '--render_test', '--max_images', '2']
+    ns = p.parse_args(['eval', '--checkpoint', 'y.tar'])
+    assert ns.func is cli._eval and ns.config.endswith('fern_trt.txt')
+    with pytest.raises(SystemExit) as e:
+        cli.main(['export-trt'])
+    assert 'ROCm' in str(e.value)
+    # every driver accepts what the CLI hands it
+    for variant, argv in (('base', ['--max_steps', '5', '--N_rand', '1024']), ('refine2', ['--pretrain_path', 'x.tar', '--no_reload']),
+                          ('trt', ['--ft_path', 'y.tar', '--render_test', '--max_images', '2'])):
+        config_parser(variant).parse_args(argv)
