@@ -602,6 +602,14 @@ struct NerfArgs {
   float* y; const int* outmap;                      // module-level consumer
 };
 
+__device__ __forceinline__ void pe_sincos(float x, float& s, float& c) {
+#ifdef PNRF_EXACT_SINCOS
+  sincosf(x, &s, &c);
+#else
+  s = __sinf(x); c = __cosf(x);
+#endif
+}
+
 // CLS = false: DoNeRFTRT; CLS = true: the NeRF class (skip-concat at layer 5, feature/alpha heads, view branch)
 template <int NCB, int NW, bool FUSED, bool CLS>
 __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArgs a) {
@@ -664,22 +672,24 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
       }
       if (FUSED) {
         // positional encoding in B-fragment order (nerf_in0 / nerf_inx): half 0 = sin, half 1 = cos.
-        // sin/cos(2^k x): one accurate sincosf at k=0, then the exact double-angle recurrence; its
-        // error (<= 2^k * 1e-7) is far below the bf16 rounding (2^-9) applied to the MLP input.
+        // sin/cos(2^k x): sin/cos at k=0, then the exact double-angle recurrence, whose error doubles per octave: with an
+        // accurate sincosf (<= 2^k * 1e-7) or, by default, the hardware v_sin/v_cos (abs error ~1e-6 for |x| of a few units ->
+        // <= 5e-4 at k=9) it stays below the bf16 rounding (2^-9 relative) applied to the MLP input; -DPNRF_EXACT_SINCOS
+        // selects the accurate one (6 calls of ~40 VALU each were 2/3 of the batch prologue).
         const float x3[3] = {raw[cb].x[0], raw[cb].x[1], raw[cb].x[2]};
         const float v3[3] = {raw[cb].v[0], raw[cb].v[1], raw[cb].v[2]};
         float f0[32], fx[16];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float s, co;
-          sincosf(x3[c], &s, &co);                                  // helpers:669-670: sin/cos(x * 2^k)
+          pe_sincos(x3[c], s, co);                                  // helpers:669-670: sin/cos(x * 2^k)
 #pragma unroll
           for (int k = 0; k < 10; ++k) {
             f0[3 * k + c] = h ? co : s;
             const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
             s = s2; co = c2;
           }
-          sincosf(v3[c], &s, &co);
+          pe_sincos(v3[c], s, co);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             fx[3 * k + c] = h ? co : s;
