@@ -53,6 +53,10 @@ struct pnrf_mlp {
   uint32_t nslots_fold;
   void* d_blob_h16;      // sampler only: folded stream in split fp16 (hi / lo*2^11 planes) for layer_h16x2
   uint32_t nslots_h16;
+  void* d_blob_b16;      // DoNeRFTRT only: bf16 stream for the 16x16x32 engine (layer_b16)
+  uint32_t nslots_b16;
+  float* d_bias_b16;     // ... and its biases, [tile of 16 rows][16]
+  int nbias_b16;
   float* d_bias;         // packed biases
   int nbias;
   int* d_in0;            // layer-0 input map   (device copy, for the module-level forward)

@@ -471,6 +471,68 @@ template <int KS, int NTP> constexpr int layer_slots_h16x2() { return (KS * NTP 
 // feature supplied by element j of lane group g in k-step ks when the B operand is the previous layer's tile pair
 __host__ __device__ constexpr int hidden_feat_h16(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
 
+// ------------------------------------------------------------------------------------------
+// bf16 layer on v_mfma_f32_16x16x32_bf16 ("b16").  Same FLOPs per fragment as layer_bf16 (one 1 KiB A fragment = 16 output
+// rows x 32 k feeds two 16-cycle MFMAs, one per 16-column block) but the chip sustains a higher clock on this shape under
+// real data: in the tile structure of these kernels (tools/mfma_shape_probe.hip, random operands, 64 VALU + barrier per
+// tile) 1.77 PFLOP/s against 1.62 for 32x32x16.
+// Geometry as layer_h16x2: lane l = column l&15 of a block, group g = l>>4; output tiles of 16 rows in PAIRS, the pair
+// (2tp, 2tp+1) is k-step tp of the next layer (element j of group g = register j&3 of tile 2tp + (j>>2));
+// fragment order in the stream: (tp, ks, tile-in-pair).  Bf(cb, ks) -> bf16x8; epi1(tp, pc, acc[2][2]) / pre1(pc): piece pc =
+// tile pc of the deferred pair, acc[t][cb].
+template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
+__device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][2]) {
+  constexpr int NF = NTP * KS * 2;
+  constexpr int AHEAD = NF < 8 ? NF : 8;
+  auto frag_ptr = [&](int g) {
+    return (const bf16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+  };
+  f32x4 pend[2][2];
+  bf16x8 aq[AHEAD];
+  f32x4 nbias[2] = {*(const f32x4*)biaslane, *(const f32x4*)(biaslane + 16)};
+#pragma unroll
+  for (int tp = 0; tp < NTP; ++tp) {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { acc[t][0] = nbias[t]; acc[t][1] = nbias[t]; }
+    if (tp + 1 < NTP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) nbias[t] = *(const f32x4*)(biaslane + (2 * (tp + 1) + t) * 16);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int f = (tp * KS + ks) * 2 + t;
+        if (f % SLOT_FRAGS == 0) {
+          st.wait_slot();
+#pragma unroll
+          for (int u = 0; u < AHEAD; ++u)
+            if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+        }
+        const bf16x8 a = aq[f % AHEAD];
+        if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bf(0, ks), acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bf(1, ks), acc[t][1], 0, 0, 0);
+        st.slot_issue(f % SLOT_FRAGS);
+      }
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;
+        if (ks == (at < KS ? at : KS - 1)) {
+          if (tp == 0) pre1(pc);
+          else epi1(tp - 1, pc, pend);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { pend[t][0] = acc[t][0]; pend[t][1] = acc[t][1]; }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { last[t][0] = pend[t][0]; last[t][1] = pend[t][1]; }
+}
+
 // Row of a 32x32 accumulator tile held in register g of a lane in half h (cdna guide §3).
 __host__ __device__ constexpr int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 

@@ -157,4 +157,35 @@ __host__ __device__ constexpr int refine_out0(int g, int h) {
 __host__ __device__ constexpr int refine_out1(int g, int h) { return (h == 0 && g < 3) ? 32 + g : -1; }
 __host__ __device__ constexpr int nerf_out(int g, int h) { return (h == 0 && g < 4) ? g : -1; }
 
+// ---- NeRF (DoNeRFTRT) on the 16x16x32 engine (layer_b16): 32-deep k-steps, 16-row output tiles handled in pairs, two
+// 16-column blocks per wave.  Lane l: column l&15, group g = l>>4.  Same slot structure as the 32x32x16 stream.
+constexpr int NB_KS_H = W_HID / 32;                         // 8 k-steps per hidden layer
+constexpr int NB_NTP_H = W_HID / 32;                        // 8 tile pairs per hidden layer
+constexpr int NB_KS0 = 2;                                   // 63 positional features padded to 64
+constexpr int NB_KS_LAST = NB_KS_H + 1;                     // hidden k-steps + one k-step of view features (27 padded to 32)
+constexpr int NB_SLOTS_L0 = (NB_NTP_H * NB_KS0 * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;      // 2
+constexpr int NB_SLOTS_H = (NB_NTP_H * NB_KS_H * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;      // 8
+constexpr int NB_SLOTS_LAST = (1 * NB_KS_LAST * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;       // 2
+constexpr int NB_POS_H = NB_SLOTS_L0 % NSLOTS;
+constexpr int NB_POS_LAST = (NB_POS_H + N_NHID * NB_SLOTS_H) % NSLOTS;
+constexpr int NB_SLOTS_USED = NB_SLOTS_L0 + N_NHID * NB_SLOTS_H + NB_SLOTS_LAST;
+constexpr int NB_SLOTS_PAD = (NSLOTS - NB_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int NB_NSLOTS = NB_SLOTS_USED + NB_SLOTS_PAD;
+static_assert(NB_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position");
+// Input feature (index into the reference's 63-wide position embedding [x, sin 2^0 x, cos 2^0 x, ...]) that element j of
+// lane group g supplies in k-step ks of layer 0.  Group g evaluates fn = g&1 (0 sin, 1 cos) on octaves 5*(g>>1) .. +4:
+// slot 8ks+j = 3*local_octave + component for slots 0..14; slot 15 = raw x / y / z for g = 0 / 1 / 2 (g = 3: padding).
+__host__ __device__ constexpr int nerf16_in0(int ks, int g, int j) {
+  const int idx = 8 * ks + j;
+  if (idx == 15) return g < 3 ? g : -1;
+  return 3 + 6 * (idx / 3 + 5 * (g >> 1)) + 3 * (g & 1) + idx % 3;
+}
+// Same for the 27-wide view embedding in its single k-step: octaves 2*(g>>1) .. +1 in slots 0..5; slot 6 / 7: raw vx / vy for
+// g = 0, raw vz / padding for g = 1, padding for g = 2, 3.
+__host__ __device__ constexpr int nerf16_inx(int g, int j) {
+  if (j == 6) return g == 0 ? 0 : (g == 1 ? 2 : -1);
+  if (j == 7) return g == 0 ? 1 : -1;
+  return 3 + 6 * (j / 3 + 2 * (g >> 1)) + 3 * (g & 1) + j % 3;
+}
+
 }  // namespace pnrf

@@ -879,6 +879,164 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
   st.drain();
 }
 
+// ------------------------------------------------------------------------------------------ DoNeRFTRT on the 16x16x32 engine
+// nerf16_kernel: the fused NeRF stage (positional encoding -> 8-layer MLP -> compositing) on layer_b16.  Per wave two blocks of
+// 16 columns (ray samples), 8 waves = 256 columns per workgroup batch, like nerf_kernel<1, 8>.  Lane l: column l&15 of each block,
+// group g = l>>4.  The four groups of a column share the positional encoding: group g evaluates sin (g&1 = 0) or cos on the
+// octaves 5*(g>>1) .. +4 (nerf16_in0 / nerf16_inx define which stream feature each register slot is).  The network output (rows
+// 0..3 of the last tile) lands in group 0: lanes 0..15 hold [r, g, b, sigma] of their column, 8 adjacent lanes = one ray.
+struct HiddenEpi16 {
+  bf16x8 (&Bn)[2][NB_KS_H];
+  __device__ __forceinline__ void operator()(int tp, int pc, f32x4 (&acc)[2][2]) const {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Bn[cb][tp][4 * pc + r] = (__bf16)act_fast(acc[pc][cb][r], ACT_RELU);
+  }
+};
+
+__global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
+  constexpr int TPB = 512, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  const bool fcos = g & 1, hi = g >> 1;
+  const int64_t nrows = a.n * a.S;
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  young_half_priority<NW>();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + 4 * g;
+  const bool composite = a.S == 8 && a.rgbd;
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    int64_t row[2];
+    bool valid[2];
+    bf16x8 Bo[2][NB_KS_H], Bn[2][NB_KS_H], Bx[2];
+    float e_dn[2], e_z[2], e_add[2], e_mul[2], e_noise[2];
+    static_for<2>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      row[cb] = (int64_t)batch * (NW * 32) + wave * 32 + cb * 16 + c16;
+      valid[cb] = row[cb] < nrows;
+      const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
+      const float* pp = a.pts + rr * 3;
+      const float* ry = a.rays + (a.S == 8 ? (rr >> 3) : rr / a.S) * 11;
+      const float x3[3] = {pp[0], pp[1], pp[2]};
+      const float v3[3] = {ry[8], ry[9], ry[10]};
+      if (composite) {
+        e_dn[cb] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ry[3], ry[3]), __fmul_rn(ry[4], ry[4])), __fmul_rn(ry[5], ry[5])));
+        e_z[cb] = a.z[rr]; e_add[cb] = a.add ? a.add[rr] : 0.f; e_mul[cb] = a.mul ? a.mul[rr] : 1.f;
+        e_noise[cb] = a.noise ? a.noise[rr] : 0.f;
+      }
+      // positional encoding straight into B-fragment order (see pe_sincos / the recurrence note in nerf_kernel)
+      float f0[16], fx[8];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float s, co, val[10];
+        pe_sincos(x3[c], s, co);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          val[k] = fcos ? co : s;
+          const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
+          s = s2; co = c2;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) f0[3 * kk + c] = hi ? val[kk + 5] : val[kk];
+        pe_sincos(v3[c], s, co);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          val[k] = fcos ? co : s;
+          const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
+          s = s2; co = c2;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fx[3 * kk + c] = hi ? val[kk + 2] : val[kk];
+      }
+      f0[15] = g == 0 ? x3[0] : (g == 1 ? x3[1] : (g == 2 ? x3[2] : 0.f));
+      fx[6] = g == 0 ? v3[0] : (g == 1 ? v3[2] : 0.f);
+      fx[7] = g == 0 ? v3[1] : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NB_KS0; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f0[ks * 8 + j];
+        Bo[cb][ks] = pack_bf16(v);
+      }
+      Bx[cb] = pack_bf16(fx);
+    });
+    f32x4 fin[2][2], pend[2][2];
+    auto hidden = [&](bf16x8(&in)[2][NB_KS_H], bf16x8(&out)[2][NB_KS_H], int l) {
+      f32x4 np[2][2];
+      layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, HiddenEpi16{out},
+                                             [&](int pc) { HiddenEpi16{in}(NB_NTP_H - 1, pc, pend); }, np);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+    };
+    layer_b16<NB_KS0, NB_NTP_H, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, HiddenEpi16{Bn}, [](int) {}, pend);
+    static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
+    for (int l = 0; l < N_NHID; l += 2) {
+      hidden(Bn, Bo, l);
+      hidden(Bo, Bn, l + 1);
+    }
+    layer_b16<NB_KS_LAST, 1, NB_POS_LAST>(
+        st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
+        [&](int, int, f32x4(&)[2][2]) {}, [&](int pc) { HiddenEpi16{Bn}(NB_NTP_H - 1, pc, pend); }, fin);
+#pragma unroll
+    for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
+
+    // ---- fused epilogue (as nerf_kernel): group 0 holds raw rgb-sigma of its column in regs 0-3 of tile 0
+    static_for<2>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
+      float r0 = fin[0][cb][0], r1 = fin[0][cb][1], r2 = fin[0][cb][2], r3 = fin[0][cb][3];
+      if (a.raw && valid[cb] && g == 0) *(float4*)(a.raw + row[cb] * 4) = make_float4(r0, r1, r2, r3);
+      if (!composite) return;
+      const int64_t ray = rr >> 3;
+      const int s = (int)(rr & 7);
+      const float dn = e_dn[cb], zc = e_z[cb], ad = e_add[cb], mu = e_mul[cb];
+      if (a.clampv > 0.f) {                                                         // base.py:523
+        r0 = fminf(fmaxf(r0, -a.clampv), a.clampv); r1 = fminf(fmaxf(r1, -a.clampv), a.clampv);
+        r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
+      }
+      const float znext = __shfl_down(zc, 1);
+      float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
+      dist = __fmul_rn(dist, dn);                                                   // :583
+      const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
+      const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
+      float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
+      if (a.mul) alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                          // :588
+      const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
+      const int base = lane & 0x38;
+      float T = 1.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const float xj = __shfl(xk, base + j);
+        T = (j < s) ? __fmul_rn(T, xj) : T;
+      }
+      const float wgt = __fmul_rn(alpha, T);
+      const float c0 = __fmul_rn(wgt, cr), c1 = __fmul_rn(wgt, cg), c2 = __fmul_rn(wgt, cbv), c3 = __fmul_rn(wgt, zc);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sa = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s0 = __fadd_rn(s0, __shfl(c0, base + j));                                   // :591 sum over samples
+        s1 = __fadd_rn(s1, __shfl(c1, base + j));
+        s2 = __fadd_rn(s2, __shfl(c2, base + j));
+        s3 = __fadd_rn(s3, __shfl(c3, base + j));                                   // :593 depth_map
+        sa = __fadd_rn(sa, __shfl(wgt, base + j));                                  // acc_map
+      }
+      if (a.white_bkgd) {                                                           // refine2.py:519-520
+        const float bg = __fsub_rn(1.f, sa);
+        s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg);
+      }
+      if (valid[cb] && g == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(s0, s1, s2, s3);
+    });
+  }
+  st.drain();
+}
+
 // ------------------------------------------------------------------------------------------ launch helpers
 int g_num_cu = 0;
 int num_cu() {
@@ -893,8 +1051,9 @@ int num_cu() {
 
 // Tuning knobs (environment, read per call so that variants can be A/B-ed inside one process):
 // PNRF_SAMPLER_PREC=f32 runs the sampler on the exact-fp32 MFMA chain instead of split fp16 (layer_h16x2, the default);
-// PNRF_SAMPLER_FOLD=0 (with f32) disables the folded first sampler layer; PNRF_BF16_VARIANT = "1x8" (default:
-// 32 columns/wave, 8 waves, 2 waves/SIMD) or "2x4" (64 columns/wave, 4 waves, 1 wave/SIMD).
+// PNRF_SAMPLER_FOLD=0 (with f32) disables the folded first sampler layer; PNRF_BF16_VARIANT: unset / "16" = the DoNeRFTRT
+// stage on v_mfma_f32_16x16x32_bf16 (nerf16_kernel) and the other bf16 kernels as "1x8"; "1x8" = 32x32x16, 32 columns/wave,
+// 8 waves, 2 waves/SIMD everywhere; "2x4" = 64 columns/wave, 4 waves, 1 wave/SIMD; "1x4" = two 4-wave workgroups per CU.
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -902,6 +1061,10 @@ int env_int(const char* name, int dflt) {
 bool variant_1x8() {
   const char* e = getenv("PNRF_BF16_VARIANT");
   return !(e && e[0] == '2');          // default: 1x8 (two waves per SIMD)
+}
+bool variant_b16() {                   // default: DoNeRFTRT on v_mfma_f32_16x16x32_bf16 (nerf16_kernel); any explicit variant opts out
+  const char* e = getenv("PNRF_BF16_VARIANT");
+  return !(e && *e) || (e[0] == '1' && e[1] == '6');
 }
 bool variant_1x4() {                   // "1x4": two independent 4-wave workgroups per CU (one wave per SIMD each)
   const char* e = getenv("PNRF_BF16_VARIANT");
@@ -1027,6 +1190,10 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);
   if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (variant_b16()) {
+    a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
+    return launch_mlp(nerf16_kernel, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+  }
   if (variant_1x4()) {
     a.nbatch = (int)((n * S + 127) / 128);
     return launch_mlp(nerf_kernel<1, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream, 2);

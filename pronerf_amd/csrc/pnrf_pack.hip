@@ -89,6 +89,21 @@ static void pack_layer_h16x2(const Layer& L, char* dst) {
       }
 }
 
+// bf16 packing for layer_b16 (16x16x32): in_map [nk][4][8], out_map [nt][16], fragments (tp, ks, tile-in-pair)
+static void pack_layer_b16(const Layer& L, char* dst) {
+  const int ntp = L.nt / 2;
+  for (int tp = 0; tp < ntp; ++tp)
+    for (int ks = 0; ks < L.nk; ++ks)
+      for (int t = 0; t < 2; ++t) {
+        uint16_t* frag = (uint16_t*)(dst + (((size_t)tp * L.nk + ks) * 2 + t) * FRAG_BYTES);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 15, g = lane >> 4;
+          const int out = L.out_map[(2 * tp + t) * 16 + r];
+          for (int j = 0; j < 8; ++j) frag[lane * 8 + j] = f2bf(wval(L, out, L.in_map[(ks * 4 + g) * 8 + j]));
+        }
+      }
+}
+
 static void pack_bias(const Layer& L, int prec, float* dst) {
   if (prec == PREC_F32 || prec == PREC_H16X2) {      // [tile][16 rows] in tile-row order: lane quarter q reads rows 4q..4q+3
     for (int i = 0; i < L.nt * 16; ++i) dst[i] = L.out_map[i] >= 0 ? L.b[L.out_map[i]] : 0.f;
@@ -373,6 +388,44 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (auto& L : Lh) { pack_layer_h16x2(L, blob_h16.data() + sh * SLOT_BYTES); sh += hs(L); }
   }
 
+  // DoNeRFTRT: second stream for the 16x16x32 engine (layer_b16): 16-row tiles in pairs, 32-deep k-steps
+  std::vector<char> blob_b16;
+  std::vector<float> bias_b16;
+  size_t slots_b16 = 0;
+  if (net == PNRF_NET_NERF) {
+    std::vector<Layer> Lb = Ls;
+    for (auto& L : Lb) {
+      L.nt = W_HID / 16; L.out_map = identity_out(W_HID);
+      L.nk = NB_KS_H; L.in_map.assign(NB_KS_H * 32, -1);
+      for (int ks = 0; ks < NB_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) L.in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+    }
+    Layer& G = Lb[0];
+    G.nk = NB_KS0; G.in_map.assign(NB_KS0 * 32, -1);
+    for (int ks = 0; ks < NB_KS0; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) G.in_map[(ks * 4 + g) * 8 + j] = nerf16_in0(ks, g, j);
+    Layer& Y = Lb[n_layers - 1];
+    Y.nt = 2; Y.out_map.assign(32, -1);
+    for (int r = 0; r < N_OUT; ++r) Y.out_map[r] = r;                     // rows 0..3 of tile 0 = rgb, sigma; tile 1 is padding
+    Y.nk = NB_KS_LAST; Y.in_map.resize(NB_KS_LAST * 32);
+    for (int ks = 0; ks < NB_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) Y.in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+    for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) {
+      const int v = nerf16_inx(g, j);
+      Y.in_map[(NB_KS_H * 4 + g) * 8 + j] = v >= 0 ? W_HID + v : -1;
+    }
+    auto bs = [&](const Layer& L) { return ((size_t)(L.nt / 2) * L.nk * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS; };
+    size_t nb = 0;
+    for (auto& L : Lb) { slots_b16 += bs(L); nb += (size_t)L.nt * 16; }
+    slots_b16 += (NSLOTS - slots_b16 % NSLOTS) % NSLOTS;
+    PNRF_REQUIRE(slots_b16 == (size_t)NB_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (b16 stream %zu slots, expected %d)", slots_b16, NB_NSLOTS);
+    blob_b16.assign(slots_b16 * SLOT_BYTES, 0);
+    bias_b16.assign(nb, 0.f);
+    size_t sb = 0, bb = 0;
+    for (auto& L : Lb) {
+      pack_layer_b16(L, blob_b16.data() + sb * SLOT_BYTES);
+      pack_bias(L, PREC_F32, bias_b16.data() + bb);                        // [tile][16 rows]
+      sb += bs(L); bb += (size_t)L.nt * 16;
+    }
+  }
+
   pnrf_mlp* h = new pnrf_mlp();
   memset(h, 0, sizeof(*h));
   h->net = net; h->prec = prec; h->in_dim = in0; h->in_dim_x = net == PNRF_NET_NERF ? N_INV : 0; h->out_dim = outN;
@@ -401,6 +454,13 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     e = hipMalloc(&h->d_blob_h16, blob_h16.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_h16, blob_h16.data(), blob_h16.size(), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && net == PNRF_NET_NERF) {
+    h->nslots_b16 = (uint32_t)slots_b16; h->nbias_b16 = (int)bias_b16.size();
+    e = hipMalloc(&h->d_blob_b16, blob_b16.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_b16, blob_b16.data(), blob_b16.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_b16, bias_b16.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_b16.data(), bias_b16.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
     float tv[S_KS0 / 3];
     pnrf_linspace(0.f, 1.f, S_KS0 / 3, tv);
@@ -421,6 +481,8 @@ extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
   if (h->d_blob) (void)hipFree(h->d_blob);
   if (h->d_blob_fold) (void)hipFree(h->d_blob_fold);
   if (h->d_blob_h16) (void)hipFree(h->d_blob_h16);
+  if (h->d_blob_b16) (void)hipFree(h->d_blob_b16);
+  if (h->d_bias_b16) (void)hipFree(h->d_bias_b16);
   if (h->d_bias) (void)hipFree(h->d_bias);
   if (h->d_in0) (void)hipFree(h->d_in0);
   if (h->d_inx) (void)hipFree(h->d_inx);

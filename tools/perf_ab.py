@@ -57,7 +57,7 @@ def main():
             _lib._lib = libs[c.get('lib', '')]
             rend = rends[c.get('lib', '')]
             os.environ['PNRF_SAMPLER_FOLD'] = c.get('fold', '1')
-            os.environ['PNRF_BF16_VARIANT'] = c.get('var', '1x8')
+            os.environ['PNRF_BF16_VARIANT'] = c.get('var', '16')
             os.environ['PNRF_SAMPLER_PREC'] = c.get('prec', 'h16')
             e = [ev() for _ in range(5)]
             e[0].record()
