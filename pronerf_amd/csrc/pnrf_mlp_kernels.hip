@@ -306,7 +306,8 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
         const float v = act_f32(fmaf(cr[pcx][g], INV, mn[pcx][g]), ACT_ELU);
         const _Float16 h = (_Float16)v;
         dh[tp][4 * pcx + g] = h;
-        dl[tp][4 * pcx + g] = (_Float16)((v - (float)h) * H16_LO_SCALE);
+        // (v - h) * 2^11 as one fused multiply-add (h * 2^11 and v * 2^11 are exact, so the value is the same): compiles to v_fma_mix*_f16
+        dl[tp][4 * pcx + g] = (_Float16)fmaf(-(float)h, H16_LO_SCALE, v * H16_LO_SCALE);
       }
     };
     auto hidden = [&](f16x8(&ih)[SH_KS_H], f16x8(&il)[SH_KS_H], f16x8(&oh)[SH_KS_H], f16x8(&ol)[SH_KS_H], int l) {
