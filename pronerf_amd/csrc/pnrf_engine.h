@@ -480,10 +480,19 @@ __host__ __device__ constexpr int hidden_feat_h16(int ks, int g, int j) { return
 // (2tp, 2tp+1) is k-step tp of the next layer (element j of group g = register j&3 of tile 2tp + (j>>2));
 // fragment order in the stream: (tp, ks, tile-in-pair).  Bf(cb, ks) -> bf16x8; epi1(tp, pc, acc[2][2]) / pre1(pc): piece pc =
 // tile pc of the deferred pair, acc[t][cb].
+#ifndef PNRF_B16_AHEAD
+#define PNRF_B16_AHEAD 8
+#endif
+#ifndef PNRF_B16_AT0
+#define PNRF_B16_AT0 1
+#endif
+#ifndef PNRF_B16_ATSTEP
+#define PNRF_B16_ATSTEP 2
+#endif
 template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][2]) {
   constexpr int NF = NTP * KS * 2;
-  constexpr int AHEAD = NF < 8 ? NF : 8;
+  constexpr int AHEAD = NF < PNRF_B16_AHEAD ? NF : PNRF_B16_AHEAD;
   auto frag_ptr = [&](int g) {
     return (const bf16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
@@ -518,7 +527,7 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
       }
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
-        const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;
+        const int at = KS >= 4 ? PNRF_B16_AT0 + pc * PNRF_B16_ATSTEP : KS - 1;
         if (ks == (at < KS ? at : KS - 1)) {
           if (tp == 0) pre1(pc);
           else epi1(tp - 1, pc, pend);

@@ -46,7 +46,7 @@ __global__ void bias_act_kernel(float* __restrict__ Y, int ld, const float* __re
 
 // dZ = dH * act'(H) in place (H = saved post-activation output) and partial column sums for the bias gradient.
 // grid (ceil(out/64), NCHUNK); block 256 = 64 columns x 4 row lanes.  part[chunk][out].
-constexpr int DB_CHUNKS = 64;
+constexpr int DB_CHUNKS = 256;
 __global__ void act_bwd_colsum_kernel(float* __restrict__ dH, int ldd, const float* __restrict__ H, int ldh, int64_t R, int out, int act,
                                       float* __restrict__ part) {
   __shared__ float red[4][64];
@@ -56,15 +56,24 @@ __global__ void act_bwd_colsum_kernel(float* __restrict__ dH, int ldd, const flo
   const int64_t r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
   float s = 0.f;
   if (j < out) {
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
-      float g = dH[r * ldd + j];
-      if (act != T_ACT_NONE) {
-        const float h = H[r * ldh + j];
-        if (act == T_ACT_RELU) g = h > 0.f ? g : 0.f;
-        else g = h > 0.f ? g : g * (h + 1.f);                            // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
-        dH[r * ldd + j] = g;
+    // 4 independent rows per trip: the loads of a trip are all in flight before the first is consumed
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      float g[4], h[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ru = r + 4 * u;
+        g[u] = ru < r1 ? dH[ru * ldd + j] : 0.f;
+        h[u] = (act != T_ACT_NONE && ru < r1) ? H[ru * ldh + j] : 1.f;
       }
-      s += g;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ru = r + 4 * u;
+        float gv = g[u];
+        if (act == T_ACT_RELU) gv = h[u] > 0.f ? gv : 0.f;
+        else if (act == T_ACT_ELU) gv = h[u] > 0.f ? gv : gv * (h[u] + 1.f);            // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
+        if (act != T_ACT_NONE && ru < r1) dH[ru * ldd + j] = gv;
+        s += gv;
+      }
     }
   }
   red[rl][c] = s;
