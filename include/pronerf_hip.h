@@ -227,6 +227,9 @@ int pnrf_trainer_free(pnrf_trainer_t* t);
 int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, float* W, float* b, void* stream);
 int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const float* W, const float* b, void* stream);
 int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step, int64_t step_nerf);
+/* Device address / element count of a flat array (kind as above): layers contiguous in trainer order, each [W, b] padded to 4
+ * floats.  For in-place collectives over data-parallel replicas (RCCL all-reduce of the gradients). */
+int pnrf_trainer_flat(pnrf_trainer_t* t, int kind, float** ptr, int64_t* count);
 
 typedef struct pnrf_train_batch {
   const float* rays;       /* dev [n,11] NDC ray batch (o, d, near, far, viewdir) */

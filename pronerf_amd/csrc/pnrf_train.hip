@@ -770,6 +770,15 @@ extern "C" int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const 
   if (b) PNRF_HIP(hipMemcpy(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault));
   return 0;
 }
+// Device address and element count of one of the flat arrays (kind as pnrf_trainer_read) — e.g. to all-reduce the gradients of
+// data-parallel replicas in place with RCCL.  Layers are contiguous in trainer order, each [W (out x in), b (out)] padded to 4 floats.
+extern "C" int pnrf_trainer_flat(pnrf_trainer_t* t, int kind, float** ptr, int64_t* count) {
+  PNRF_REQUIRE(t && ptr && count && kind >= 0 && kind <= 5, PNRF_E_ARG, "pnrf_trainer_flat: bad arguments");
+  *ptr = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
+  *count = (int64_t)t->nparam;
+  return 0;
+}
+
 extern "C" int pnrf_trainer_set_step(pnrf_trainer_t* t, int64_t step, int64_t step_nerf) {
   PNRF_REQUIRE(t && step >= 0 && step_nerf >= 0, PNRF_E_ARG, "pnrf_trainer_set_step: bad arguments");
   t->step = step; t->step2 = step_nerf;

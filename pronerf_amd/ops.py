@@ -417,6 +417,19 @@ class Trainer:
 
     _KINDS = {'param': 0, 'grad': 1, 'm': 2, 'v': 3, 'm_nerf': 4, 'v_nerf': 5}
 
+    def flat(self, kind='grad'):
+        """Zero-copy torch view [nparam] of one of the trainer's flat device arrays (all layers, trainer order) — e.g. for
+        ``torch.distributed.all_reduce`` of the gradients of data-parallel replicas (pronerf_amd.dist.allreduce_gradients)."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        check(_lib.load().pnrf_trainer_flat(self.handle, self._KINDS[kind], C.byref(ptr), C.byref(n)), 'pnrf_trainer_flat')
+
+        class _Dev:                                      # __cuda_array_interface__ v3: torch wraps the memory without copying
+            __cuda_array_interface__ = {'shape': (int(n.value),), 'typestr': '<f4', 'data': (int(ptr.value), False), 'version': 3}
+        with torch.cuda.device(self.device):
+            t = torch.as_tensor(_Dev(), device=self.device)
+        t._pnrf_owner = self                             # keep the trainer alive as long as the view is
+        return t
+
     def set_step(self, step, step_nerf=0):
         check(_lib.load().pnrf_trainer_set_step(self.handle, int(step), int(step_nerf)), 'pnrf_trainer_set_step')
 

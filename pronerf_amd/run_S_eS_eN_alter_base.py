@@ -106,7 +106,7 @@ def train(argv=None, device='cuda'):
     checkpoints with the reference's keys.  Returns (trainer, list of (iteration, loss, psnr))."""
     import os
     from .load_llff import load_llff_data
-    from .run_S_eS_eN_alter_base_refine2 import save_checkpoint, trainer_layer_list
+    from .run_S_eS_eN_alter_base_refine2 import dist_setup, save_checkpoint, shared_permutation, trainer_layer_list
     args = config_parser().parse_args(argv)
     if args.dataset_type != 'llff':
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
@@ -114,7 +114,10 @@ def train(argv=None, device='cuda'):
         raise PnrfError('--epi_nerf references a class the reference does not define (SURVEY.md Appendix B-7)')
     if args.N_samples != 8 or args.num_neighbor != 4 or args.N_point_ray_enc != 48 or args.mmnetdepth != 6:
         raise PnrfError('the HIP trainer is built for N_samples=8, num_neighbor=4, N_point_ray_enc=48, mmnetdepth=6 (fern_epi.txt)')
-    dev = torch.device(device)
+    replica, world, dev = dist_setup(device)
+    if args.N_rand % world:
+        raise ValueError(f'N_rand = {args.N_rand} is not divisible by the {world} replicas')
+    n_local = args.N_rand // world
     images, poses, bds, _, i_test = load_llff_data(args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
     hwf = poses[0, :3, -1]
     poses = poses[:, :3, :4]
@@ -137,7 +140,12 @@ def train(argv=None, device='cuda'):
                MinMaxRay_Net(D=6, W=256, input_ch=144, output_ch=35, skips=[10000]).state_dict(),
                NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True).state_dict())
     max_mult = 64 // 8                                                                                        # :690
-    tr = ops.Trainer(*zip(*trainer_layer_list(*sds)), max_rays=args.N_rand, device=dev, max_samples=8 * max_mult)
+    if world > 1:                                        # replicas start from the same weights: rank 0's initialisation
+        import torch.distributed as dist
+        box = [sds]
+        dist.broadcast_object_list(box, src=0)
+        sds = box[0]
+    tr = ops.Trainer(*zip(*trainer_layer_list(*sds)), max_rays=n_local, device=dev, max_samples=8 * max_mult)
     with torch.cuda.device(dev):
         pr = [ops.frame_rays(K, poses[i], H, W, near=1e-6, far=1., device=dev) for i in i_train]               # near = 1e-6 (:798)
         rays_all = torch.cat([p[0] for p in pr], 0); or_rays_all = torch.cat([p[1] for p in pr], 0)
@@ -146,7 +154,8 @@ def train(argv=None, device='cuda'):
         own_all = torch.arange(len(i_train), device=dev).repeat_interleave(H * W)
         img4, poses_t, K_t, rank = _train_views(images[i_train], poses[i_train], K, dev)
     n_total = rays_all.shape[0]
-    perm = torch.randperm(n_total, device=dev)
+    epoch = 0
+    perm = shared_permutation(n_total, epoch, dev) if world > 1 else torch.randperm(n_total, device=dev)
     i_batch, global_step, log = 0, start, []
     n_iters = 500000 + 1 if args.max_steps is None else start + args.max_steps + 1
     lr, nv = args.lrate, len(i_train)
@@ -154,9 +163,11 @@ def train(argv=None, device='cuda'):
         idx = perm[i_batch:i_batch + args.N_rand]
         i_batch += args.N_rand
         if i_batch >= n_total:
-            perm = torch.randperm(n_total, device=dev); i_batch = 0
+            epoch += 1
+            perm = shared_permutation(n_total, epoch, dev) if world > 1 else torch.randperm(n_total, device=dev); i_batch = 0
         if idx.shape[0] < args.N_rand:
             continue
+        idx = idx[replica * n_local:(replica + 1) * n_local]                                                          # this replica's share
         n = idx.shape[0]
         order = torch.as_tensor(sorted(random.sample(range(nv - 1), 4)), device=dev)                           # :629-634
         ref_nos = rank[own_all[idx]][:, 1:][:, order].contiguous()
@@ -169,12 +180,18 @@ def train(argv=None, device='cuda'):
             noise = torch.randn(n, 8 * n_mult, device=dev) * args.raw_noise_std if args.raw_noise_std > 0 else None
             loss, _ = tr.explore_fwd_bwd(*batch, n_mult=n_mult, dir1=dir1, jitter=jitter, dir2=dir2, raw_noise=noise, white_bkgd=args.white_bkgd,
                                          want_rgb=False)
+            if world > 1:
+                from .dist import allreduce_gradients
+                allreduce_gradients(tr)
             tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay, nerf_only=True)
         else:                                                                                                  # :941-958
             loss, _ = tr.fwd_bwd(*batch, white_bkgd=args.white_bkgd, eps=1e-6, a_mmrgb=1.0, clamp=10.0, layout=1, want_rgb=False)
+            if world > 1:
+                from .dist import allreduce_gradients
+                allreduce_gradients(tr)
             tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay)
         lr = args.lrate * (0.1 ** ((global_step / 2) / (args.lrate_decay * 1000)))                            # :961-967
-        if i % args.i_weights == 0 or i == n_iters - 1:
+        if (i % args.i_weights == 0 or i == n_iters - 1) and replica == 0:
             path = os.path.join(out_root, '{:06d}.tar'.format(i))
             save_checkpoint(path, tr, global_step)
             print('Saved checkpoints at', path)
@@ -182,6 +199,7 @@ def train(argv=None, device='cuda'):
             lh = loss.cpu().numpy()
             psnr = float(-10.0 * np.log10(max(float(lh[1]), 1e-12)))
             log.append((i, float(lh[0]), psnr))
-            print(f'[TRAIN] Iter: {i} Loss: {float(lh[0])}  PSNR: {psnr}')
+            if replica == 0:
+                print(f'[TRAIN] Iter: {i} Loss: {float(lh[0])}  PSNR: {psnr}')
         global_step += 1
     return tr, log

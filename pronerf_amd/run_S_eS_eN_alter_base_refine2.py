@@ -145,6 +145,31 @@ def save_checkpoint(path, tr, global_step):
                 'pnrf_adam_v_nerf': adam['v_nerf']}, path)
 
 
+def dist_setup(device):
+    """Data-parallel replicas (not in the reference): under ``torchrun`` (WORLD_SIZE > 1) every rank takes GPU LOCAL_RANK, joins the
+    process group (nccl = RCCL; PNRF_DIST_BACKEND overrides, e.g. gloo to rehearse on one GPU) and seeds Python's ``random`` alike,
+    so the per-batch draws (neighbour ranks, coin flips, n_mult) coincide.  Returns (rank, world, device)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return 0, 1, torch.device(device)
+    import torch.distributed as dist
+    backend = os.environ.get('PNRF_DIST_BACKEND', 'nccl')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        dist.init_process_group(backend)
+    random.seed(20240611)
+    return dist.get_rank(), world, dev
+
+
+def shared_permutation(n, epoch, dev):
+    """The same ray permutation on every rank (CPU generator seeded by the epoch)."""
+    gen = torch.Generator().manual_seed(1000003 * (epoch + 1))
+    return torch.randperm(n, generator=gen).to(dev)
+
+
 def config_parser():
     """Options of the stage-2 script (run_S_eS_eN_alter_base_refine2.py:27-160); see ``pronerf_amd.config``."""
     from .config import config_parser as _cp
@@ -166,7 +191,10 @@ def train(argv=None, device='cuda'):
         raise ValueError('Stage 2 refinement requires --pretrain_path with a stage 1 checkpoint.')
     if args.N_samples != N_SAMPLES or args.num_neighbor != 4 or args.N_point_ray_enc != 48 or args.mmnetdepth != 6:
         raise PnrfError('the HIP trainer is built for N_samples=8, num_neighbor=4, N_point_ray_enc=48, mmnetdepth=6 (fern_refine.txt)')
-    dev = torch.device(device)
+    replica, world, dev = dist_setup(device)
+    if args.N_rand % world:
+        raise ValueError(f'N_rand = {args.N_rand} is not divisible by the {world} replicas')
+    n_local = args.N_rand // world
     images, poses, bds, _, i_test = load_llff_data(args.datadir, args.factor, recenter=True, bd_factor=.75, spherify=args.spherify)
     hwf = poses[0, :3, -1]
     poses = poses[:, :3, :4]
@@ -182,7 +210,7 @@ def train(argv=None, device='cuda'):
     ck = torch.load(args.pretrain_path, map_location='cpu')
     start = 0
     tr = ops.Trainer(*zip(*trainer_layer_list(ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], ck['network_fn_state_dict'])),
-                     max_rays=args.N_rand, device=dev)
+                     max_rays=n_local, device=dev)
     # rays of all training views, as render() prepares them (:206-279): NDC batch + world-space batch, [n_train*H*W, 11] each
     with torch.cuda.device(dev):
         pr = [ops.frame_rays(K, poses[i], H, W, near=0., far=1., device=dev) for i in i_train]
@@ -192,7 +220,8 @@ def train(argv=None, device='cuda'):
         own_all = torch.arange(len(i_train), device=dev).repeat_interleave(H * W)
         img4, poses_t, K_t, rank = _train_views(images[i_train], poses[i_train], K, dev)
     n_total = rays_all.shape[0]
-    perm = torch.randperm(n_total, device=dev)                                                                 # :796-799
+    epoch = 0
+    perm = shared_permutation(n_total, epoch, dev) if world > 1 else torch.randperm(n_total, device=dev)       # :796-799
     i_batch, global_step, log = 0, start, []
     n_iters = 500000 + 1 if args.max_steps is None else start + args.max_steps + 1                              # :808-810
     lr = args.lrate
@@ -201,9 +230,11 @@ def train(argv=None, device='cuda'):
         idx = perm[i_batch:i_batch + args.N_rand]
         i_batch += args.N_rand
         if i_batch >= n_total:                                                                                  # :840-844
-            perm = torch.randperm(n_total, device=dev); i_batch = 0
+            epoch += 1
+            perm = shared_permutation(n_total, epoch, dev) if world > 1 else torch.randperm(n_total, device=dev); i_batch = 0
         if idx.shape[0] < args.N_rand:
             continue
+        idx = idx[replica * n_local:(replica + 1) * n_local]                                                          # this replica's share
         # the per-batch draws of render_rays (:594-600, :649-661, raw2outputs :497)
         order = torch.as_tensor(sorted(random.sample(range(nv - 1), 4)), device=dev)
         ref_nos = rank[own_all[idx]][:, 1:][:, order].contiguous()
@@ -212,9 +243,12 @@ def train(argv=None, device='cuda'):
         noise = torch.randn(idx.shape[0], 8, device=dev) * args.raw_noise_std if args.raw_noise_std > 0 else None
         loss, _ = tr.fwd_bwd(rays_all[idx], or_rays_all[idx], target_all[idx], img4, poses_t, K_t, ref_nos, jitter=jitter, jitter_dir=jdir,
                              raw_noise=noise, white_bkgd=args.white_bkgd, a_mmrgb=args.a_mmrgb, want_rgb=False)
+        if world > 1:
+            from .dist import allreduce_gradients
+            allreduce_gradients(tr)
         tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay)
         lr = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1000)))                                   # :872-878
-        if i % args.i_weights == 0 or i == n_iters - 1:
+        if (i % args.i_weights == 0 or i == n_iters - 1) and replica == 0:
             path = os.path.join(out_root, '{:06d}.tar'.format(i))
             save_checkpoint(path, tr, global_step)
             print('Saved checkpoints at', path)
@@ -222,6 +256,7 @@ def train(argv=None, device='cuda'):
             lh = loss.cpu().numpy()
             psnr = float(-10.0 * np.log10(max(float(lh[1]), 1e-12)))
             log.append((i, float(lh[0]), psnr))
-            print(f'[TRAIN] Iter: {i} Loss: {float(lh[0])}  PSNR: {psnr}')
+            if replica == 0:
+                print(f'[TRAIN] Iter: {i} Loss: {float(lh[0])}  PSNR: {psnr}')
         global_step += 1
     return tr, log
