@@ -182,12 +182,32 @@ def main():
         out = torch.zeros(cmax, 4, device=dev)                  # padded to the largest shard (sizes differ by <= 1 ray)
         full = torch.empty(world * cmax, 4, device=dev)         # rank r's pixels are full[r*cmax : r*cmax+counts[r]]
 
+    # N > 1: the gather of frame i runs on the collective's stream while frame i+1 renders (two output / frame buffers; the
+    # wait before a buffer is reused is a stream wait, the host never blocks).  Every frame is complete when fence() returns.
+    pipeline = world > 1 and os.environ.get('PNRF_BENCH_PIPELINE', '1') != '0'
+    outs, fulls, pending = [out], [full if world > 1 else None], [None, None]
+    if pipeline:
+        outs.append(torch.zeros_like(out)); fulls.append(torch.empty_like(full))
+    frame_no = [0]
+
     def step():
-        rend.render_rays(rays, or_rays, out=out)
+        b = frame_no[0] & 1 if pipeline else 0
+        frame_no[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        rend.render_rays(rays, or_rays, out=outs[b])
         if world > 1:
-            dist.all_gather_into_tensor(full, out)
+            if pipeline:
+                pending[b] = dist.all_gather_into_tensor(fulls[b], outs[b], async_op=True)
+            else:
+                dist.all_gather_into_tensor(fulls[b], outs[b])
 
     def fence():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -209,7 +229,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    finite = bool(torch.isfinite(out).all().item())
+    finite = bool(all(torch.isfinite(o).all().item() for o in outs))
 
     sampler_f32 = os.environ.get('PNRF_SAMPLER_PREC', '').startswith('f3')
     res = None
@@ -228,7 +248,7 @@ def main():
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, '
                                    '48 ray-encoding points, 1024-ray chunks (4x256-column workgroup batches), bf16 MLP',
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0],
-                       'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
+                       'gather_pipelined': bool(pipeline), 'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
             'outputs_finite': finite,
             'algorithmic_flop_per_ray': FLOP_PER_RAY,
             'e2e_mfma_tflops': value * FLOP_PER_RAY / 1e12,
