@@ -106,7 +106,7 @@ def train(argv=None, device='cuda'):
     checkpoints with the reference's keys.  Returns (trainer, list of (iteration, loss, psnr))."""
     import os
     from .load_llff import load_llff_data
-    from .run_S_eS_eN_alter_base_refine2 import dist_setup, save_checkpoint, shared_permutation, trainer_layer_list
+    from .run_S_eS_eN_alter_base_refine2 import dist_setup, evaluate_views, save_checkpoint, shared_permutation, trainer_layer_list
     args = config_parser().parse_args(argv)
     if args.dataset_type != 'llff':
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
@@ -195,6 +195,11 @@ def train(argv=None, device='cuda'):
             path = os.path.join(out_root, '{:06d}.tar'.format(i))
             save_checkpoint(path, tr, global_step)
             print('Saved checkpoints at', path)
+        if i % args.i_testset == 0 and i > 0 and replica == 0:                                                  # :984-996
+            ps = evaluate_views(tr, 1, poses[i_test], images[i_test], images[i_train], poses[i_train], K, H, W,
+                                savedir=os.path.join(out_root, 'testset_{:06d}'.format(i)), near=1e-6, white_bkgd=args.white_bkgd)
+            print(f'[TEST] Iter: {i} PSNR per view: {[round(p, 2) for p in ps]} mean {float(np.mean(ps)):.2f}')
+            log.append((i, 'test_psnr', float(np.mean(ps))))
         if i % args.i_print == 0 or i == n_iters - 1:
             lh = loss.cpu().numpy()
             psnr = float(-10.0 * np.log10(max(float(lh[1]), 1e-12)))

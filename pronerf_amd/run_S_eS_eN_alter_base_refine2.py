@@ -170,6 +170,42 @@ def shared_permutation(n, epoch, dev):
     return torch.randperm(n, generator=gen).to(dev)
 
 
+def evaluate_views(tr, stage, test_poses, test_images, train_images, train_poses, K, H, W, savedir=None, near=0., white_bkgd=False):
+    """The periodic test-set render of the training scripts (refine2.py:905-917, base.py:984-996): every hold-out view through
+    the evaluation branch of the stage's own ``render_rays`` (nearest ``num_neighbor`` training views of the target pose, no
+    jitter / exploration / noise) with the trainer's current weights, on the training-time forward kernels.  stage 2: eps 1e-5,
+    neighbour-major epi; stage 1: eps 1e-6, sample-major epi, raw clamp 10.  Returns the PSNR of each view; writes
+    ``{i:03d}.png`` into ``savedir`` if given."""
+    import os
+    from .run_S_eS_eN_alter_trt import _write_png
+    dev = tr.device
+    s_sd, r_sd, f_sd = state_dicts_from_trainer(tr)
+    sampler = ops.PackedMLP(ops.NET_SAMPLER, [s_sd[k + '.weight'] for k in _MM_KEYS], [s_sd[k + '.bias'] for k in _MM_KEYS])
+    refine = ops.PackedMLP(ops.NET_REFINE, [r_sd[k + '.weight'] for k in _MM_KEYS], [r_sd[k + '.bias'] for k in _MM_KEYS])
+    fine = ops.PackedMLP(ops.NET_NERFCLS, [f_sd[k + '.weight'] for k in _FINE_KEYS], [f_sd[k + '.bias'] for k in _FINE_KEYS])
+    eps, layout, clamp = (1e-5, 0, 0.0) if stage == 2 else (1e-6, 1, 10.0)
+    img4, poses_t, K_t, _ = _train_views(train_images, train_poses, K, dev)
+    pt = np.asarray(train_poses, dtype=np.float32)[:, :3, :4]
+    psnrs = []
+    with torch.cuda.device(dev):
+        for i, (c2w, gt) in enumerate(zip(np.asarray(test_poses, dtype=np.float32), np.asarray(test_images, dtype=np.float32))):
+            rays, or_rays = ops.frame_rays(np.asarray(K, dtype=np.float32), c2w[:3, :4], H, W, near=near, far=1., device=dev)
+            d = np.sqrt(((c2w[None, :3, 3] - pt[:, :3, 3]) ** 2).sum(1, dtype=np.float32))
+            ref = np.argsort(d, kind='stable')[:4]                                       # evaluation: the nearest views, in rank order
+            ref_nos = torch.as_tensor(ref, dtype=torch.int64, device=dev)[None].expand(rays.shape[0], -1).contiguous()
+            depth, _, add, mul, _, _ = ops.sampler_fwd(sampler, rays, want_idx=False, want_rgb=False)
+            rin = ops.refine_input_train(rays, or_rays, depth, img4, poses_t, K_t, ref_nos, eps=eps, layout=layout)
+            z, pts, _ = ops.refine_train_fwd(refine, rin, rays, depth, want_rgb0=False)
+            rgbd, _ = ops.nerf_train_fwd(fine, pts, rays, z, add, mul, clamp=clamp, white_bkgd=white_bkgd)
+            rgb = rgbd[:, :3].reshape(H, W, 3)
+            mse = float(torch.mean((rgb - torch.as_tensor(gt, device=dev)) ** 2))
+            psnrs.append(-10.0 * np.log10(max(mse, 1e-12)))
+            if savedir is not None:
+                os.makedirs(savedir, exist_ok=True)
+                _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgb.cpu().numpy()))
+    return psnrs
+
+
 def config_parser():
     """Options of the stage-2 script (run_S_eS_eN_alter_base_refine2.py:27-160); see ``pronerf_amd.config``."""
     from .config import config_parser as _cp
@@ -252,6 +288,11 @@ def train(argv=None, device='cuda'):
             path = os.path.join(out_root, '{:06d}.tar'.format(i))
             save_checkpoint(path, tr, global_step)
             print('Saved checkpoints at', path)
+        if i % args.i_testset == 0 and i > 0 and replica == 0:                                                  # :905-917
+            ps = evaluate_views(tr, 2, poses[i_test], images[i_test], images[i_train], poses[i_train], K, H, W,
+                                savedir=os.path.join(out_root, 'testset_{:06d}'.format(i)), white_bkgd=args.white_bkgd)
+            print(f'[TEST] Iter: {i} PSNR per view: {[round(p, 2) for p in ps]} mean {float(np.mean(ps)):.2f}')
+            log.append((i, 'test_psnr', float(np.mean(ps))))
         if i % args.i_print == 0 or i == n_iters - 1:
             lh = loss.cpu().numpy()
             psnr = float(-10.0 * np.log10(max(float(lh[1]), 1e-12)))

@@ -356,10 +356,15 @@ def test_stage1_then_stage2_then_inference_chain(dev, tmp_path):
     from pronerf_amd import run_S_eS_eN_alter_trt as trt
     root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=3, n=10, H=24, W=32, factor=4)
     common = (f'basedir = {tmp_path}/logs\ndatadir = {root}\nfactor = 4\nllffhold = 8\nN_rand = 512\nN_samples = 8\nN_point_ray_enc = 48\nmmnetdepth = 6\n'
-              'mmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\nraw_noise_std = 1e0\nlrate = 5e-4\nweight_decay = 5e-8\ni_print = 4\ni_weights = 1000\n')
+              'mmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\nraw_noise_std = 1e0\nlrate = 5e-4\nweight_decay = 5e-8\ni_print = 4\ni_weights = 1000\n'
+              'i_testset = 8\n')
     (tmp_path / 'epi.txt').write_text('expname = s1\n' + common)
     torch.manual_seed(0)
     tr1, log1 = s1.train(['--config', str(tmp_path / 'epi.txt'), '--max_steps', '24'], device=dev)
+    tests1 = [e for e in log1 if e[1] == 'test_psnr']
+    log1 = [e for e in log1 if e[1] != 'test_psnr']
+    assert [e[0] for e in tests1] == [8, 16, 24] and all(np.isfinite(e[2]) for e in tests1)          # i_testset renders of the 2 hold-out views
+    assert sorted(os.listdir(tmp_path / 'logs' / 's1' / 'testset_000016')) == ['000.png', '001.png']
     assert [e[0] for e in log1] == [4, 8, 12, 16, 20, 24] and all(np.isfinite(e[1]) for e in log1)
     assert log1[-1][1] < log1[0][1]                                   # even iterations' joint loss goes down from the random initialisation
     ck1 = tmp_path / 'logs' / 's1' / '000024.tar'
@@ -368,6 +373,7 @@ def test_stage1_then_stage2_then_inference_chain(dev, tmp_path):
     assert float(c['pnrf_adam_m_nerf'][20][0].abs().max()) > 0 and float(c['pnrf_adam_m'][3][0].abs().max()) > 0     # both optimizers stepped
     (tmp_path / 'refine.txt').write_text(f'expname = s2\npretrain_path = {ck1}\n' + common)
     tr2, log2 = s2.train(['--config', str(tmp_path / 'refine.txt'), '--max_steps', '8'], device=dev)
+    assert [e[0] for e in log2 if e[1] == 'test_psnr'] == [8] and os.path.exists(tmp_path / 'logs' / 's2' / 'testset_000008' / '001.png')
     ck2 = tmp_path / 'logs' / 's2' / '000008.tar'
     (tmp_path / 'infer.txt').write_text(f'expname = inf\nft_path = {ck2}\n' + common)
     kw = trt.train(['--config', str(tmp_path / 'infer.txt'), '--render_test', '--max_images', '1'], device=dev)
