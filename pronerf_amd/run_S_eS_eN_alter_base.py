@@ -106,7 +106,8 @@ def train(argv=None, device='cuda'):
     checkpoints with the reference's keys.  Returns (trainer, list of (iteration, loss, psnr))."""
     import os
     from .load_llff import load_llff_data
-    from .run_S_eS_eN_alter_base_refine2 import dist_setup, evaluate_views, save_checkpoint, shared_permutation, trainer_layer_list
+    from .run_S_eS_eN_alter_base_refine2 import (dist_setup, evaluate_views, newest_checkpoint, restore_optimizer, save_checkpoint,
+                                                 shared_permutation, trainer_layer_list)
     args = config_parser().parse_args(argv)
     if args.dataset_type != 'llff':
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
@@ -130,11 +131,13 @@ def train(argv=None, device='cuda'):
     with open(os.path.join(out_root, 'args.txt'), 'w') as f:
         for k in sorted(vars(args)):
             f.write('{} = {}\n'.format(k, getattr(args, k)))
-    start = 0
-    if args.ft_path is not None and args.ft_path != 'None':
-        ck = torch.load(args.ft_path, map_location='cpu')
+    start, ck = 0, None
+    resume = None if args.no_reload else (args.ft_path if args.ft_path not in (None, 'None') else newest_checkpoint(out_root))   # base.py:429-446
+    if resume is not None:
+        ck = torch.load(resume, map_location='cpu')
         start = int(ck.get('global_step', 0))
         sds = (ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], ck['network_fn_state_dict'])
+        print('Reloading from', resume, 'at step', start)
     else:                                                # create_nerf (:337-380): torch's default nn.Linear initialisation
         sds = (MinMaxRay_Net(D=6, W=256, input_ch=288, output_ch=27, skips=[10000]).state_dict(),
                MinMaxRay_Net(D=6, W=256, input_ch=144, output_ch=35, skips=[10000]).state_dict(),
@@ -146,6 +149,9 @@ def train(argv=None, device='cuda'):
         dist.broadcast_object_list(box, src=0)
         sds = box[0]
     tr = ops.Trainer(*zip(*trainer_layer_list(*sds)), max_rays=n_local, device=dev, max_samples=8 * max_mult)
+    if ck is not None:
+        restore_optimizer(tr, ck, 1)
+    adam_steps = [start - start // 2, start // 2] if ck is not None and 'pnrf_adam_steps' not in ck else ([0, 0] if ck is None else list(ck['pnrf_adam_steps']))
     with torch.cuda.device(dev):
         pr = [ops.frame_rays(K, poses[i], H, W, near=1e-6, far=1., device=dev) for i in i_train]               # near = 1e-6 (:798)
         rays_all = torch.cat([p[0] for p in pr], 0); or_rays_all = torch.cat([p[1] for p in pr], 0)
@@ -184,16 +190,18 @@ def train(argv=None, device='cuda'):
                 from .dist import allreduce_gradients
                 allreduce_gradients(tr)
             tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay, nerf_only=True)
+            adam_steps[1] += 1
         else:                                                                                                  # :941-958
             loss, _ = tr.fwd_bwd(*batch, white_bkgd=args.white_bkgd, eps=1e-6, a_mmrgb=1.0, clamp=10.0, layout=1, want_rgb=False)
             if world > 1:
                 from .dist import allreduce_gradients
                 allreduce_gradients(tr)
             tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay)
+            adam_steps[0] += 1
         lr = args.lrate * (0.1 ** ((global_step / 2) / (args.lrate_decay * 1000)))                            # :961-967
         if (i % args.i_weights == 0 or i == n_iters - 1) and replica == 0:
             path = os.path.join(out_root, '{:06d}.tar'.format(i))
-            save_checkpoint(path, tr, global_step)
+            save_checkpoint(path, tr, global_step + 1, adam_steps)
             print('Saved checkpoints at', path)
         if i % args.i_testset == 0 and i > 0 and replica == 0:                                                  # :984-996
             ps = evaluate_views(tr, 1, poses[i_test], images[i_test], images[i_train], poses[i_train], K, H, W,

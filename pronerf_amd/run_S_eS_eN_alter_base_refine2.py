@@ -134,7 +134,59 @@ def state_dicts_from_trainer(tr):
     return sds
 
 
-def save_checkpoint(path, tr, global_step):
+# order of a reference module's .parameters() (definition order in run_nerf_helpers.py) expressed in trainer layer indices
+_FINE_PARAM_ORDER = list(range(14, 22)) + [24, 22, 23, 25]          # pts_linears.0..7, views_linears.0, feature_linear, alpha_linear, rgb_linear
+_SAMPLER_PARAM_ORDER = list(range(0, 7))
+_REFINE_PARAM_ORDER = list(range(7, 14))
+
+
+def _import_torch_adam(tr, opt_sd, layer_order, kinds):
+    """Moments of a reference ``torch.optim.Adam`` state dict -> the trainer.  ``layer_order``: trainer layer of every (weight,
+    bias) pair in the optimizer's parameter order; kinds: ('m', 'v') or ('m_nerf', 'v_nerf').  Returns the optimizer's step."""
+    st = opt_sd.get('state', {})
+    step = 0
+    for k, li in enumerate(layer_order):
+        sw, sb = st.get(2 * k), st.get(2 * k + 1)
+        if sw is None or sb is None:
+            continue
+        tr.write(kinds[0], li, sw['exp_avg'].float(), sb['exp_avg'].float())
+        tr.write(kinds[1], li, sw['exp_avg_sq'].float(), sb['exp_avg_sq'].float())
+        step = max(step, int(sw['step']))
+    return step
+
+
+def restore_optimizer(tr, ck, stage):
+    """Adam state of a checkpoint -> trainer: this package's own keys ('pnrf_adam_*', steps in 'pnrf_adam_steps') or the
+    reference's torch.optim state dicts (stage 2: 'optimizer_state_dict' = [fine, sampler, refine], refine2.py:358-394; stage 1:
+    's_optimizer_state_dict' = [NeRF, sampler, refine] and 'optimizer_state_dict' = [NeRF], base.py:398-422)."""
+    if 'pnrf_adam_m' in ck:
+        for kind, key in (('m', 'pnrf_adam_m'), ('v', 'pnrf_adam_v'), ('m_nerf', 'pnrf_adam_m_nerf'), ('v_nerf', 'pnrf_adam_v_nerf')):
+            if key in ck:
+                for li, (W, b) in enumerate(ck[key]):
+                    tr.write(kind, li, W, b)
+        steps = ck.get('pnrf_adam_steps', (int(ck.get('global_step', 0)), 0))
+        tr.set_step(int(steps[0]), int(steps[1]))
+        return
+    joint_order = _FINE_PARAM_ORDER + _SAMPLER_PARAM_ORDER + _REFINE_PARAM_ORDER
+    s_joint = s_nerf = 0
+    if stage == 2 and 'optimizer_state_dict' in ck:
+        s_joint = _import_torch_adam(tr, ck['optimizer_state_dict'], joint_order, ('m', 'v'))
+    if stage == 1:
+        if 's_optimizer_state_dict' in ck:
+            s_joint = _import_torch_adam(tr, ck['s_optimizer_state_dict'], joint_order, ('m', 'v'))
+        if 'optimizer_state_dict' in ck:
+            s_nerf = _import_torch_adam(tr, ck['optimizer_state_dict'], _FINE_PARAM_ORDER, ('m_nerf', 'v_nerf'))
+    tr.set_step(s_joint, s_nerf)
+
+
+def newest_checkpoint(out_root):
+    """The newest ``*.tar`` of an experiment directory (the reference's resume rule, refine2.py:402-412), or None."""
+    import os
+    c = sorted(f for f in os.listdir(out_root) if f.endswith('.tar')) if os.path.isdir(out_root) else []
+    return os.path.join(out_root, c[-1]) if c else None
+
+
+def save_checkpoint(path, tr, global_step, steps=None):
     """``torch.save`` of a dict with the reference's keys (refine2.py:884-893).  'network_fn_state_dict' carries the fine net as
     well: the next stage / a restart reads the NeRF from that key (refine2.py:365).  The optimizer state is this trainer's Adam
     moments ('pnrf_adam_m' / 'pnrf_adam_v', one [W, b] pair per layer) instead of torch.optim state dicts."""
@@ -142,7 +194,7 @@ def save_checkpoint(path, tr, global_step):
     adam = {k: [[t.cpu() for t in tr.read(k, li)] for li in range(ops.TRAINER_LAYERS)] for k in ('m', 'v', 'm_nerf', 'v_nerf')}
     torch.save({'global_step': int(global_step), 'network_fn_state_dict': f_sd, 'network_fine_state_dict': f_sd, 'mmr_network_fn_state_dict': s_sd,
                 'refine_net_state_dict': r_sd, 'pnrf_adam_m': adam['m'], 'pnrf_adam_v': adam['v'], 'pnrf_adam_m_nerf': adam['m_nerf'],
-                'pnrf_adam_v_nerf': adam['v_nerf']}, path)
+                'pnrf_adam_v_nerf': adam['v_nerf'], 'pnrf_adam_steps': tuple(int(x) for x in (steps or (global_step, 0)))}, path)
 
 
 def dist_setup(device):
@@ -245,8 +297,17 @@ def train(argv=None, device='cuda'):
             f.write('{} = {}\n'.format(k, getattr(args, k)))
     ck = torch.load(args.pretrain_path, map_location='cpu')
     start = 0
-    tr = ops.Trainer(*zip(*trainer_layer_list(ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], ck['network_fn_state_dict'])),
-                     max_rays=n_local, device=dev)
+    fine_sd = ck['network_fn_state_dict']
+    resume = None if args.no_reload else (args.ft_path if args.ft_path not in (None, 'None') else newest_checkpoint(out_root))   # :402-412
+    if resume is not None:
+        ck = torch.load(resume, map_location='cpu')
+        start = int(ck.get('global_step', 0))
+        fine_sd = ck['network_fine_state_dict']
+        print('Reloading from', resume, 'at step', start)
+    tr = ops.Trainer(*zip(*trainer_layer_list(ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], fine_sd)), max_rays=n_local, device=dev)
+    if resume is not None:
+        restore_optimizer(tr, ck, 2)
+    adam_steps = [start, 0]
     # rays of all training views, as render() prepares them (:206-279): NDC batch + world-space batch, [n_train*H*W, 11] each
     with torch.cuda.device(dev):
         pr = [ops.frame_rays(K, poses[i], H, W, near=0., far=1., device=dev) for i in i_train]
@@ -283,10 +344,11 @@ def train(argv=None, device='cuda'):
             from .dist import allreduce_gradients
             allreduce_gradients(tr)
         tr.adam_step(lr, betas=(0.9, 0.999), weight_decay=args.weight_decay)
+        adam_steps[0] += 1
         lr = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1000)))                                   # :872-878
         if (i % args.i_weights == 0 or i == n_iters - 1) and replica == 0:
             path = os.path.join(out_root, '{:06d}.tar'.format(i))
-            save_checkpoint(path, tr, global_step)
+            save_checkpoint(path, tr, global_step + 1, adam_steps)
             print('Saved checkpoints at', path)
         if i % args.i_testset == 0 and i > 0 and replica == 0:                                                  # :905-917
             ps = evaluate_views(tr, 2, poses[i_test], images[i_test], images[i_train], poses[i_train], K, H, W,

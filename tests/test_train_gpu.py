@@ -288,7 +288,7 @@ def test_stage2_train_driver_end_to_end(dev, tmp_path):
     ck_path = tmp_path / 'logs' / 's2' / '000020.tar'
     ck = torch.load(str(ck_path), map_location='cpu')
     assert sorted(ck['network_fine_state_dict']) == sorted(synth.nerfcls_state_dict(wc))
-    assert sorted(ck['mmr_network_fn_state_dict']) == sorted(sds['sampler']) and ck['global_step'] == 19
+    assert sorted(ck['mmr_network_fn_state_dict']) == sorted(sds['sampler']) and ck['global_step'] == 20
     moved = float((ck['refine_net_state_dict']['fc_output.weight'] - sds['refine']['fc_output.weight']).abs().max())
     assert 0 < moved <= 20 * 5e-4 * 1.01                              # Adam moves a weight by at most lr per step
     icfg = tmp_path / 'infer.txt'
@@ -432,3 +432,58 @@ def test_data_parallel_training_driver(dev, tmp_path):
     a, b = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
     assert np.array_equal(a['param'], b['param']) and np.isfinite(a['loss']).all()
     assert sorted(os.listdir(tmp_path / 'logs' / 'ddp')) == ['000006.tar', 'args.txt']
+
+
+def test_resume_and_reference_optimizer_state_import(dev, tmp_path):
+    """(i) A reference-style checkpoint with torch.optim.Adam state dicts (stage-2 group order [fine, sampler, refine], the
+    modules' own parameter order) is imported into the trainer's moments / step counts; (ii) the stage-2 driver resumes from the
+    newest .tar of its experiment directory with moments and step counts restored."""
+    import llff_synth
+    from pronerf_amd import ops
+    from pronerf_amd import run_nerf_helpers as h
+    from pronerf_amd import run_S_eS_eN_alter_base_refine2 as s2
+    # ---- (i)
+    fine = h.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    smp = h.MinMaxRay_Net(D=6, W=256, input_ch=288, output_ch=27, skips=[10000])
+    rfn = h.MinMaxRay_Net(D=6, W=256, input_ch=144, output_ch=35, skips=[10000])
+    opt = torch.optim.Adam([{'params': fine.parameters()}, {'params': smp.parameters()}, {'params': rfn.parameters()}], lr=5e-4)
+    g = torch.Generator().manual_seed(0)
+    for p in [q for grp in opt.param_groups for q in grp['params']]:
+        p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    opt.step(); opt.step()
+    ck = {'global_step': 2, 'network_fine_state_dict': fine.state_dict(), 'network_fn_state_dict': fine.state_dict(), 'mmr_network_fn_state_dict': smp.state_dict(),
+          'refine_net_state_dict': rfn.state_dict(), 'optimizer_state_dict': opt.state_dict()}
+    layers = s2.trainer_layer_list(ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], ck['network_fine_state_dict'])
+    tr = ops.Trainer(*zip(*layers), max_rays=8, device=dev)
+    s2.restore_optimizer(tr, ck, 2)
+    for mod, li in ((fine.rgb_linear, 25), (fine.views_linears[0], 24), (fine.alpha_linear, 23), (fine.pts_linears[5], 19), (smp.fc_output, 6), (rfn.fc_backbone[2], 9)):
+        mW, mb = tr.read('m', li); vW, vb = tr.read('v', li)
+        assert torch.equal(mW.cpu(), opt.state[mod.weight]['exp_avg']) and torch.equal(vb.cpu(), opt.state[mod.bias]['exp_avg_sq'])
+        assert torch.equal(tr.read('param', li)[0].cpu(), mod.weight.detach())
+    # the next Adam step continues torch's bias correction (step 3)
+    for p in [q for grp in opt.param_groups for q in grp['params']]:
+        p.grad = torch.full(p.shape, 2e-3)
+    for li, (W, b) in enumerate(layers):
+        tr.write('grad', li, torch.full(W.shape, 2e-3).to(dev), torch.full(b.shape, 2e-3).to(dev))
+    opt.step(); tr.adam_step(5e-4)
+    np.testing.assert_allclose(tr.read('param', 24)[0].cpu().numpy(), fine.views_linears[0].weight.detach().numpy(), rtol=0, atol=2e-7)
+    # ---- (ii)
+    root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=5, n=10, H=24, W=32, factor=4)
+    pre = str(tmp_path / 'stage1.tar')
+    torch.save(ck, pre)
+    cfg = tmp_path / 'refine.txt'
+    cfg.write_text(f'expname = rs\nbasedir = {tmp_path}/logs\ndatadir = {root}\npretrain_path = {pre}\nfactor = 4\nllffhold = 8\nN_rand = 256\nN_samples = 8\n'
+                   'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\nraw_noise_std = 1e0\nlrate = 5e-4\n'
+                   'weight_decay = 5e-8\ni_print = 100\ni_weights = 100\n')
+    s2.train(['--config', str(cfg), '--max_steps', '6'], device=dev)
+    c1 = torch.load(str(tmp_path / 'logs' / 'rs' / '000006.tar'), map_location='cpu')
+    assert c1['global_step'] == 6 and tuple(c1['pnrf_adam_steps']) == (6, 0)
+    tr2, _ = s2.train(['--config', str(cfg), '--max_steps', '3'], device=dev)            # resumes from 000006.tar
+    assert sorted(f for f in os.listdir(tmp_path / 'logs' / 'rs') if f.endswith('.tar')) == ['000006.tar', '000009.tar']
+    c2 = torch.load(str(tmp_path / 'logs' / 'rs' / '000009.tar'), map_location='cpu')
+    assert c2['global_step'] == 9 and tuple(c2['pnrf_adam_steps']) == (9, 0)
+    # the moments were carried over, not restarted: after 3 more steps v >= 0.999^3 * v_saved
+    v6, v9 = c1['pnrf_adam_v'][20][0], c2['pnrf_adam_v'][20][0]
+    assert float(v6.max()) > 0 and bool((v9 >= 0.996 * v6).all())
+    tr3, _ = s2.train(['--config', str(cfg), '--max_steps', '1', '--no_reload'], device=dev)     # --no_reload starts again from the stage-1 weights
+    assert torch.load(str(tmp_path / 'logs' / 'rs' / '000001.tar'), map_location='cpu')['global_step'] == 1
