@@ -277,6 +277,8 @@ def train(argv=None, device='cuda'):
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
     if not args.pretrain_path:
         raise ValueError('Stage 2 refinement requires --pretrain_path with a stage 1 checkpoint.')
+    if args.no_ndc or args.lindisp:
+        raise PnrfError('--no_ndc / --lindisp: the HIP path is built for forward-facing scenes in NDC with samples linear in depth (the LLFF configs)')
     if args.N_samples != N_SAMPLES or args.num_neighbor != 4 or args.N_point_ray_enc != 48 or args.mmnetdepth != 6:
         raise PnrfError('the HIP trainer is built for N_samples=8, num_neighbor=4, N_point_ray_enc=48, mmnetdepth=6 (fern_refine.txt)')
     replica, world, dev = dist_setup(device)

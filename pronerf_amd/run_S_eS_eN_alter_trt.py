@@ -261,6 +261,8 @@ def train(argv=None, device='cuda'):
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
     if args.use_trt:
         raise PnrfError('--use_trt: TensorRT does not exist on ROCm; the fused HIP path is the engine')
+    if args.no_ndc or args.lindisp:
+        raise PnrfError('--no_ndc / --lindisp: the HIP path is built for forward-facing scenes in NDC with samples linear in depth (the LLFF configs)')
     images, poses, bds, render_poses, i_test, i_ref = load_llff_data_infer(args.datadir, args.factor, recenter=True, bd_factor=.75,
                                                                             spherify=args.spherify)
     hwf = poses[0, :3, -1]
