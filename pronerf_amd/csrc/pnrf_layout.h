@@ -90,30 +90,30 @@ constexpr int N_NBIAS = (1 + N_NHID) * W_HID + 32;
 
 // ---- nerf class (bf16): the `NeRF` module that stages 1/2 train (run_nerf_helpers.py:792-847).
 // Engine layers: E0 pts0 (63->256) | E1-E4 pts1-4 | E5 pts5 ([63+256]->256) | E6,E7 pts6,7 |
-// E8 feature (256->256, linear) + alpha (256->1) as a 9th tile | E9 views ([256+27]->128, ReLU) | E10 rgb (128->3)
+// E89 views layer with feature_linear folded in + alpha as a 5th tile ([256+27] -> 128 ReLU + 1) | E10 rgb (128->3).
+// feature_linear has no activation, so views(cat[feature(h), v]) = (Wv[:, :256] Wf) h + Wv[:, 256:] v + (bv + Wv[:, :256] bf): the packer
+// multiplies the two weight matrices in fp64 once — one 256x256 layer (11 % of the fine net's MFMAs) less per sample, and one bf16
+// rounding of an intermediate less.  alpha = Wa h + ba reads the same h and rides along as output row 128.
 constexpr int C_NLIN = 12;                                // nn.Linear modules, pack order: pts0..7, feature, alpha, views, rgb
 constexpr int C_KS5 = KS_HID + N_KS0;                     // 20: hidden k-steps first, then the 4 positional k-steps
-constexpr int C_NT8 = NT_HID + 1;                         // 9 tiles: 8 feature + 1 alpha
 constexpr int C_KS9 = KS_HID + N_KSX;                     // 18
-constexpr int C_NT9 = 4;                                  // 128 outputs
+constexpr int C_NT9 = 4;                                  // 128 view-layer outputs
+constexpr int C_NT89 = C_NT9 + 1;                         // + the alpha tile
 constexpr int C_KS10 = 8;                                 // 128 inputs
 constexpr int C_SLOTS_E5 = layer_slots_bf16<C_KS5, NT_HID>();     // 10
-constexpr int C_SLOTS_E8 = layer_slots_bf16<KS_HID, C_NT8>();     // 9
-constexpr int C_SLOTS_E9 = layer_slots_bf16<C_KS9, C_NT9>();      // 5
+constexpr int C_SLOTS_E89 = layer_slots_bf16<C_KS9, C_NT89>();    // 6
 constexpr int C_SLOTS_E10 = layer_slots_bf16<C_KS10, 1>();        // 1
 constexpr int C_POS_E1 = N_SLOTS_L0 % NSLOTS;
 constexpr int C_POS_E5 = (C_POS_E1 + 4 * SLOTS_HID) % NSLOTS;
 constexpr int C_POS_E6 = (C_POS_E5 + C_SLOTS_E5) % NSLOTS;
-constexpr int C_POS_E8 = (C_POS_E6 + 2 * SLOTS_HID) % NSLOTS;
-constexpr int C_POS_E9 = (C_POS_E8 + C_SLOTS_E8) % NSLOTS;
-constexpr int C_POS_E10 = (C_POS_E9 + C_SLOTS_E9) % NSLOTS;
-constexpr int C_SLOTS_USED = N_SLOTS_L0 + 4 * SLOTS_HID + C_SLOTS_E5 + 2 * SLOTS_HID + C_SLOTS_E8 + C_SLOTS_E9 + C_SLOTS_E10;
+constexpr int C_POS_E89 = (C_POS_E6 + 2 * SLOTS_HID) % NSLOTS;
+constexpr int C_POS_E10 = (C_POS_E89 + C_SLOTS_E89) % NSLOTS;
+constexpr int C_SLOTS_USED = N_SLOTS_L0 + 4 * SLOTS_HID + C_SLOTS_E5 + 2 * SLOTS_HID + C_SLOTS_E89 + C_SLOTS_E10;
 constexpr int C_SLOTS_PAD = (NSLOTS - C_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int C_NSLOTS = C_SLOTS_USED + C_SLOTS_PAD;
-// packed bias offsets (floats): E0..E7 8x256, E8 9x32, E9 4x32, E10 32
-constexpr int C_BIAS_E8 = 8 * W_HID;
-constexpr int C_BIAS_E9 = C_BIAS_E8 + 32 * C_NT8;
-constexpr int C_BIAS_E10 = C_BIAS_E9 + 32 * C_NT9;
+// packed bias offsets (floats): E0..E7 8x256, E89 5x32, E10 32
+constexpr int C_BIAS_E89 = 8 * W_HID;
+constexpr int C_BIAS_E10 = C_BIAS_E89 + 32 * C_NT89;
 constexpr int C_NBIAS = C_BIAS_E10 + 32;
 
 // ---- input-feature maps of layer 0 (and of the NeRF view k-steps); -1 = zero padding.

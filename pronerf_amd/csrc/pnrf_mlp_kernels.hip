@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
       for (int i = 0; i < N_SLOTS_PAD; ++i) st.begin();
     } else {
       // NeRF class (helpers:824-847).  E0 Bo->Bn | E1..E4 ping-pong (ends in Bn) | E5 [Bn, P]->Bo | E6 Bo->Bn | E7 Bn->Bo |
-      // E8 Bo->Bn (feature, linear) + alpha | E9 [Bn, Bx]->Bo (128 wide) | E10 Bo -> rgb
+      // E89 [Bo, Bx]->Bn (views layer with feature_linear folded in, 128 wide) + alpha | E10 Bn -> rgb
       bf16x8 P[NCB][N_KS0];                 // positional B fragments, needed again by the skip connection at layer 5
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
@@ -798,24 +798,17 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
       hidden(Bo, Bn, 6, std::integral_constant<int, C_POS_E6>{});
       hidden(Bn, Bo, 7, std::integral_constant<int, C_POS_E6>{});
       float alpha[NCB];
-      {                                       // E8: feature (tiles 0-7, no activation) + alpha (tile 8, row 0)
-        f32x16 np[NCB];
-        layer_bf16<NCB, KS_HID, C_NT8, C_POS_E8>(st, ringlane, biaslane + C_BIAS_E8, [&](int cb, int ks) { return Bo[cb][ks]; },
-                                                 HiddenEpi<NCB, ACT_NONE>{Bn}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bo}(NT_HID - 1, pc, pend); }, np);
+      {                                       // E89: views layer (feature_linear folded in) on cat[h, view encoding] -> 128 ReLU (tiles 0-3 -> Bn)
+        f32x16 np[NCB];                       //      + alpha (tile 4, row 0, no activation)
+        layer_bf16<NCB, C_KS9, C_NT89, C_POS_E89>(
+            st, ringlane, biaslane + C_BIAS_E89,
+            [&](int cb, int ks) { return ks < KS_HID ? Bo[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
+            HiddenEpi<NCB, ACT_RELU>{Bn}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bo}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) alpha[cb] = np[cb][0];
       }
-      {                                       // E9: views layer on cat[feature, view encoding] -> 128, ReLU
-        f32x16 np[NCB];
-        layer_bf16<NCB, C_KS9, C_NT9, C_POS_E9>(
-            st, ringlane, biaslane + C_BIAS_E9,
-            [&](int cb, int ks) { return ks < KS_HID ? Bn[cb][ks < KS_HID ? ks : 0] : Bx[cb][ks >= KS_HID ? ks - KS_HID : 0]; },
-            HiddenEpi<NCB, ACT_RELU>{Bo}, [](int) {}, np);
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
-      }
-      layer_bf16<NCB, C_KS10, 1, C_POS_E10>(st, ringlane, biaslane + C_BIAS_E10, [&](int cb, int ks) { return Bo[cb][ks]; },
-                                            [&](int, int, f32x16(&)[NCB]) {}, [&](int pc) { HiddenEpi<NCB, ACT_RELU>{Bo}(C_NT9 - 1, pc, pend); }, fin);
+      layer_bf16<NCB, C_KS10, 1, C_POS_E10>(st, ringlane, biaslane + C_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks]; },
+                                            [&](int, int, f32x16(&)[NCB]) {}, [](int) {}, fin);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) fin[cb][3] = alpha[cb];          // raw = [rgb, alpha] (helpers:851)
 #pragma unroll

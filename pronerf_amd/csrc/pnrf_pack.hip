@@ -169,7 +169,7 @@ static int pack_nerfcls(const float* const* W, const float* const* b, const int*
                  l, out_dim[l], in_dim[l], eo[l], ei[l]);
   }
   const std::vector<int> hid = hidden_in(PREC_BF16);
-  std::vector<Layer> Ls(11);
+  std::vector<Layer> Ls(10);
   auto base = [&](Layer& L, int lin) {
     L.W = W[lin]; L.b = b[lin]; L.in_dim = in_dim[lin]; L.out_dim = out_dim[lin];
     L.nt = NT_HID; L.nk = KS_HID; L.in_map = hid; L.out_map = identity_out(W_HID);
@@ -182,30 +182,44 @@ static int pack_nerfcls(const float* const* W, const float* const* b, const int*
   Ls[5].nk = C_KS5; Ls[5].in_map.assign(C_KS5 * 16, -1);
   for (int ks = 0; ks < KS_HID; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) Ls[5].in_map[(ks * 2 + h) * 8 + j] = N_IN + hidden_feat_bf16(ks, h, j);
   for (int ks = 0; ks < N_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) Ls[5].in_map[((KS_HID + ks) * 2 + h) * 8 + j] = nerf_in0(ks, h, j);
-  // E8: feature (rows 0..255) + alpha (tile 8, row 0) from the same input (helpers:842-843)
-  std::vector<float> Wc((size_t)(W_HID + 1) * W_HID), bc(W_HID + 1);
-  memcpy(Wc.data(), W[8], sizeof(float) * W_HID * W_HID);
-  memcpy(Wc.data() + (size_t)W_HID * W_HID, W[9], sizeof(float) * W_HID);
-  memcpy(bc.data(), b[8], sizeof(float) * W_HID); bc[W_HID] = b[9][0];
-  Layer& E8 = Ls[8];
-  E8.W = Wc.data(); E8.b = bc.data(); E8.in_dim = W_HID; E8.out_dim = W_HID + 1; E8.nt = C_NT8; E8.nk = KS_HID; E8.in_map = hid;
-  E8.out_map.assign(32 * C_NT8, -1);
-  for (int i = 0; i < W_HID; ++i) E8.out_map[i] = i;
-  E8.out_map[W_HID] = W_HID;                       // alpha -> tile 8 row 0 = half 0, register 0
-  // E9: views layer on cat[feature(256), views(27)] (helpers:844-848)
-  Layer& E9 = Ls[9];
-  E9.W = W[10]; E9.b = b[10]; E9.in_dim = W_HID + N_INV; E9.out_dim = W_HID / 2; E9.nt = C_NT9; E9.nk = C_KS9;
-  E9.in_map.assign(C_KS9 * 16, -1);
+  // E89: views layer with feature_linear folded in (helpers:842-848; see pnrf_layout.h) + alpha as row 128.
+  //   rows 0..127: Wc[r, :256] = sum_k Wv[r, k] Wf[k, :]  (fp64), Wc[r, 256:283] = Wv[r, 256:283], bc[r] = bv[r] + sum_k Wv[r, k] bf[k]
+  //   row 128    : Wc[128, :256] = Wa, no view inputs, bc[128] = ba
+  const int VI = W_HID + N_INV, VO = W_HID / 2;
+  std::vector<float> Wc((size_t)(VO + 1) * VI, 0.f), bc(VO + 1, 0.f);
+  {
+    const float *Wf = W[8], *bf = b[8], *Wa = W[9], *Wv = W[10], *bv = b[10];
+    std::vector<double> acc(W_HID);
+    for (int r = 0; r < VO; ++r) {
+      for (int c = 0; c < W_HID; ++c) acc[c] = 0.0;
+      double ab = (double)bv[r];
+      for (int k = 0; k < W_HID; ++k) {
+        const double wv = (double)Wv[(size_t)r * VI + k];
+        const float* row = Wf + (size_t)k * W_HID;
+        for (int c = 0; c < W_HID; ++c) acc[c] += wv * (double)row[c];
+        ab += wv * (double)bf[k];
+      }
+      for (int c = 0; c < W_HID; ++c) Wc[(size_t)r * VI + c] = (float)acc[c];
+      for (int c = 0; c < N_INV; ++c) Wc[(size_t)r * VI + W_HID + c] = Wv[(size_t)r * VI + W_HID + c];
+      bc[r] = (float)ab;
+    }
+    for (int c = 0; c < W_HID; ++c) Wc[(size_t)VO * VI + c] = Wa[c];
+    bc[VO] = b[9][0];
+  }
+  Layer& E89 = Ls[8];
+  E89.W = Wc.data(); E89.b = bc.data(); E89.in_dim = VI; E89.out_dim = VO + 1; E89.nt = C_NT89; E89.nk = C_KS9;
+  E89.in_map.assign(C_KS9 * 16, -1);
   std::vector<int> inx_map(N_KSX * 16, -1);
-  for (int ks = 0; ks < KS_HID; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) E9.in_map[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
+  for (int ks = 0; ks < KS_HID; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) E89.in_map[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
   for (int e = 0; e < N_KSX; ++e) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) {
     const int v = nerf_inx(e, h, j);
     inx_map[(e * 2 + h) * 8 + j] = v;
-    E9.in_map[((KS_HID + e) * 2 + h) * 8 + j] = v >= 0 ? W_HID + v : -1;
+    E89.in_map[((KS_HID + e) * 2 + h) * 8 + j] = v >= 0 ? W_HID + v : -1;
   }
-  E9.out_map = identity_out(32 * C_NT9);
+  E89.out_map.assign(32 * C_NT89, -1);
+  for (int i = 0; i <= VO; ++i) E89.out_map[i] = i;     // alpha = output 128 -> tile 4 row 0 = half 0, register 0
   // E10: rgb (helpers:850)
-  Layer& E10 = Ls[10];
+  Layer& E10 = Ls[9];
   E10.W = W[11]; E10.b = b[11]; E10.in_dim = W_HID / 2; E10.out_dim = 3; E10.nt = 1; E10.nk = C_KS10;
   E10.in_map.assign(C_KS10 * 16, -1);
   for (int ks = 0; ks < C_KS10; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) E10.in_map[(ks * 2 + h) * 8 + j] = hidden_feat_bf16(ks, h, j);
