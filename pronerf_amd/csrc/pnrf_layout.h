@@ -172,6 +172,25 @@ constexpr int NB_SLOTS_USED = NB_SLOTS_L0 + N_NHID * NB_SLOTS_H + NB_SLOTS_LAST;
 constexpr int NB_SLOTS_PAD = (NSLOTS - NB_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int NB_NSLOTS = NB_SLOTS_USED + NB_SLOTS_PAD;
 static_assert(NB_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position");
+// NeRF class on the same engine: E0 | E1-E4 | E5 ([h, pos] -> 256: 8 + 2 k-steps) | E6, E7 | E89 ([h, views] -> 128 ReLU + alpha: 9
+// k-steps, 8 view tiles + the alpha tile = 5 tile pairs) | E10 (128 -> 3: 4 k-steps, 1 pair)
+constexpr int CB_KS5 = NB_KS_H + NB_KS0;                                                // 10
+constexpr int CB_NTP89 = 5;
+constexpr int CB_KS10 = (W_HID / 2) / 32;                                               // 4
+constexpr int CB_SLOTS_E5 = (NB_NTP_H * CB_KS5 * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;      // 10
+constexpr int CB_SLOTS_E89 = (CB_NTP89 * NB_KS_LAST * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS; // 6
+constexpr int CB_SLOTS_E10 = (1 * CB_KS10 * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;           // 1
+constexpr int CB_POS_E1 = NB_SLOTS_L0 % NSLOTS;
+constexpr int CB_POS_E5 = (CB_POS_E1 + 4 * NB_SLOTS_H) % NSLOTS;
+constexpr int CB_POS_E6 = (CB_POS_E5 + CB_SLOTS_E5) % NSLOTS;
+constexpr int CB_POS_E89 = (CB_POS_E6 + 2 * NB_SLOTS_H) % NSLOTS;
+constexpr int CB_POS_E10 = (CB_POS_E89 + CB_SLOTS_E89) % NSLOTS;
+constexpr int CB_SLOTS_USED = NB_SLOTS_L0 + 4 * NB_SLOTS_H + CB_SLOTS_E5 + 2 * NB_SLOTS_H + CB_SLOTS_E89 + CB_SLOTS_E10;
+constexpr int CB_SLOTS_PAD = (NSLOTS - CB_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int CB_NSLOTS = CB_SLOTS_USED + CB_SLOTS_PAD;
+constexpr int CB_BIAS_E89 = 8 * W_HID;                                                  // [tile of 16 rows][16]
+constexpr int CB_BIAS_E10 = CB_BIAS_E89 + 16 * 2 * CB_NTP89;
+constexpr int CB_NBIAS = CB_BIAS_E10 + 32;
 // Input feature (index into the reference's 63-wide position embedding [x, sin 2^0 x, cos 2^0 x, ...]) that element j of
 // lane group g supplies in k-step ks of layer 0.  Group g evaluates fn = g&1 (0 sin, 1 cos) on octaves 5*(g>>1) .. +4:
 // slot 8ks+j = 3*local_octave + component for slots 0..14; slot 15 = raw x / y / z for g = 0 / 1 / 2 (g = 3: padding).

@@ -889,6 +889,8 @@ struct HiddenEpi16 {
   }
 };
 
+// CLS = false: DoNeRFTRT; CLS = true: the NeRF class (layer sequence as nerf_kernel<.., CLS>, feature_linear folded, alpha as a 9th tile)
+template <bool CLS>
 __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
   constexpr int TPB = 512, NW = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -962,24 +964,67 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       Bx[cb] = pack_bf16(fx);
     });
     f32x4 fin[2][2], pend[2][2];
-    auto hidden = [&](bf16x8(&in)[2][NB_KS_H], bf16x8(&out)[2][NB_KS_H], int l) {
-      f32x4 np[2][2];
-      layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, HiddenEpi16{out},
-                                             [&](int pc) { HiddenEpi16{in}(NB_NTP_H - 1, pc, pend); }, np);
+    if constexpr (!CLS) {
+      auto hidden = [&](bf16x8(&in)[2][NB_KS_H], bf16x8(&out)[2][NB_KS_H], int l) {
+        f32x4 np[2][2];
+        layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, HiddenEpi16{out},
+                                               [&](int pc) { HiddenEpi16{in}(NB_NTP_H - 1, pc, pend); }, np);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
-    };
-    layer_b16<NB_KS0, NB_NTP_H, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, HiddenEpi16{Bn}, [](int) {}, pend);
-    static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
-    for (int l = 0; l < N_NHID; l += 2) {
-      hidden(Bn, Bo, l);
-      hidden(Bo, Bn, l + 1);
+        for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+      };
+      layer_b16<NB_KS0, NB_NTP_H, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, HiddenEpi16{Bn}, [](int) {}, pend);
+      static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
+      for (int l = 0; l < N_NHID; l += 2) {
+        hidden(Bn, Bo, l);
+        hidden(Bo, Bn, l + 1);
+      }
+      layer_b16<NB_KS_LAST, 1, NB_POS_LAST>(
+          st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
+          [&](int, int, f32x4(&)[2][2]) {}, [&](int pc) { HiddenEpi16{Bn}(NB_NTP_H - 1, pc, pend); }, fin);
+#pragma unroll
+      for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
+    } else {
+      // E0 Bo->Bn | E1..E4 ping-pong (ends in Bn) | E5 [Bn, P]->Bo | E6 Bo->Bn | E7 Bn->Bo | E89 [Bo, Bx]->Bn (128 wide) + alpha | E10 Bn -> rgb
+      bf16x8 P[2][NB_KS0];                  // positional fragments, needed again by the skip connection at layer 5
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int k = 0; k < NB_KS0; ++k) P[cb][k] = Bo[cb][k];
+      auto hidden = [&](bf16x8(&in)[2][NB_KS_H], bf16x8(&out)[2][NB_KS_H], int l, auto posc) {
+        constexpr int POS = decltype(posc)::value;
+        f32x4 np[2][2];
+        layer_b16<NB_KS_H, NB_NTP_H, POS>(st, ringlane, biaslane + l * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, HiddenEpi16{out},
+                                          [&](int pc) { HiddenEpi16{in}(NB_NTP_H - 1, pc, pend); }, np);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+      };
+      layer_b16<NB_KS0, NB_NTP_H, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, HiddenEpi16{Bn}, [](int) {}, pend);
+      for (int l = 1; l < 5; l += 2) {        // E1..E4
+        hidden(Bn, Bo, l, std::integral_constant<int, CB_POS_E1>{});
+        hidden(Bo, Bn, l + 1, std::integral_constant<int, CB_POS_E1>{});
+      }
+      {                                       // E5: cat[pts, h] -> 256 (skip connection after layer 4)
+        f32x4 np[2][2];
+        layer_b16<CB_KS5, NB_NTP_H, CB_POS_E5>(
+            st, ringlane, biaslane + 5 * W_HID,
+            [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : P[cb][ks >= NB_KS_H ? ks - NB_KS_H : 0]; }, HiddenEpi16{Bo},
+            [&](int pc) { HiddenEpi16{Bn}(NB_NTP_H - 1, pc, pend); }, np);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+      }
+      hidden(Bo, Bn, 6, std::integral_constant<int, CB_POS_E6>{});
+      hidden(Bn, Bo, 7, std::integral_constant<int, CB_POS_E6>{});
+      f32x4 al[2][2];                         // E89: view tiles (pairs 0..3, ReLU -> Bn k-steps 0..3) + alpha (pair 4, tile 0, row 0)
+      layer_b16<NB_KS_LAST, CB_NTP89, CB_POS_E89>(
+          st, ringlane, biaslane + CB_BIAS_E89, [&](int cb, int ks) { return ks < NB_KS_H ? Bo[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; }, HiddenEpi16{Bn},
+          [&](int pc) { HiddenEpi16{Bo}(NB_NTP_H - 1, pc, pend); }, al);
+      layer_b16<CB_KS10, 1, CB_POS_E10>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
+                                        [&](int, int, f32x4(&)[2][2]) {}, [](int) {}, fin);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) fin[0][cb][3] = al[0][cb][0];          // raw = [rgb, alpha] (helpers:851)
+#pragma unroll
+      for (int i = 0; i < CB_SLOTS_PAD; ++i) st.begin();
     }
-    layer_b16<NB_KS_LAST, 1, NB_POS_LAST>(
-        st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
-        [&](int, int, f32x4(&)[2][2]) {}, [&](int pc) { HiddenEpi16{Bn}(NB_NTP_H - 1, pc, pend); }, fin);
-#pragma unroll
-    for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
 
     // ---- fused epilogue (as nerf_kernel): group 0 holds raw rgb-sigma of its column in regs 0-3 of tile 0
     static_for<2>([&](auto cbc) {
@@ -1183,10 +1228,16 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);
-  if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (h->net == PNRF_NET_NERFCLS) {
+    if (variant_b16()) {
+      a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
+      return launch_mlp(nerf16_kernel<true>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+    }
+    return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  }
   if (variant_b16()) {
     a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
-    return launch_mlp(nerf16_kernel, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+    return launch_mlp(nerf16_kernel<false>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
   }
   if (variant_1x4()) {
     a.nbatch = (int)((n * S + 127) / 128);

@@ -238,12 +238,59 @@ static int pack_nerfcls(const float* const* W, const float* const* b, const int*
     pack_bias(L, PREC_BF16, bias.data() + bo);
     so += layer_slots(L, PREC_BF16); bo += (size_t)L.nt * 32;
   }
+  // second stream for the 16x16x32 engine (nerf16_kernel<true>): same ten engine layers, 16-row tiles in pairs, 32-deep k-steps
+  std::vector<Layer> Lb = Ls;
+  std::vector<int> hid16(NB_KS_H * 32);
+  for (int ks = 0; ks < NB_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) hid16[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+  for (int e = 0; e < 8; ++e) { Lb[e].nt = W_HID / 16; Lb[e].out_map = identity_out(W_HID); Lb[e].nk = NB_KS_H; Lb[e].in_map = hid16; }
+  Lb[0].nk = NB_KS0; Lb[0].in_map.assign(NB_KS0 * 32, -1);
+  for (int ks = 0; ks < NB_KS0; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) Lb[0].in_map[(ks * 4 + g) * 8 + j] = nerf16_in0(ks, g, j);
+  Lb[5].nk = CB_KS5; Lb[5].in_map.assign(CB_KS5 * 32, -1);
+  for (int ks = 0; ks < NB_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) Lb[5].in_map[(ks * 4 + g) * 8 + j] = N_IN + hidden_feat_h16(ks, g, j);
+  for (int ks = 0; ks < NB_KS0; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) Lb[5].in_map[((NB_KS_H + ks) * 4 + g) * 8 + j] = nerf16_in0(ks, g, j);
+  Lb[8].nt = 2 * CB_NTP89; Lb[8].nk = NB_KS_LAST; Lb[8].in_map.assign(NB_KS_LAST * 32, -1);
+  for (int ks = 0; ks < NB_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) Lb[8].in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+  for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) {
+    const int v = nerf16_inx(g, j);
+    Lb[8].in_map[(NB_KS_H * 4 + g) * 8 + j] = v >= 0 ? W_HID + v : -1;
+  }
+  Lb[8].out_map.assign(16 * 2 * CB_NTP89, -1);
+  for (int i = 0; i <= VO; ++i) Lb[8].out_map[i] = i;                      // rows 0..127 = view layer, row 128 (tile 8, row 0) = alpha
+  Lb[9].nt = 2; Lb[9].nk = CB_KS10; Lb[9].in_map.assign(CB_KS10 * 32, -1);
+  for (int ks = 0; ks < CB_KS10; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) Lb[9].in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+  Lb[9].out_map.assign(32, -1);
+  for (int r = 0; r < 3; ++r) Lb[9].out_map[r] = r;
+  auto bs = [&](const Layer& L) { return ((size_t)(L.nt / 2) * L.nk * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS; };
+  size_t slots_b16 = 0, nb16 = 0;
+  for (auto& L : Lb) { slots_b16 += bs(L); nb16 += (size_t)L.nt * 16; }
+  slots_b16 += (NSLOTS - slots_b16 % NSLOTS) % NSLOTS;
+  PNRF_REQUIRE(slots_b16 == (size_t)CB_NSLOTS && nb16 == (size_t)CB_NBIAS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal NeRF-class b16 layout mismatch (%zu slots, %zu bias floats)",
+               slots_b16, nb16);
+  std::vector<char> blob_b16(slots_b16 * SLOT_BYTES, 0);
+  std::vector<float> bias_b16(nb16, 0.f);
+  {
+    size_t sb = 0, bb = 0;
+    for (auto& L : Lb) {
+      pack_layer_b16(L, blob_b16.data() + sb * SLOT_BYTES);
+      pack_bias(L, PREC_F32, bias_b16.data() + bb);
+      sb += bs(L); bb += (size_t)L.nt * 16;
+    }
+  }
+
   std::vector<int> outm(64, -1);                  // module-level store map: (half, reg) -> output index, rgb only (alpha handled by the kernel)
   pnrf_mlp* h = new pnrf_mlp();
   memset(h, 0, sizeof(*h));
   h->net = PNRF_NET_NERFCLS; h->prec = PREC_BF16; h->in_dim = N_IN; h->in_dim_x = N_INV; h->out_dim = 4;
   h->nslots = (uint32_t)slots; h->nbias = (int)nbias;
   int rc = upload(h, blob, bias, Ls[0].in_map, inx_map, outm);
+  if (rc == 0) {
+    h->nslots_b16 = (uint32_t)slots_b16; h->nbias_b16 = (int)nb16;
+    hipError_t e = hipMalloc(&h->d_blob_b16, blob_b16.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_b16, blob_b16.data(), blob_b16.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_b16, nb16 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_b16.data(), nb16 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error("pnrf_mlp_pack: device allocation/copy failed: %s", hipGetErrorString(e)); rc = (int)e; }
+  }
   if (rc) { pnrf_mlp_free(h); return rc; }
   *out = h;
   return 0;
