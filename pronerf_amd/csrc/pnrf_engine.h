@@ -220,7 +220,11 @@ __device__ __forceinline__ float act_fast(float v, int act) {
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
   }
+#ifdef PNRF_PROBE_ELU_AS_RELU
+  return fmaxf(v, 0.f);                                // diagnostic only: what the ELU itself costs
+#else
   return v > 0.f ? v : __expf(v) - 1.f;                // see act_f32
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
