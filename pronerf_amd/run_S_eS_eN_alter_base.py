@@ -92,6 +92,14 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
     return ret
 
 
+def _make_render():
+    from .run_S_eS_eN_alter_base_refine2 import make_render
+    return make_render(render_rays)
+
+
+render = _make_render()          # base.py:215-288
+
+
 # ------------------------------------------------------------------------------------ training loop
 def config_parser():
     """Options of the stage-1 script (run_S_eS_eN_alter_base.py:31-164); see ``pronerf_amd.config``."""

@@ -108,6 +108,41 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
             'z_vals': z.mean(dim=-1), 'z_vals0': depth.mean(dim=-1)}
 
 
+def make_render(render_rays_fn):
+    """``render`` of the training scripts (refine2.py:206-279; base.py:215-288) around a given ``render_rays``: rays from ``c2w`` or the
+    given (rays_o, rays_d) pair, view directions, the world-space ``or_rays`` batch, NDC, near / far columns, one ``render_rays`` call
+    (no chunking: the kernels take the whole batch), outputs reshaped to the ray shape.  Returns [rgb_map0, rgb_map1, depth_map, extras]."""
+    from .run_nerf_helpers import get_rays, ndc_rays
+
+    def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., or_near=1., or_far=10., use_viewdirs=False,
+               c2w_staticcam=None, **kwargs):
+        if not ndc or not use_viewdirs:
+            raise PnrfError('render: the HIP path is built for ndc=True, use_viewdirs=True (the LLFF configs)')
+        Kt = torch.as_tensor(K, dtype=torch.float32)
+        if c2w is not None:
+            rays_o, rays_d = get_rays(H, W, Kt, c2w)
+        else:
+            rays_o, rays_d = rays
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, Kt, c2w_staticcam)
+        viewdirs = (viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)).reshape(-1, 3).float()
+        sh = rays_d.shape
+        or_o, or_d = rays_o.reshape(-1, 3).float().contiguous(), rays_d.reshape(-1, 3).float().contiguous()
+        one = torch.ones_like(or_d[..., :1])
+        or_rays = torch.cat([or_o, or_d, or_near * one, or_far * one, viewdirs], -1)
+        o, d = ndc_rays(H, W, float(Kt[0][0]), 1., or_o, or_d)
+        ray_batch = torch.cat([o.reshape(-1, 3), d.reshape(-1, 3), near * one, far * one, viewdirs], -1)
+        ret = render_rays_fn(ray_batch.contiguous(), or_rays.contiguous(), **kwargs)
+        ret = {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
+        keys = ['rgb_map0', 'rgb_map1', 'depth_map']
+        return [ret[k] for k in keys] + [{k: v for k, v in ret.items() if k not in keys}]
+    return render
+
+
+render = make_render(render_rays)
+
+
 # ------------------------------------------------------------------------------------ training loop (SURVEY.md 8(f)1)
 _MM_KEYS = [f'fc_backbone.{i}' for i in range(6)] + ['fc_output']
 _FINE_KEYS = [f'pts_linears.{i}' for i in range(8)] + ['feature_linear', 'alpha_linear', 'views_linears.0', 'rgb_linear']

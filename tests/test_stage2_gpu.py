@@ -146,6 +146,15 @@ def test_stage2_render_rays_mirror(dev, golden_dir):
                          batch_rays_nearest_id=torch.full((N, 1), int(g['own']), dtype=torch.int64), train_nerf=True, **common)
     assert all(bool(torch.isfinite(v).all()) for v in ret.values())
     assert float(ret['rgb_map1'].min()) >= 0 and float(ret['z_vals'].min()) >= -0.25 and float(ret['z_vals'].max()) <= 1.25
+    # render(): the script-level wrapper (rays from c2w, NDC, or_rays, reshape) gives the same image as render_rays on the golden's rays
+    Hh, Ww, own = int(g['H']), int(g['W']), int(g['own'])
+    c2w = torch.from_numpy(scene['poses'][own]).to(dev)
+    rgb0, rgb1, depth, extras = s2.render(Hh, Ww, scene['K'], c2w=c2w, near=0., far=1., use_viewdirs=True, white_bkgd=True, raw_noise_std=0., randomize=False,
+                                          target_pose=torch.from_numpy(scene['poses'][own]), train_nerf=False, **common)
+    ref = s2.render_rays(rays, or_rays, white_bkgd=True, raw_noise_std=0., randomize=False, target_pose=torch.from_numpy(scene['poses'][own]),
+                         train_nerf=False, **common)
+    assert rgb1.shape == (Hh, Ww, 3) and depth.shape == (Hh, Ww) and set(extras) == {'mm_rgb', 'z_vals', 'z_vals0'}
+    assert orc.psnr(rgb1.reshape(-1, 3).cpu()[m], ref['rgb_map1'].cpu()[m]) > 60.0
 
 
 @pytest.mark.parametrize('name', ['stage1_joint_12x16', 'stage1_explore_a_12x16', 'stage1_explore_b_10x14', 'stage1_explore_c_8x12'])
