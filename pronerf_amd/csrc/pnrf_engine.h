@@ -398,7 +398,7 @@ template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + 
 //   22 significand bits per operand, the dropped W_lo.x_lo term is 2^-22 relative.  Three v_mfma_f32_16x16x32_f16
 //   per 32-deep k-step instead of eight v_mfma_f32_16x16x4_f32 of twice the duration: 3/16 of the MFMA cycles.
 //   Two fp32 accumulators per tile: `main` (hi.hi, initialised with the bias) and `cross` (the two mixed terms).
-//   Measured (oracle emulation and on the GPU, tools/idxcheck.py): depth error and sort indices indistinguishable from
+//   Measured (oracle emulation and on the GPU, tests/idxcheck_gpu.py): depth error and sort indices indistinguishable from
 //   the exact-fp32 MFMA chain.
 // Geometry: 16 columns per wave (lane l: column l&15, group g = l>>4), output tiles of 16 rows handled in PAIRS — the
 //   pair (2tp, 2tp+1) is exactly the k-step tp (32 features) of the next layer: element j of group g = register j&3 of

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Stage-2 training iteration at BASELINE config-4 size (N_rand = 4096 rays, 17 training views of 756x1008, 8 samples):
+"""(Checker-side script, not a pytest test: it times the oracle's eager torch graph next to the HIP trainer.)
+Stage-2 training iteration at BASELINE config-4 size (N_rand = 4096 rays, 17 training views of 756x1008, 8 samples):
 HIP trainer (pnrf_train_stage2_fwd_bwd + pnrf_trainer_adam_step) vs reference-style eager PyTorch on the same GPU (the
 oracle's torch graph with autograd + torch.optim.Adam; note the reference itself additionally replicates all 17 images x8
 per step, run_S_eS_eN_alter_base_refine2.py:602-604, which the oracle's projection does not).  Prints one JSON line."""
