@@ -405,12 +405,21 @@ template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + 
 //   tile 2tp + (j>>2) = feature 32tp + 16(j>>2) + 4g + (j&3).
 //   Fragment order in the stream: (tp, ks, tile-in-pair, plane) -> 4 fragments per k-step; NTP tile pairs, KS k-steps.
 //   Bf(ks, plane) -> f16x8 B operand; epi1(tp, pc, main[2], cross[2]) / pre1(pc): piece pc = tile pc of the deferred pair.
+#ifndef PNRF_H16_AHEAD
+#define PNRF_H16_AHEAD 8
+#endif
+#ifndef PNRF_H16_AT0
+#define PNRF_H16_AT0 2
+#endif
+#ifndef PNRF_H16_ATSTEP
+#define PNRF_H16_ATSTEP 3
+#endif
 constexpr float H16_LO_SCALE = 2048.f;
 template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1,
                                             f32x4 (&last_main)[2], f32x4 (&last_cross)[2]) {
   constexpr int NF = NTP * KS * 4;
-  constexpr int AHEAD = NF < 8 ? NF : 8;
+  constexpr int AHEAD = NF < PNRF_H16_AHEAD ? NF : PNRF_H16_AHEAD;
   auto frag_ptr = [&](int g) {
     return (const f16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
@@ -452,7 +461,7 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
       }
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
-        const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;
+        const int at = KS >= 4 ? PNRF_H16_AT0 + pc * PNRF_H16_ATSTEP : KS - 1;
         if (ks == (at < KS ? at : KS - 1)) {
           if (tp == 0) pre1(pc);
           else epi1(tp - 1, pc, pm, pc_);
