@@ -246,6 +246,12 @@ __device__ __forceinline__ float act_fast(float v, int act) {
 //   Bi(cb,ks) = B operand of k-step ks for column block cb
 //   epi1(to, piece, acc[NCB]) / pre1(piece): piece = 0,1 = accumulator registers 8*piece..8*piece+7
 //               (= one packed bf16 B fragment of the next layer per column block).
+#ifndef PNRF_BF16_AT0
+#define PNRF_BF16_AT0 6
+#endif
+#ifndef PNRF_BF16_ATSTEP
+#define PNRF_BF16_ATSTEP 6
+#endif
 constexpr int BF16_PIECES = 2;
 template <int NCB, int KS, int NT, int POS0, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const float* biaslane, BFn Bi, Epi1 epi1, Pre1 pre1,
@@ -302,7 +308,7 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
       // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
 #pragma unroll
       for (int pc = 0; pc < BF16_PIECES; ++pc) {
-        const int at = KS >= 4 ? 1 + pc * (KS / 4) : KS - 1;       // k-step after which piece pc is issued
+        const int at = KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1);       // k-step after which piece pc is issued
 #ifndef PNRF_PROBE_NOEPI
         if (ks == (at < KS ? at : KS - 1)) {
           if (to == 0) pre1(pc);
