@@ -54,6 +54,20 @@ int pnrf_mlp_pack(int net, const float* const* W, const float* const* b, const i
                   const int* out_dim, int n_layers, pnrf_mlp_t** out);
 int pnrf_mlp_free(pnrf_mlp_t* h);
 
+/* ---- engine files -------------------------------------------------------------------------
+ * A packed network as one flat byte image (128-byte header + the weight stream and its maps):
+ * the counterpart of the serialized TensorRT engines the reference builds with `export-trt`
+ * (pronerf/cli.py:105-157, onnx2trt.get_engine) and deserializes at start-up
+ * (run_S_eS_eN_alter_trt.py:490-499, trt_infer_v2.py NeRFEngine/MMEngine/RefineEngine).
+ * serialize: buf == NULL only reports the size in *size; otherwise capacity >= *size and the image
+ * is written to HOST memory (synchronous device read).  deserialize builds a new handle on the
+ * current device from a HOST image; images from another library build (ABI version / stream layout
+ * tag), truncated or corrupt images are refused with PNRF_E_STATE / PNRF_E_ARG.
+ * pnrf_mlp_kind reports what a handle holds (any out pointer may be NULL). */
+int pnrf_mlp_serialize(const pnrf_mlp_t* h, void* buf, int64_t capacity, int64_t* size);
+int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** out);
+int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int* out_dim);
+
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear
  * (MinMaxRay_Net.forward, DoNeRFTRT.forward); head_act = 1: with the head activations of the TRT
  * wrapper classes applied in place of their slicing ops — sampler: sigmoid on y[0:8] and y[24:27];

@@ -30,6 +30,9 @@ SIGNATURES = {
     'pnrf_last_error': (C.c_char_p, []),
     'pnrf_mlp_pack': (_i, [_i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, C.POINTER(_p)]),
     'pnrf_mlp_free': (_i, [_p]),
+    'pnrf_mlp_serialize': (_i, [_p, _p, _i64, C.POINTER(_i64)]),
+    'pnrf_mlp_deserialize': (_i, [_p, _i64, C.POINTER(_p)]),
+    'pnrf_mlp_kind': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'pnrf_mlp_fwd': (_i, [_p, _p, _p, _p, _i64, _i, _p]),
     'pnrf_posenc_fwd': (_i, [_p, _p, _i64, _i, _p]),
     'pnrf_plucker_fwd': (_i, [_p, _p, _p, _i64, _p]),

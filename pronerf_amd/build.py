@@ -32,6 +32,15 @@ def _hipcc():
     raise RuntimeError('hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)')
 
 
+def _layout_tag():
+    """32-bit tag of the files that define the packed weight-stream layout; engine files carry it (pnrf_mlp_serialize)."""
+    import zlib
+    c = 0
+    for f in ('pnrf_layout.h', 'pnrf_pack.hip'):
+        c = zlib.crc32(open(os.path.join(CSRC, f), 'rb').read(), c)
+    return c & 0xffffffff
+
+
 def _digest():
     h = hashlib.sha256()
     files = sorted(os.listdir(CSRC)) + ['../../include/pronerf_hip.h']
@@ -55,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(LIBDIR, s.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [hipcc] + FLAGS + ['-I', INCLUDE, '-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [hipcc] + FLAGS + [f'-DPNRF_LAYOUT_TAG=0x{_layout_tag():08x}u', '-I', INCLUDE, '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

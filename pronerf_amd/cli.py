@@ -2,9 +2,9 @@
 reference's ``pronerf/cli.py`` (:170-219) on top of this package's three drivers.
 
 Each sub-command builds the driver's argument list (``--config`` plus the mapped options plus whatever follows ``--``) and
-calls the driver's ``train(argv)`` in-process; nothing is re-executed.  ``export-trt`` has no ROCm counterpart: the packed
-weight stream is built from the checkpoint at load time (``pnrf_mlp_pack``), there is no engine file to export — it exits
-with an explanation.
+calls the driver's ``train(argv)`` in-process; nothing is re-executed.  ``export-trt`` keeps its name but writes this build's
+engine files (the packed weight streams, ``pnrf_mlp_serialize``) instead of ONNX / TensorRT plans; ``infer --use-trt`` /
+``eval --use-trt`` then start from those files instead of packing the checkpoint.
 """
 from __future__ import annotations
 
@@ -70,9 +70,22 @@ def _eval(ns):
     return _infer(ns)
 
 
+def export_argv(ns):
+    argv = ['--config', ns.config, '--export_only']
+    if ns.checkpoint is not None:
+        argv += ['--ft_path', ns.checkpoint]
+    return argv + _extra(ns)
+
+
 def _export_trt(ns):
-    raise SystemExit('export-trt: TensorRT / ONNX engines do not exist on ROCm.  `infer` packs the checkpoint into the HIP weight stream when it '
-                     'loads it (pnrf_mlp_pack); there is nothing to export.')
+    """cli.py:105-157 writes nerf/minmaxrays_net/refine_net ONNX files and FP16 TensorRT engines into <basedir>/<expname>; here
+    the driver's ``--export_only`` writes the three engine files of this build (the packed weight stream) there.  ``--onnx-only``,
+    ``--height`` and ``--width`` are accepted for command-line compatibility: there is no ONNX stage, and the engines are not
+    specialised to a batch size."""
+    from . import run_S_eS_eN_alter_trt as m
+    kw = m.train(export_argv(ns))
+    print('Engine files written to:', ', '.join(sorted(kw['engine_paths'].values())))
+    return kw
 
 
 def build_parser():
@@ -106,7 +119,7 @@ def build_parser():
     q.add_argument('--use-trt', action='store_true', dest='use_trt')
     q.add_argument('--max-images', type=int, default=None, dest='max_images')
     passthrough(q); q.set_defaults(func=_eval)
-    q = sub.add_parser('export-trt', help='(no ROCm counterpart)')
+    q = sub.add_parser('export-trt', help='write the engine files (packed weight streams) of a checkpoint')
     q.add_argument('--config', default='configs/llff/fern/fern_trt.txt')
     q.add_argument('--checkpoint', default=None)
     q.add_argument('--onnx-only', action='store_true', dest='onnx_only')

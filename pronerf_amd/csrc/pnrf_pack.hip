@@ -552,3 +552,154 @@ extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
   delete h;
   return 0;
 }
+
+// ---- engine files -----------------------------------------------------------------------------------------------------
+// One packed network as one flat byte image: a 128-byte header followed by the device buffers of the handle in a fixed order.
+// This is what the reference keeps in its serialized TensorRT engines (pronerf/cli.py:105-157 builds them, trt_infer_v2.py
+// deserializes them at start-up); here the "engine" is the pre-tiled weight stream, so the file is the stream.  Like a TensorRT
+// plan it is only valid for the library build that wrote it: the header carries the ABI version and a tag of the stream layout.
+#ifndef PNRF_LAYOUT_TAG
+#define PNRF_LAYOUT_TAG 0u
+#endif
+
+namespace pnrf {
+
+struct EngineHeader {
+  char magic[8];                 // "PNRFENG\0"
+  uint32_t format, abi, layout_tag, slot_bytes;
+  int32_t net, prec, in_dim, in_dim_x, out_dim;
+  uint32_t nslots, nslots_fold, nslots_h16, nslots_b16;
+  int32_t nbias_b16, nbias, n_in0, n_inx, n_out, n_tvals;
+  uint64_t payload_bytes, checksum;   // FNV-1a 64 of the payload
+  uint8_t reserved[24];
+};
+static_assert(sizeof(EngineHeader) == 128, "engine header is 128 bytes");
+static const char ENGINE_MAGIC[8] = {'P', 'N', 'R', 'F', 'E', 'N', 'G', 0};
+
+struct Section { void** dptr; size_t bytes; };
+
+// the buffers of a handle, in file order; sizes come from the counts in `h` (which the header restores on load)
+static int sections(pnrf_mlp* h, int n_tvals, Section* s) {
+  int n = 0;
+  s[n++] = {&h->d_blob, (size_t)h->nslots * SLOT_BYTES};
+  s[n++] = {&h->d_blob_fold, (size_t)h->nslots_fold * SLOT_BYTES};
+  s[n++] = {&h->d_blob_h16, (size_t)h->nslots_h16 * SLOT_BYTES};
+  s[n++] = {&h->d_blob_b16, (size_t)h->nslots_b16 * SLOT_BYTES};
+  s[n++] = {(void**)&h->d_bias_b16, (size_t)h->nbias_b16 * sizeof(float)};
+  s[n++] = {(void**)&h->d_bias, (size_t)h->nbias * sizeof(float)};
+  s[n++] = {(void**)&h->d_in0, (size_t)h->n_in0 * sizeof(int)};
+  s[n++] = {(void**)&h->d_inx, (size_t)h->n_inx * sizeof(int)};
+  s[n++] = {(void**)&h->d_out, (size_t)h->n_out * sizeof(int)};
+  s[n++] = {(void**)&h->d_tvals, (size_t)n_tvals * sizeof(float)};
+  return n;
+}
+
+static uint64_t fnv1a(const uint8_t* p, size_t n) {
+  uint64_t x = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) { x ^= p[i]; x *= 1099511628211ull; }
+  return x;
+}
+
+}  // namespace pnrf
+
+extern "C" int pnrf_mlp_serialize(const pnrf_mlp_t* hc, void* buf, int64_t capacity, int64_t* size) {
+  using namespace pnrf;
+  PNRF_REQUIRE(hc && size, PNRF_E_ARG, "pnrf_mlp_serialize: null argument");
+  pnrf_mlp* h = const_cast<pnrf_mlp*>(hc);
+  const int n_tvals = h->d_tvals ? S_KS0 / 3 : 0;
+  Section sec[10];
+  const int ns = sections(h, n_tvals, sec);
+  size_t payload = 0;
+  for (int i = 0; i < ns; ++i) {
+    PNRF_REQUIRE((sec[i].bytes == 0) == (*sec[i].dptr == nullptr), PNRF_E_STATE, "pnrf_mlp_serialize: inconsistent handle (section %d)", i);
+    payload += sec[i].bytes;
+  }
+  *size = (int64_t)(sizeof(EngineHeader) + payload);
+  if (!buf) return 0;                                               // size query
+  PNRF_REQUIRE(capacity >= *size, PNRF_E_ARG, "pnrf_mlp_serialize: buffer of %lld bytes, need %lld", (long long)capacity, (long long)*size);
+  int prev = 0;
+  PNRF_HIP(hipGetDevice(&prev));
+  PNRF_HIP(hipSetDevice(h->device));
+  uint8_t* p = (uint8_t*)buf + sizeof(EngineHeader);
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < ns && e == hipSuccess; ++i) {
+    if (sec[i].bytes) e = hipMemcpy(p, *sec[i].dptr, sec[i].bytes, hipMemcpyDeviceToHost);
+    p += sec[i].bytes;
+  }
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) { set_error("pnrf_mlp_serialize: device read failed: %s", hipGetErrorString(e)); return (int)e; }
+  EngineHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  memcpy(hd.magic, ENGINE_MAGIC, 8);
+  hd.format = 1; hd.abi = PNRF_ABI_VERSION; hd.layout_tag = PNRF_LAYOUT_TAG; hd.slot_bytes = SLOT_BYTES;
+  hd.net = h->net; hd.prec = h->prec; hd.in_dim = h->in_dim; hd.in_dim_x = h->in_dim_x; hd.out_dim = h->out_dim;
+  hd.nslots = h->nslots; hd.nslots_fold = h->nslots_fold; hd.nslots_h16 = h->nslots_h16; hd.nslots_b16 = h->nslots_b16;
+  hd.nbias_b16 = h->nbias_b16; hd.nbias = h->nbias; hd.n_in0 = h->n_in0; hd.n_inx = h->n_inx; hd.n_out = h->n_out; hd.n_tvals = n_tvals;
+  hd.payload_bytes = payload;
+  hd.checksum = fnv1a((const uint8_t*)buf + sizeof(EngineHeader), payload);
+  memcpy(buf, &hd, sizeof(hd));
+  return 0;
+}
+
+extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** out) {
+  using namespace pnrf;
+  PNRF_REQUIRE(buf && out, PNRF_E_ARG, "pnrf_mlp_deserialize: null argument");
+  PNRF_REQUIRE(size >= (int64_t)sizeof(EngineHeader), PNRF_E_ARG, "pnrf_mlp_deserialize: %lld bytes is shorter than the header", (long long)size);
+  EngineHeader hd;
+  memcpy(&hd, buf, sizeof(hd));
+  PNRF_REQUIRE(memcmp(hd.magic, ENGINE_MAGIC, 8) == 0, PNRF_E_ARG, "pnrf_mlp_deserialize: not an engine file (bad magic)");
+  PNRF_REQUIRE(hd.format == 1 && hd.abi == PNRF_ABI_VERSION && hd.layout_tag == PNRF_LAYOUT_TAG && hd.slot_bytes == SLOT_BYTES, PNRF_E_STATE,
+               "pnrf_mlp_deserialize: engine written by another build (format %u abi %u layout %08x, this library: 1 %d %08x); export it again",
+               hd.format, hd.abi, hd.layout_tag, PNRF_ABI_VERSION, (unsigned)PNRF_LAYOUT_TAG);
+  PNRF_REQUIRE(hd.net == PNRF_NET_SAMPLER || hd.net == PNRF_NET_REFINE || hd.net == PNRF_NET_NERF || hd.net == PNRF_NET_NERFCLS, PNRF_E_ARG,
+               "pnrf_mlp_deserialize: unknown net kind %d", hd.net);
+  PNRF_REQUIRE(hd.nbias_b16 >= 0 && hd.nbias >= 0 && hd.n_in0 >= 0 && hd.n_inx >= 0 && hd.n_out >= 0 && (hd.n_tvals == 0 || hd.n_tvals == S_KS0 / 3) &&
+                   hd.nslots > 0 && hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
+                   hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20),
+               PNRF_E_ARG, "pnrf_mlp_deserialize: implausible section counts");
+  pnrf_mlp* h = new pnrf_mlp();
+  memset(h, 0, sizeof(*h));
+  h->net = hd.net; h->prec = hd.prec; h->in_dim = hd.in_dim; h->in_dim_x = hd.in_dim_x; h->out_dim = hd.out_dim;
+  h->nslots = hd.nslots; h->nslots_fold = hd.nslots_fold; h->nslots_h16 = hd.nslots_h16; h->nslots_b16 = hd.nslots_b16;
+  h->nbias_b16 = hd.nbias_b16; h->nbias = hd.nbias; h->n_in0 = hd.n_in0; h->n_inx = hd.n_inx; h->n_out = hd.n_out;
+  Section sec[10];
+  const int ns = sections(h, hd.n_tvals, sec);
+  size_t payload = 0;
+  for (int i = 0; i < ns; ++i) payload += sec[i].bytes;
+  const uint8_t* p = (const uint8_t*)buf + sizeof(EngineHeader);
+  if (payload != hd.payload_bytes || (int64_t)(sizeof(EngineHeader) + payload) != size) {
+    set_error("pnrf_mlp_deserialize: truncated or padded engine (%lld bytes, header describes %lld)", (long long)size,
+              (long long)(sizeof(EngineHeader) + payload));
+    delete h;
+    return PNRF_E_ARG;
+  }
+  if (fnv1a(p, payload) != hd.checksum) {
+    set_error("pnrf_mlp_deserialize: checksum mismatch (corrupt engine file)");
+    delete h;
+    return PNRF_E_ARG;
+  }
+  hipError_t e = hipGetDevice(&h->device);
+  for (int i = 0; i < ns && e == hipSuccess; ++i) {
+    if (sec[i].bytes) {
+      e = hipMalloc(sec[i].dptr, sec[i].bytes);
+      if (e == hipSuccess) e = hipMemcpy(*sec[i].dptr, p, sec[i].bytes, hipMemcpyHostToDevice);
+    }
+    p += sec[i].bytes;
+  }
+  if (e != hipSuccess) {
+    set_error("pnrf_mlp_deserialize: device allocation/copy failed: %s", hipGetErrorString(e));
+    pnrf_mlp_free(h);
+    return (int)e;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int* out_dim) {
+  PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_kind: null handle");
+  if (net) *net = h->net;
+  if (in_dim) *in_dim = h->in_dim;
+  if (in_dim_x) *in_dim_x = h->in_dim_x;
+  if (out_dim) *out_dim = h->out_dim;
+  return 0;
+}

@@ -61,6 +61,40 @@ class PackedMLP:
         except Exception:
             pass
 
+    # ---- engine files: the packed stream as bytes (pnrf_mlp_serialize / pnrf_mlp_deserialize)
+    def serialize(self) -> bytes:
+        lib = _lib.load()
+        size = C.c_int64()
+        check(lib.pnrf_mlp_serialize(self.handle, None, 0, C.byref(size)), 'pnrf_mlp_serialize')
+        buf = (C.c_char * size.value)()
+        check(lib.pnrf_mlp_serialize(self.handle, buf, size.value, C.byref(size)), 'pnrf_mlp_serialize')
+        return bytes(buf)
+
+    @classmethod
+    def deserialize(cls, data: bytes, expect_net=None):
+        """New handle on the current device from ``serialize()`` output; ``expect_net`` (NET_*) guards against swapped files."""
+        lib = _lib.load()
+        data = bytes(data)
+        h = C.c_void_p()
+        check(lib.pnrf_mlp_deserialize(data, len(data), C.byref(h)), 'pnrf_mlp_deserialize')
+        self = cls.__new__(cls)
+        self.handle = h
+        net, ind, indx, outd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib.pnrf_mlp_kind(h, C.byref(net), C.byref(ind), C.byref(indx), C.byref(outd)), 'pnrf_mlp_kind')
+        self.net, self.in_dim, self.out_dim = net.value, ind.value, outd.value
+        if expect_net is not None and self.net != expect_net:
+            raise PnrfError(f'engine holds net kind {self.net}, expected {expect_net}')
+        return self
+
+    def save(self, path):
+        with open(path, 'wb') as f:
+            f.write(self.serialize())
+
+    @classmethod
+    def load(cls, path, expect_net=None):
+        with open(path, 'rb') as f:
+            return cls.deserialize(f.read(), expect_net)
+
     def forward(self, x, x_views=None, head_act=False):
         """Output of the last Linear, [m, out_dim]; head_act applies the TRT classes' sigmoid/tanh heads."""
         x = _chk(x, 'x', (self.in_dim,))

@@ -47,23 +47,51 @@ class Renderer:
 
     weights: dict with 'sampler'/'refine'/'nerf' -> {'W': [...], 'b': [...]} (torch layout
     ``W[out,in]``, numpy or torch) — e.g. ``pronerf_amd.synthetic.make_weights`` or the tensors of
-    a checkpoint's state dicts (see ``run_nerf_helpers.weights_from_state_dicts``).
+    a checkpoint's state dicts (see ``run_nerf_helpers.weights_from_state_dicts``); an entry may also be an
+    ``ops.PackedMLP`` (a module's ``packed()``, or one loaded from an engine file).
     """
 
     def __init__(self, weights, max_rays: int, device='cuda:0'):
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise ops.PnrfError('Renderer needs a GPU device (pronerf_amd has no CPU path)')
-        with torch.cuda.device(self.device):
-            self.sampler = ops.PackedMLP(ops.NET_SAMPLER, weights['sampler']['W'], weights['sampler']['b'])
-            self.refine = ops.PackedMLP(ops.NET_REFINE, weights['refine']['W'], weights['refine']['b'])
+        def pack(net, w):
+            if isinstance(w, ops.PackedMLP):                  # already packed (module.packed(), an engine file)
+                if w.net not in net:
+                    raise ops.PnrfError(f'Renderer: packed network of kind {w.net} where one of {net} is needed')
+                return w
             # 8 Linear layers = DoNeRFTRT; 12 = the NeRF class (pts0..7, feature, alpha, views, rgb)
-            nerf_kind = ops.NET_NERFCLS if len(weights['nerf']['W']) == 12 else ops.NET_NERF
-            self.nerf = ops.PackedMLP(nerf_kind, weights['nerf']['W'], weights['nerf']['b'])
+            kind = net[0] if len(net) == 1 else (ops.NET_NERFCLS if len(w['W']) == 12 else ops.NET_NERF)
+            return ops.PackedMLP(kind, w['W'], w['b'])
+        with torch.cuda.device(self.device):
+            self.sampler = pack((ops.NET_SAMPLER,), weights['sampler'])
+            self.refine = pack((ops.NET_REFINE,), weights['refine'])
+            self.nerf = pack((ops.NET_NERF, ops.NET_NERFCLS), weights['nerf'])
             self.ctx = ops.RenderContext(self.sampler, self.refine, self.nerf, max_rays)
         self.img4 = None
         self.proj = None
         self.ref_nos = None
+
+    # ---- engine files (the reference's <export_dir>/*_fp16.trt, pronerf/tensorrt.py:8-14)
+    ENGINE_FILES = {'nerf': 'nerf.pnrf', 'sampler': 'minmaxrays_net.pnrf', 'refine': 'refine_net.pnrf'}
+
+    def save_engines(self, export_dir):
+        import os
+        os.makedirs(export_dir, exist_ok=True)
+        paths = {k: os.path.join(export_dir, f) for k, f in self.ENGINE_FILES.items()}
+        for k, path in paths.items():
+            getattr(self, k).save(path)
+        return paths
+
+    @classmethod
+    def from_engines(cls, export_dir, max_rays: int, device='cuda:0'):
+        import os
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise ops.PnrfError('Renderer needs a GPU device (pronerf_amd has no CPU path)')
+        with torch.cuda.device(dev):
+            packed = {k: ops.PackedMLP.load(os.path.join(export_dir, f)) for k, f in cls.ENGINE_FILES.items()}
+        return cls(packed, max_rays, device)
 
     # ---- per frame (outside the timed region, like run_S_eS_eN_alter_trt.py:281-302)
     def set_views(self, c2w, poses, images_nhwc, K, num_neighbor=NUM_NEIGHBOR):

@@ -69,11 +69,12 @@ def _renderer(min_max_ray_net, refine_net, network_fine, n_rays, device):
         if not hasattr(m, 'weights'):
             raise PnrfError(f'render_rays: expected a pronerf_amd.run_nerf_helpers.{cls.__name__}, got {type(m).__name__}')
     key = tuple(id(m) for m in mods)
-    ver = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+    packed = [m.packed() for m in mods]              # from the parameters, or the engine file loaded into the module
+    ver = tuple(id(p) for p in packed)               # the cached Renderer keeps these objects alive, so ids are not reused
     ent = _RENDERERS.get(key)
     if ent is None or ent[0] != ver or ent[1].ctx.max_rays < n_rays or ent[1].device != device:
         cap = max(n_rays, ent[1].ctx.max_rays if ent else 0)
-        _RENDERERS[key] = ent = (ver, Renderer(weights_from_modules(*mods), max_rays=cap, device=device))
+        _RENDERERS[key] = ent = (ver, Renderer(dict(zip(('sampler', 'refine', 'nerf'), packed)), max_rays=cap, device=device))
     return ent[1]
 
 
@@ -108,8 +109,11 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
     homogeneous rays from ray_batch / or_ray_batch, of which they are pure functions,
     trt.py:250-277).  Returns ``{'rgb_map0', 'rgb_map1', 'depth_map'}``.
     """
-    if kwargs.get('use_trt'):
-        raise PnrfError('render_rays(use_trt=True): TensorRT engines do not exist on ROCm; the fused HIP path is used with use_trt=False')
+    if kwargs.get('use_trt'):                                # engines = engine files loaded into the modules (no TensorRT on ROCm)
+        for m in (min_max_ray_net, refine_net, network_fine):
+            if getattr(m, 'engine_path', None) is None:
+                raise PnrfError(f'render_rays(use_trt=True): {type(m).__name__} has no engine file loaded (module.load_engine(path), '
+                                'written by --export_only / save_engine); with use_trt=False the parameters are packed on first use')
     num_neighbor = kwargs['num_neighbor']
     if N_samples != 8 or num_neighbor != 4 or N_point_ray_enc not in (0, 48):
         raise PnrfError(f'render_rays: kernels are built for N_samples=8, num_neighbor=4, N_point_ray_enc=48 '
@@ -164,6 +168,38 @@ def create_nerf(args, device='cuda'):
           'embed_rays': Pluecker(), 'embed_fn': embed_fn, 'embeddirs_fn': embeddirs_fn, 'num_neighbor': args.num_neighbor,
           'use_trt': False, 'randomize': False, 'count_flops': False}
     return kw, start
+
+
+def engine_paths(export_dir, args=None):
+    """Engine files of one experiment (pronerf/tensorrt.py:8-14 ``expected_engine_paths``), with the per-net overrides of the
+    script's ``--*_engine_path`` options."""
+    out = {'nerf': os.path.join(export_dir, 'nerf.pnrf'), 'sampler': os.path.join(export_dir, 'minmaxrays_net.pnrf'),
+           'refine': os.path.join(export_dir, 'refine_net.pnrf')}
+    for key, opt in (('nerf', 'nerf_engine_path'), ('sampler', 'mm_engine_path'), ('refine', 'refine_engine_path')):
+        v = getattr(args, opt, None) if args is not None else None
+        if v not in (None, 'None'):
+            out[key] = v
+    return out
+
+
+def load_fine_engine(model_fine, path, args, device):
+    """Load the fine-network engine; it may hold either fine class (a checkpoint saved by the stage-2 trainer exports a ``NeRF``-class
+    engine), so the module is swapped to the class the file was written from."""
+    try:
+        model_fine.load_engine(path)
+        return model_fine
+    except PnrfError as e:
+        if 'expected' not in str(e):
+            raise
+    embed_ch = get_embedder(args.multires, getattr(args, 'i_embed', 0))[1]
+    views_ch = get_embedder(args.multires_views, getattr(args, 'i_embed', 0))[1]
+    if isinstance(model_fine, DoNeRFTRT):
+        other = NeRF(D=args.netdepth, W=args.netwidth, input_ch=embed_ch, input_ch_views=views_ch, output_ch=4, skips=[4], use_viewdirs=True)
+    else:
+        other = DoNeRFTRT(D=args.netdepth, W=args.netwidth, n_in=embed_ch + views_ch, n_out=4, skip='auto')
+    other = other.to(device)
+    other.load_engine(path)
+    return other
 
 
 # ------------------------------------------------------------------------------------ render_path
@@ -254,15 +290,30 @@ def train(argv=None, device='cuda'):
     write PNGs + PSNR.  Returns the ``render_kwargs`` dict (per-frame milliseconds in ``render_ms``, PSNRs in ``psnrs``).
 
     Deviations, all from SURVEY.md Appendix B: ``load_llff_data_infer`` gets ``num_neighbor=None`` like the reference's call
-    (B-2), which here ranks all training views instead of raising; no ONNX export side effect (B-4); ``--use_trt`` raises."""
+    (B-2), which here ranks all training views instead of raising; no ONNX export side effect (B-4).
+
+    Engines: where the reference exports ONNX and runs serialized TensorRT engines, this build has engine files holding the packed
+    weight stream (``pnrf_mlp_serialize``).  ``--export_only`` writes ``nerf.pnrf``, ``minmaxrays_net.pnrf`` and ``refine_net.pnrf``
+    into ``<basedir>/<expname>`` (the directory of the reference's ``*_fp16.trt`` files, :497-499) and returns before rendering
+    (:768-770); ``--use_trt`` loads the three networks from those files (or from ``--nerf_engine_path`` / ``--mm_engine_path`` /
+    ``--refine_engine_path``) instead of packing the checkpoint — ``--ft_path`` is then not needed."""
     from .load_llff import load_llff_data_infer
     args = config_parser().parse_args(argv)
     if args.dataset_type != 'llff':
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
-    if args.use_trt:
-        raise PnrfError('--use_trt: TensorRT does not exist on ROCm; the fused HIP path is the engine')
     if args.no_ndc or args.lindisp:
         raise PnrfError('--no_ndc / --lindisp: the HIP path is built for forward-facing scenes in NDC with samples linear in depth (the LLFF configs)')
+    out_root = os.path.join(args.basedir, args.expname or 'pronerf')
+    if args.export_only:                                       # :768-770; needs the checkpoint only, so it runs before the scene is read
+        os.makedirs(out_root, exist_ok=True)
+        kw, _ = create_nerf(args, device=device)
+        engines = engine_paths(out_root, args)
+        kw['min_max_ray_net'].save_engine(engines['sampler'])
+        kw['refine_net'].save_engine(engines['refine'])
+        kw['network_fine'].save_engine(engines['nerf'])
+        kw['engine_paths'] = engines
+        print('Exported engine files; export_only requested, skipping render:', ', '.join(engines[k] for k in ('nerf', 'sampler', 'refine')))
+        return kw
     images, poses, bds, render_poses, i_test, i_ref = load_llff_data_infer(args.datadir, args.factor, recenter=True, bd_factor=.75,
                                                                             spherify=args.spherify)
     hwf = poses[0, :3, -1]
@@ -273,12 +324,18 @@ def train(argv=None, device='cuda'):
     near, far = (float(bds.min()) * .9, float(bds.max())) if args.no_ndc else (0., 1.)    # :731-738
     H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)  # :746-751
-    out_root = os.path.join(args.basedir, args.expname or 'pronerf')
     os.makedirs(out_root, exist_ok=True)
     with open(os.path.join(out_root, 'args.txt'), 'w') as f:                                 # :757-761
         for k in sorted(vars(args)):
             f.write('{} = {}\n'.format(k, getattr(args, k)))
     kw, start = create_nerf(args, device=device)
+    if args.use_trt:                                                                          # :490-499
+        engines = engine_paths(out_root, args)
+        kw['network_fine'] = load_fine_engine(kw['network_fine'], engines['nerf'], args, device)
+        kw['min_max_ray_net'].load_engine(engines['sampler'])
+        kw['refine_net'].load_engine(engines['refine'])
+        kw['engine_paths'] = engines
+        kw['use_trt'] = True
     kw.update({'near': near, 'far': far, 'images': images[i_ref], 'poses': poses[i_ref], 'ref_K': K})   # :773-787
     if args.max_images is not None:
         i_test = i_test[:args.max_images]

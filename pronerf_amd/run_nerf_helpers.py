@@ -85,13 +85,14 @@ class Pluecker(nn.Module):
 class _PackedNet(nn.Module):
     """nn.Linear parameters + a lazily refreshed packed copy for the MFMA kernels."""
     _NET = None
+    engine_path = None          # set while the packed copy comes from an engine file (load_engine)
 
     def _linears(self):
         raise NotImplementedError
 
     def packed(self) -> ops.PackedMLP:
         lins = self._linears()
-        key = tuple((p.data_ptr(), p._version) for l in lins for p in (l.weight, l.bias))
+        key = self._param_key()
         if getattr(self, '_pack_key', None) != key:
             dev = lins[0].weight.device
             if dev.type != 'cuda':
@@ -100,7 +101,28 @@ class _PackedNet(nn.Module):
             with torch.cuda.device(dev):
                 self._packed = ops.PackedMLP(self._NET, [l.weight for l in lins], [l.bias for l in lins])
             self._pack_key = key
+            self.engine_path = None
         return self._packed
+
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for l in self._linears() for p in (l.weight, l.bias))
+
+    def save_engine(self, path):
+        """Write the packed weight stream of the current parameters to ``path`` — this build's counterpart of the reference's
+        serialized TensorRT engine (pronerf/cli.py:131-156)."""
+        self.packed().save(path)
+
+    def load_engine(self, path):
+        """Use the engine file at ``path`` instead of packing the parameters (the reference's ``NeRFEngine(path)`` etc.,
+        run_S_eS_eN_alter_trt.py:497-499).  The nn.Linear parameters are left alone and no longer describe what runs; the engine
+        stays in use until they are next modified (``load_state_dict``, an optimizer step), which repacks from them."""
+        dev = self._linears()[0].weight.device
+        if dev.type != 'cuda':
+            raise PnrfError(f'{type(self).__name__}: move the module to the GPU before load_engine (pronerf_amd has no CPU path)')
+        with torch.cuda.device(dev):
+            self._packed = ops.PackedMLP.load(path, expect_net=self._NET)
+        self._pack_key = self._param_key()
+        self.engine_path = path
 
     def weights(self):
         lins = self._linears()

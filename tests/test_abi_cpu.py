@@ -46,6 +46,22 @@ def test_argument_errors_are_reported(lib):
     assert lib.pnrf_posenc_fwd(None, None, 0, 10, None) == 0      # empty input is a no-op
 
 
+def test_engine_images_are_validated_before_any_device_work(lib):
+    """pnrf_mlp_deserialize refuses short / foreign / inconsistent images on the host (no GPU here, so reaching hipMalloc would fail
+    differently); pnrf_mlp_serialize refuses null arguments."""
+    import ctypes as C
+    import struct
+    h = C.c_void_p()
+    assert lib.pnrf_mlp_deserialize(b'x' * 16, 16, C.byref(h)) == -1 and b'shorter than the header' in lib.pnrf_last_error()
+    assert lib.pnrf_mlp_deserialize(b'\0' * 128, 128, C.byref(h)) == -1 and b'bad magic' in lib.pnrf_last_error()
+    hdr = b'PNRFENG\0' + struct.pack('<IIII', 99, 1, 0, 16384) + b'\0' * 104
+    assert lib.pnrf_mlp_deserialize(hdr, 128, C.byref(h)) == -3 and b'another build' in lib.pnrf_last_error()
+    assert not h.value
+    size = C.c_int64()
+    assert lib.pnrf_mlp_serialize(None, None, 0, C.byref(size)) == -1
+    assert lib.pnrf_mlp_kind(None, None, None, None, None) == -1
+
+
 def test_cpu_tensors_are_refused():
     from pronerf_amd import ops, _lib
     with pytest.raises(_lib.PnrfError):

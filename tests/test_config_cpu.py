@@ -76,10 +76,12 @@ def test_cli_subcommands_map_to_driver_arguments():
     assert cli.infer_argv(ns) == ['--config', 'c.txt', '--ft_path', 'y.tar', '--render_test', '--max_images', '2']
     ns = p.parse_args(['eval', '--checkpoint', 'y.tar'])
     assert ns.func is cli._eval and ns.config.endswith('fern_trt.txt')
-    with pytest.raises(SystemExit) as e:
-        cli.main(['export-trt'])
-    assert 'ROCm' in str(e.value)
+    ns = p.parse_args(['export-trt', '--config', 'c.txt', '--checkpoint', 'y.tar', '--onnx-only', '--height', '378', '--', '--expname', 'e'])
+    assert ns.func is cli._export_trt and cli.export_argv(ns) == ['--config', 'c.txt', '--export_only', '--ft_path', 'y.tar', '--expname', 'e']
+    ns = p.parse_args(['infer', '--use-trt'])
+    assert cli.infer_argv(ns)[-1] == '--use_trt'
     # every driver accepts what the CLI hands it
     for variant, argv in (('base', ['--max_steps', '5', '--N_rand', '1024']), ('refine2', ['--pretrain_path', 'x.tar', '--no_reload']),
-                          ('trt', ['--ft_path', 'y.tar', '--render_test', '--max_images', '2'])):
+                          ('trt', ['--ft_path', 'y.tar', '--render_test', '--max_images', '2']),
+                          ('trt', ['--export_only', '--use_trt', '--nerf_engine_path', 'n.pnrf', '--mm_engine_path', 'm.pnrf', '--refine_engine_path', 'r.pnrf'])):
         config_parser(variant).parse_args(argv)
