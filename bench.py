@@ -47,39 +47,13 @@ PEAK_F32 = 157.3       # TFLOP/s, f32-input MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10, help='the chip needs ~5 frames from idle to its steady clock')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (rank 0, N=1)')
     ap.add_argument('--cpu-sample-rays', type=int, default=16384)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
                     'the multi-rank path with several ranks sharing one GPU)')
     return ap.parse_args()
-
-
-def stage_profile(rend, rays, or_rays, reps=5):
-    """Per-kernel durations with HIP events on the launch stream (torch's current stream is the
-    stream the C ABI launches on).  Returns {kernel: ms}."""
-    from pronerf_amd import ops
-    n = rays.shape[0]
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    acc = {'sampler_kernel': 0.0, 'refine_input_kernel': 0.0, 'refine_kernel': 0.0, 'nerf_kernel': 0.0}
-    for it in range(reps + 1):
-        e = [ev() for _ in range(5)]
-        e[0].record()
-        depth, _, add, mul, _, _ = ops.sampler_fwd(rend.sampler, rays, want_idx=False, want_rgb=False)
-        e[1].record()
-        rin = ops.refine_input(rays, or_rays, depth, rend.img4, rend.proj)
-        e[2].record()
-        z, pts = ops.refine_fwd(rend.refine, rin, rays, depth)
-        e[3].record()
-        rgbd, _ = ops.nerf_fwd(rend.nerf, pts, rays, z, add, mul)
-        e[4].record()
-        torch.cuda.synchronize()
-        if it == 0:
-            continue          # warm-up
-        for k, (a, b) in zip(acc, zip(e[:-1], e[1:])):
-            acc[k] += a.elapsed_time(b) / reps
-    return acc
 
 
 def host_cores():
@@ -219,11 +193,17 @@ def main():
     dbg('warm-up issued')
     fence()
     dbg('warm-up done')
+    # per-kernel durations over the timed region itself: the library records a HIP event before / after each of the four
+    # kernels of a frame on the launch stream (pnrf_ctx_profile_begin), five event records per frame, read after the region
+    PROF_FRAMES = 256
+    if world == 1:
+        rend.ctx.profile_begin(min(args.steps, PROF_FRAMES))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    prof, prof_frames = rend.ctx.profile_end() if world == 1 else (None, 0)
     dbg(f'timed region done: {dt:.3f}s')
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -254,7 +234,6 @@ def main():
             'e2e_mfma_tflops': value * FLOP_PER_RAY / 1e12,
         }
         if world == 1:
-            prof = stage_profile(rend, rays, or_rays)
             flops = {'sampler_kernel': 2 * MAC_SAMPLER, 'refine_kernel': 2 * MAC_REFINE, 'nerf_kernel': 2 * MAC_NERF}
             # the sampler's algorithmic FLOPs are priced against the peak of the MFMA dtype it runs on (f16 = bf16 rate)
             peaks = {'sampler_kernel': PEAK_F32 if sampler_f32 else PEAK_BF16, 'refine_kernel': PEAK_BF16, 'nerf_kernel': PEAK_BF16}
@@ -267,7 +246,8 @@ def main():
             dom = max(flops, key=lambda k: prof[k])
             res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
                                'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': pmc_traffic(dom),
-                               'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total}
+                               'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
+                               'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
             res['kernels'] = kern
             if not args.no_cpu_baseline:
                 res['cpu_baseline'] = cpu_baseline(weights, scene, args.cpu_sample_rays)

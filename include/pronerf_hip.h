@@ -195,6 +195,13 @@ int pnrf_ctx_free(pnrf_ctx_t* ctx);
 int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_rays,
                          const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
                          float* rgbd, int64_t* sort_idx, int64_t n, void* stream);
+/* Per-stage device time of pnrf_render_rays_fwd (what the reference gets from line_profiler / the cuda events around
+ * render(), run_S_eS_eN_alter_trt.py:327-332, at frame granularity): after _begin, the next max_frames calls on this
+ * context record an event before and after each of the four stages on the caller's stream; _end waits for the last
+ * recorded call and returns the mean milliseconds ms[4] = {sampler, refine input (projection), refine, NeRF + compositing}
+ * over *frames calls.  Recording costs five event records per call and changes no result. */
+int pnrf_ctx_profile_begin(pnrf_ctx_t* ctx, int max_frames);
+int pnrf_ctx_profile_end(pnrf_ctx_t* ctx, float* ms, int* frames);
 
 /* ---- stage-2 training step --------------------------------------------------
  * fp32 throughout, like the reference's training.  Layer products are rocBLAS GEMMs inside the library; every other

@@ -54,6 +54,8 @@ SIGNATURES = {
     'pnrf_ctx_create': (_i, [_p, _p, _p, _i64, C.POINTER(_p)]),
     'pnrf_ctx_free': (_i, [_p]),
     'pnrf_render_rays_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
+    'pnrf_ctx_profile_begin': (_i, [_p, _i]),
+    'pnrf_ctx_profile_end': (_i, [_p, C.POINTER(C.c_float), C.POINTER(_i)]),
     'pnrf_linspace': (_i, [_f, _f, _i, C.POINTER(_f)]),
     # stage-2 training step
     'pnrf_composite_bwd': (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),

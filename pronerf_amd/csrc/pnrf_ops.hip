@@ -646,7 +646,21 @@ struct pnrf_ctx {
   int64_t max_rays;
   float* ws;             // one allocation: depth[8] add[8] mul[8] refine_in[144] z[8] pts[24] per ray
   int device;
+  // per-stage timing (pnrf_ctx_profile_begin / _end): 5 events per profiled call, recorded on the caller's stream
+  hipEvent_t* ev;
+  int prof_cap, prof_n;
+  bool prof_on;
 };
+static constexpr int PROF_EVENTS = 5;
+static constexpr int PROF_MAX_FRAMES = 4096;
+
+static void profile_release(pnrf_ctx* c) {
+  if (c->ev) {
+    for (int i = 0; i < c->prof_cap * PROF_EVENTS; ++i) (void)hipEventDestroy(c->ev[i]);
+    delete[] c->ev;
+  }
+  c->ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_on = false;
+}
 static constexpr int WS_FLOATS_PER_RAY = 8 + 8 + 8 + 144 + 8 + 24;
 
 extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refine, const pnrf_mlp_t* nerf, int64_t max_rays, pnrf_ctx_t** out) {
@@ -655,6 +669,7 @@ extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refi
                PNRF_E_ARG, "pnrf_ctx_create: handles must be (sampler, refine, nerf | nerf-class)");
   pnrf_ctx* c = new pnrf_ctx();
   c->sampler = sampler; c->refine = refine; c->nerf = nerf; c->max_rays = max_rays; c->ws = nullptr;
+  c->ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_on = false;
   hipError_t e = hipGetDevice(&c->device);
   if (e == hipSuccess) e = hipMalloc((void**)&c->ws, (size_t)max_rays * WS_FLOATS_PER_RAY * sizeof(float));
   if (e != hipSuccess) {
@@ -669,6 +684,7 @@ extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refi
 extern "C" int pnrf_ctx_free(pnrf_ctx_t* c) {
   if (!c) return 0;
   if (c->ws) (void)hipFree(c->ws);
+  profile_release(c);
   delete c;
   return 0;
 }
@@ -687,9 +703,60 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
   float* z = rin + c->max_rays * 144;
   float* pts = z + c->max_rays * 8;
   int rc;
+  hipEvent_t* ev = (c->prof_on && c->prof_n < c->prof_cap) ? c->ev + (size_t)c->prof_n * PROF_EVENTS : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (ev) PNRF_HIP(hipEventRecord(ev[0], st));
   if ((rc = pnrf_sampler_fwd(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, stream))) return rc;   // trt.py:628-635
+  if (ev) PNRF_HIP(hipEventRecord(ev[1], st));
   if ((rc = pnrf_refine_input_fwd(rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, rin, n, stream))) return rc;      // :637-661
+  if (ev) PNRF_HIP(hipEventRecord(ev[2], st));
   if ((rc = pnrf_refine_fwd(c->refine, rin, rays, depth, z, pts, n, stream))) return rc;                               // :668-681
+  if (ev) PNRF_HIP(hipEventRecord(ev[3], st));
   if ((rc = pnrf_nerf_fwd(c->nerf, pts, rays, z, add, mul, rgbd, nullptr, n, stream))) return rc;                      // :691-694
+  if (ev) {
+    PNRF_HIP(hipEventRecord(ev[4], st));
+    c->prof_n += 1;
+  }
+  return 0;
+}
+
+extern "C" int pnrf_ctx_profile_begin(pnrf_ctx_t* c, int max_frames) {
+  PNRF_REQUIRE(c && max_frames > 0 && max_frames <= PROF_MAX_FRAMES, PNRF_E_ARG, "pnrf_ctx_profile_begin: need a context and 1..%d frames", PROF_MAX_FRAMES);
+  if (max_frames > c->prof_cap) {
+    profile_release(c);
+    c->ev = new hipEvent_t[(size_t)max_frames * PROF_EVENTS];
+    for (int i = 0; i < max_frames * PROF_EVENTS; ++i) {
+      hipError_t e = hipEventCreate(&c->ev[i]);
+      if (e != hipSuccess) {
+        for (int j = 0; j < i; ++j) (void)hipEventDestroy(c->ev[j]);
+        delete[] c->ev;
+        c->ev = nullptr;
+        set_error("pnrf_ctx_profile_begin: hipEventCreate failed: %s", hipGetErrorString(e));
+        return (int)e;
+      }
+    }
+    c->prof_cap = max_frames;
+  }
+  c->prof_n = 0;
+  c->prof_on = true;
+  return 0;
+}
+
+extern "C" int pnrf_ctx_profile_end(pnrf_ctx_t* c, float* ms, int* frames) {
+  PNRF_REQUIRE(c && ms && frames, PNRF_E_ARG, "pnrf_ctx_profile_end: null argument");
+  PNRF_REQUIRE(c->prof_on, PNRF_E_STATE, "pnrf_ctx_profile_end: no pnrf_ctx_profile_begin before it");
+  c->prof_on = false;
+  *frames = c->prof_n;
+  for (int k = 0; k < PROF_EVENTS - 1; ++k) ms[k] = 0.f;
+  if (c->prof_n == 0) return 0;
+  PNRF_HIP(hipEventSynchronize(c->ev[(size_t)c->prof_n * PROF_EVENTS - 1]));
+  double acc[PROF_EVENTS - 1] = {0, 0, 0, 0};
+  for (int i = 0; i < c->prof_n; ++i)
+    for (int k = 0; k < PROF_EVENTS - 1; ++k) {
+      float t = 0.f;
+      PNRF_HIP(hipEventElapsedTime(&t, c->ev[(size_t)i * PROF_EVENTS + k], c->ev[(size_t)i * PROF_EVENTS + k + 1]));
+      acc[k] += t;
+    }
+  for (int k = 0; k < PROF_EVENTS - 1; ++k) ms[k] = (float)(acc[k] / c->prof_n);
   return 0;
 }

@@ -320,6 +320,19 @@ class RenderContext:
         except Exception:
             pass
 
+    STAGES = ('sampler_kernel', 'refine_input_kernel', 'refine_kernel', 'nerf_kernel')
+
+    def profile_begin(self, max_frames=64):
+        """Record per-stage events on the next ``max_frames`` render_rays calls (pnrf_ctx_profile_begin)."""
+        check(_lib.load().pnrf_ctx_profile_begin(self.handle, int(max_frames)), 'pnrf_ctx_profile_begin')
+
+    def profile_end(self):
+        """-> ({stage: mean ms}, frames recorded); waits for the last recorded call."""
+        ms = (C.c_float * 4)()
+        frames = C.c_int()
+        check(_lib.load().pnrf_ctx_profile_end(self.handle, ms, C.byref(frames)), 'pnrf_ctx_profile_end')
+        return dict(zip(self.STAGES, (float(v) for v in ms))), frames.value
+
     def render_rays(self, rays, or_rays, img4, proj, eps=1e-5, want_idx=False, out=None):
         rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,))
         img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))

@@ -104,3 +104,30 @@ def test_empty_and_ragged(dev):
     with pytest.raises(_lib.PnrfError):
         big = torch.zeros(301, 11, device=dev)
         rend.render_rays(big, big)
+
+
+def test_stage_timing_of_the_fused_path(dev):
+    """pnrf_ctx_profile_begin / _end: events around the four kernels of the next calls; results untouched, bounded by the wall clock."""
+    import time
+    from pronerf_amd.ops import PnrfError
+    from pronerf_amd.render import Renderer
+    scene = synth.make_scene(0, H=96, W=128, rotate=True)
+    rend = Renderer(synth.make_weights(0, 'trained'), max_rays=96 * 128, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, orr = rend.frame_rays(scene['K'], scene['c2w'], 96, 128)
+    ref = rend.render_rays(rays, orr)[0].clone()
+    with pytest.raises(PnrfError, match='profile_begin'):
+        rend.ctx.profile_end()
+    rend.ctx.profile_begin(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):                                   # only the first 3 calls are recorded
+        out = rend.render_rays(rays, orr)[0]
+    ms, frames = rend.ctx.profile_end()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    assert frames == 3 and list(ms) == ['sampler_kernel', 'refine_input_kernel', 'refine_kernel', 'nerf_kernel']
+    assert all(v > 0 for v in ms.values()) and 3 * sum(ms.values()) < wall_ms
+    assert torch.equal(out, ref)
+    rend.ctx.profile_begin(2)                            # re-arm with a smaller window; nothing rendered -> zero frames
+    assert rend.ctx.profile_end() == ({k: 0.0 for k in ms}, 0)
