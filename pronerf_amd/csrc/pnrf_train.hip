@@ -163,6 +163,82 @@ __global__ __launch_bounds__(256) void dw_splitk_kernel(const float* __restrict_
         if (m < out && n < in) p[(size_t)m * in + n] = acc[i][j][e];
       }
 }
+// 128 x 128 tiles for the square hidden layers: each workgroup reads its row range of dZ and X half as often as with 64 x 64 tiles
+// (the kernel is bound by those reads: 16 FLOP per byte at 64 x 64), and an operand fetch is one ds_read_b128 per four MFMAs.
+// Wave (wm, wn) owns 64 x 64 as 4 x 4 MFMA tiles; a lane's four columns 16 i + c16 of its 64-column span sit side by side in LDS
+// (position 4 c16 + i), rows are 128 floats apart: the b128 reads of the four row groups of a wave hit disjoint banks.
+// Requires out, in multiples of 128 and 16-byte aligned rows (ldz, ldx multiples of 4).
+constexpr int DW128_ROWS = 32, DW128_MAX_SPLITS = 128;
+__global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
+                                                           float* __restrict__ part, int out, int in, int64_t R, int64_t rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float sAB[2][2][DW128_ROWS * 128];     // [buffer][A | B]: double buffered, one barrier per row block
+  const int tiles_n = in / 128;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, q = lane >> 4;
+  const int64_t r_begin = blockIdx.y * rows_per_split;
+  const int64_t r_end = (r_begin + rows_per_split < R) ? r_begin + rows_per_split : R;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // loader: thread = 4 consecutive columns (float4) of rows lr, lr + 8, lr + 16, lr + 24
+  const int lcol = (threadIdx.x & 31) * 4, lr = threadIdx.x >> 5;
+  const int lpos = (lcol & 64) + 4 * (lcol & 15) + ((lcol & 63) >> 4);        // LDS position of column lcol; columns lcol + e sit 4 e further
+  const float* gA = dZ + (size_t)tm * 128 + lcol;
+  const float* gB = X + (size_t)tn * 128 + lcol;
+  f32x4_t pa[DW128_ROWS / 8], pb[DW128_ROWS / 8];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int k = 0; k < DW128_ROWS / 8; ++k) {
+      const int64_t r = r0 + lr + 8 * k;
+      if (r < r_end) {
+        pa[k] = *(const f32x4_t*)(gA + r * ldz);
+        pb[k] = *(const f32x4_t*)(gB + r * ldx);
+      } else {
+        pa[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        pb[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  fetch(r_begin);
+  int buf = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += DW128_ROWS, buf ^= 1) {
+    // the block before last was read from this buffer; every wave has passed the barrier of the last block since, so it is free
+    float* sA = sAB[buf][0];
+    float* sB = sAB[buf][1];
+#pragma unroll
+    for (int k = 0; k < DW128_ROWS / 8; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sA[(lr + 8 * k) * 128 + lpos + 4 * e] = pa[k][e];
+        sB[(lr + 8 * k) * 128 + lpos + 4 * e] = pb[k][e];
+      }
+    __syncthreads();
+    if (r0 + DW128_ROWS < r_end) fetch(r0 + DW128_ROWS);
+#pragma unroll
+    for (int kk = 0; kk < DW128_ROWS / 4; ++kk) {
+      const f32x4_t a = *(const f32x4_t*)(sA + (4 * kk + q) * 128 + wm * 64 + 4 * c16);
+      const f32x4_t b = *(const f32x4_t*)(sB + (4 * kk + q) * 128 + wn * 64 + 4 * c16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* p = part + (size_t)blockIdx.y * out * in;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = tm * 128 + wm * 64 + 16 * i + 4 * q + e, n = tn * 128 + wn * 64 + 16 * j + c16;
+        p[(size_t)m * in + n] = acc[i][j][e];
+      }
+}
 __global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int64_t numel, float* __restrict__ dW) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -581,6 +657,25 @@ int gemm_dx(pnrf_trainer* t, const float* dY, int ldy, const float* W, int in, i
 }
 // dW[out,in] = dY^T X  (dw_splitk_kernel + dw_reduce_kernel)
 int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R, hipStream_t s) {
+  static const int use128 = [] { const char* e = getenv("PNRF_DW_TILE"); return (e && atoi(e) == 64) ? 0 : 1; }();
+  static const int64_t dw128_min_rows = [] { const char* e = getenv("PNRF_DW128_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)65536; }();
+  if (use128 && out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)dY & 15) == 0 && R >= dw128_min_rows) {
+    const int tiles = (out / 128) * (in / 128);
+    int64_t splits = (512 + tiles - 1) / tiles;                 // two workgroups per CU
+    const int64_t by_rows = R / 256;
+    if (splits > by_rows) splits = by_rows;
+    if (splits > DW128_MAX_SPLITS) splits = DW128_MAX_SPLITS;
+    if (splits < 1) splits = 1;
+    int64_t rows_per = (R + splits - 1) / splits;
+    rows_per = (rows_per + DW128_ROWS - 1) / DW128_ROWS * DW128_ROWS;
+    splits = (R + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dY, ldy, X, ldx, t->dw_part, out, in, R, rows_per);
+    PNRF_LAUNCH_CHECK();
+    const int64_t numel = (int64_t)out * in;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel)), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW);
+    PNRF_LAUNCH_CHECK();
+    return 0;
+  }
   const int tiles = ((out + DW_TILE - 1) / DW_TILE) * ((in + DW_TILE - 1) / DW_TILE);
   // enough workgroups for 4 per CU (they hide each other's load latency), at least 128 rows per split, at most DW_MAX_SPLITS partials
   int64_t splits = (1024 + tiles - 1) / tiles;
@@ -737,14 +832,14 @@ extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b,
   T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
-  T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->dw_part, (size_t)DW_MAX_SPLITS * 256 * 320); T_ALLOC(t->loss, 4);
+  T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->dw_part, std::max((size_t)DW_MAX_SPLITS * 256 * 320, (size_t)DW128_MAX_SPLITS * 256 * 256)); T_ALLOC(t->loss, 4);
   *out = t;
   return 0;
 }
 
 extern "C" int pnrf_trainer_free(pnrf_trainer_t* t) {
   if (!t) return 0;
-  for (void* p : t->allocs) hipFree(p);
+  for (void* p : t->allocs) (void)hipFree(p);
   if (t->blas) rocblas_destroy_handle(t->blas);
   delete t;
   return 0;

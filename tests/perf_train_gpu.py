@@ -18,6 +18,7 @@ from oracle import pronerf_oracle as orc   # noqa: E402  (baseline leg only)
 from pronerf_amd import ops, synthetic     # noqa: E402
 
 dev = torch.device('cuda:0')
+HIP_ONLY = '--hip-only' in sys.argv        # skip the eager legs (for rocprofv3 runs)
 H, W, NV, N = 756, 1008, 17, 4096
 scene = synthetic.make_scene(0, H=H, W=W, n_views=NV, sigma_t=0.2, rotate=True, focal=815.13)
 w = synthetic.make_weights(0, 'trained'); w['nerfcls'] = synthetic.make_nerfcls_weights(0, head_scale=0.3)
@@ -76,8 +77,37 @@ def eager_step():
     opt.step()
 
 
-eager_ms, eager_wall = timed(eager_step, 10, 2)
+eager_ms, eager_wall = timed(eager_step, 10, 2) if not HIP_ONLY else (float('nan'), float('nan'))
+
+# stage-1 odd iteration (config 5): NeRF-only step on 8*n_mult explored samples per ray (run_S_eS_eN_alter_base.py:689-729, 929-944)
+torch.set_default_device('cpu')
+explore = {}
+opt_n = torch.optim.Adam([p for pair in tl[14:] for p in pair], lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-8)
+for n_mult in (1, 4, 8):
+    S = 8 * n_mult
+    jit = torch.from_numpy(np.minimum(np.abs(rs.randn(N, S)) / 5, 0.99).astype(np.float32))
+    tr_x = ops.Trainer([W_ for W_, _ in layers], [b for _, b in layers], max_rays=N, device=dev, max_samples=S)
+    jd = cu(jit)
+
+    def hip_x():
+        tr_x.explore_fwd_bwd(*args, n_mult=n_mult, dir1=1, jitter=jd, dir2=-1, raw_noise=None, want_rgb=False)
+        tr_x.adam_step(5e-4, weight_decay=5e-8, nerf_only=True)
+
+    hx_ms, hx_wall = timed(hip_x, 20, 3)
+    torch.set_default_device(dev)
+
+    def eager_x():
+        opt_n.zero_grad()
+        loss, _, _ = orc.stage1_loss(tl, gi['rays'], gi['or_rays'], gi['target'], gi['images'], gi['poses'], gi['K'], gi['ref_nos'], False, n_mult=n_mult,
+                                     dir1=1, jitter=jd, dir2=-1)
+        loss.backward()
+        opt_n.step()
+
+    ex_ms, ex_wall = timed(eager_x, 5, 1) if not HIP_ONLY else (float('nan'), float('nan'))
+    torch.set_default_device('cpu')
+    explore[S] = {'hip_ms': round(hx_wall, 3), 'eager_ms': round(ex_wall, 3), 'speedup': round(ex_wall / hx_wall, 2)}
+    del tr_x
 print(json.dumps({'workload': 'stage-2 training iteration, 4096 rays, 17 views 756x1008, 8 samples, NeRF-class fine net, fp32',
                   'hip_trainer_ms': round(hip_ms, 3), 'hip_trainer_wall_ms': round(hip_wall, 3), 'eager_torch_gpu_ms': round(eager_ms, 3),
                   'eager_torch_gpu_wall_ms': round(eager_wall, 3), 'speedup': round(eager_wall / hip_wall, 2),
-                  'rays_per_s_hip': round(N / (hip_wall * 1e-3))}))
+                  'rays_per_s_hip': round(N / (hip_wall * 1e-3)), 'stage1_explore_by_samples_per_ray': explore}))

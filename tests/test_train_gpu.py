@@ -3,6 +3,7 @@ forward functions, then the whole step (loss, the gradients of all 26 Linear lay
 ``loss.backward()`` + ``torch.optim.Adam``, and against goldens from the reference's own training iteration.
 Tolerances: everything is fp32; differences are summation order (rocBLAS vs CPU BLAS) -> relative L2 error per tensor."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -487,3 +488,25 @@ def test_resume_and_reference_optimizer_state_import(dev, tmp_path):
     assert float(v6.max()) > 0 and bool((v9 >= 0.996 * v6).all())
     tr3, _ = s2.train(['--config', str(cfg), '--max_steps', '1', '--no_reload'], device=dev)     # --no_reload starts again from the stage-1 weights
     assert torch.load(str(tmp_path / 'logs' / 'rs' / '000001.tar'), map_location='cpu')['global_step'] == 1
+
+
+def test_weight_gradient_kernels_agree(dev, tmp_path):
+    """dW = dY^T X has two split-K MFMA kernels (64 x 64 tiles; 128 x 128 tiles for the square hidden layers on many rows).  The
+    library picks per call by shape and row count, so the same batch is run in two processes, once with each kernel forced for the
+    256 x 256 layers: the gradients may differ by fp32 summation order only."""
+    import subprocess
+    worker = os.path.join(os.path.dirname(__file__), 'dw_tile_worker.py')
+    outs = []
+    for name, extra in (('t64', {'PNRF_DW_TILE': '64'}), ('t128', {'PNRF_DW_TILE': '128', 'PNRF_DW128_MIN_ROWS': '1024'})):
+        out = str(tmp_path / f'{name}.npz')
+        r = subprocess.run([sys.executable, worker, out], env={**os.environ, **extra}, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(out)))
+    a, b = outs
+    assert sorted(a) == sorted(b) and len(a) == 52
+    differ = 0
+    for k in a:
+        scale = np.abs(a[k]).max() + 1e-30
+        assert np.abs(a[k] - b[k]).max() <= 2e-5 * scale, (k, np.abs(a[k] - b[k]).max() / scale)
+        differ += int(not np.array_equal(a[k], b[k]))
+    assert differ >= 4          # (some of) the seven square NeRF layers, 3072 rows each, did go through the other kernel
