@@ -9,7 +9,18 @@ engine files (the packed weight streams, ``pnrf_mlp_serialize``) instead of ONNX
 from __future__ import annotations
 
 import argparse
+import os
 import sys
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _config(path):
+    """A config path as given, or relative to the repository root when it does not exist under the working directory (the shipped
+    configs/llff/fern/*.txt; the reference's `_repo_relative`, cli.py:22-26)."""
+    if not os.path.exists(path) and not os.path.isabs(path) and os.path.exists(os.path.join(REPO_ROOT, path)):
+        return os.path.join(REPO_ROOT, path)
+    return path
 
 
 def _extra(ns):
@@ -18,7 +29,7 @@ def _extra(ns):
 
 
 def stage1_argv(ns):
-    argv = ['--config', ns.config]
+    argv = ['--config', _config(ns.config)]
     if ns.no_reload:
         argv.append('--no_reload')
     if ns.max_steps is not None:
@@ -27,7 +38,7 @@ def stage1_argv(ns):
 
 
 def stage2_argv(ns):
-    argv = ['--config', ns.config]
+    argv = ['--config', _config(ns.config)]
     if ns.pretrain_path is not None:
         argv += ['--pretrain_path', ns.pretrain_path]
     if ns.no_reload:
@@ -38,7 +49,7 @@ def stage2_argv(ns):
 
 
 def infer_argv(ns):
-    argv = ['--config', ns.config]
+    argv = ['--config', _config(ns.config)]
     if ns.checkpoint is not None:
         argv += ['--ft_path', ns.checkpoint]
     if getattr(ns, 'render_test', False):
@@ -71,7 +82,7 @@ def _eval(ns):
 
 
 def export_argv(ns):
-    argv = ['--config', ns.config, '--export_only']
+    argv = ['--config', _config(ns.config), '--export_only']
     if ns.checkpoint is not None:
         argv += ['--ft_path', ns.checkpoint]
     return argv + _extra(ns)

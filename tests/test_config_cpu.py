@@ -85,3 +85,33 @@ def test_cli_subcommands_map_to_driver_arguments():
                           ('trt', ['--ft_path', 'y.tar', '--render_test', '--max_images', '2']),
                           ('trt', ['--export_only', '--use_trt', '--nerf_engine_path', 'n.pnrf', '--mm_engine_path', 'm.pnrf', '--refine_engine_path', 'r.pnrf'])):
         config_parser(variant).parse_args(argv)
+
+
+def test_shipped_configs_carry_the_reference_hyperparameters():
+    """configs/llff/fern/*.txt (the CLI's default --config files): parse with this package's parser; spot values of the reference's
+    files (fern_trt.txt:10-34, fern_refine.txt, fern_epi.txt); equal to the reference's own files where those are present."""
+    from pronerf_amd import cli
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'llff', 'fern')
+    want = {'fern_trt.txt': ('trt', dict(expname='fern_8samples_trtinfer', factor=4, llffhold=8, N_samples=8, N_point_ray_enc=48, num_neighbor=4,
+                                         mmnetdepth=6, mmnetwidth=256, mmnetskips=[10000], use_viewdirs=True, use_trt=False, k_ref=1, weight_decay=5e-8)),
+            'fern_refine.txt': ('refine2', dict(expname='fern_refine_8samples_v2', N_rand=4096, lrate=3e-4, a_mmrgb=0.0, k_ref=1, weight_decay=0.0,
+                                                pretrain_path='logs_epi_RR/fern_sampler_e2e_donerf_8samples/500000.tar')),
+            'fern_epi.txt': ('base', dict(expname='fern_sampler_e2e_donerf_8samples_cc', N_rand=4096, lrate=5e-4, a_mmrgb=1.0, a_mmdisp=1.0, k_ref=0,
+                                          mmnetskips=[1000], raw_noise_std=1.0))}
+    for f, (variant, vals) in want.items():
+        a = config_parser(variant).parse_args(['--config', os.path.join(root, f)])
+        for k, v in vals.items():
+            assert getattr(a, k) == v, (f, k, getattr(a, k))
+        ref = os.path.join('/root/reference/configs/llff/fern', f)
+        if os.path.exists(ref):
+            b = config_parser(variant).parse_args(['--config', ref])
+            diff = {k for k in vars(a) if getattr(a, k) != getattr(b, k)} - {'config', 'nerf_engine_path', 'mm_engine_path', 'refine_engine_path'}
+            assert not diff, (f, diff)
+    # the CLI finds them from any working directory
+    ns = cli.build_parser().parse_args(['infer'])
+    cwd = os.getcwd()
+    try:
+        os.chdir('/')
+        assert cli.infer_argv(ns)[1] == os.path.join(root, 'fern_trt.txt')
+    finally:
+        os.chdir(cwd)
