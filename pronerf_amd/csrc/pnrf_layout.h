@@ -191,20 +191,22 @@ constexpr int CB_NSLOTS = CB_SLOTS_USED + CB_SLOTS_PAD;
 constexpr int CB_BIAS_E89 = 8 * W_HID;                                                  // [tile of 16 rows][16]
 constexpr int CB_BIAS_E10 = CB_BIAS_E89 + 16 * 2 * CB_NTP89;
 constexpr int CB_NBIAS = CB_BIAS_E10 + 32;
-// Input feature (index into the reference's 63-wide position embedding [x, sin 2^0 x, cos 2^0 x, ...]) that element j of
-// lane group g supplies in k-step ks of layer 0.  Group g evaluates fn = g&1 (0 sin, 1 cos) on octaves 5*(g>>1) .. +4:
-// slot 8ks+j = 3*local_octave + component for slots 0..14; slot 15 = raw x / y / z for g = 0 / 1 / 2 (g = 3: padding).
+// Input feature (index into the reference's 63-wide position embedding [x, sin 2^0 x, cos 2^0 x, ...]: 3 + 6 k + 3 fn + c) that
+// element j of lane group g supplies in k-step ks of layer 0.  The 30 (component, octave) combinations are cut into 15 chains of two
+// consecutive octaves; a lane group evaluates four chains q = 4g .. 4g+3 (component q % 3, octaves 2 (q/3), 2 (q/3) + 1) and chain
+// j4 fills slots 4 j4 .. 4 j4 + 3 = [sin k0, cos k0, sin k0+1, cos k0+1].  The 16th chain position (g = 3, slots 12..15) carries
+// the raw x, y, z and one padding slot instead.
 __host__ __device__ constexpr int nerf16_in0(int ks, int g, int j) {
-  const int idx = 8 * ks + j;
-  if (idx == 15) return g < 3 ? g : -1;
-  return 3 + 6 * (idx / 3 + 5 * (g >> 1)) + 3 * (g & 1) + idx % 3;
+  const int idx = 8 * ks + j, q = 4 * g + idx / 4, e = idx % 4;
+  if (q == 15) return e < 3 ? e : -1;
+  return 3 + 6 * (2 * (q / 3) + (e >> 1)) + 3 * (e & 1) + q % 3;
 }
-// Same for the 27-wide view embedding in its single k-step: octaves 2*(g>>1) .. +1 in slots 0..5; slot 6 / 7: raw vx / vy for
-// g = 0, raw vz / padding for g = 1, padding for g = 2, 3.
+// Same for the 27-wide view embedding in its single k-step: group g evaluates octave g of the three components, slots 2c, 2c+1 =
+// sin, cos of component c; slots 6 / 7: raw vx / vy for g = 0, raw vz / padding for g = 1, padding for g = 2, 3.
 __host__ __device__ constexpr int nerf16_inx(int g, int j) {
   if (j == 6) return g == 0 ? 0 : (g == 1 ? 2 : -1);
   if (j == 7) return g == 0 ? 1 : -1;
-  return 3 + 6 * (j / 3 + 2 * (g >> 1)) + 3 * (g & 1) + j % 3;
+  return 3 + 6 * g + 3 * (j & 1) + j / 2;
 }
 
 }  // namespace pnrf

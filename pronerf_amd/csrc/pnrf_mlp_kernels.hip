@@ -34,6 +34,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// hardware exp2 / reciprocal (1 ulp each): for the fused bf16 kernels' epilogues
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
+// DPP lane moves inside a row of 16 lanes; lanes without a source read 0 (bound_ctrl)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 8 lanes, result in all 8: xor 1, xor 2 (quad_perm), then the mirrored half row
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v = __fadd_rn(v, dpp_mov<0xB1>(v));
+  v = __fadd_rn(v, dpp_mov<0x4E>(v));
+  return __fadd_rn(v, dpp_mov<0x141>(v));
+}
 
 // Two waves per SIMD: the second-dispatched half of the workgroup (waves NW/2..NW-1) loses every VALU/MFMA
 // arbitration to its older partner, finishes each tile late and makes the older half wait at the slot barrier
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
       for (int s4 = 0; s4 < 4; ++s4) {
         const float lower = __fmul_rn(0.5f, __fadd_rn(w[s4 + 1], w[s4]));       // trt.py:673-675
         const float upper = __fmul_rn(0.5f, __fadd_rn(w[s4 + 2], w[s4 + 1]));
-        const float rf = sigmoid_f(fin[cb][4 * s4]);
+        const float rf = sigmoid_fast(fin[cb][4 * s4]);                           // bf16-grade logits: hardware exp / rcp are exact enough
         zz[s4] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), rf));     // :676
       }
       if (MODE == 2) {           // depth jitter toward the next / previous refined sample (refine2.py:646-662)
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const float zv = zz[s4];
-        const float fx = tanhf(fin[cb][4 * s4 + 1]), fy = tanhf(fin[cb][4 * s4 + 2]), fz = tanhf(fin[cb][4 * s4 + 3]);
+        const float fx = tanh_fast(fin[cb][4 * s4 + 1]), fy = tanh_fast(fin[cb][4 * s4 + 2]), fz = tanh_fast(fin[cb][4 * s4 + 3]);
         pp[3 * s4 + 0] = __fadd_rn(__fadd_rn(ox, __fmul_rn(dx, zv)), __fmul_rn(1e-2f, fx));   // :679-681
         pp[3 * s4 + 1] = __fadd_rn(__fadd_rn(oy, __fmul_rn(dy, zv)), __fmul_rn(1e-2f, fy));
         pp[3 * s4 + 2] = __fadd_rn(__fadd_rn(oz, __fmul_rn(dz, zv)), __fmul_rn(1e-2f, fz));
@@ -603,6 +617,16 @@ struct NerfArgs {
   float* y; const int* outmap;                      // module-level consumer
 };
 
+// sin / cos of scale * x, scale a power of two: hardware v_sin / v_cos on the fraction of the angle in revolutions (valid for any
+// magnitude; error of the fraction 2^-24 * |scale x / 2 pi|, far below the bf16 rounding of the MLP input)
+__device__ __forceinline__ void pe_sincos_scaled(float x, float scale, float& s, float& c) {
+#ifdef PNRF_EXACT_SINCOS
+  sincosf(x * scale, &s, &c);
+#else
+  const float rev = __builtin_amdgcn_fractf(x * (scale * 0.15915494309189535f));
+  s = __builtin_amdgcn_sinf(rev); c = __builtin_amdgcn_cosf(rev);
+#endif
+}
 __device__ __forceinline__ void pe_sincos(float x, float& s, float& c) {
 #ifdef PNRF_EXACT_SINCOS
   sincosf(x, &s, &c);
@@ -876,8 +900,8 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
 // ------------------------------------------------------------------------------------------ DoNeRFTRT on the 16x16x32 engine
 // nerf16_kernel: the fused NeRF stage (positional encoding -> 8-layer MLP -> compositing) on layer_b16.  Per wave two blocks of
 // 16 columns (ray samples), 8 waves = 256 columns per workgroup batch, like nerf_kernel<1, 8>.  Lane l: column l&15 of each block,
-// group g = l>>4.  The four groups of a column share the positional encoding: group g evaluates sin (g&1 = 0) or cos on the
-// octaves 5*(g>>1) .. +4 (nerf16_in0 / nerf16_inx define which stream feature each register slot is).  The network output (rows
+// group g = l>>4.  The four groups of a column share the positional encoding: group g evaluates four chains of two consecutive
+// octaves of one component each and octave g of the view direction (nerf16_in0 / nerf16_inx define which stream feature each register slot is).  The network output (rows
 // 0..3 of the last tile) lands in group 0: lanes 0..15 hold [r, g, b, sigma] of their column, 8 adjacent lanes = one ray.
 struct HiddenEpi16 {
   bf16x8 (&Bn)[2][NB_KS_H];
@@ -898,7 +922,15 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
-  const bool fcos = g & 1, hi = g >> 1;
+  int pe_c[4];                 // chain j4 of this lane group: component and 2^(first octave) (nerf16_in0)
+  float pe_sc[4];
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4) {
+    const int q = 4 * g + j4;
+    pe_c[j4] = q % 3;
+    pe_sc[j4] = (float)(1 << (2 * (q / 3)));
+  }
+  const float pe_vs = (float)(1 << g);
   const int64_t nrows = a.n * a.S;
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
@@ -929,29 +961,19 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       }
       // positional encoding straight into B-fragment order (see pe_sincos / the recurrence note in nerf_kernel)
       float f0[16], fx[8];
+      // positional encoding in the slot order of nerf16_in0 / nerf16_inx: four chains of two octaves per lane (hardware sin / cos at the
+      // chain's first octave, one double-angle step for the second), the view octave of the lane group directly
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float s, co, val[10];
-        pe_sincos(x3[c], s, co);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-          val[k] = fcos ? co : s;
-          const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
-          s = s2; co = c2;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 5; ++kk) f0[3 * kk + c] = hi ? val[kk + 5] : val[kk];
-        pe_sincos(v3[c], s, co);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          val[k] = fcos ? co : s;
-          const float s2 = 2.f * s * co, c2 = (co - s) * (co + s);
-          s = s2; co = c2;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fx[3 * kk + c] = hi ? val[kk + 2] : val[kk];
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const float xv = pe_c[j4] == 0 ? x3[0] : (pe_c[j4] == 1 ? x3[1] : x3[2]);
+        float s, co;
+        pe_sincos_scaled(xv, pe_sc[j4], s, co);
+        f0[4 * j4 + 0] = s; f0[4 * j4 + 1] = co;
+        f0[4 * j4 + 2] = 2.f * s * co; f0[4 * j4 + 3] = (co - s) * (co + s);
       }
-      f0[15] = g == 0 ? x3[0] : (g == 1 ? x3[1] : (g == 2 ? x3[2] : 0.f));
+      if (g == 3) { f0[12] = x3[0]; f0[13] = x3[1]; f0[14] = x3[2]; f0[15] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pe_sincos_scaled(v3[c], pe_vs, fx[2 * c], fx[2 * c + 1]);
       fx[6] = g == 0 ? v3[0] : (g == 1 ? v3[2] : 0.f);
       fx[7] = g == 0 ? v3[1] : 0.f;
 #pragma unroll
@@ -1040,32 +1062,28 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
         r0 = fminf(fmaxf(r0, -a.clampv), a.clampv); r1 = fminf(fmaxf(r1, -a.clampv), a.clampv);
         r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
       }
-      const float znext = __shfl_down(zc, 1);
+      // the 8 samples of a ray sit in 8 adjacent lanes: neighbour, exclusive product and the sums go through DPP lane moves
+      // (row_shl / row_shr / quad_perm / row_half_mirror) instead of LDS permutes; tree order instead of torch's left-to-right order,
+      // a difference of fp32 round-off under a bf16-grade network output
+      const float znext = dpp_mov<0x101>(zc);                                       // row_shl:1
       float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
       dist = __fmul_rn(dist, dn);                                                   // :583
-      const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
+      const float cr = sigmoid_fast(r0), cg = sigmoid_fast(r1), cbv = sigmoid_fast(r2);   // :585
       const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
-      float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
+      float alpha = __fsub_rn(1.f, __expf(__fmul_rn(-sg, dist)));                   // :577,587
       if (a.mul) alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                          // :588
       const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
-      const int base = lane & 0x38;
-      float T = 1.f;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const float xj = __shfl(xk, base + j);
-        T = (j < s) ? __fmul_rn(T, xj) : T;
-      }
+      // exclusive cumprod: shift by one (row_shr:1), then scan.  Every lane move is executed by all lanes and selected afterwards: under
+      // a branch the lanes switched off would read as zero in their neighbours' moves
+      const float xprev = dpp_mov<0x111>(xk);
+      float T = s >= 1 ? xprev : 1.f;
+      { const float t = dpp_mov<0x111>(T); T = __fmul_rn(T, s >= 1 ? t : 1.f); }
+      { const float t = dpp_mov<0x112>(T); T = __fmul_rn(T, s >= 2 ? t : 1.f); }
+      { const float t = dpp_mov<0x114>(T); T = __fmul_rn(T, s >= 4 ? t : 1.f); }
       const float wgt = __fmul_rn(alpha, T);
-      const float c0 = __fmul_rn(wgt, cr), c1 = __fmul_rn(wgt, cg), c2 = __fmul_rn(wgt, cbv), c3 = __fmul_rn(wgt, zc);
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sa = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s0 = __fadd_rn(s0, __shfl(c0, base + j));                                   // :591 sum over samples
-        s1 = __fadd_rn(s1, __shfl(c1, base + j));
-        s2 = __fadd_rn(s2, __shfl(c2, base + j));
-        s3 = __fadd_rn(s3, __shfl(c3, base + j));                                   // :593 depth_map
-        sa = __fadd_rn(sa, __shfl(wgt, base + j));                                  // acc_map
-      }
+      float s0 = sum8_dpp(__fmul_rn(wgt, cr)), s1 = sum8_dpp(__fmul_rn(wgt, cg)), s2 = sum8_dpp(__fmul_rn(wgt, cbv));    // :591 sum over samples
+      const float s3 = sum8_dpp(__fmul_rn(wgt, zc));                                // :593 depth_map
+      const float sa = a.white_bkgd ? sum8_dpp(wgt) : 0.f;                          // acc_map
       if (a.white_bkgd) {                                                           // refine2.py:519-520
         const float bg = __fsub_rn(1.f, sa);
         s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg);
