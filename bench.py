@@ -244,7 +244,13 @@ def main():
                     ach = flops[k] * n_total / (ms_k * 1e-3) / 1e12
                     kern[k].update(achieved_tflops=ach, peak_tflops=peaks[k], frac=ach / peaks[k])
             dom = max(flops, key=lambda k: prof[k])
-            res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
+            # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
+            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_h16_kernel', 'refine_input_kernel': 'refine_input_kernel',
+                       'refine_kernel': 'refine_kernel<1, 8, 1>',
+                       'nerf_kernel': 'nerf16_kernel<false>' if os.environ.get('PNRF_BF16_VARIANT', '16') == '16' else 'nerf_kernel<...>'}
+            for k in kern:
+                kern[k]['symbol'] = symbols[k]
+            res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
                                'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': pmc_traffic(dom),
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
                                'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
