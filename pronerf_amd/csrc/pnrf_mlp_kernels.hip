@@ -952,8 +952,15 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       const float* pp = a.pts + rr * 3;
       const float* ry = a.rays + (a.S == 8 ? (rr >> 3) : rr / a.S) * 11;
+#ifdef PNRF_PROBE_NOHEADLOAD      // diagnostic only: what the latency of the batch-head loads costs (inputs made up from the row index)
+      const float fr = (float)(rr & 1023) * 9.765625e-4f;
+      const float x3[3] = {fr, 1.f - fr, fr * 0.5f};
+      const float v3[3] = {fr, 0.5f, -fr};
+      (void)pp;
+#else
       const float x3[3] = {pp[0], pp[1], pp[2]};
       const float v3[3] = {ry[8], ry[9], ry[10]};
+#endif
       if (composite) {
         e_dn[cb] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ry[3], ry[3]), __fmul_rn(ry[4], ry[4])), __fmul_rn(ry[5], ry[5])));
         e_z[cb] = a.z[rr]; e_add[cb] = a.add ? a.add[rr] : 0.f; e_mul[cb] = a.mul ? a.mul[rr] : 1.f;
