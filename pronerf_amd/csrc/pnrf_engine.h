@@ -87,6 +87,9 @@ struct WStream {
   uint32_t dst_pos;    // next ring position
   uint32_t woff;       // per-lane byte offset inside a slot (source side)
   uint32_t wbase;      // wave-uniform byte offset inside a slot (LDS side)
+#ifdef PNRF_PROBE_DMA_ONCE
+  uint32_t n_issued = 0;
+#endif
 #ifdef PNRF_DIAG
   unsigned long long t_vm = 0, t_bar = 0, n_begin = 0, t_start = 0;
 #endif
@@ -105,6 +108,10 @@ struct WStream {
   // before its first MFMA.  Hidden from the compiler the reads keep their counted lgkmcnt(N).  Completion is counted by
   // wait_slot()'s own vmcnt; M0 (compiler-reserved) is saved and restored inside the statement.
   __device__ __forceinline__ void issue_loads() {
+#ifdef PNRF_PROBE_DMA_ONCE      // diagnostic only: the ring is filled once with real weights (realistic operand bits and power), then no more DMA
+    if (n_issued >= NSLOTS) return;
+    n_issued += 1;
+#endif
 #ifndef PNRF_PROBE_NODMA
     const uint64_t src = (uint64_t)(uintptr_t)g + (uint64_t)src_slot * SLOT_BYTES;                 // wave-uniform
     const uint32_t dst = (uint32_t)(uintptr_t)(lptr_t)ring + dst_pos * SLOT_BYTES + wbase;       // wave-uniform LDS byte address
