@@ -968,6 +968,12 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       }
       // positional encoding straight into B-fragment order (see pe_sincos / the recurrence note in nerf_kernel)
       float f0[16], fx[8];
+#ifdef PNRF_PROBE_NOBATCHWORK      // diagnostic only: ceiling of what the per-batch VALU work (encoding, compositing) still costs
+#pragma unroll
+      for (int i = 0; i < 16; ++i) f0[i] = x3[i % 3] + (float)i;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fx[i] = v3[i % 3] - (float)i;
+#else
       // positional encoding in the slot order of nerf16_in0 / nerf16_inx: four chains of two octaves per lane (hardware sin / cos at the
       // chain's first octave, one double-angle step for the second), the view octave of the lane group directly
 #pragma unroll
@@ -983,6 +989,7 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       for (int c = 0; c < 3; ++c) pe_sincos_scaled(v3[c], pe_vs, fx[2 * c], fx[2 * c + 1]);
       fx[6] = g == 0 ? v3[0] : (g == 1 ? v3[2] : 0.f);
       fx[7] = g == 0 ? v3[1] : 0.f;
+#endif
 #pragma unroll
       for (int ks = 0; ks < NB_KS0; ++ks) {
         float v[8];
@@ -1065,6 +1072,10 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       const int64_t ray = rr >> 3;
       const int s = (int)(rr & 7);
       const float dn = e_dn[cb], zc = e_z[cb], ad = e_add[cb], mu = e_mul[cb];
+#ifdef PNRF_PROBE_NOBATCHWORK
+      if (valid[cb] && g == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(r0 + dn, r1 + zc, r2 + ad, r3 + mu);
+      return;
+#endif
       if (a.clampv > 0.f) {                                                         // base.py:523
         r0 = fminf(fmaxf(r0, -a.clampv), a.clampv); r1 = fminf(fmaxf(r1, -a.clampv), a.clampv);
         r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
