@@ -352,6 +352,14 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) vals[i] = fmaf(fc[i >> 2][i & 3], INV, fm[i >> 2][i & 3]);
 
+#ifdef PNRF_PROBE_NOBATCHWORK      // diagnostic only: store the raw logits, skip sigmoid / sort / permutation
+    if (valid && q < 3) {
+      float4* p = (float4*)((q == 0 ? a.depth_sorted : (q == 1 ? a.add_sorted : a.mul_sorted)) + row * 8);
+      p[0] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+      p[1] = make_float4(vals[4], vals[5] + near, vals[6] + far, vals[7]);
+    }
+    continue;
+#endif
     // ---- fused epilogue.  Quarter 0 of a column holds the 8 depth logits, quarter 1 add, quarter 2 mul,
     // quarter 3 rgb (sampler_out).  Quarter 0 sorts; the permutation goes to the other quarters as a word.
     float dep[8];
