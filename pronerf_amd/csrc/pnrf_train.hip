@@ -80,13 +80,6 @@ __global__ void act_bwd_colsum_kernel(float* __restrict__ dH, int ldd, const flo
   __syncthreads();
   if (rl == 0 && j < out) part[blockIdx.y * out + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int out, float* __restrict__ db) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= out) return;
-  float s = 0.f;
-  for (int k = 0; k < DB_CHUNKS; ++k) s += part[k * out + j];
-  db[j] = s;
-}
 
 
 // ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
@@ -239,8 +232,21 @@ __global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restri
         p[(size_t)m * in + n] = acc[i][j][e];
       }
 }
-__global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int64_t numel, float* __restrict__ dW) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+// Adds the split-K partials of dW in a fixed order; the last `db_blocks` workgroups of the grid do the same for the bias gradient's
+// column-sum partials of act_bwd_colsum_kernel (one launch per layer instead of two: the iteration is launch-bound at 4096 rays).
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int64_t numel, float* __restrict__ dW, int db_blocks,
+                                 const float* __restrict__ db_part, int out, float* __restrict__ db) {
+  const int dw_blocks = (int)gridDim.x - db_blocks;
+  if ((int)blockIdx.x >= dw_blocks) {
+    const int j = ((int)blockIdx.x - dw_blocks) * (int)blockDim.x + (int)threadIdx.x;
+    if (j < out) {
+      float s = 0.f;
+      for (int k = 0; k < DB_CHUNKS; ++k) s += db_part[k * out + j];
+      db[j] = s;
+    }
+    return;
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)dw_blocks * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += part[(size_t)k * numel + i];
     dW[i] = s;
@@ -656,7 +662,9 @@ int gemm_dx(pnrf_trainer* t, const float* dY, int ldy, const float* W, int in, i
   return 0;
 }
 // dW[out,in] = dY^T X  (dw_splitk_kernel + dw_reduce_kernel)
-int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R, hipStream_t s) {
+int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R, hipStream_t s,
+            const float* db_part = nullptr, float* db = nullptr) {
+  const int db_blocks = db ? (out + TPB - 1) / TPB : 0;
   static const int use128 = [] { const char* e = getenv("PNRF_DW_TILE"); return (e && atoi(e) == 64) ? 0 : 1; }();
   static const int64_t dw128_min_rows = [] { const char* e = getenv("PNRF_DW128_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)65536; }();
   if (use128 && out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)dY & 15) == 0 && R >= dw128_min_rows) {
@@ -672,7 +680,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, 
     hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dY, ldy, X, ldx, t->dw_part, out, in, R, rows_per);
     PNRF_LAUNCH_CHECK();
     const int64_t numel = (int64_t)out * in;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel)), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, db_part, out, db);
     PNRF_LAUNCH_CHECK();
     return 0;
   }
@@ -689,7 +697,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, 
   hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dY, ldy, X, ldx, t->dw_part, out, in, R, rows_per);
   PNRF_LAUNCH_CHECK();
   const int64_t numel = (int64_t)out * in;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel)), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, db_part, out, db);
   PNRF_LAUNCH_CHECK();
   return 0;
 }
@@ -709,9 +717,7 @@ int layer_bwd(pnrf_trainer* t, int li, float* dH, int ldd, const float* H, int l
   const TLin& l = t->L[li];
   hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((l.out + 63) / 64, DB_CHUNKS), dim3(256), 0, s, dH, ldd, H, ldh, R, l.out, act, t->part);
   PNRF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((l.out + 255) / 256), dim3(256), 0, s, t->part, l.out, t->G + l.b);
-  PNRF_LAUNCH_CHECK();
-  int rc = gemm_dw(t, X, ldx, dH, ldd, t->G + l.w, l.in, l.out, R, s);
+  int rc = gemm_dw(t, X, ldx, dH, ldd, t->G + l.w, l.in, l.out, R, s, t->part, t->G + l.b);      // + the bias gradient's final column sums
   if (rc) return rc;
   if (dX) rc = gemm_dx(t, dH, ldd, t->P + l.w, l.in, l.out, dX, lddx, R, beta);
   return rc;
