@@ -131,3 +131,25 @@ def test_stage_timing_of_the_fused_path(dev):
     assert torch.equal(out, ref)
     rend.ctx.profile_begin(2)                            # re-arm with a smaller window; nothing rendered -> zero frames
     assert rend.ctx.profile_end() == ({k: 0.0 for k in ms}, 0)
+
+
+def test_ray_counts_past_two_gib_of_workspace(dev):
+    """4.2 M rays in one call: the refine-input workspace alone is 2.4 GB, so every per-ray byte offset passes 2^31.  The rays are a
+    756 x 1008 frame repeated; each repetition must equal the single frame bit for bit, and a ragged tail must equal its prefix."""
+    from pronerf_amd.render import Renderer
+    H, W = 756, 1008
+    scene = synth.make_scene(0, H=H, W=W, focal=815.13, rotate=True)
+    rend = Renderer(synth.make_weights(0, 'trained'), max_rays=4_200_000, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, orr = rend.frame_rays(scene['K'], scene['c2w'], H, W)
+    one = rend.render_rays(rays, orr, want_idx=True)
+    one = (one[0].clone(), one[1].clone())
+    n = H * W
+    reps, tail = 5, 4_200_000 - 5 * n                    # 5 frames + 389 760 rays
+    big_r = torch.cat([rays] * reps + [rays[:tail]]).contiguous()
+    big_o = torch.cat([orr] * reps + [orr[:tail]]).contiguous()
+    assert big_r.shape[0] == 4_200_000 and big_r.shape[0] * 144 * 4 > 2 ** 31
+    out, idx = rend.render_rays(big_r, big_o, want_idx=True)
+    for k in range(reps):
+        assert torch.equal(out[k * n:(k + 1) * n], one[0]) and torch.equal(idx[k * n:(k + 1) * n], one[1]), k
+    assert torch.equal(out[reps * n:], one[0][:tail]) and torch.equal(idx[reps * n:], one[1][:tail])
