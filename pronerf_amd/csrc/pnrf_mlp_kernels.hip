@@ -911,13 +911,30 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
 // group g = l>>4.  The four groups of a column share the positional encoding: group g evaluates four chains of two consecutive
 // octaves of one component each and octave g of the view direction (nerf16_in0 / nerf16_inx define which stream feature each register slot is).  The network output (rows
 // 0..3 of the last tile) lands in group 0: lanes 0..15 hold [r, g, b, sigma] of their column, 8 adjacent lanes = one ray.
+// ReLU after the conversion, on the packed pair: as 16-bit integers the bf16 patterns of negative values (and -0) are negative, so one
+// v_pk_max_i16 against 0 clears them — the same bits as converting max(x, 0), with one instruction per two values instead of two.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int relu_pack_bf16(float a, float b) {
+#ifdef PNRF_RELU_F32
+  return __builtin_bit_cast(int, bf16x2_t{(__bf16)act_fast(a, ACT_RELU), (__bf16)act_fast(b, ACT_RELU)});
+#else
+  int pk;                                    // one conversion for the pair (the vector-of-two form compiles to two conversions and a v_perm)
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+  return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, pk), i16x2_t{0, 0}));
+#endif
+}
 struct HiddenEpi16 {
   bf16x8 (&Bn)[2][NB_KS_H];
   __device__ __forceinline__ void operator()(int tp, int pc, f32x4 (&acc)[2][2]) const {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Bn[cb][tp][4 * pc + r] = (__bf16)act_fast(acc[pc][cb][r], ACT_RELU);
+    for (int cb = 0; cb < 2; ++cb) {
+      i32x4_t w = __builtin_bit_cast(i32x4_t, Bn[cb][tp]);
+      w[2 * pc] = relu_pack_bf16(acc[pc][cb][0], acc[pc][cb][1]);
+      w[2 * pc + 1] = relu_pack_bf16(acc[pc][cb][2], acc[pc][cb][3]);
+      Bn[cb][tp] = __builtin_bit_cast(bf16x8, w);
+    }
   }
 };
 
