@@ -149,39 +149,21 @@ def main():
     rend = Renderer(weights, max_rays=count, device=dev)
     rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W, first=first, count=count)
-    out = torch.empty(count, 4, device=dev)
     counts = [shard_range(n_total, r, world)[1] for r in range(world)]
-    cmax = max(counts)
-    if world > 1:
-        out = torch.zeros(cmax, 4, device=dev)                  # padded to the largest shard (sizes differ by <= 1 ray)
-        full = torch.empty(world * cmax, 4, device=dev)         # rank r's pixels are full[r*cmax : r*cmax+counts[r]]
-
-    # N > 1: the gather of frame i runs on the collective's stream while frame i+1 renders (two output / frame buffers; the
-    # wait before a buffer is reused is a stream wait, the host never blocks).  Every frame is complete when fence() returns.
+    # N > 1: the gather of frame i runs on the collective's stream while frame i+1 renders (pronerf_amd.dist.FrameGather: two output /
+    # frame buffers; the wait before a buffer is reused is a stream wait, the host never blocks).  Every frame is complete when fence() returns.
+    from pronerf_amd.dist import FrameGather
     pipeline = world > 1 and os.environ.get('PNRF_BENCH_PIPELINE', '1') != '0'
-    outs, fulls, pending = [out], [full if world > 1 else None], [None, None]
-    if pipeline:
-        outs.append(torch.zeros_like(out)); fulls.append(torch.empty_like(full))
-    frame_no = [0]
+    fg = FrameGather(n_total, 4, device=dev, pipelined=pipeline)
+    outs = fg.outs
 
     def step():
-        b = frame_no[0] & 1 if pipeline else 0
-        frame_no[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        rend.render_rays(rays, or_rays, out=outs[b])
-        if world > 1:
-            if pipeline:
-                pending[b] = dist.all_gather_into_tensor(fulls[b], outs[b], async_op=True)
-            else:
-                dist.all_gather_into_tensor(fulls[b], outs[b])
+        b = fg.acquire()
+        rend.render_rays(rays, or_rays, out=outs[b][:count])
+        fg.submit(b)
 
     def fence():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        fg.fence()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

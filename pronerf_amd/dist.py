@@ -59,6 +59,61 @@ def render_frame_sharded(render_fn, n_total: int, out_channels: int = 4, device=
     return torch.cat([buf[r * cmax:r * cmax + c] for r, c in enumerate(counts)], 0)
 
 
+class FrameGather:
+    """The per-frame exchange step for a stream of frames: every rank renders its contiguous shard into ``acquire()``'s buffer and calls
+    ``submit()``; the all-gather of that frame then runs on the collective's stream while the next frame renders into the other buffer
+    (``depth`` buffers, ``async_op=True``; ``acquire`` waits — a stream wait on GPU backends, the host does not block — until the gather
+    that last used a buffer is done).  Shards are padded to the largest one (they differ by at most one ray); ``frame(b)`` is the
+    assembled [n_total, C] frame of buffer ``b``.  ``bench.py`` times exactly this at N > 1."""
+
+    def __init__(self, n_total: int, channels: int = 4, device=None, dtype=torch.float32, depth: int = 2, pipelined: bool = True):
+        self.rank, self.world = world()
+        self.n_total, self.channels = int(n_total), int(channels)
+        self.counts = [shard_range(n_total, r, self.world)[1] for r in range(self.world)]
+        self.first, self.count = shard_range(n_total, self.rank, self.world)
+        self.cmax = max(self.counts) if self.counts else 0
+        self.pipelined = bool(pipelined) and self.world > 1
+        self.depth = depth if self.pipelined else 1
+        self.outs = [torch.zeros(self.cmax, channels, device=device, dtype=dtype) for _ in range(self.depth)]
+        self.fulls = [torch.empty(self.world * self.cmax, channels, device=device, dtype=dtype) if self.world > 1 else None for _ in range(self.depth)]
+        self.pending = [None] * self.depth
+        self._next = 0
+
+    def acquire(self) -> int:
+        """Index of the buffer the next frame renders into (``outs[b][:count]``), free of any gather still reading it."""
+        b = self._next
+        self._next = (self._next + 1) % self.depth
+        self._wait(b)
+        return b
+
+    def submit(self, b: int):
+        if self.world == 1:
+            return
+        if self.pipelined:
+            self.pending[b] = dist.all_gather_into_tensor(self.fulls[b], self.outs[b], async_op=True)
+        else:
+            dist.all_gather_into_tensor(self.fulls[b], self.outs[b])
+
+    def _wait(self, b: int):
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
+    def fence(self):
+        for b in range(self.depth):
+            self._wait(b)
+
+    def frame(self, b: int):
+        """The gathered frame of buffer ``b`` ([n_total, C]; a view when the shards are equal)."""
+        self._wait(b)
+        if self.world == 1:
+            return self.outs[b][:self.count]
+        full = self.fulls[b]
+        if self.cmax * self.world == self.n_total:
+            return full
+        return torch.cat([full[r * self.cmax:r * self.cmax + c] for r, c in enumerate(self.counts)], 0)
+
+
 def allreduce_gradients(trainer, group=None):
     """Data-parallel training (not in the reference): average the gradients of the replicas in place — one
     all-reduce of the trainer's flat gradient array (1.4 M floats = 5.5 MB, a single RCCL launch over xGMI) — so that every

@@ -80,3 +80,49 @@ def test_sharded_render_matches_single_process(ws, H, W):
             np.testing.assert_allclose(root, ref, rtol=0, atol=2e-5)
         else:
             assert root is None
+
+
+def _gather_worker(rank, ws, port, n_total, frames, pipelined, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    try:
+        from pronerf_amd.dist import FrameGather
+        fg = FrameGather(n_total, 4, device='cpu', pipelined=pipelined)
+        assert (fg.first, fg.count) == shard_range(n_total, rank, ws) and fg.depth == (2 if pipelined else 1)
+        rows = torch.arange(fg.first, fg.first + fg.count, dtype=torch.float32)[:, None] + torch.tensor([0., .25, .5, .75])
+        got = []
+        for f in range(frames):                       # frame f: pixel value = 1000 f + global row (+ channel / 4)
+            b = fg.acquire()
+            fg.outs[b][:fg.count] = rows + 1000. * f
+            fg.submit(b)
+            if f >= 1 and pipelined:                  # the previous frame sits in the other buffer, complete or in flight
+                got.append(fg.frame(1 - b).clone())
+        fg.fence()
+        last = (frames - 1) % fg.depth
+        got.append(fg.frame(last).clone())
+        q.put((rank, [g.numpy() for g in got]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ws,n_total,pipelined', [(2, 48, True), (3, 35, True), (2, 35, False)])
+def test_frame_gather_pipeline(ws, n_total, pipelined):
+    """pronerf_amd.dist.FrameGather (what bench.py times at N > 1): two buffers in flight, async all-gather, ragged shards."""
+    frames = 5
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, ws, port, n_total, frames, pipelined, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(ws)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(n_total, dtype=np.float32)[:, None] + np.array([0., .25, .5, .75], dtype=np.float32)
+    for rank, got in res:
+        seen = list(range(frames)) if pipelined else [frames - 1]
+        assert len(got) == len(seen)
+        for f, g in zip(seen, got):
+            np.testing.assert_array_equal(g, want + 1000. * f)
