@@ -136,6 +136,21 @@ def render(rays, or_rays, sh, **kwargs):
     return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
 
 
+def render_sharded(rays, or_rays, sh, **kwargs):
+    """``render`` with the frame's rays sharded over the ranks of the process group (not in the reference; the multi-GPU shape of
+    SURVEY.md §8(e)): rank r renders the contiguous flat range ``shard_range(N, r, world)`` and one all-gather of the packed
+    [n, 7] = (rgb_map0, rgb_map1, depth_map) tiles rebuilds the frame on every rank.  Returns (rgb0, rgb1, depth) shaped like ``render``'s."""
+    from .dist import render_frame_sharded
+
+    def part(first, count):
+        r = render_rays(rays[first:first + count].contiguous(), or_rays[first:first + count].contiguous(), **kwargs)
+        return torch.cat([r['rgb_map0'], r['rgb_map1'], r['depth_map'][:, None]], 1)
+
+    full = render_frame_sharded(part, rays.shape[0], out_channels=7, device=rays.device)
+    hw = list(sh[:-1])
+    return full[:, 0:3].reshape(hw + [3]), full[:, 3:6].reshape(hw + [3]), full[:, 6].reshape(hw)
+
+
 # ------------------------------------------------------------------------------------ model construction
 def create_nerf(args, device='cuda'):
     """Build the inference modules and the test-time render kwargs (run_S_eS_eN_alter_trt.py:412-544),
@@ -240,6 +255,9 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
     ref_Kh = np.asarray(ref_K.detach().cpu() if isinstance(ref_K, torch.Tensor) else ref_K, dtype=np.float32)
     dev = next(render_kwargs['network_fine'].parameters()).device
     rgbs0, rgbs1, depths, psnrs, times = [], [], [], [], []
+    from .dist import world as _world
+    rank, world_size = _world()               # under torchrun every frame's rays are sharded over the ranks (render_sharded)
+    verbose = verbose and rank == 0
     t1, t2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fwd = {k: render_kwargs[k] for k in ('network_fn', 'network_query_fn', 'N_samples', 'network_fine', 'min_max_ray_net', 'refine_net',
                                           'N_point_ray_enc', 'embed_fn', 'embeddirs_fn', 'num_neighbor', 'use_trt', 'embed_rays')
@@ -255,7 +273,10 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         frame_ms = []
         for _ in range(n_timing_reps):                                                                                     # :327-332
             t1.record()
-            rgb0, rgb1, depth_map, _ = render(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)
+            if world_size > 1:
+                rgb0, rgb1, depth_map = render_sharded(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)
+            else:
+                rgb0, rgb1, depth_map, _ = render(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)
             t2.record()
             torch.cuda.synchronize(device=dev)
             frame_ms.append(t1.elapsed_time(t2))
@@ -265,7 +286,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         rgbs0.append(rgb0.cpu().numpy()); rgbs1.append(rgb1.cpu().numpy()); depths.append(depth_map.cpu().numpy())
         if gt_imgs is not None and render_factor == 0:
             psnrs.append(mse2psnr(img2mse(rgb1, torch.as_tensor(gt_imgs[i], dtype=torch.float32).to(dev))))
-        if savedir is not None:
+        if savedir is not None and rank == 0:
             os.makedirs(savedir, exist_ok=True)
             _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs1[-1]))
             _write_png(os.path.join(savedir, 'depth_{:03d}.png'.format(i)), to8b(depths[-1] / np.max(depths[-1])))
@@ -298,7 +319,9 @@ def train(argv=None, device='cuda'):
     (:768-770); ``--use_trt`` loads the three networks from those files (or from ``--nerf_engine_path`` / ``--mm_engine_path`` /
     ``--refine_engine_path``) instead of packing the checkpoint — ``--ft_path`` is then not needed."""
     from .load_llff import load_llff_data_infer
+    from .run_S_eS_eN_alter_base_refine2 import dist_setup
     args = config_parser().parse_args(argv)
+    rank, _, device = dist_setup(device)        # torchrun: one process per GPU, each frame's rays sharded over them; rank 0 writes the output
     if args.dataset_type != 'llff':
         raise ValueError('only dataset_type=llff is supported (as in the reference release)')
     if args.no_ndc or args.lindisp:
@@ -324,10 +347,11 @@ def train(argv=None, device='cuda'):
     near, far = (float(bds.min()) * .9, float(bds.max())) if args.no_ndc else (0., 1.)    # :731-738
     H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)  # :746-751
-    os.makedirs(out_root, exist_ok=True)
-    with open(os.path.join(out_root, 'args.txt'), 'w') as f:                                 # :757-761
-        for k in sorted(vars(args)):
-            f.write('{} = {}\n'.format(k, getattr(args, k)))
+    if rank == 0:
+        os.makedirs(out_root, exist_ok=True)
+        with open(os.path.join(out_root, 'args.txt'), 'w') as f:                             # :757-761
+            for k in sorted(vars(args)):
+                f.write('{} = {}\n'.format(k, getattr(args, k)))
     kw, start = create_nerf(args, device=device)
     if args.use_trt:                                                                          # :490-499
         engines = engine_paths(out_root, args)
@@ -347,7 +371,8 @@ def train(argv=None, device='cuda'):
     with torch.no_grad():
         render_path(targets, [H, W, focal], K, args.chunk, kw, gt_imgs=gt, savedir=savedir, render_factor=args.render_factor,
                     near=near, far=far)
-    print('Saved test set' if args.render_test else 'Saved render path', savedir)
+    if rank == 0:
+        print('Saved test set' if args.render_test else 'Saved render path', savedir)
     return kw
 
 

@@ -198,3 +198,32 @@ def test_frame_driver_on_an_llff_directory(dev, tmp_path):
 def _read_png(path):
     from PIL import Image
     return np.asarray(Image.open(path).convert('RGB'))
+
+
+def test_frame_driver_under_torchrun_shards_every_frame(dev, tmp_path):
+    """Two processes (one GPU here, gloo; one per GPU over RCCL in production) run the inference script: every frame's rays are split
+    over the ranks and gathered; rank 0 writes the same PNG bytes as the single-process run."""
+    import subprocess
+    import sys
+    import llff_synth
+    from pronerf_amd import run_S_eS_eN_alter_trt as trt
+    root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=1, n=10, H=24, W=32, factor=4)
+    sds = synth.state_dicts(synth.make_weights(0, 'trained'))
+    ck = str(tmp_path / '000123.tar')
+    torch.save({'global_step': 123, 'mmr_network_fn_state_dict': sds['sampler'], 'refine_net_state_dict': sds['refine'],
+                'network_fine_state_dict': sds['nerf']}, ck)
+    body = (f'basedir = {tmp_path}/logs\ndatadir = {root}\nft_path = {ck}\nfactor = 4\nllffhold = 8\nN_samples = 8\nN_point_ray_enc = 48\n'
+            'mmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\n')
+    (tmp_path / 'one.txt').write_text('expname = one\n' + body)
+    (tmp_path / 'two.txt').write_text('expname = two\n' + body)
+    kw = trt.train(['--config', str(tmp_path / 'one.txt'), '--render_test'], device=dev)
+    env = {**os.environ, 'PNRF_DIST_BACKEND': 'gloo', 'PYTHONPATH': os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29549', '-m', 'pronerf_amd.run_S_eS_eN_alter_trt', '--config', str(tmp_path / 'two.txt'), '--render_test'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d1, d2 = tmp_path / 'logs' / 'one' / 'renderonly_test_000123', tmp_path / 'logs' / 'two' / 'renderonly_test_000123'
+    assert sorted(os.listdir(d1)) == sorted(os.listdir(d2)) == ['000.png', '001.png', 'depth_000.png', 'depth_001.png']
+    for f in os.listdir(d1):
+        assert (d1 / f).read_bytes() == (d2 / f).read_bytes(), f
+    assert r.stdout.count('Mean Test PSNR') == 1 and f"{kw['psnrs'][0]:.4f}"[:6] in r.stdout        # only rank 0 reports
