@@ -260,7 +260,7 @@ __device__ __forceinline__ float act_fast(float v, int act) {
 #define PNRF_BF16_ATSTEP 6
 #endif
 constexpr int BF16_PIECES = 2;
-template <int NCB, int KS, int NT, int POS0, class ST, class BFn, class Epi1, class Pre1>
+template <int NCB, int KS, int NT, int POS0, int PIECES = BF16_PIECES, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const float* biaslane, BFn Bi, Epi1 epi1, Pre1 pre1,
                                            f32x16 (&last)[NCB]) {
   constexpr int NF = KS * NT;
@@ -314,8 +314,12 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
       for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
       // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
 #pragma unroll
-      for (int pc = 0; pc < BF16_PIECES; ++pc) {
-        const int at = KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1);       // k-step after which piece pc is issued
+      for (int pc = 0; pc < PIECES; ++pc) {
+        // k-step after which piece pc is issued.  More than two pieces (PIECES = 8: two accumulator registers each): one piece every
+        // second k-step; in a layer's first tile one per k-step, so that the previous layer's last fragments are complete before the
+        // k-steps 14 and 15 that read them.
+        const int at = PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : 1 + 2 * pc)
+                                   : (KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1));
 #ifndef PNRF_PROBE_NOEPI
         if (ks == (at < KS ? at : KS - 1)) {
           if (to == 0) pre1(pc);

@@ -417,16 +417,33 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
 // ------------------------------------------------------------------------------------------ bf16 nets
 // Deferred hidden-layer epilogue, one piece at a time: piece pc = accumulator registers 8pc..8pc+7 of tile
 // `to` -> activation -> packed bf16 B fragment of k-step 2*to+pc of the next layer.
-template <int NCB, int ACT>
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32 for the pair (a in the low half)
+  int pk;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+  return pk;
+}
+// PIECES = 2: piece pc = registers 8pc..8pc+7 = one whole B fragment; PIECES = 8: registers 2pc, 2pc+1 = one dword of a fragment.
+template <int NCB, int ACT, int PIECES = 2>
 struct HiddenEpi {
   bf16x8 (&Bn)[NCB][KS_HID];
   __device__ __forceinline__ void operator()(int to, int pc, f32x16 (&acc)[NCB]) const {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      float v[8];
+      if constexpr (PIECES == 2) {
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * pc + j], ACT);
-      Bn[cb][2 * to + pc] = pack_bf16(v);
+        for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * pc + j], ACT);
+        Bn[cb][2 * to + pc] = pack_bf16(v);
+      } else {
+        constexpr int E = 16 / PIECES;
+        bf16x8& frag = Bn[cb][2 * to + (E * pc) / 8];
+        i32x4_t w = __builtin_bit_cast(i32x4_t, frag);
+#pragma unroll
+        for (int d = 0; d < E / 2; ++d)
+          w[((E * pc) % 8) / 2 + d] = cvt_pk_bf16(act_fast(acc[cb][E * pc + 2 * d], ACT), act_fast(acc[cb][E * pc + 2 * d + 1], ACT));
+        frag = __builtin_bit_cast(bf16x8, w);
+      }
     }
   }
 };
@@ -487,14 +504,18 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
     // ping-pong: layer 0 Bo -> Bn, then Bn -> Bo, Bo -> Bn, ... (5 hidden layers end in Bo);
     // `pend` = raw accumulators of the previous layer's last tile (its epilogue is deferred into the next layer)
     f32x16 pend[NCB];
+#ifndef PNRF_REFINE_PIECES
+#define PNRF_REFINE_PIECES 8
+#endif
+    constexpr int RP = PNRF_REFINE_PIECES;      // pieces of the deferred hidden-layer epilogue (2 or 8)
     auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
-      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
-                                               HiddenEpi<NCB, ACT_ELU>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU>{in}(NT_HID - 1, pc, pend); }, np);
+      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H, RP>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+                                                   HiddenEpi<NCB, ACT_ELU, RP>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU, RP>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
     };
-    layer_bf16<NCB, R_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU>{Bn}, [](int) {}, pend);
+    layer_bf16<NCB, R_KS0, NT_HID, 0, RP>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU, RP>{Bn}, [](int) {}, pend);
     static_assert(R_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
     for (int l = 0; l < 4; l += 2) {
       hidden(Bn, Bo, l);
@@ -915,7 +936,6 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
 // v_pk_max_i16 against 0 clears them — the same bits as converting max(x, 0), with one instruction per two values instead of two.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short i16x2_t __attribute__((ext_vector_type(2)));
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int relu_pack_bf16(float a, float b) {
 #ifdef PNRF_RELU_F32
   return __builtin_bit_cast(int, bf16x2_t{(__bf16)act_fast(a, ACT_RELU), (__bf16)act_fast(b, ACT_RELU)});
