@@ -318,7 +318,13 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
         // k-step after which piece pc is issued.  More than two pieces (PIECES = 8: two accumulator registers each): one piece every
         // second k-step; in a layer's first tile one per k-step, so that the previous layer's last fragments are complete before the
         // k-steps 14 and 15 that read them.
-        const int at = PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : 1 + 2 * pc)
+#ifndef PNRF_BF16_P8_AT0
+#define PNRF_BF16_P8_AT0 1
+#endif
+#ifndef PNRF_BF16_P8_STEP
+#define PNRF_BF16_P8_STEP 2
+#endif
+        const int at = PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : PNRF_BF16_P8_AT0 + PNRF_BF16_P8_STEP * pc)
                                    : (KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1));
 #ifndef PNRF_PROBE_NOEPI
         if (ks == (at < KS ? at : KS - 1)) {
