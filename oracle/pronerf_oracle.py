@@ -354,6 +354,26 @@ def project_train(images_nchw, poses, K, or_o, or_d, depth_ndc, ref_nos, eps=1e-
     return vals.reshape(N, nb * S * 3), margin                                          # :626
 
 
+def warp_train(img, depth, ro1, rd1, c2w2, K):
+    """The training warp as an operator, inverse_warp.py:515-581 (inverse_warp_rod1_rt2_coords), padding_mode='zeros', scale=1.
+    img [B,3,Hf,Wf]; depth [B,n]; ro1, rd1 [3,n] (the reference's repeat()-ed operands, stored once); c2w2 [B,3,4]; K [B,3,3].
+    Returns (projected [B,3,n], margin [B,n]): margin = distance of the sample's normalised coordinates to the in/out boundary."""
+    img, depth, ro1, rd1, c2w2, K = (_t(x) for x in (img, depth, ro1, rd1, c2w2, K))
+    B, _, Hf, Wf = img.shape
+    Rt = c2w2[:, :, :3].transpose(1, 2)                                         # :530-533
+    tt = -torch.bmm(Rt, c2w2[:, :, 3:4])
+    w = ro1[None] + rd1[None] * depth[:, None, :]                               # :536
+    c2 = torch.bmm(Rt, w) + tt                                                  # :539
+    c2n = c2 / (c2[:, 2:3].abs() + 1e-8)                                        # :543-544
+    c2n = torch.stack([c2n[:, 0], -c2n[:, 1], torch.ones_like(c2n[:, 0])], 1)   # :545-546
+    p = torch.bmm(K, c2n)                                                       # :547
+    X, Y = p[:, 0], p[:, 1]
+    xn = 2 * X / (Wf - 1) - 1; yn = 2 * Y / (Hf - 1) - 1                        # :552-553
+    inside = (xn <= 1) & (xn >= -1) & (yn <= 1) & (yn >= -1)                    # :557-561
+    out = torch.stack([bilinear_zeros(img[b], X[b], Y[b]) * inside[b][None] for b in range(B)], 0)
+    return out, torch.minimum((xn.abs() - 1).abs(), (yn.abs() - 1).abs())
+
+
 def select_neighbors_train(target_poses, poses, num_neighbor, order_idx=None):
     """Per-ray ranking of the training cameras by distance to the ray's own camera.
     refine2.py:590-600: randomize -> drop rank 0 (self) and take the rank positions ``order_idx`` (a sorted random

@@ -87,6 +87,37 @@ def test_cli_subcommands_map_to_driver_arguments():
         config_parser(variant).parse_args(argv)
 
 
+def test_reference_entry_point_name(monkeypatch):
+    """`python -m pronerf.cli` — the module path of the reference's CLI (pronerf/cli.py:180-230; BASELINE.json configs[0]:
+    `infer --render-test --max-images 1`): same parser, dispatched to this build's inference driver with the mapped argv."""
+    import subprocess
+    import sys
+    import pronerf
+    import pronerf.cli as rcli
+    from pronerf_amd import run_S_eS_eN_alter_trt as drv
+    assert pronerf.__version__
+    p = rcli.build_parser()
+    assert p.prog == 'python -m pronerf.cli'
+    ns = p.parse_args(['infer', '--render-test', '--max-images', '1'])
+    assert rcli.infer_argv(ns)[0] == '--config' and rcli.infer_argv(ns)[1].endswith(os.path.join('configs', 'llff', 'fern', 'fern_trt.txt'))
+    assert rcli.infer_argv(ns)[2:] == ['--render_test', '--max_images', '1']
+    seen = {}
+    monkeypatch.setattr(drv, 'train', lambda argv: seen.setdefault('argv', list(argv)))
+    rcli.main(['infer', '--render-test', '--max-images', '1', '--', '--chunk', '1024'])
+    assert seen['argv'][2:] == ['--render_test', '--max_images', '1', '--chunk', '1024']
+    seen.clear()
+    rcli.main(['eval', '--checkpoint', 'z.tar'])
+    assert seen['argv'][2:] == ['--ft_path', 'z.tar', '--render_test']
+    # as a module, from another working directory, with both spellings (`-m pronerf.cli`, `-m pronerf`)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    for mod in ('pronerf.cli', 'pronerf'):
+        r = subprocess.run([sys.executable, '-m', mod, 'infer', '--help'], cwd='/', env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and '--render-test' in r.stdout and '--max-images' in r.stdout, r.stderr
+    r = subprocess.run([sys.executable, '-m', 'pronerf.cli'], cwd='/', env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'train-stage1' in r.stderr and 'export-trt' in r.stderr
+
+
 def test_shipped_configs_carry_the_reference_hyperparameters():
     """configs/llff/fern/*.txt (the CLI's default --config files): parse with this package's parser; spot values of the reference's
     files (fern_trt.txt:10-34, fern_refine.txt, fern_epi.txt); equal to the reference's own files where those are present."""

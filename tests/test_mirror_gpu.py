@@ -91,6 +91,43 @@ def test_module_forwards_and_operators(dev, golden_dir):
         np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize('case', ['op', 'cap'])
+def test_training_warp_by_its_reference_name(dev, golden_dir, case):
+    """inverse_warp.inverse_warp_rod1_rt2_coords (reference signature, (projected, None)) against the reference's own outputs:
+    a direct call and the call of the stage-2 driver at refine2.py:617 with its repeat()-ed operands (oracle/gen_golden_warp.py)."""
+    from pronerf_amd import inverse_warp as iw
+    from pronerf_amd.ops import PnrfError
+    g = dict(np.load(os.path.join(golden_dir, 'warp_train.npz')))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if case == 'op':
+        img, depth = t(g['op_img']), t(g['op_depth'])
+    else:                                     # ref_rgb = repeat_interleave(images, 8): b = view * S + sample (refine2.py:602-604)
+        img, depth = torch.repeat_interleave(t(g['cap_img_views']), int(g['cap_S']), dim=0), t(g['cap_depth'])
+    B, n = depth.shape[0], depth.shape[2]
+    ro1, rd1 = t(g[case + '_ro1'])[None].repeat(B, 1, 1), t(g[case + '_rd1'])[None].repeat(B, 1, 1)       # :606-607
+    K = t(g[case + '_K'])
+    warped, none = iw.inverse_warp_rod1_rt2_coords(img, depth, ro1, rd1, t(g[case + '_c2w2']), K, torch.inverse(K), padding_mode='zeros')
+    assert none is None and warped.shape == (B, 3, 1, n)
+    ref = g[case + '_out'][:, :, 0, :]
+    _, margin = orc.warp_train(img.cpu(), depth[:, 0].cpu(), g[case + '_ro1'], g[case + '_rd1'], g[case + '_c2w2'], g[case + '_K'])
+    safe = (margin > 1e-5).numpy()
+    got = warped[:, :, 0, :].cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(got[b][:, safe[b]], ref[b][:, safe[b]], rtol=0, atol=2e-5)
+    # samples on the in/out boundary itself (the own view's border pixels): either the reference's value or the other branch's zero
+    edge = ~safe
+    assert edge.mean() < 0.1
+    for b in range(B):
+        e = edge[b]
+        assert np.all((np.abs(got[b][:, e] - ref[b][:, e]).max(0) < 2e-5) | (np.abs(got[b][:, e]).max(0) == 0) | (np.abs(ref[b][:, e]).max(0) == 0))
+    # the expand()-ed form (stride-0 batch dimension) gives the same result without materialising the copies
+    w2, _ = iw.inverse_warp_rod1_rt2_coords(img, depth, ro1[:1].expand(B, -1, -1), rd1[:1].expand(B, -1, -1), t(g[case + '_c2w2']), K, None)
+    assert torch.equal(w2, warped)
+    for bad in (dict(padding_mode='border'), dict(scale=0.5)):
+        with pytest.raises(PnrfError):
+            iw.inverse_warp_rod1_rt2_coords(img, depth, ro1, rd1, t(g[case + '_c2w2']), K, None, **bad)
+
+
 @pytest.mark.parametrize('name', ['infer_trained_24x32', 'infer_spread_20x28_img48x64'])
 def test_render_rays_like_the_reference_driver(dev, golden_dir, name):
     """Build the kwargs exactly as render_path does in the reference (x8 replicated ref_rgb / ref_pose,

@@ -106,6 +106,26 @@ def test_operator_goldens(golden_dir):
     np.testing.assert_allclose(y.numpy(), g['nc_y'], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('case', ['op', 'cap'])
+def test_training_warp_matches_reference(golden_dir, case):
+    """oracle.warp_train against the reference's own inverse_warp_rod1_rt2_coords: a direct call ('op') and the call the
+    stage-2 driver makes at refine2.py:617 ('cap', all training views x 8 samples), oracle/gen_golden_warp.py."""
+    g = load(golden_dir, 'warp_train')
+    if case == 'op':
+        img, depth = g['op_img'], g['op_depth'][:, 0]
+    else:                                     # replicated per sample in the reference: b = view * S + sample
+        S = int(g['cap_S'])
+        img, depth = np.repeat(g['cap_img_views'], S, axis=0), g['cap_depth'][:, 0]
+    out, margin = orc.warp_train(img, depth, g[case + '_ro1'], g[case + '_rd1'], g[case + '_c2w2'], g[case + '_K'])
+    ref = g[case + '_out'][:, :, 0, :]
+    safe = (margin > 1e-5).numpy()
+    assert safe.mean() > 0.9             # 'cap': the rays' own view projects its border pixels exactly onto |x| = 1 (5 % of the samples)
+    for b in range(ref.shape[0]):
+        np.testing.assert_allclose(out[b][:, safe[b]].numpy(), ref[b][:, safe[b]], rtol=0, atol=2e-5)
+    nz = (np.abs(ref).sum(1) > 0).mean()
+    assert 0.2 < nz < 0.9                     # both the inside and the outside branch are exercised
+
+
 @pytest.mark.parametrize('name', ['stage2_train_16x20', 'stage2_eval_white_12x18'])
 def test_stage2_forward_matches_reference(golden_dir, name):
     """Stage-2 training-time render_rays (refine2.py:525-680) with the reference's random draws replayed."""
