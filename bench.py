@@ -9,15 +9,21 @@ Workload (BASELINE.json configs[1]): one 1008x756 LLFF-Fern-geo
 762 048 rays, 8 samples/ray, 4 neighbour views, 48 ray-encoding points; synthetic poses/images
 and seeded "trained-like" weights (no dataset/checkpoint ships).  A step = one pass of the hot
 path (sampler MLP fp32-grade split fp16 -> neighbour projection -> refine MLP bf16 -> NeRF MLP bf16 -> alpha
-compositing) over one frame; the kernels tile the frame into 1024-ray chunks (4 workgroup
-batches of 256 columns) inside a single launch per stage.  Rays, images and weights are resident
+compositing) over one frame: ONE pnrf_render_rays_fwd call renders the whole frame, as the reference
+renders it in one render() call (run_S_eS_eN_alter_trt.py:329); the "1024-ray chunks" of BASELINE.json
+configs[1] are four of the 256-column workgroup batches each persistent kernel walks through inside its
+single launch.  Rays, images and weights are resident
 in HBM before the timed region, exactly like the reference's timed loop
 (run_S_eS_eN_alter_trt.py:327-332).  At N>1 the frame's rays are split into contiguous ranges,
 one per rank, and the per-rank [n,4] rgb+depth tiles are all-gathered over RCCL inside the timed
 region ("strong" scaling: the frame is fixed).
 
-Rank 0 prints ONE JSON line (see the driver contract); `roofline` and `cpu_baseline` are added
-at N=1.
+Rank 0 prints ONE JSON line (see the driver contract); at N=1 it carries `roofline`, `cpu_baseline`
+(the CPU oracle on the host cores, 65 536 rays of the same frame) and `gpu_eager_baseline`: the oracle's
+eager fp32 torch graph on the same GPU, whole frame in one call, device events — BASELINE.md §4 item 2,
+"the reference single-GPU PyTorch rays/s" that BASELINE.json's >= 10x target is measured against.  No
+published number exists for the metric, so `vs_baseline` is value / that measured baseline
+and `vs_baseline_kind` says so.  Both baselines run after the timed region; oracle/ is imported only there.
 """
 from __future__ import annotations
 
@@ -50,7 +56,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10, help='the chip needs ~5 frames from idle to its steady clock')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (rank 0, N=1)')
-    ap.add_argument('--cpu-sample-rays', type=int, default=16384)
+    ap.add_argument('--cpu-sample-rays', type=int, default=65536, help='SURVEY.md §8(d): >= 65 536 rays')
+    ap.add_argument('--no-gpu-eager-baseline', action='store_true', help='skip the eager-PyTorch-on-GPU baseline (rank 0, N=1)')
+    ap.add_argument('--eager-reps', type=int, default=5)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
                     'the multi-rank path with several ranks sharing one GPU)')
     return ap.parse_args()
@@ -97,10 +105,48 @@ def cpu_baseline(weights, scene, n_rays, budget_s=20.0):
                       f'best of {reps} passes of oracle.render_rays_infer (fp32 torch CPU)'}
 
 
+def gpu_eager_baseline(weights, scene, dev, reps=5):
+    """the reference-style eager PyTorch path on this GPU — the oracle's torch graph (validated against the
+    reference's own outputs, tests/test_oracle_golden.py) with every tensor on `dev`, fp32 (TF32 off), unfused, the whole 762 048-ray
+    frame in one call like run_S_eS_eN_alter_trt.py:329, `mm_input` precomputed outside the timed call as in the reference
+    (trt.py:274-278), device events, `reps` timed calls after two warm-up calls.  Checker-side code, run after the timed region."""
+    from oracle import pronerf_oracle as orc
+    torch.backends.cuda.matmul.allow_tf32 = False
+    wd = {k: {'W': [torch.as_tensor(w).to(dev) for w in v['W']], 'b': [torch.as_tensor(b).to(dev) for b in v['b']]} for k, v in weights.items()}
+    fr = orc.frame_setup(scene)
+    rays, or_rays, mm_input = fr['rays'].to(dev), fr['or_rays'].to(dev), fr['mm_input'].to(dev)
+    images, proj = fr['images'].to(dev), fr['proj'].to(dev)
+    n = rays.shape[0]
+    t1, t2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    with torch.no_grad():
+        for i in range(reps + 2):
+            t1.record()
+            out = orc.render_rays_infer(wd, rays, or_rays, images, proj, mm_input=mm_input)
+            t2.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ms.append(t1.elapsed_time(t2))
+            rgb = out['rgb']
+            del out
+    del wd, fr, rays, or_rays, mm_input, images, proj
+    torch.cuda.empty_cache()
+    mean = sum(ms) / len(ms)
+    return {'value': n / mean * 1e3, 'unit': 'rays/s', 'ms_per_frame': mean, 'ms_per_frame_best': min(ms), 'reps': reps, 'rays': n, 'dtype': 'f32',
+            'kind': 'port', 'what': 'oracle torch graph on the same GPU (eager, fp32, unfused, whole frame in one call; BASELINE.md §4 item 2)',
+            'torch': torch.__version__}, rgb
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the latest committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE
-    passes, gfx950 FETCH_SIZE x2 correction applied there), if any."""
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (profiles/r<round>_v<version>_pmc_summary.json,
+    newest = highest (round, version), not lexicographic: v9 < v11): separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2
+    correction applied there.  None when there is no summary or it does not list the kernel."""
+    import re
+
+    def key(f):
+        m = re.search(r'r(\d+)(?:_v(\d+))?_pmc_summary\.json$', os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2) or 0)) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')), key=key)
     if not files:
         return None
     try:
@@ -193,7 +239,7 @@ def main():
         dt = float(t.item())
     finite = bool(all(torch.isfinite(o).all().item() for o in outs))
 
-    sampler_f32 = os.environ.get('PNRF_SAMPLER_PREC', '').startswith('f3')
+    sampler_f32 = False                      # the product path: default kernel variants (the library reads no environment)
     res = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -207,8 +253,9 @@ def main():
                                                                   'f16x2 (sampler MLP: split fp16 hi+lo operands, fp32 accumulate, fp32-grade)'),
             'data': 'synthetic',
             'backend': (args.backend if world > 1 else None),
-            'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, '
-                                   '48 ray-encoding points, 1024-ray chunks (4x256-column workgroup batches), bf16 MLP',
+            'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, 48 ray-encoding points, '
+                                   'bf16 MLP; one pnrf_render_rays_fwd call renders the whole frame (the 1024-ray chunks of configs[1] = 4 of the '
+                                   '256-column workgroup batches each persistent kernel walks inside its single launch)',
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0],
                        'gather_pipelined': bool(pipeline), 'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
             'outputs_finite': finite,
@@ -229,7 +276,7 @@ def main():
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
             symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_h16_kernel', 'refine_input_kernel': 'refine_input_kernel',
                        'refine_kernel': 'refine_kernel<1, 8, 1>',
-                       'nerf_kernel': 'nerf16_kernel<false>' if os.environ.get('PNRF_BF16_VARIANT', '16') == '16' else 'nerf_kernel<...>'}
+                       'nerf_kernel': 'nerf16_kernel<false>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
             res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
@@ -237,6 +284,17 @@ def main():
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
                                'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
             res['kernels'] = kern
+            if not args.no_gpu_eager_baseline:
+                last = outs[0][:count, :3].clone() if not pipeline else None
+                eager, eager_rgb = gpu_eager_baseline(weights, scene, dev, args.eager_reps)
+                if last is not None:             # the two paths rendered the same frame: error of the HIP path against the eager fp32 graph
+                    mse = float(((last.double() - eager_rgb.double()) ** 2).mean())
+                    eager['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse))) if mse > 0 else float('inf')
+                del eager_rgb
+                res['gpu_eager_baseline'] = eager
+                res['vs_baseline'] = value / eager['value']
+                res['vs_baseline_kind'] = ('value / gpu_eager_baseline.value, measured in this run (BASELINE.md §4 item 2: the denominator of the >= 10x '
+                                           'target); the reference publishes no number for this metric')
             if not args.no_cpu_baseline:
                 res['cpu_baseline'] = cpu_baseline(weights, scene, args.cpu_sample_rays)
     if world > 1:

@@ -13,7 +13,8 @@
  *     there is no hidden device synchronisation;
  *   - return 0 = ok, < 0 = argument error (PNRF_E_*), > 0 = hipError_t; the message for the
  *     last non-zero return of the calling thread is available from pnrf_last_error();
- *   - handles are immutable after creation: entry points are re-entrant across streams.
+ *   - handles are immutable once configured (pack / deserialize [+ pnrf_mlp_set_variant]): entry points are re-entrant across
+ *     streams, and no entry point reads the process environment.
  */
 #ifndef PRONERF_HIP_H
 #define PRONERF_HIP_H
@@ -67,6 +68,21 @@ int pnrf_mlp_free(pnrf_mlp_t* h);
 int pnrf_mlp_serialize(const pnrf_mlp_t* h, void* buf, int64_t capacity, int64_t* size);
 int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** out);
 int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int* out_dim);
+
+/* Kernel variant of a packed network.  PNRF_VARIANT_DEFAULT is what pack / deserialize produce and what every product path runs:
+ * sampler in split fp16 (fp32-grade, three v_mfma_f32_16x16x32_f16 per product) with the folded first layer, refine and NeRF stages
+ * on v_mfma_f32_16x16x32_bf16.  The others exist for parity tests and A/B timing (tools/perf_ab.py):
+ *   SAMPLER_F32       sampler on the exact fp32 FMA chain (v_mfma_f32_16x16x4_f32), folded first layer;
+ *   SAMPLER_F32_FULL  ... with the full K = 288 first layer on the 48 Pluecker points (no fold);
+ *   BF16_32X32        refine / NeRF handles: the v_mfma_f32_32x32x16_bf16 engine.
+ * A variant is part of a handle's configuration, like its weights: set it right after pack / deserialize, before the handle is given to
+ * a context or a stream (the call is not synchronised against launches that use the handle).  Nothing in the library reads the process
+ * environment to pick kernels.  Returns PNRF_E_ARG for a variant the handle's net kind does not have. */
+#define PNRF_VARIANT_DEFAULT 0
+#define PNRF_VARIANT_SAMPLER_F32 1
+#define PNRF_VARIANT_SAMPLER_F32_FULL 2
+#define PNRF_VARIANT_BF16_32X32 3
+int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear
  * (MinMaxRay_Net.forward, DoNeRFTRT.forward); head_act = 1: with the head activations of the TRT

@@ -92,14 +92,17 @@ def reference_frame(helpers, trt, scene):
                 embed_rays=embed_rays, rays_o=rays_o, rays_d=rays_d)
 
 
-def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, rotate=False, sigma_t=0.05, take=None):
+def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, rotate=False, sigma_t=0.05, take=None, sel=None, slim=False):
     torch.manual_seed(3407)
     weights = synth.make_weights(seed, kind)
     scene = synth.make_scene(seed, H=H, W=W, Hf=Hf, Wf=Wf, rotate=rotate, sigma_t=sigma_t)
     sampler, refine, nerf = build_models(helpers, weights)
     fr = reference_frame(helpers, trt, scene)
     N_full = fr['rays'].shape[0]
-    sel = np.arange(N_full) if take is None else np.linspace(0, N_full - 1, take).astype(np.int64)
+    if sel is None:
+        sel = np.arange(N_full) if take is None else np.linspace(0, N_full - 1, take).astype(np.int64)
+    else:
+        take = len(sel)
     if take is not None:      # render only the selected rays of the frame (render_rays is per-ray independent)
         st = torch.from_numpy(sel)
         for k in ('rays', 'or_rays', 'mm_input'):
@@ -163,6 +166,12 @@ def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, r
         rgb=g(ret['rgb_map1']), depth=g(ret['depth_map']),
         disp=g(cap['disp']), acc=g(cap['acc']), weights=g(cap['weights']),
     )
+    if slim:                  # large ray sets: inputs, the sampler's decision and the final outputs only
+        oob = (epi.reshape(N, -1, 3) == 0).all(-1).sum(-1).astype(np.uint8)       # (view, sample) taps that fell outside their source image
+        keep = ('seed', 'kind', 'H', 'W', 'Hf', 'Wf', 'rotate', 'sigma_t', 'sel', 'n_full', 'rays', 'ref_nos', 'proj', 'depth_sorted', 'z', 'rgb', 'depth')
+        out = {k: out[k] for k in keep}
+        out['sort_idx'] = g(cap['sort_idx']).astype(np.int8)
+        out['oob_taps'] = oob
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, f'{name}.npz')
     np.savez_compressed(path, **out)
@@ -401,5 +410,30 @@ def main_infer(helpers, iw, trt):
     run_infer_case(helpers, iw, trt, 'infer_trained_fern_756x1008', 4, 'trained', 756, 1008, rotate=True, take=512)
 
 
+def fern_8k_selection(H=756, W=1008, seed=12):
+    """More than 8192 rays of the 756x1008 frame, stratified: the two outermost rows / columns on every side (whose samples project outside the
+    neighbour images) and one seeded random pixel in each cell of an 84 x 84 grid over the frame (8 8xx rays after de-duplication)."""
+    rs = np.random.RandomState(seed)
+    cols = np.linspace(0, W - 1, 256).astype(np.int64)
+    rows = np.linspace(0, H - 1, 192).astype(np.int64)
+    border = [r * W + cols for r in (0, 1, H - 2, H - 1)] + [rows * W + c for c in (0, 1, W - 2, W - 1)]
+    ys = np.linspace(0, H, 85).astype(np.int64); xs = np.linspace(0, W, 85).astype(np.int64)
+    cells = []
+    for i in range(84):
+        for j in range(84):
+            cells.append(rs.randint(ys[i], ys[i + 1]) * W + rs.randint(xs[j], xs[j + 1]))
+    sel = np.unique(np.concatenate(border + [np.array(cells, dtype=np.int64)]))
+    return sel
+
+
+def main_fern_8k():
+    helpers, iw, trt = load_reference()
+    sel = fern_8k_selection()
+    run_infer_case(helpers, iw, trt, 'infer_trained_fern_756x1008_8k', 4, 'trained', 756, 1008, rotate=True, sel=sel, slim=True)
+
+
 if __name__ == '__main__':
-    main()
+    if '--fern-8k' in sys.argv:
+        main_fern_8k()
+    else:
+        main()

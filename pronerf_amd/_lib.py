@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpronerf_hip.so')
 
 NET_SAMPLER, NET_REFINE, NET_NERF, NET_NERFCLS = 0, 1, 2, 3
+# kernel variants of a packed handle (pnrf_mlp_set_variant)
+VARIANTS = {'default': 0, 'sampler_f32': 1, 'sampler_f32_full': 2, 'bf16_32x32': 3}
 ABI_VERSION = 1
 
 
@@ -33,6 +35,7 @@ SIGNATURES = {
     'pnrf_mlp_serialize': (_i, [_p, _p, _i64, C.POINTER(_i64)]),
     'pnrf_mlp_deserialize': (_i, [_p, _i64, C.POINTER(_p)]),
     'pnrf_mlp_kind': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'pnrf_mlp_set_variant': (_i, [_p, _i]),
     'pnrf_mlp_fwd': (_i, [_p, _p, _p, _p, _i64, _i, _p]),
     'pnrf_posenc_fwd': (_i, [_p, _p, _i64, _i, _p]),
     'pnrf_plucker_fwd': (_i, [_p, _p, _p, _i64, _p]),

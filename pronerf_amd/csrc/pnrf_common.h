@@ -65,4 +65,5 @@ struct pnrf_mlp {
   int n_in0, n_inx, n_out;
   float* d_tvals;        // sampler only: t = torch.linspace(0,1,48) of the ray points (trt.py:556-557)
   int device;
+  int variant;           // PNRF_VARIANT_* (pnrf_mlp_set_variant); 0 = default kernels
 };

@@ -40,18 +40,6 @@ constexpr int RING_BYTES = NSLOTS * SLOT_BYTES;
 
 enum { ACT_RELU = 0, ACT_ELU = 1, ACT_NONE = 2 };
 
-// Diagnostic build only (-DPNRF_DIAG, tools/diag_stamps.py): per-wave s_memtime shares.  No stamp executes in
-// the product build.
-#ifdef PNRF_DIAG
-__device__ unsigned long long g_pnrf_diag[4 * 8 * 1024];      // [block*NW + wave] x {total, vmcnt wait, barrier wait, n begin}
-__device__ unsigned long long g_pnrf_tl[16 * 8 * 64];            // timeline stamps of two steady-state tiles, first 64 workgroups
-#define PNRF_TL(i) asm volatile("s_memtime %0" : "=s"(tlv[i]))
-__device__ __forceinline__ unsigned long long diag_now() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -87,12 +75,6 @@ struct WStream {
   uint32_t dst_pos;    // next ring position
   uint32_t woff;       // per-lane byte offset inside a slot (source side)
   uint32_t wbase;      // wave-uniform byte offset inside a slot (LDS side)
-#ifdef PNRF_PROBE_DMA_ONCE
-  uint32_t n_issued = 0;
-#endif
-#ifdef PNRF_DIAG
-  unsigned long long t_vm = 0, t_bar = 0, n_begin = 0, t_start = 0;
-#endif
 
   __device__ __forceinline__ void init(const void* blob, uint32_t nslots_, char* ring_) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -108,11 +90,6 @@ struct WStream {
   // before its first MFMA.  Hidden from the compiler the reads keep their counted lgkmcnt(N).  Completion is counted by
   // wait_slot()'s own vmcnt; M0 (compiler-reserved) is saved and restored inside the statement.
   __device__ __forceinline__ void issue_loads() {
-#ifdef PNRF_PROBE_DMA_ONCE      // diagnostic only: the ring is filled once with real weights (realistic operand bits and power), then no more DMA
-    if (n_issued >= NSLOTS) return;
-    n_issued += 1;
-#endif
-#ifndef PNRF_PROBE_NODMA
     const uint64_t src = (uint64_t)(uintptr_t)g + (uint64_t)src_slot * SLOT_BYTES;                 // wave-uniform
     const uint32_t dst = (uint32_t)(uintptr_t)(lptr_t)ring + dst_pos * SLOT_BYTES + wbase;       // wave-uniform LDS byte address
 #pragma unroll
@@ -128,7 +105,6 @@ struct WStream {
           : "v"(woff), "s"(src + (uint64_t)(i * FRAG_BYTES)), "s"(dst + (uint32_t)(i * FRAG_BYTES))
           : "memory");
     }
-#endif
   }
   __device__ __forceinline__ void advance() {
     src_slot = (src_slot + 1 == nslots) ? 0u : src_slot + 1;
@@ -145,9 +121,6 @@ struct WStream {
   __device__ __forceinline__ void prologue() {
 #pragma unroll
     for (int i = 0; i < PD; ++i) issue();
-#ifdef PNRF_DIAG
-    t_start = diag_now();
-#endif
   }
   // Called at the boundary between slot q-1 and slot q, by every wave, in the same order.
   //  vmcnt(N): my share of slot q has landed (N = LOADS_PER_WAVE * (PD-1) younger loads may still be in
@@ -158,29 +131,12 @@ struct WStream {
   //  the barrier with an 8-slot ring bought nothing, so reads stay inside their slot.)
   __device__ __forceinline__ void begin() { wait_slot(); issue(); }
   __device__ __forceinline__ void wait_slot() {
-#ifdef PNRF_DIAG
-    const unsigned long long t0 = diag_now();
-#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD - 1 - XSLOT)) : "memory");
-#ifdef PNRF_DIAG
-    const unsigned long long t1 = diag_now();
-#endif
-#ifndef PNRF_PROBE_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
-#ifdef PNRF_DIAG
-    t_vm += t1 - t0; t_bar += diag_now() - t1; n_begin += 1;
-#endif
   }
   // LDS-DMA still in flight at kernel end would land in another workgroup's LDS: drain.
   __device__ __forceinline__ void drain() {
-#ifdef PNRF_DIAG
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
-      const unsigned w = blockIdx.x * NW + (threadIdx.x >> 6);
-      g_pnrf_diag[4 * w + 0] = diag_now() - t_start; g_pnrf_diag[4 * w + 1] = t_vm; g_pnrf_diag[4 * w + 2] = t_bar; g_pnrf_diag[4 * w + 3] = n_begin;
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -227,11 +183,7 @@ __device__ __forceinline__ float act_fast(float v, int act) {
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
   }
-#ifdef PNRF_PROBE_ELU_AS_RELU
-  return fmaxf(v, 0.f);                                // diagnostic only: what the ELU itself costs
-#else
   return v > 0.f ? v : __expf(v) - 1.f;                // see act_f32
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,10 +222,6 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
   };
   f32x16 pend[NCB];
   bf16x8 aq[AHEAD];
-#ifdef PNRF_DIAG
-  constexpr bool TL = KS == 16 && NT == 8;      // timeline of tiles 4 and 5 of a full hidden layer (tools/diag_stamps.py)
-  unsigned long long tlv[13];
-#endif
   // the bias of tile to+1 is read from LDS at the head of tile `to` (software pipelined): read in place, the first MFMA of
   // every tile would wait a full LDS round trip for its accumulator with both waves of the SIMD phase-locked behind the barrier
   f32x4 nb0, nb1, nb2, nb3;
@@ -294,16 +242,7 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
     for (int ks = 0; ks < KS; ++ks) {
       const int f = to * KS + ks;
       if (f % SLOT_FRAGS == 0) {
-#ifdef PNRF_DIAG
-        if (TL && to == 4) PNRF_TL(0);
-        if (TL && to == 5) PNRF_TL(6);
-        if (TL && to == 6) PNRF_TL(12);
-#endif
         st.wait_slot();          // the slot is readable now: (re)fill the queue from its head
-#ifdef PNRF_DIAG
-        if (TL && to == 4) PNRF_TL(1);
-        if (TL && to == 5) PNRF_TL(7);
-#endif
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
           if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
@@ -326,30 +265,12 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
 #endif
         const int at = PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : PNRF_BF16_P8_AT0 + PNRF_BF16_P8_STEP * pc)
                                    : (KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1));
-#ifndef PNRF_PROBE_NOEPI
         if (ks == (at < KS ? at : KS - 1)) {
           if (to == 0) pre1(pc);
           else epi1(to - 1, pc, pend);
         }
-#endif
       }
       st.slot_issue(f % SLOT_FRAGS);
-#ifdef PNRF_DIAG
-      if (TL && (to == 4 || to == 5)) {
-        const int b = (to - 4) * 6;
-        if (ks == 0) PNRF_TL(b + 2);
-        if (ks == 1) PNRF_TL(b + 3);
-        if (ks == 8) PNRF_TL(b + 4);
-        if (ks == 15) PNRF_TL(b + 5);
-      }
-      if (TL && to == 6 && ks == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) {
-#pragma unroll
-          for (int i = 0; i < 13; ++i) g_pnrf_tl[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + i] = tlv[i];
-        }
-      }
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll

@@ -352,14 +352,6 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) vals[i] = fmaf(fc[i >> 2][i & 3], INV, fm[i >> 2][i & 3]);
 
-#ifdef PNRF_PROBE_NOBATCHWORK      // diagnostic only: store the raw logits, skip sigmoid / sort / permutation
-    if (valid && q < 3) {
-      float4* p = (float4*)((q == 0 ? a.depth_sorted : (q == 1 ? a.add_sorted : a.mul_sorted)) + row * 8);
-      p[0] = make_float4(vals[0], vals[1], vals[2], vals[3]);
-      p[1] = make_float4(vals[4], vals[5] + near, vals[6] + far, vals[7]);
-    }
-    continue;
-#endif
     // ---- fused epilogue.  Quarter 0 of a column holds the 8 depth logits, quarter 1 add, quarter 2 mul,
     // quarter 3 rgb (sampler_out).  Quarter 0 sorts; the permutation goes to the other quarters as a word.
     float dep[8];
@@ -997,15 +989,8 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       const float* pp = a.pts + rr * 3;
       const float* ry = a.rays + (a.S == 8 ? (rr >> 3) : rr / a.S) * 11;
-#ifdef PNRF_PROBE_NOHEADLOAD      // diagnostic only: what the latency of the batch-head loads costs (inputs made up from the row index)
-      const float fr = (float)(rr & 1023) * 9.765625e-4f;
-      const float x3[3] = {fr, 1.f - fr, fr * 0.5f};
-      const float v3[3] = {fr, 0.5f, -fr};
-      (void)pp;
-#else
       const float x3[3] = {pp[0], pp[1], pp[2]};
       const float v3[3] = {ry[8], ry[9], ry[10]};
-#endif
       if (composite) {
         e_dn[cb] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ry[3], ry[3]), __fmul_rn(ry[4], ry[4])), __fmul_rn(ry[5], ry[5])));
         e_z[cb] = a.z[rr]; e_add[cb] = a.add ? a.add[rr] : 0.f; e_mul[cb] = a.mul ? a.mul[rr] : 1.f;
@@ -1013,12 +998,6 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       }
       // positional encoding straight into B-fragment order (see pe_sincos / the recurrence note in nerf_kernel)
       float f0[16], fx[8];
-#ifdef PNRF_PROBE_NOBATCHWORK      // diagnostic only: ceiling of what the per-batch VALU work (encoding, compositing) still costs
-#pragma unroll
-      for (int i = 0; i < 16; ++i) f0[i] = x3[i % 3] + (float)i;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fx[i] = v3[i % 3] - (float)i;
-#else
       // positional encoding in the slot order of nerf16_in0 / nerf16_inx: four chains of two octaves per lane (hardware sin / cos at the
       // chain's first octave, one double-angle step for the second), the view octave of the lane group directly
 #pragma unroll
@@ -1034,7 +1013,6 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       for (int c = 0; c < 3; ++c) pe_sincos_scaled(v3[c], pe_vs, fx[2 * c], fx[2 * c + 1]);
       fx[6] = g == 0 ? v3[0] : (g == 1 ? v3[2] : 0.f);
       fx[7] = g == 0 ? v3[1] : 0.f;
-#endif
 #pragma unroll
       for (int ks = 0; ks < NB_KS0; ++ks) {
         float v[8];
@@ -1117,10 +1095,6 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       const int64_t ray = rr >> 3;
       const int s = (int)(rr & 7);
       const float dn = e_dn[cb], zc = e_z[cb], ad = e_add[cb], mu = e_mul[cb];
-#ifdef PNRF_PROBE_NOBATCHWORK
-      if (valid[cb] && g == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(r0 + dn, r1 + zc, r2 + ad, r3 + mu);
-      return;
-#endif
       if (a.clampv > 0.f) {                                                         // base.py:523
         r0 = fminf(fmaxf(r0, -a.clampv), a.clampv); r1 = fminf(fmaxf(r1, -a.clampv), a.clampv);
         r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
@@ -1169,47 +1143,18 @@ int num_cu() {
   return g_num_cu;
 }
 
-// Tuning knobs (environment, read per call so that variants can be A/B-ed inside one process):
-// PNRF_SAMPLER_PREC=f32 runs the sampler on the exact-fp32 MFMA chain instead of split fp16 (layer_h16x2, the default);
-// PNRF_SAMPLER_FOLD=0 (with f32) disables the folded first sampler layer; PNRF_BF16_VARIANT: unset / "16" = the DoNeRFTRT
-// stage on v_mfma_f32_16x16x32_bf16 (nerf16_kernel) and the other bf16 kernels as "1x8"; "1x8" = 32x32x16, 32 columns/wave,
-// 8 waves, 2 waves/SIMD everywhere; "2x4" = 64 columns/wave, 4 waves, 1 wave/SIMD; "1x4" = two 4-wave workgroups per CU.
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-bool variant_1x8() {
-  const char* e = getenv("PNRF_BF16_VARIANT");
-  return !(e && e[0] == '2');          // default: 1x8 (two waves per SIMD)
-}
-bool variant_b16() {                   // default: DoNeRFTRT on v_mfma_f32_16x16x32_bf16 (nerf16_kernel); any explicit variant opts out
-  const char* e = getenv("PNRF_BF16_VARIANT");
-  return !(e && *e) || (e[0] == '1' && e[1] == '6');
-}
-bool variant_1x4() {                   // "1x4": two independent 4-wave workgroups per CU (one wave per SIMD each)
-  const char* e = getenv("PNRF_BF16_VARIANT");
-  return e && e[0] == '1' && e[1] == 'x' && e[2] == '4';
-}
-bool sampler_fold() { return env_int("PNRF_SAMPLER_FOLD", 1) != 0; }
-bool sampler_f16x2() {
-  const char* e = getenv("PNRF_SAMPLER_PREC");
-  return !(e && e[0] == 'f' && e[1] == '3');       // default: split fp16 (f16x2); "f32" selects the exact-fp32 MFMA chain
-}
-
+// Kernel variants are a property of the packed handle (pnrf_mlp_set_variant, include/pronerf_hip.h); nothing on the launch path reads the
+// process environment.  Default: split-fp16 sampler with the folded first layer, refine and NeRF stages on v_mfma_f32_16x16x32_bf16.
 template <class K, class A>
 int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream, int wg_per_cu = 1) {
-  // the ring + bias region exceeds the 64 KiB default dynamic-LDS limit: raise it once per kernel
-  static thread_local const void* done[16] = {};
-  static thread_local int ndone = 0;
-  bool seen = false;
-  for (int i = 0; i < ndone; ++i) seen |= (done[i] == (const void*)kern);
-  if (!seen) {
+  // the ring + bias region exceeds the 64 KiB default dynamic-LDS limit.  The attribute is per device, and the call is a table update in
+  // the runtime, so it is simply made on every launch (a per-process "done" cache skipped it on a second GPU).
+  {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RING_BYTES + 8192));
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
       return (int)e;
     }
-    if (ndone < 16) done[ndone++] = (const void*)kern;
   }
   const int ncu = num_cu() * wg_per_cu;
   const int grid = nbatch < ncu ? nbatch : ncu;
@@ -1231,8 +1176,8 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd: handle is not a sampler net");
   PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
   if (n == 0) return 0;
-  const bool fold = sampler_fold();
-  const bool h16 = sampler_f16x2();
+  const bool h16 = h->variant != PNRF_VARIANT_SAMPLER_F32 && h->variant != PNRF_VARIANT_SAMPLER_F32_FULL;
+  const bool fold = h->variant != PNRF_VARIANT_SAMPLER_F32_FULL;
   SamplerArgs a = {};
   a.blob = fold ? h->d_blob_fold : h->d_blob; a.nslots = fold ? h->nslots_fold : h->nslots;
   a.bias = h->d_bias; a.nbias = h->nbias;
@@ -1275,14 +1220,8 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   a.n = n;
   a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  if (variant_1x4()) {
-    a.nbatch = (int)((n + 127) / 128);
-    return launch_mlp(refine_kernel<1, 4, 1>, a, 256, lds, a.nbatch, (hipStream_t)stream, 2);
-  }
-  const int rows = 256;            // both variants: 256 columns per workgroup batch
-  a.nbatch = (int)((n + rows - 1) / rows);
-  return variant_1x8() ? launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream)
-                       : launch_mlp(refine_kernel<2, 4, 1>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  a.nbatch = (int)((n + 255) / 256);      // 256 columns per workgroup batch
+  return launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
@@ -1309,23 +1248,19 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);
+  const bool b16 = h->variant != PNRF_VARIANT_BF16_32X32;
   if (h->net == PNRF_NET_NERFCLS) {
-    if (variant_b16()) {
+    if (b16) {
       a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
       return launch_mlp(nerf16_kernel<true>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
     }
     return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
   }
-  if (variant_b16()) {
+  if (b16) {
     a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
     return launch_mlp(nerf16_kernel<false>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
   }
-  if (variant_1x4()) {
-    a.nbatch = (int)((n * S + 127) / 128);
-    return launch_mlp(nerf_kernel<1, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream, 2);
-  }
-  return variant_1x8() ? launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream)
-                       : launch_mlp(nerf_kernel<2, 4, true, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  return launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, int head_act, void* stream) {
@@ -1356,16 +1291,3 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
   return launch_mlp(nerf_kernel<1, 4, false, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
 }
 
-#ifdef PNRF_DIAG
-// diagnostic build only: copy the stamp sums of the last MLP kernel launch to the host
-extern "C" int pnrf_diag_read(unsigned long long* out, int n) {
-  PNRF_HIP(hipDeviceSynchronize());
-  PNRF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pnrf::g_pnrf_diag), sizeof(unsigned long long) * n));
-  return 0;
-}
-extern "C" int pnrf_diag_read_timeline(unsigned long long* out, int n) {
-  PNRF_HIP(hipDeviceSynchronize());
-  PNRF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pnrf::g_pnrf_tl), sizeof(unsigned long long) * n));
-  return 0;
-}
-#endif

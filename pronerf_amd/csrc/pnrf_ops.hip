@@ -696,6 +696,12 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
                (long long)n, (long long)c->max_rays);
   if (n == 0) return 0;
   PNRF_REQUIRE(rays && or_rays && img4 && proj && rgbd, PNRF_E_ARG, "pnrf_render_rays_fwd: null pointer");
+  {
+    int cur = -1;
+    PNRF_HIP(hipGetDevice(&cur));
+    PNRF_REQUIRE(cur == c->device, PNRF_E_STATE, "pnrf_render_rays_fwd: the context lives on device %d, the calling thread's current device is %d",
+                 c->device, cur);
+  }
   float* depth = c->ws;
   float* add = depth + c->max_rays * 8;
   float* mul = add + c->max_rays * 8;

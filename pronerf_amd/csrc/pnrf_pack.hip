@@ -594,6 +594,28 @@ static int sections(pnrf_mlp* h, int n_tvals, Section* s) {
   return n;
 }
 
+// what pnrf_mlp_pack produces for a net kind (the counts the kernels rely on)
+static void expected_counts(int net, EngineHeader* w) {
+  memset(w, 0, sizeof(*w));
+  switch (net) {
+    case PNRF_NET_SAMPLER:
+      w->prec = PREC_F32; w->in_dim = S_IN; w->out_dim = S_OUT; w->nslots = S_NSLOTS; w->nslots_fold = SF_NSLOTS; w->nslots_h16 = SH_NSLOTS;
+      w->nbias = S_NBIAS; w->n_in0 = S_KS0 * 4; w->n_out = 16 * S_NT_LAST; w->n_tvals = S_KS0 / 3;
+      break;
+    case PNRF_NET_REFINE:
+      w->prec = PREC_BF16; w->in_dim = R_IN; w->out_dim = R_OUT; w->nslots = R_NSLOTS; w->nbias = R_NBIAS; w->n_in0 = R_KS0 * 16; w->n_out = R_NT_LAST * 32;
+      break;
+    case PNRF_NET_NERF:
+      w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = N_OUT; w->nslots = N_NSLOTS; w->nslots_b16 = NB_NSLOTS;
+      w->nbias = N_NBIAS; w->nbias_b16 = ((1 + N_NHID) * (W_HID / 16) + 2) * 16; w->n_in0 = N_KS0 * 16; w->n_inx = N_KSX * 16; w->n_out = 32;
+      break;
+    default:      // PNRF_NET_NERFCLS
+      w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = 4; w->nslots = C_NSLOTS; w->nslots_b16 = CB_NSLOTS;
+      w->nbias = C_NBIAS; w->nbias_b16 = CB_NBIAS; w->n_in0 = N_KS0 * 16; w->n_inx = N_KSX * 16; w->n_out = 64;
+      break;
+  }
+}
+
 static uint64_t fnv1a(const uint8_t* p, size_t n) {
   uint64_t x = 1469598103934665603ull;
   for (size_t i = 0; i < n; ++i) { x ^= p[i]; x *= 1099511628211ull; }
@@ -657,6 +679,17 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
                    hd.nslots > 0 && hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
                    hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20),
                PNRF_E_ARG, "pnrf_mlp_deserialize: implausible section counts");
+  {
+    // section counts the kernels of this net kind index with compile-time constants: an image whose counts differ (a crafted file with a
+    // matching non-cryptographic checksum, or a stale one under the same layout tag) would make them read past the buffers
+    EngineHeader want;
+    expected_counts(hd.net, &want);
+    PNRF_REQUIRE(hd.prec == want.prec && hd.in_dim == want.in_dim && hd.in_dim_x == want.in_dim_x && hd.out_dim == want.out_dim &&
+                     hd.nslots == want.nslots && hd.nslots_fold == want.nslots_fold && hd.nslots_h16 == want.nslots_h16 &&
+                     hd.nslots_b16 == want.nslots_b16 && hd.nbias_b16 == want.nbias_b16 && hd.nbias == want.nbias && hd.n_in0 == want.n_in0 &&
+                     hd.n_inx == want.n_inx && hd.n_out == want.n_out && hd.n_tvals == want.n_tvals,
+                 PNRF_E_ARG, "pnrf_mlp_deserialize: section counts do not match what net kind %d is packed as by this build", hd.net);
+  }
   pnrf_mlp* h = new pnrf_mlp();
   memset(h, 0, sizeof(*h));
   h->net = hd.net; h->prec = hd.prec; h->in_dim = hd.in_dim; h->in_dim_x = hd.in_dim_x; h->out_dim = hd.out_dim;
@@ -692,6 +725,16 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
     return (int)e;
   }
   *out = h;
+  return 0;
+}
+
+extern "C" int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant) {
+  PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_set_variant: null handle");
+  const bool sampler = h->net == PNRF_NET_SAMPLER;
+  const bool ok = variant == PNRF_VARIANT_DEFAULT || (sampler && (variant == PNRF_VARIANT_SAMPLER_F32 || variant == PNRF_VARIANT_SAMPLER_F32_FULL)) ||
+                  (!sampler && variant == PNRF_VARIANT_BF16_32X32);
+  PNRF_REQUIRE(ok, PNRF_E_ARG, "pnrf_mlp_set_variant: variant %d does not exist for net kind %d", variant, h->net);
+  h->variant = variant;
   return 0;
 }
 

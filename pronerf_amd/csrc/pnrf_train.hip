@@ -792,6 +792,9 @@ extern "C" int pnrf_refine_head_bwd(const float* y, const float* rays, const flo
 }
 
 // ------------------------------------------------------------------------------------------ C ABI: trainer
+static int trainer_init(pnrf_trainer* t, const float* const* W, const float* const* b, const int* in_dim, const int* out_dim, int64_t max_rays,
+                        int max_samples);
+
 extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim, int n_layers,
                                    int64_t max_rays, int max_samples, pnrf_trainer_t** out) {
   PNRF_REQUIRE(W && b && in_dim && out_dim && out && max_rays >= 1, PNRF_E_ARG, "pnrf_trainer_create: null pointer / max_rays < 1");
@@ -805,6 +808,17 @@ extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b,
     PNRF_REQUIRE(in_dim[i] == want_in[i] && out_dim[i] == want_out[i], PNRF_E_ARG, "pnrf_trainer_create: layer %d is %dx%d, expected %dx%d", i, out_dim[i],
                  in_dim[i], want_out[i], want_in[i]);
   pnrf_trainer* t = new pnrf_trainer();
+  const int rc = trainer_init(t, W, b, in_dim, out_dim, max_rays, max_samples);
+  if (rc) {                          // an allocation failed part-way (e.g. out of memory at a large max_rays * max_samples): give everything back
+    pnrf_trainer_free(t);
+    return rc;
+  }
+  *out = t;
+  return 0;
+}
+
+static int trainer_init(pnrf_trainer* t, const float* const* W, const float* const* b, const int* in_dim, const int* out_dim, int64_t max_rays,
+                        int max_samples) {
   PNRF_HIP(hipGetDevice(&t->device));
   t->max_rays = max_rays;
   t->max_samples = max_samples;
@@ -839,7 +853,6 @@ extern "C" int pnrf_trainer_create(const float* const* W, const float* const* b,
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
   T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->dw_part, std::max((size_t)DW_MAX_SPLITS * 256 * 320, (size_t)DW128_MAX_SPLITS * 256 * 256)); T_ALLOC(t->loss, 4);
-  *out = t;
   return 0;
 }
 

@@ -37,7 +37,9 @@ def _chk(t, name, shape_tail=None):
 class PackedMLP:
     """Device-resident pre-tiled weights of one network (pnrf_mlp_pack)."""
 
-    def __init__(self, net: int, weights, biases):
+    def __init__(self, net: int, weights, biases, variant=None):
+        """variant: None / 'default', or one of ``_lib.VARIANTS`` ('sampler_f32', 'sampler_f32_full', 'bf16_32x32') — fixed for the
+        life of the handle (pnrf_mlp_set_variant); nothing is read from the environment."""
         lib = _lib.load()
         n = len(weights)
         ws = [np.ascontiguousarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float32) for w in weights]
@@ -52,6 +54,17 @@ class PackedMLP:
         self.net = net
         self.in_dim = ws[0].shape[1]
         self.out_dim = 4 if net == NET_NERFCLS else ws[-1].shape[0]      # NeRF class: [rgb(3), alpha]
+        self.variant = 'default'
+        if variant not in (None, 'default'):
+            self.set_variant(variant)
+
+    def set_variant(self, variant):
+        """Configuration step (before the handle is used by a context / stream)."""
+        if variant not in _lib.VARIANTS:
+            raise PnrfError(f'unknown kernel variant {variant!r}; one of {sorted(_lib.VARIANTS)}')
+        check(_lib.load().pnrf_mlp_set_variant(self.handle, _lib.VARIANTS[variant]), 'pnrf_mlp_set_variant')
+        self.variant = variant
+        return self
 
     def __del__(self):
         try:
@@ -82,6 +95,7 @@ class PackedMLP:
         net, ind, indx, outd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib.pnrf_mlp_kind(h, C.byref(net), C.byref(ind), C.byref(indx), C.byref(outd)), 'pnrf_mlp_kind')
         self.net, self.in_dim, self.out_dim = net.value, ind.value, outd.value
+        self.variant = 'default'
         if expect_net is not None and self.net != expect_net:
             raise PnrfError(f'engine holds net kind {self.net}, expected {expect_net}')
         return self
@@ -338,6 +352,10 @@ class RenderContext:
         img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
         n = rays.shape[0]
         nb, Hf, Wf, _ = img4.shape
+        if out is not None:
+            if not isinstance(out, torch.Tensor) or out.device != rays.device or out.dtype != f32 or tuple(out.shape) != (n, 4) or not out.is_contiguous():
+                raise PnrfError(f'render_rays: out must be a contiguous float32 tensor [{n}, 4] on {rays.device}, got '
+                                f'{getattr(out, "dtype", type(out))} {tuple(getattr(out, "shape", ()))} on {getattr(out, "device", "?")}')
         rgbd = out if out is not None else torch.empty(n, 4, device=rays.device, dtype=f32)
         idx = torch.empty(n, 8, device=rays.device, dtype=torch.int64) if want_idx else None
         check(_lib.load().pnrf_render_rays_fwd(self.handle, _ptr(rays), _ptr(or_rays), _ptr(img4), _ptr(proj), nb, Hf, Wf, eps,

@@ -51,7 +51,9 @@ class Renderer:
     ``ops.PackedMLP`` (a module's ``packed()``, or one loaded from an engine file).
     """
 
-    def __init__(self, weights, max_rays: int, device='cuda:0'):
+    def __init__(self, weights, max_rays: int, device='cuda:0', variants=None):
+        """variants: optional {'sampler' | 'refine' | 'nerf': kernel variant} (``ops.PackedMLP.set_variant``; parity tests and A/B
+        timing — the default kernels are the product path)."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise ops.PnrfError('Renderer needs a GPU device (pronerf_amd has no CPU path)')
@@ -67,6 +69,8 @@ class Renderer:
             self.sampler = pack((ops.NET_SAMPLER,), weights['sampler'])
             self.refine = pack((ops.NET_REFINE,), weights['refine'])
             self.nerf = pack((ops.NET_NERF, ops.NET_NERFCLS), weights['nerf'])
+            for k, v in (variants or {}).items():
+                getattr(self, k).set_variant(v)
             self.ctx = ops.RenderContext(self.sampler, self.refine, self.nerf, max_rays)
         self.img4 = None
         self.proj = None

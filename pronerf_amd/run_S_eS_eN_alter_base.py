@@ -174,7 +174,7 @@ def train(argv=None, device='cuda'):
     perm = shared_permutation(n_total, epoch, dev) if world > 1 else torch.randperm(n_total, device=dev)
     i_batch, global_step, log = 0, start, []
     n_iters = 500000 + 1 if args.max_steps is None else start + args.max_steps + 1
-    lr, nv = args.lrate, len(i_train)
+    lr, nv = args.lrate * (0.1 ** ((start / 2) / (args.lrate_decay * 1000))), len(i_train)      # resumed runs: the decayed schedule
     for i in range(start + 1, n_iters):
         idx = perm[i_batch:i_batch + args.N_rand]
         i_batch += args.N_rand

@@ -52,19 +52,23 @@ def _packed(mod, kind):
     raise PnrfError(f'render_rays: expected a pronerf_amd.run_nerf_helpers module for the {kind} net, got {type(mod).__name__}')
 
 
-_VIEWS = {}
+_VIEWS = []          # at most one entry: (images, its version, poses, its version, device, packed views)
 
 
 def _train_views(images, poses, ref_K, device):
-    key = (id(images), getattr(images, '_version', 0), id(poses), getattr(poses, '_version', 0))
-    ent = _VIEWS.get(key)
-    if ent is None:
-        img = torch.as_tensor(images, dtype=torch.float32).to(device)
-        img4 = ops.images_pack(img.permute(0, 3, 1, 2).contiguous())                      # [nv,H,W,3] -> [nv,H,W,4]
-        pz = torch.as_tensor(poses, dtype=torch.float32).to(device)[:, :3, :4].contiguous()
-        K = torch.as_tensor(ref_K, dtype=torch.float32).to(device).reshape(3, 3).contiguous()
-        _VIEWS.clear()
-        _VIEWS[key] = ent = (img4, pz, K, torch.from_numpy(neighbor_rank_table(pz)).to(device))
+    """Packed training views of (images, poses).  The entry keeps the caller's objects themselves and is matched by identity (+ the
+    in-place version of tensors): id() of a temporary such as ``images[i_train]`` is recycled once it is freed, a referenced object's is not."""
+    ver = lambda x: getattr(x, '_version', 0)
+    if _VIEWS:
+        im, iv, po, pv, dv, ent = _VIEWS[0]
+        if im is images and po is poses and iv == ver(images) and pv == ver(poses) and dv == device:
+            return ent
+    img = torch.as_tensor(images, dtype=torch.float32).to(device)
+    img4 = ops.images_pack(img.permute(0, 3, 1, 2).contiguous())                      # [nv,H,W,3] -> [nv,H,W,4]
+    pz = torch.as_tensor(poses, dtype=torch.float32).to(device)[:, :3, :4].contiguous()
+    K = torch.as_tensor(ref_K, dtype=torch.float32).to(device).reshape(3, 3).contiguous()
+    ent = (img4, pz, K, torch.from_numpy(neighbor_rank_table(pz)).to(device))
+    _VIEWS[:] = [(images, ver(images), poses, ver(poses), device, ent)]
     return ent
 
 
@@ -358,7 +362,8 @@ def train(argv=None, device='cuda'):
     perm = shared_permutation(n_total, epoch, dev) if world > 1 else torch.randperm(n_total, device=dev)       # :796-799
     i_batch, global_step, log = 0, start, []
     n_iters = 500000 + 1 if args.max_steps is None else start + args.max_steps + 1                              # :808-810
-    lr = args.lrate
+    # resumed runs continue on the decayed schedule (the reference restores it through optimizer.load_state_dict, :402-412)
+    lr = args.lrate * (0.1 ** (start / (args.lrate_decay * 1000)))
     nv = len(i_train)
     for i in range(start + 1, n_iters):
         idx = perm[i_batch:i_batch + args.N_rand]

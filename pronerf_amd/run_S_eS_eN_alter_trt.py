@@ -68,33 +68,39 @@ def _renderer(min_max_ray_net, refine_net, network_fine, n_rays, device):
     for m, cls in zip(mods, (MinMaxRaySamplerTRT_Net, MinMaxRayEpiSamplerTRT_Net, DoNeRFTRT)):
         if not hasattr(m, 'weights'):
             raise PnrfError(f'render_rays: expected a pronerf_amd.run_nerf_helpers.{cls.__name__}, got {type(m).__name__}')
-    key = tuple(id(m) for m in mods)
     packed = [m.packed() for m in mods]              # from the parameters, or the engine file loaded into the module
-    ver = tuple(id(p) for p in packed)               # the cached Renderer keeps these objects alive, so ids are not reused
-    ent = _RENDERERS.get(key)
-    if ent is None or ent[0] != ver or ent[1].ctx.max_rays < n_rays or ent[1].device != device:
-        cap = max(n_rays, ent[1].ctx.max_rays if ent else 0)
-        _RENDERERS[key] = ent = (ver, Renderer(dict(zip(('sampler', 'refine', 'nerf'), packed)), max_rays=cap, device=device))
-    return ent[1]
+    # one cached Renderer (its workspace is 800 B per ray: 610 MB for a full frame).  The entry holds the modules and their packed
+    # handles themselves and is matched by identity, so neither can be freed and have its id() reused while cached.
+    ent = _RENDERERS.get('r')
+    same = ent is not None and all(a is b for a, b in zip(ent[0], mods)) and all(a is b for a, b in zip(ent[1], packed))
+    if not same or ent[2].ctx.max_rays < n_rays or ent[2].device != device:
+        cap = max(n_rays, ent[2].ctx.max_rays if same else 0)
+        _RENDERERS.clear()                               # free the old workspace before the new one is allocated
+        ent = None
+        _RENDERERS['r'] = ent = (mods, packed, Renderer(dict(zip(('sampler', 'refine', 'nerf'), packed)), max_rays=cap, device=device))
+    return ent[2]
 
 
-_VIEWS = {}
+_VIEWS = []          # at most one entry: (ref_rgb, its _version, ref_pose, its _version, n_samples, (img4, mats))
 
 
 def _packed_views(ref_rgb, ref_pose, n_samples, num_neighbor):
     """The reference hands over the neighbour images replicated x N_samples ([nb*S,3,Hf,Wf],
-    trt.py:296-298) and the matrices likewise ([nb*S,3,4], :299-300): take one copy of each."""
-    key = (ref_rgb.data_ptr(), ref_rgb._version, ref_pose.data_ptr(), ref_pose._version, tuple(ref_rgb.shape))
-    ent = _VIEWS.get(key)
-    if ent is None:
-        if ref_rgb.shape[0] == num_neighbor * n_samples:
-            imgs, mats = ref_rgb[::n_samples], ref_pose[::n_samples]
-        elif ref_rgb.shape[0] == num_neighbor:
-            imgs, mats = ref_rgb, ref_pose
-        else:
-            raise PnrfError(f'render_rays: ref_rgb has {ref_rgb.shape[0]} images, expected num_neighbor*N_samples = {num_neighbor * n_samples}')
-        _VIEWS.clear()
-        _VIEWS[key] = ent = (ops.images_pack(imgs.contiguous()), mats.contiguous())
+    trt.py:296-298) and the matrices likewise ([nb*S,3,4], :299-300): take one copy of each.
+    The entry keeps the caller's tensors themselves and is matched by identity (+ in-place version): an address or id() can be
+    handed out again by the caching allocator after the caller frees a frame's tensor, an object that is still referenced cannot."""
+    if _VIEWS:
+        r, rv, q, qv, ns, ent = _VIEWS[0]
+        if r is ref_rgb and q is ref_pose and rv == ref_rgb._version and qv == ref_pose._version and ns == n_samples:
+            return ent
+    if ref_rgb.shape[0] == num_neighbor * n_samples:
+        imgs, mats = ref_rgb[::n_samples], ref_pose[::n_samples]
+    elif ref_rgb.shape[0] == num_neighbor:
+        imgs, mats = ref_rgb, ref_pose
+    else:
+        raise PnrfError(f'render_rays: ref_rgb has {ref_rgb.shape[0]} images, expected num_neighbor*N_samples = {num_neighbor * n_samples}')
+    ent = (ops.images_pack(imgs.contiguous()), mats.contiguous().clone())
+    _VIEWS[:] = [(ref_rgb, ref_rgb._version, ref_pose, ref_pose._version, n_samples, ent)]
     return ent
 
 
@@ -122,7 +128,8 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
         raise PnrfError('render_rays: ray batches must be [N,11] (use_viewdirs=True)')
     rend = _renderer(min_max_ray_net, refine_net, network_fine, ray_batch.shape[0], ray_batch.device)
     img4, proj = _packed_views(kwargs['ref_rgb'], kwargs['ref_pose'], N_samples, num_neighbor)
-    rgbd, _ = rend.ctx.render_rays(ray_batch, or_ray_batch, img4, proj)
+    with torch.cuda.device(rend.device):                     # the context's kernels go to ITS device's current stream
+        rgbd, _ = rend.ctx.render_rays(ray_batch, or_ray_batch, img4, proj)
     rgb_map, depth_map = rgbd[:, :3], rgbd[:, 3]
     return {'rgb_map0': rgb_map, 'rgb_map1': rgb_map, 'depth_map': depth_map}
 

@@ -156,13 +156,14 @@ def test_mlp_linearity_exact_integers(dev):
     np.testing.assert_array_equal(got.numpy(), h.numpy())
 
 
-@pytest.mark.parametrize('prec', ['h16', 'f32'])
+@pytest.mark.parametrize('prec', ['default', 'sampler_f32', 'sampler_f32_full'])
 @pytest.mark.parametrize('kind,seed', [('trained', 0), ('spread', 2), ('default', 1)])
-def test_sampler_stage(dev, kind, seed, prec, monkeypatch):
-    """Both sampler precisions: split fp16 (default; 22-bit operands, fp32 accumulate) and the exact-fp32 MFMA chain."""
+def test_sampler_stage(dev, kind, seed, prec):
+    """The sampler's kernel variants (pnrf_mlp_set_variant): split fp16 (default; 22-bit operands, fp32 accumulate), the exact-fp32 MFMA
+    chain with the folded first layer, and the exact-fp32 chain on all 288 inputs."""
     from pronerf_amd import ops
-    monkeypatch.setenv('PNRF_SAMPLER_PREC', prec)
     w, mlps = _packed(dev, seed, kind)
+    mlps['sampler'].set_variant(prec)
     scene = synth.make_scene(seed, H=40, W=52, rotate=True)
     fr = orc.frame_setup(scene)
     rays = fr['rays']

@@ -75,6 +75,24 @@ def test_render_rays_infer_matches_reference(golden_dir, name):
     assert orc.psnr(out['rgb'][m], torch.from_numpy(g['rgb'][m])) > 80.0
 
 
+def test_fern_8k_matches_reference(golden_dir):
+    """8 829 rays of the full 756x1008 Fern-geometry frame (borders whose samples leave the neighbour images + a stratified interior sample),
+    rendered by the reference: the oracle reproduces the sampler's decision and the final outputs."""
+    g = load(golden_dir, 'infer_trained_fern_756x1008_8k')
+    _, fr, sel, w = rebuild(g)
+    assert len(sel) >= 8192 and (g['oob_taps'] > 0).sum() > 1000          # really includes rays whose taps fall outside the source images
+    np.testing.assert_allclose(fr['rays'][sel].numpy(), g['rays'], rtol=0, atol=2e-6)
+    out = orc.render_rays_infer(w, torch.from_numpy(g['rays']), fr['or_rays'][sel].contiguous(), fr['images'], torch.from_numpy(g['proj']))
+    np.testing.assert_allclose(out['depth_sorted'].numpy(), g['depth_sorted'], rtol=0, atol=2e-6)
+    tie_free = np.diff(g['depth_sorted'], axis=1).min(axis=1) > 1e-6
+    assert (~tie_free).sum() <= 4
+    np.testing.assert_array_equal(out['sort_idx'].numpy()[tie_free], g['sort_idx'][tie_free].astype(np.int64))
+    np.testing.assert_allclose(out['z'].numpy()[tie_free], g['z'][tie_free], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out['rgb'].numpy()[tie_free], g['rgb'][tie_free], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out['depth'].numpy()[tie_free], g['depth'][tie_free], rtol=0, atol=2e-4)
+    assert orc.psnr(out['rgb'][torch.from_numpy(tie_free)], torch.from_numpy(g['rgb'][tie_free])) > 80.0
+
+
 def test_operator_goldens(golden_dir):
     g = load(golden_dir, 'operators')
     x = torch.from_numpy(g['pe_x'])
