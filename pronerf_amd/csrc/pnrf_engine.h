@@ -175,6 +175,19 @@ __device__ __forceinline__ float act_f32(float v, int act) {
   return v > 0.f ? v : __expf(v) - 1.f;
 #endif
 }
+// ELU on log2(e)-scaled values (bf16 refine net, split-fp16 sampler).  The packer multiplies the first layer's weights and the bias of
+// every ELU layer by log2(e) and divides the output layer's weights by it (pnrf_pack.hip: Layer::wscale / bscale), so a pre-activation
+// arrives as y = log2(e) x and the activation is kept as h' = log2(e) ELU(x) = (y > 0 ? y : f(y)), f(y) = log2(e) (2^y - 1).
+// f(y) >= y everywhere (their difference has its minimum 0 at y = 0) and f has the sign of y, so h' is the MEDIAN of (y, f(y), 0):
+// v_exp_f32 straight on the accumulator, v_fma_f32, v_med3_f32 — 16 issue cycles instead of the 24 of v_mul (x log2 e), v_exp, v_add (-1),
+// v_cmp, v_cndmask.  2^y = inf for large y gives f = inf and the median is y.  Same accuracy as exp(x) - 1 through v_exp_f32: an absolute
+// error of one fp32 rounding of an O(1) value.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr double LOG2E_D = 1.4426950408889634074;
+__device__ __forceinline__ float elu_scaled(float y) {
+  const float f = fmaf(__builtin_amdgcn_exp2f(y), LOG2E, -LOG2E);
+  return __builtin_amdgcn_fmed3f(y, f, 0.f);
+}
 __device__ __forceinline__ float act_fast(float v, int act) {
   // bf16 path: the result is rounded to 8 significant bits, v_exp_f32 is accurate enough.
   if (act == ACT_NONE) return v;
@@ -183,7 +196,7 @@ __device__ __forceinline__ float act_fast(float v, int act) {
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
   }
-  return v > 0.f ? v : __expf(v) - 1.f;                // see act_f32
+  return elu_scaled(v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,17 +267,20 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
       // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
 #pragma unroll
       for (int pc = 0; pc < PIECES; ++pc) {
-        // k-step after which piece pc is issued.  More than two pieces (PIECES = 8: two accumulator registers each): one piece every
-        // second k-step; in a layer's first tile one per k-step, so that the previous layer's last fragments are complete before the
-        // k-steps 14 and 15 that read them.
+        // k-step after which piece pc is issued.  PIECES = 16 (one activation each; the ELU nets): one piece per k-step, so that every MFMA
+        // gap carries the same three or four VALU instructions (v_exp, v_fma, v_med3, every second time v_cvt_pk) — 8 + 16..20 issue cycles
+        // inside the MFMA's 32.  In a layer's first tile the pieces are the previous layer's last tile, whose two fragments are read by
+        // k-steps 14 and 15: pieces 0..13 behind k-steps 0..13, the last two behind k-step 14; in the other tiles one k-step later (the
+        // previous tile's last MFMA is still in flight at k-step 0).  PIECES = 8: one piece every second k-step.  PIECES = 2: two halves.
 #ifndef PNRF_BF16_P8_AT0
 #define PNRF_BF16_P8_AT0 1
 #endif
 #ifndef PNRF_BF16_P8_STEP
 #define PNRF_BF16_P8_STEP 2
 #endif
-        const int at = PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : PNRF_BF16_P8_AT0 + PNRF_BF16_P8_STEP * pc)
-                                   : (KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1));
+        const int at = PIECES == 16 ? (KS >= 16 ? (to == 0 ? (pc < 14 ? pc : 14) : (pc < 15 ? pc + 1 : 15)) : 1 + (pc * (KS - 1)) / PIECES)
+                       : PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : PNRF_BF16_P8_AT0 + PNRF_BF16_P8_STEP * pc)
+                                     : (KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1));
         if (ks == (at < KS ? at : KS - 1)) {
           if (to == 0) pre1(pc);
           else epi1(to - 1, pc, pend);
@@ -348,16 +364,20 @@ template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + 
 //   pair (2tp, 2tp+1) is exactly the k-step tp (32 features) of the next layer: element j of group g = register j&3 of
 //   tile 2tp + (j>>2) = feature 32tp + 16(j>>2) + 4g + (j&3).
 //   Fragment order in the stream: (tp, ks, tile-in-pair, plane) -> 4 fragments per k-step; NTP tile pairs, KS k-steps.
-//   Bf(ks, plane) -> f16x8 B operand; epi1(tp, pc, main[2], cross[2]) / pre1(pc): piece pc = tile pc of the deferred pair.
+//   Bf(ks, plane) -> f16x8 B operand; epi1(tp, pc, main[2], cross[2]) / pre1(pc): piece pc (0..3) = accumulator registers 2(pc&1), 2(pc&1)+1 of tile
+//   pc>>1 of the deferred pair = one packed dword of the next layer's hi plane and one of its lo plane.  One piece every second k-step (a k-step
+//   carries six MFMAs); in a layer's first tile pair one per k-step from k-step 1, so that the previous layer's activations are complete before
+//   the k-step that reads them.
 #ifndef PNRF_H16_AHEAD
 #define PNRF_H16_AHEAD 8
 #endif
 #ifndef PNRF_H16_AT0
-#define PNRF_H16_AT0 2
+#define PNRF_H16_AT0 1
 #endif
 #ifndef PNRF_H16_ATSTEP
-#define PNRF_H16_ATSTEP 3
+#define PNRF_H16_ATSTEP 2
 #endif
+constexpr int H16_PIECES = 4;             // deferred epilogue pieces per tile pair: piece pc = registers 2(pc&1), 2(pc&1)+1 of tile pc>>1
 constexpr float H16_LO_SCALE = 2048.f;
 template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1,
@@ -404,8 +424,8 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
         }
       }
 #pragma unroll
-      for (int pc = 0; pc < 2; ++pc) {
-        const int at = KS >= 4 ? PNRF_H16_AT0 + pc * PNRF_H16_ATSTEP : KS - 1;
+      for (int pc = 0; pc < H16_PIECES; ++pc) {
+        const int at = KS >= 8 ? (tp == 0 ? 1 + pc : PNRF_H16_AT0 + pc * PNRF_H16_ATSTEP) : KS - 1;
         if (ks == (at < KS ? at : KS - 1)) {
           if (tp == 0) pre1(pc);
           else epi1(tp - 1, pc, pm, pc_);

@@ -21,6 +21,7 @@ constexpr int NT16_HID = 16;              // f32 engine: 256 / 16 output tiles p
 // ---- sampler (f32, v_mfma_f32_16x16x4_f32): k-step = 4 features (one per lane quarter)
 constexpr int S_IN = 288, S_OUT = 27, S_NHID = 5;      // hidden 256->256 layers after layer 0
 constexpr int S_KS0 = S_IN / 4;                          // 72 k-steps
+constexpr int S_NPTS = S_IN / 6;                         // 48 ray points t = linspace(0, 1, 48), one Pluecker 6-vector each (trt.py:274-277, 556-557)
 constexpr int S_KS4_0 = S_KS0 / 4;                       // 18 fragments per tile
 constexpr int S_KS4_H = (W_HID / 4) / 4;                 // 16 fragments per tile (= one slot)
 constexpr int S_NT_LAST = 2;                             // 27 outputs in two 16-row tiles

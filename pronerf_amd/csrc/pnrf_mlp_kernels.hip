@@ -33,6 +33,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 // hardware exp2 / reciprocal (1 ulp each): for the fused bf16 kernels' epilogues
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
   constexpr int TPB = 512, NW = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
-  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  // the handle's bias table is shared with the exact-fp32 kernels (true scale); this kernel's stream is packed for log2(e)-scaled
+  // activations (elu_scaled): the biases of the six ELU layers are scaled here, the output layer's stay as they are
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = i < (1 + S_NHID) * W_HID ? a.bias[i] * LOG2E : a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
   WStream<NW> st;
@@ -313,16 +316,22 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
     // activations ping-pong between X and Y: per 32-feature k-step one hi and one lo plane
     f16x8 Xh[SH_KS_H], Xl[SH_KS_H], Yh[SH_KS_H], Yl[SH_KS_H];
     f32x4 pm[2], pc[2];                   // pending (deferred) tile pair of the previous layer
-    // piece pcx of tile pair tp -> elements 4*pcx..4*pcx+3 of k-step tp of the next layer's planes
+    // piece pcx (0..3) of tile pair tp: registers 2p, 2p+1 (p = pcx & 1) of tile t = pcx >> 1 -> dword 2t + p of k-step tp of the next layer's
+    // planes.  Per activation: combine (v_fma), ELU on the log2(e) scale (v_exp, v_fma, v_med3), then per PAIR one v_cvt_pk_f16_f32 for the
+    // high plane and per value v_mul (x 2^11) + v_fma_mix{lo,hi}_f16 for the low plane ((v - hi) 2^11 in one fused step: hi 2^11 and v 2^11 are
+    // exact).  Written with the instructions spelled out: left to the compiler this came out as v_cvt_f32_f16 round trips and SLP-packed
+    // v_pk_*_f32, which cost more beside MFMAs than the scalar forms (MI355X_MICROARCH.md, issue-cost table).
     auto store_piece = [&](f16x8(&dh)[SH_KS_H], f16x8(&dl)[SH_KS_H], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float v = act_f32(fmaf(cr[pcx][g], INV, mn[pcx][g]), ACT_ELU);
-        const _Float16 h = (_Float16)v;
-        dh[tp][4 * pcx + g] = h;
-        // (v - h) * 2^11 as one fused multiply-add (h * 2^11 and v * 2^11 are exact, so the value is the same): compiles to v_fma_mix*_f16
-        dl[tp][4 * pcx + g] = (_Float16)fmaf(-(float)h, H16_LO_SCALE, v * H16_LO_SCALE);
-      }
+      const int t = pcx >> 1, p = pcx & 1;
+      const float v0 = elu_scaled(fmaf(cr[t][2 * p], INV, mn[t][2 * p])), v1 = elu_scaled(fmaf(cr[t][2 * p + 1], INV, mn[t][2 * p + 1]));
+      int hi, lo;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+      const float s0 = v0 * H16_LO_SCALE, s1 = v1 * H16_LO_SCALE, sc = H16_LO_SCALE;
+      asm("v_fma_mixlo_f16 %0, -%1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(sc), "v"(s0));
+      asm("v_fma_mixhi_f16 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(sc), "v"(s1));
+      i32x4_t wh = __builtin_bit_cast(i32x4_t, dh[tp]), wl = __builtin_bit_cast(i32x4_t, dl[tp]);
+      wh[2 * t + p] = hi; wl[2 * t + p] = lo;
+      dh[tp] = __builtin_bit_cast(f16x8, wh); dl[tp] = __builtin_bit_cast(f16x8, wl);
     };
     auto hidden = [&](f16x8(&ih)[SH_KS_H], f16x8(&il)[SH_KS_H], f16x8(&oh)[SH_KS_H], f16x8(&ol)[SH_KS_H], int l) {
       f32x4 nm[2], nc[2];
@@ -409,13 +418,12 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
 // ------------------------------------------------------------------------------------------ bf16 nets
 // Deferred hidden-layer epilogue, one piece at a time: piece pc = accumulator registers 8pc..8pc+7 of tile
 // `to` -> activation -> packed bf16 B fragment of k-step 2*to+pc of the next layer.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32 for the pair (a in the low half)
   int pk;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
   return pk;
 }
-// PIECES = 2: piece pc = registers 8pc..8pc+7 = one whole B fragment; PIECES = 8: registers 2pc, 2pc+1 = one dword of a fragment.
+// PIECES = 2: piece pc = registers 8pc..8pc+7 = one whole B fragment; PIECES = 8: registers 2pc, 2pc+1 = one dword of a fragment; PIECES = 16: register pc.
 template <int NCB, int ACT, int PIECES = 2>
 struct HiddenEpi {
   bf16x8 (&Bn)[NCB][KS_HID];
@@ -427,6 +435,14 @@ struct HiddenEpi {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * pc + j], ACT);
         Bn[cb][2 * to + pc] = pack_bf16(v);
+      } else if constexpr (PIECES == 16) {      // one activation per piece: the even one waits, activated, in its accumulator register
+        acc[cb][pc] = act_fast(acc[cb][pc], ACT);
+        if (pc & 1) {
+          bf16x8& frag = Bn[cb][2 * to + pc / 8];
+          i32x4_t w = __builtin_bit_cast(i32x4_t, frag);
+          w[(pc % 8) / 2] = cvt_pk_bf16(acc[cb][pc - 1], acc[cb][pc]);
+          frag = __builtin_bit_cast(bf16x8, w);
+        }
       } else {
         constexpr int E = 16 / PIECES;
         bf16x8& frag = Bn[cb][2 * to + (E * pc) / 8];
@@ -497,9 +513,9 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
     // `pend` = raw accumulators of the previous layer's last tile (its epilogue is deferred into the next layer)
     f32x16 pend[NCB];
 #ifndef PNRF_REFINE_PIECES
-#define PNRF_REFINE_PIECES 8
+#define PNRF_REFINE_PIECES 16
 #endif
-    constexpr int RP = PNRF_REFINE_PIECES;      // pieces of the deferred hidden-layer epilogue (2 or 8)
+    constexpr int RP = PNRF_REFINE_PIECES;      // pieces of the deferred hidden-layer epilogue (2, 8 or 16)
     auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
       layer_bf16<NCB, KS_HID, NT_HID, R_POS_H, RP>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },

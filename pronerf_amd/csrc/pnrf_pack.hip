@@ -34,12 +34,20 @@ struct Layer {
   int nk;                    // k-steps (bf16: 16 features each; f32: 4 features each, multiple of 4)
   std::vector<int> in_map;   // bf16: [nk][2][8]; f32: [nk][4]   -> input feature or -1
   std::vector<int> out_map;  // bf16: [nt][32], f32: [nt][16]  tile row -> output index or -1
+  double wscale = 1.0;       // weights / biases are stored multiplied by these (in double, before the rounding to the stream's type):
+  double bscale = 1.0;       // the log2(e) scaling of the ELU nets' streams, see elu_scaled() in pnrf_engine.h
 };
+// ELU nets on log2(e)-scaled activations: first layer W, every ELU layer's bias x log2(e); output layer W / log2(e)
+static void scale_for_elu(std::vector<Layer>& Ls) {
+  for (size_t l = 0; l + 1 < Ls.size(); ++l) Ls[l].bscale = LOG2E_D;
+  Ls.front().wscale = LOG2E_D;
+  Ls.back().wscale = 1.0 / LOG2E_D;
+}
 
 static size_t layer_frags(const Layer& L, int prec) { return (size_t)L.nt * (prec == PREC_BF16 ? L.nk : L.nk / 4); }
 static size_t layer_slots(const Layer& L, int prec) { return (layer_frags(L, prec) + SLOT_FRAGS - 1) / SLOT_FRAGS; }
 
-static inline float wval(const Layer& L, int out, int in) { return (out >= 0 && in >= 0) ? L.W[(size_t)out * L.in_dim + in] : 0.f; }
+static inline float wval(const Layer& L, int out, int in) { return (out >= 0 && in >= 0) ? (float)((double)L.W[(size_t)out * L.in_dim + in] * L.wscale) : 0.f; }
 
 static void pack_layer(const Layer& L, int prec, char* dst) {
   if (prec == PREC_BF16) {
@@ -80,10 +88,11 @@ static void pack_layer_h16x2(const Layer& L, char* dst) {
           const int r = lane & 15, g = lane >> 4;
           const int out = L.out_map[(2 * tp + t) * 16 + r];
           for (int j = 0; j < 8; ++j) {
-            const float w = wval(L, out, L.in_map[(ks * 4 + g) * 8 + j]);
-            const uint16_t h = f2h(w);
+            const int in = L.in_map[(ks * 4 + g) * 8 + j];
+            const double w = (out >= 0 && in >= 0) ? (double)L.W[(size_t)out * L.in_dim + in] * L.wscale : 0.0;     // split the scaled value itself
+            const uint16_t h = f2h((float)w);
             hi[lane * 8 + j] = h;
-            lo[lane * 8 + j] = f2h((w - h2f(h)) * H16_LO_SCALE);
+            lo[lane * 8 + j] = f2h((float)((w - (double)h2f(h)) * H16_LO_SCALE));
           }
         }
       }
@@ -106,14 +115,14 @@ static void pack_layer_b16(const Layer& L, char* dst) {
 
 static void pack_bias(const Layer& L, int prec, float* dst) {
   if (prec == PREC_F32 || prec == PREC_H16X2) {      // [tile][16 rows] in tile-row order: lane quarter q reads rows 4q..4q+3
-    for (int i = 0; i < L.nt * 16; ++i) dst[i] = L.out_map[i] >= 0 ? L.b[L.out_map[i]] : 0.f;
+    for (int i = 0; i < L.nt * 16; ++i) dst[i] = L.out_map[i] >= 0 ? (float)((double)L.b[L.out_map[i]] * L.bscale) : 0.f;
     return;
   }
   for (int to = 0; to < L.nt; ++to)
     for (int h = 0; h < 2; ++h)
       for (int g = 0; g < 16; ++g) {
         const int out = L.out_map[to * 32 + acc_row(g, h)];
-        dst[(to * 2 + h) * 16 + g] = out >= 0 ? L.b[out] : 0.f;
+        dst[(to * 2 + h) * 16 + g] = out >= 0 ? (float)((double)L.b[out] * L.bscale) : 0.f;
       }
 }
 
@@ -347,6 +356,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     L.nk = prec == PREC_BF16 ? KS_HID : W_HID / 4;
     L.in_map = hidden_in(prec);
   }
+  if (net == PNRF_NET_REFINE) scale_for_elu(Ls);          // every refine kernel computes its ELU on the log2(e) scale
   std::vector<int> in0_map, inx_map, out_map;
   Layer& F = Ls[0];
   Layer& Z = Ls[n_layers - 1];
@@ -433,6 +443,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   size_t slots_h16 = 0;
   if (net == PNRF_NET_SAMPLER) {
     std::vector<Layer> Lh = Ls;
+    scale_for_elu(Lh);                                         // weights only: this stream's kernel scales the shared bias table itself
     for (auto& L : Lh) {                                       // hidden geometry of the 16x16x32 engine
       L.nk = SH_KS_H; L.in_map.assign(SH_KS_H * 32, -1);
       for (int ks = 0; ks < SH_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) L.in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
@@ -523,8 +534,8 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_b16.data(), bias_b16.size() * sizeof(float), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
-    float tv[S_KS0 / 3];
-    pnrf_linspace(0.f, 1.f, S_KS0 / 3, tv);
+    float tv[S_NPTS];
+    pnrf_linspace(0.f, 1.f, S_NPTS, tv);
     e = hipMalloc((void**)&h->d_tvals, sizeof(tv));
     if (e == hipSuccess) e = hipMemcpy(h->d_tvals, tv, sizeof(tv), hipMemcpyHostToDevice);
   }
@@ -600,7 +611,7 @@ static void expected_counts(int net, EngineHeader* w) {
   switch (net) {
     case PNRF_NET_SAMPLER:
       w->prec = PREC_F32; w->in_dim = S_IN; w->out_dim = S_OUT; w->nslots = S_NSLOTS; w->nslots_fold = SF_NSLOTS; w->nslots_h16 = SH_NSLOTS;
-      w->nbias = S_NBIAS; w->n_in0 = S_KS0 * 4; w->n_out = 16 * S_NT_LAST; w->n_tvals = S_KS0 / 3;
+      w->nbias = S_NBIAS; w->n_in0 = S_KS0 * 4; w->n_out = 16 * S_NT_LAST; w->n_tvals = S_NPTS;
       break;
     case PNRF_NET_REFINE:
       w->prec = PREC_BF16; w->in_dim = R_IN; w->out_dim = R_OUT; w->nslots = R_NSLOTS; w->nbias = R_NBIAS; w->n_in0 = R_KS0 * 16; w->n_out = R_NT_LAST * 32;
@@ -628,7 +639,7 @@ extern "C" int pnrf_mlp_serialize(const pnrf_mlp_t* hc, void* buf, int64_t capac
   using namespace pnrf;
   PNRF_REQUIRE(hc && size, PNRF_E_ARG, "pnrf_mlp_serialize: null argument");
   pnrf_mlp* h = const_cast<pnrf_mlp*>(hc);
-  const int n_tvals = h->d_tvals ? S_KS0 / 3 : 0;
+  const int n_tvals = h->d_tvals ? S_NPTS : 0;
   Section sec[10];
   const int ns = sections(h, n_tvals, sec);
   size_t payload = 0;
@@ -675,7 +686,7 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
                hd.format, hd.abi, hd.layout_tag, PNRF_ABI_VERSION, (unsigned)PNRF_LAYOUT_TAG);
   PNRF_REQUIRE(hd.net == PNRF_NET_SAMPLER || hd.net == PNRF_NET_REFINE || hd.net == PNRF_NET_NERF || hd.net == PNRF_NET_NERFCLS, PNRF_E_ARG,
                "pnrf_mlp_deserialize: unknown net kind %d", hd.net);
-  PNRF_REQUIRE(hd.nbias_b16 >= 0 && hd.nbias >= 0 && hd.n_in0 >= 0 && hd.n_inx >= 0 && hd.n_out >= 0 && (hd.n_tvals == 0 || hd.n_tvals == S_KS0 / 3) &&
+  PNRF_REQUIRE(hd.nbias_b16 >= 0 && hd.nbias >= 0 && hd.n_in0 >= 0 && hd.n_inx >= 0 && hd.n_out >= 0 && (hd.n_tvals == 0 || hd.n_tvals == S_NPTS) &&
                    hd.nslots > 0 && hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
                    hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20),
                PNRF_E_ARG, "pnrf_mlp_deserialize: implausible section counts");

@@ -28,7 +28,9 @@ def load_lib(name):
     path = _lib.LIB_PATH if not name else os.path.join(os.path.dirname(_lib.LIB_PATH), f'libpronerf_hip_{name}.so')
     lib = C.CDLL(path)
     for fn, (res, args) in _lib.SIGNATURES.items():
-        f = getattr(lib, fn); f.restype = res; f.argtypes = args
+        f = getattr(lib, fn, None)            # an older build under comparison may lack the newest entry points
+        if f is not None:
+            f.restype = res; f.argtypes = args
     return lib
 
 
@@ -49,7 +51,8 @@ def main():
             libs[n] = load_lib(n)
         _lib._lib = libs[n]
         bf = c.get('bf16', 'default')
-        r = Renderer(weights, max_rays=H * W, device=dev, variants={'sampler': c.get('sampler', 'default'), 'refine': bf, 'nerf': bf})
+        var = {k: v for k, v in (('sampler', c.get('sampler', 'default')), ('refine', bf), ('nerf', bf)) if v != 'default'}
+        r = Renderer(weights, max_rays=H * W, device=dev, variants=var)
         r.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
         rends.append(r)
     _lib._lib = libs[cfgs[0].get('lib', '')]
