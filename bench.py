@@ -8,7 +8,7 @@
 Workload (BASELINE.json configs[1]): one 1008x756 LLFF-Fern-geometry frame =
 762 048 rays, 8 samples/ray, 4 neighbour views, 48 ray-encoding points; synthetic poses/images
 and seeded "trained-like" weights (no dataset/checkpoint ships).  A step = one pass of the hot
-path (sampler MLP fp32-grade split fp16 -> neighbour projection -> refine MLP bf16 -> NeRF MLP bf16 -> alpha
+path (three kernels: sampler MLP fp32-grade split fp16 | neighbour projection + refine MLP bf16 | NeRF MLP bf16 + alpha
 compositing) over one frame: ONE pnrf_render_rays_fwd call renders the whole frame, as the reference
 renders it in one render() call (run_S_eS_eN_alter_trt.py:329); the "1024-ray chunks" of BASELINE.json
 configs[1] are four of the 256-column workgroup batches each persistent kernel walks through inside its
@@ -221,8 +221,8 @@ def main():
     dbg('warm-up issued')
     fence()
     dbg('warm-up done')
-    # per-kernel durations over the timed region itself: the library records a HIP event before / after each of the four
-    # kernels of a frame on the launch stream (pnrf_ctx_profile_begin), five event records per frame, read after the region
+    # per-kernel durations over the timed region itself: the library records a HIP event before / after each of the three
+    # kernels of a frame on the launch stream (pnrf_ctx_profile_begin), four event records per frame, read after the region
     PROF_FRAMES = 256
     if world == 1:
         rend.ctx.profile_begin(min(args.steps, PROF_FRAMES))
@@ -274,8 +274,7 @@ def main():
                     kern[k].update(achieved_tflops=ach, peak_tflops=peaks[k], frac=ach / peaks[k])
             dom = max(flops, key=lambda k: prof[k])
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
-            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_h16_kernel', 'refine_input_kernel': 'refine_input_kernel',
-                       'refine_kernel': 'refine_kernel<1, 8, 1>',
+            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_h16_kernel', 'refine_kernel': 'refine_kernel<1, 8, 1, 1>',
                        'nerf_kernel': 'nerf16_kernel<false>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]

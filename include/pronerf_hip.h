@@ -167,6 +167,14 @@ int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* d
  * Outputs dev: z[n,8], pts[n,8,3]  (run_S_eS_eN_alter_trt.py:668-681). */
 int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
                     const float* depth_sorted, float* z, float* pts, int64_t n, void* stream);
+/* Projection + refine in ONE kernel: what pnrf_refine_input_fwd followed by pnrf_refine_fwd compute (bit for bit), without the
+ * refine_in [n,144] round trip through HBM: every workgroup projects the samples of its 256 rays into the four neighbour views, fetches
+ * the colours and encodes the sample Pluecker values in the head of its batch, straight into the MFMA operand registers.
+ * rays, or_rays dev [n,11]; depth_sorted dev [n,8]; img4 dev [4,Hf,Wf,4] (pnrf_images_pack); proj dev [4,3,4]; eps as pnrf_refine_input_fwd.
+ * This is the refine stage of pnrf_render_rays_fwd.  (run_S_eS_eN_alter_trt.py:637-681; inverse_warp.py:584-619) */
+int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float* or_rays, const float* depth_sorted,
+                            const float* img4, const float* proj, int nb, int Hf, int Wf, float eps, float* z,
+                            float* pts, int64_t n, void* stream);
 /* Training-time refine stage (stage 2): as pnrf_refine_fwd, plus the depth jitter of refine2.py:646-662 —
  * jitter dev [n,8] = min(|N(0,1)|/5, 1-2e-6) or NULL, jitter_dir +1 (toward the next refined sample / far) or -1 (toward
  * the previous / near): z += dir * jitter * |z - neighbour| — and the refine rgb head rgb0 dev [n,3] =
@@ -213,9 +221,9 @@ int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_ray
                          float* rgbd, int64_t* sort_idx, int64_t n, void* stream);
 /* Per-stage device time of pnrf_render_rays_fwd (what the reference gets from line_profiler / the cuda events around
  * render(), run_S_eS_eN_alter_trt.py:327-332, at frame granularity): after _begin, the next max_frames calls on this
- * context record an event before and after each of the four stages on the caller's stream; _end waits for the last
- * recorded call and returns the mean milliseconds ms[4] = {sampler, refine input (projection), refine, NeRF + compositing}
- * over *frames calls.  Recording costs five event records per call and changes no result. */
+ * context record an event before and after each of the three kernels on the caller's stream; _end waits for the last
+ * recorded call and returns the mean milliseconds ms[3] = {sampler, projection + refine, NeRF + compositing}
+ * over *frames calls.  Recording costs four event records per call and changes no result. */
 int pnrf_ctx_profile_begin(pnrf_ctx_t* ctx, int max_frames);
 int pnrf_ctx_profile_end(pnrf_ctx_t* ctx, float* ms, int* frames);
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     'pnrf_composite_fwd': (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
     'pnrf_sampler_fwd': (_i, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
     'pnrf_refine_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i64, _p]),
+    'pnrf_refine_project_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
     'pnrf_nerf_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     'pnrf_ctx_create': (_i, [_p, _p, _p, _i64, C.POINTER(_p)]),
     'pnrf_ctx_free': (_i, [_p]),

@@ -120,8 +120,16 @@ constexpr int C_NBIAS = C_BIAS_E10 + 32;
 // ---- input-feature maps of layer 0 (and of the NeRF view k-steps); -1 = zero padding.
 // sampler: k-step kk, quarter q  ->  mm_input feature (natural order)
 __host__ __device__ constexpr int sampler_in0(int kk, int q) { return 4 * kk + q; }
-// refine: k-step ks, half h, element j -> refine_input feature (natural order)
-__host__ __device__ constexpr int refine_in0(int ks, int h, int j) { return 16 * ks + 8 * h + j; }
+// refine layer 0: the lane half h of a column (ray) supplies, in k-step ks, the values n = 8 ks + j of ITS 72 of the 144 inputs —
+//   n <  48: colour channel n % 3 of sample (n % 24) / 3 in neighbour view 2h + n / 24   = refine_in[48 + ((2h + n/24) 8 + (n%24)/3) 3 + n%3]
+//   n >= 48: Pluecker value (n - 48) % 6 of sample 4h + (n - 48) / 6                      = refine_in[(4h + (n-48)/6) 6 + (n-48)%6]
+// (refine_in = [pluecker(48: s*6+j), epi(96: (k*8+s)*3+c)], run_S_eS_eN_alter_trt.py:653-661).  A lane that projects "its" two views and
+// encodes "its" four samples therefore holds exactly its own B fragments: the projection runs in the head of the refine kernel with no
+// exchange between lanes and no refine_in round trip through HBM (refine_kernel, HEAD = 1).
+__host__ __device__ constexpr int refine_in0(int ks, int h, int j) {
+  const int n = 8 * ks + j;
+  return n < 48 ? 48 + (((2 * h + n / 24) * 8 + (n % 24) / 3) * 3 + n % 3) : (4 * h + (n - 48) / 6) * 6 + (n - 48) % 6;
+}
 // nerf layer 0: slot n = ks*8+j.  n<30: (freq k=n/3, coord c=n%3), half 0 = sin, half 1 = cos;
 // n=30: x0|x2, n=31: x1|pad.  Feature order of the embedder: [x, sin f0 x, cos f0 x, ...]
 // (run_nerf_helpers.py:666-671).

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "pnrf_common.h"
+#include "pnrf_geom.h"
 
 #ifndef PNRF_YOUNG_PRIO
 #define PNRF_YOUNG_PRIO 1
@@ -70,12 +71,6 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
 
 // Pluecker moment of point p=o+t*d with unit direction hd, arithmetic un-fused like the
 // reference's separate torch ops (trt.py:559-560 mul,add; helpers:630-631 cross).
-struct Pl6 { float hx, hy, hz; };
-__device__ __forceinline__ void unit_dir(float dx, float dy, float dz, float& hx, float& hy, float& hz) {
-  const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-  const float den = fmaxf(__fsqrt_rn(n2), 1e-12f);
-  hx = __fdiv_rn(dx, den); hy = __fdiv_rn(dy, den); hz = __fdiv_rn(dz, den);
-}
 __device__ __forceinline__ void moment(float ox, float oy, float oz, float dx, float dy, float dz, float t,
                                        float hx, float hy, float hz, float& m0, float& m1, float& m2) {
   const float px = __fadd_rn(ox, __fmul_rn(dx, t)), py = __fadd_rn(oy, __fmul_rn(dy, t)), pz = __fadd_rn(oz, __fmul_rn(dz, t));
@@ -459,7 +454,8 @@ struct HiddenEpi {
 struct RefineArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
   int64_t n; int nbatch;
-  const float* x;                                   // refine_in [n,144]
+  const float* x;                                   // refine_in [n,144] (HEAD = 0)
+  const float* or_rays; const float4* img4; const float* proj; int Hf, Wf; float eps;   // HEAD = 1: the projection runs in the kernel
   const float* rays; const float* depth_sorted;     // fused consumer
   float* z; float* pts;
   const float* jitter; int jitter_dir; float* rgb0;  // training mode: depth jitter [n,8] (>= 0), its direction, refine rgb head [n,3]
@@ -467,9 +463,13 @@ struct RefineArgs {
 };
 
 // MODE 0: module-level (x -> y); 1: fused inference epilogue; 2: fused training-time epilogue (depth jitter, refine rgb head)
-template <int NCB, int NW, int MODE>
+// HEAD 0: the 144 inputs of a ray come from refine_in [n,144] in memory; 1: they are produced in the batch head — neighbour projection +
+// bilinear colour fetch + sample Pluecker (run_S_eS_eN_alter_trt.py:637-661), each lane for its own two views and four samples
+// (refine_in0): no [n,144] round trip through HBM, one kernel launch less per frame.
+template <int NCB, int NW, int MODE, int HEAD = 0>
 __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(RefineArgs a) {
   constexpr bool FUSED = MODE != 0;
+  static_assert(HEAD == 0 || (NCB == 1 && MODE == 1), "the projecting head exists for the fused inference stage");
   constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
@@ -501,12 +501,89 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         for (int i = 0; i < 8; ++i) e_ray[cb][i] = r[i];
         e_d0[cb] = *(const float4*)(a.depth_sorted + rr * 8); e_d1[cb] = *(const float4*)(a.depth_sorted + rr * 8 + 4);
       }
-      const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN + 8 * h;      // natural order: refine_in0()
+      if constexpr (HEAD == 0) {
+        const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN;
 #pragma unroll
-      for (int ks = 0; ks < R_KS0; ++ks) {
-        const float4 lo = *(const float4*)(xr + 16 * ks), hi = *(const float4*)(xr + 16 * ks + 4);
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        Bo[cb][ks] = pack_bf16(v);
+        for (int ks = 0; ks < R_KS0; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = xr[h ? refine_in0(ks, 1, j) : refine_in0(ks, 0, j)];
+          Bo[cb][ks] = pack_bf16(v);
+        }
+      } else {
+        // lane (ray, h): views 2h, 2h+1 x 8 samples (48 colours) + Pluecker of samples 4h..4h+3 (24 values), in the order of refine_in0
+        const int64_t rr = valid[cb] ? row[cb] : a.n - 1;
+        const float* orr = a.or_rays + rr * 11;
+        const float o0 = orr[0], o1 = orr[1], o2 = orr[2], w0 = orr[3], w1 = orr[4], w2 = orr[5];
+        const float dn8[8] = {e_d0[cb].x, e_d0[cb].y, e_d0[cb].z, e_d0[cb].w, e_d1[cb].x, e_d1[cb].y, e_d1[cb].z, e_d1[cb].w};
+        const int plane = a.Hf * a.Wf;
+        float feat[72];
+        // 16 projections per lane (view vv = p / 8, sample p % 8) in a software pipeline: the four texel fetches of projection p + D are issued
+        // before projection p is blended, so D projections (4 D x 16 B per lane) are in flight.  The fences keep the compiler from hoisting
+        // all 64 fetches to the top of the batch (256 registers of texels: it spilled 187).
+        constexpr int D = 4;
+        float wt[D][4];
+        float4 tx[D][4];
+        ViewRay vr[2];
+        float z3d[8];
+#pragma unroll
+        for (int vv = 0; vv < 2; ++vv) {
+          float M[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) M[i] = a.proj[(2 * h + vv) * 12 + i];
+          vr[vv] = view_ray(o0, o1, o2, w0, w1, w2, M);
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) z3d[s8] = __builtin_amdgcn_rcpf(1.f - dn8[s8] - a.eps);                     // trt.py:637
+        // texel addresses as 32-bit byte offsets from the uniform image base (4 views x Hf x Wf x 16 B < 2^31, checked by the entry point)
+        const char* imb = (const char*)a.img4;
+        auto texel = [&](uint32_t view_off, uint32_t idx) { return *(const float4*)(imb + ((view_off + idx) << 4)); };
+        auto issue = [&](auto pc) {
+          constexpr int p = decltype(pc)::value, vv = p / 8, sl = p % D;
+          const uint32_t vo = (uint32_t)((2 * h + vv) * plane);
+          const Taps t = project_taps_fast(vr[vv], z3d[p % 8], a.Hf, a.Wf);
+          tx[sl][0] = texel(vo, t.i00); tx[sl][1] = texel(vo, t.i01); tx[sl][2] = texel(vo, t.i10); tx[sl][3] = texel(vo, t.i11);
+          wt[sl][0] = t.a00; wt[sl][1] = t.a01; wt[sl][2] = t.a10; wt[sl][3] = t.a11;
+        };
+        auto blend = [&](auto pc) {
+          constexpr int p = decltype(pc)::value, sl = p % D;
+          Taps t;
+          t.a00 = wt[sl][0]; t.a01 = wt[sl][1]; t.a10 = wt[sl][2]; t.a11 = wt[sl][3];
+          feat[3 * p + 0] = blend4(tx[sl][0].x, tx[sl][1].x, tx[sl][2].x, tx[sl][3].x, t);
+          feat[3 * p + 1] = blend4(tx[sl][0].y, tx[sl][1].y, tx[sl][2].y, tx[sl][3].y, t);
+          feat[3 * p + 2] = blend4(tx[sl][0].z, tx[sl][1].z, tx[sl][2].z, tx[sl][3].z, t);
+        };
+        static_for<D>([&](auto pc) { issue(pc); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto pc) {
+          constexpr int p = decltype(pc)::value;
+          blend(pc);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (p + D < 16) {
+            issue(std::integral_constant<int, p + D>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        {                                                                                          // trt.py:656-658
+          const float* r = e_ray[cb];
+          float hx, hy, hz;
+          unit_dir(r[3], r[4], r[5], hx, hy, hz);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float dn = h ? dn8[4 + u] : dn8[u];
+            float m0, m1, m2;
+            moment(r[0], r[1], r[2], r[3], r[4], r[5], dn, hx, hy, hz, m0, m1, m2);
+            float* q = feat + 48 + 6 * u;
+            q[0] = hx; q[1] = hy; q[2] = hz; q[3] = m0; q[4] = m1; q[5] = m2;
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < R_KS0; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = feat[8 * ks + j];
+          Bo[cb][ks] = pack_bf16(v);
+        }
       }
     });
     // ping-pong: layer 0 Bo -> Bn, then Bn -> Bo, Bo -> Bn, ... (5 hidden layers end in Bo);
@@ -1238,6 +1315,23 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   a.nbatch = (int)((n + 255) / 256);      // 256 columns per workgroup batch
   return launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+}
+
+extern "C" int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
+                                       const float* proj, int nb, int Hf, int Wf, float eps, float* z, float* pts, int64_t n, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_REFINE, PNRF_E_ARG, "pnrf_refine_project_fwd: handle is not a refine net");
+  PNRF_REQUIRE(n >= 0 && nb == 4 && Hf >= 2 && Wf >= 2 && (int64_t)Hf * Wf * nb < (int64_t)1 << 27, PNRF_E_ARG,
+               "pnrf_refine_project_fwd: bad sizes (nb must be 4, got %d; nb * Hf * Wf must stay below 2^27 texels)", nb);
+  if (n == 0) return 0;
+  PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && proj && z && pts, PNRF_E_ARG, "pnrf_refine_project_fwd: null pointer");
+  PNRF_REQUIRE(h->variant == PNRF_VARIANT_DEFAULT, PNRF_E_STATE, "pnrf_refine_project_fwd: the refine net has one kernel variant");
+  RefineArgs a = {};
+  a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+  a.n = n;
+  a.or_rays = or_rays; a.img4 = (const float4*)img4; a.proj = proj; a.Hf = Hf; a.Wf = Wf; a.eps = eps;
+  a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
+  a.nbatch = (int)((n + 255) / 256);
+  return launch_mlp(refine_kernel<1, 8, 1, 1>, a, 512, RING_BYTES + (size_t)h->nbias * 4, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,

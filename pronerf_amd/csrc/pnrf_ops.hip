@@ -2,6 +2,7 @@
 // the whole-path entry point.  All kernels are HBM/L2-bound streaming kernels: one thread per
 // output element group, coalesced 16-byte accesses where the layout allows, grid-stride loops.
 #include "pnrf_common.h"
+#include "pnrf_geom.h"
 
 using namespace pnrf;
 
@@ -35,16 +36,6 @@ __global__ void posenc_kernel(const float* __restrict__ x, float* __restrict__ o
 }
 
 // ---------------------------------------------------------------- Pluecker (helpers:629-632)
-__device__ __forceinline__ void unit_dir(float dx, float dy, float dz, float& hx, float& hy, float& hz) {
-  const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-  const float den = fmaxf(__fsqrt_rn(n2), 1e-12f);
-  hx = __fdiv_rn(dx, den); hy = __fdiv_rn(dy, den); hz = __fdiv_rn(dz, den);
-}
-__device__ __forceinline__ void cross_rn(float ax, float ay, float az, float bx, float by, float bz, float& m0, float& m1, float& m2) {
-  m0 = __fsub_rn(__fmul_rn(ay, bz), __fmul_rn(az, by));
-  m1 = __fsub_rn(__fmul_rn(az, bx), __fmul_rn(ax, bz));
-  m2 = __fsub_rn(__fmul_rn(ax, by), __fmul_rn(ay, bx));
-}
 __global__ void plucker_kernel(const float* __restrict__ o, const float* __restrict__ d, float* __restrict__ out, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float hx, hy, hz, m0, m1, m2;
@@ -132,20 +123,7 @@ __global__ void ndc_rays_kernel(const float* __restrict__ o, const float* __rest
   }
 }
 
-// ---------------------------------------------------------------- bilinear fetch, zero padding, align_corners=True
-// grid_sample's coordinate round trip (inverse_warp.py:607-608 then unnormalise) is replayed in fp32.
-__device__ __forceinline__ void bilinear_setup(float X, float Y, int Hf, int Wf, int& x0, int& y0, float& wx0, float& wx1, float& wy0, float& wy1, bool& finite) {
-  const float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, X), (float)(Wf - 1)), 1.f);
-  const float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, Y), (float)(Hf - 1)), 1.f);
-  const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(Wf - 1));
-  const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(Hf - 1));
-  finite = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
-  const float fx = floorf(ix), fy = floorf(iy);
-  wx1 = __fsub_rn(ix, fx); wx0 = __fsub_rn(__fadd_rn(fx, 1.f), ix);
-  wy1 = __fsub_rn(iy, fy); wy0 = __fsub_rn(__fadd_rn(fy, 1.f), iy);
-  x0 = finite ? (int)fx : -4; y0 = finite ? (int)fy : -4;
-}
-
+// ---------------------------------------------------------------- warps (bilinear fetch, zero padding, align_corners=True: pnrf_geom.h)
 // inverse_warp_rod1_rt2_coords_trt on planar images: one thread per (b, pixel)  (inverse_warp.py:584-619)
 __global__ void warp_trt_kernel(const float* __restrict__ img, const float* __restrict__ depth, const float* __restrict__ ro1,
                                 const float* __restrict__ rd1, int64_t ray_bstride, const float* __restrict__ w2c,
@@ -644,14 +622,14 @@ struct pnrf_ctx {
   const pnrf_mlp* refine;
   const pnrf_mlp* nerf;
   int64_t max_rays;
-  float* ws;             // one allocation: depth[8] add[8] mul[8] refine_in[144] z[8] pts[24] per ray
+  float* ws;             // one allocation: depth[8] add[8] mul[8] z[8] pts[24] per ray
   int device;
-  // per-stage timing (pnrf_ctx_profile_begin / _end): 5 events per profiled call, recorded on the caller's stream
+  // per-stage timing (pnrf_ctx_profile_begin / _end): 4 events per profiled call, recorded on the caller's stream
   hipEvent_t* ev;
   int prof_cap, prof_n;
   bool prof_on;
 };
-static constexpr int PROF_EVENTS = 5;
+static constexpr int PROF_EVENTS = 4;
 static constexpr int PROF_MAX_FRAMES = 4096;
 
 static void profile_release(pnrf_ctx* c) {
@@ -661,7 +639,7 @@ static void profile_release(pnrf_ctx* c) {
   }
   c->ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_on = false;
 }
-static constexpr int WS_FLOATS_PER_RAY = 8 + 8 + 8 + 144 + 8 + 24;
+static constexpr int WS_FLOATS_PER_RAY = 8 + 8 + 8 + 8 + 24;      // 224 B per ray
 
 extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refine, const pnrf_mlp_t* nerf, int64_t max_rays, pnrf_ctx_t** out) {
   PNRF_REQUIRE(sampler && refine && nerf && out && max_rays > 0, PNRF_E_ARG, "pnrf_ctx_create: bad arguments");
@@ -705,8 +683,7 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
   float* depth = c->ws;
   float* add = depth + c->max_rays * 8;
   float* mul = add + c->max_rays * 8;
-  float* rin = mul + c->max_rays * 8;
-  float* z = rin + c->max_rays * 144;
+  float* z = mul + c->max_rays * 8;
   float* pts = z + c->max_rays * 8;
   int rc;
   hipEvent_t* ev = (c->prof_on && c->prof_n < c->prof_cap) ? c->ev + (size_t)c->prof_n * PROF_EVENTS : nullptr;
@@ -714,13 +691,11 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
   if (ev) PNRF_HIP(hipEventRecord(ev[0], st));
   if ((rc = pnrf_sampler_fwd(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, stream))) return rc;   // trt.py:628-635
   if (ev) PNRF_HIP(hipEventRecord(ev[1], st));
-  if ((rc = pnrf_refine_input_fwd(rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, rin, n, stream))) return rc;      // :637-661
+  if ((rc = pnrf_refine_project_fwd(c->refine, rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, z, pts, n, stream))) return rc;   // :637-681
   if (ev) PNRF_HIP(hipEventRecord(ev[2], st));
-  if ((rc = pnrf_refine_fwd(c->refine, rin, rays, depth, z, pts, n, stream))) return rc;                               // :668-681
-  if (ev) PNRF_HIP(hipEventRecord(ev[3], st));
   if ((rc = pnrf_nerf_fwd(c->nerf, pts, rays, z, add, mul, rgbd, nullptr, n, stream))) return rc;                      // :691-694
   if (ev) {
-    PNRF_HIP(hipEventRecord(ev[4], st));
+    PNRF_HIP(hipEventRecord(ev[3], st));
     c->prof_n += 1;
   }
   return 0;
@@ -756,7 +731,7 @@ extern "C" int pnrf_ctx_profile_end(pnrf_ctx_t* c, float* ms, int* frames) {
   for (int k = 0; k < PROF_EVENTS - 1; ++k) ms[k] = 0.f;
   if (c->prof_n == 0) return 0;
   PNRF_HIP(hipEventSynchronize(c->ev[(size_t)c->prof_n * PROF_EVENTS - 1]));
-  double acc[PROF_EVENTS - 1] = {0, 0, 0, 0};
+  double acc[PROF_EVENTS - 1] = {0, 0, 0};
   for (int i = 0; i < c->prof_n; ++i)
     for (int k = 0; k < PROF_EVENTS - 1; ++k) {
       float t = 0.f;

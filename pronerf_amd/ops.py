@@ -307,6 +307,18 @@ def refine_fwd(mlp: PackedMLP, refine_in, rays, depth_sorted):
     return z, pts
 
 
+def refine_project_fwd(mlp: PackedMLP, rays, or_rays, depth_sorted, img4, proj, eps=1e-5):
+    """Projection into the neighbour views + refine MLP + interval refinement in one kernel (pnrf_refine_project_fwd) -> (z [n,8], pts [n,8,3])."""
+    rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
+    nb, Hf, Wf, _ = img4.shape
+    n, dev = rays.shape[0], rays.device
+    z = torch.empty(n, 8, device=dev, dtype=f32); pts = torch.empty(n, 8, 3, device=dev, dtype=f32)
+    check(_lib.load().pnrf_refine_project_fwd(mlp.handle, _ptr(rays), _ptr(or_rays), _ptr(depth_sorted), _ptr(img4), _ptr(proj), nb, Hf, Wf, eps,
+                                              _ptr(z), _ptr(pts), n, _stream()), 'pnrf_refine_project_fwd')
+    return z, pts
+
+
 def nerf_fwd(mlp: PackedMLP, pts, rays, z, add, mul, want_raw=False):
     pts = _chk(pts, 'pts', (8, 3)); rays = _chk(rays, 'rays', (11,)); z = _chk(z, 'z', (8,)); add = _chk(add, 'add', (8,)); mul = _chk(mul, 'mul', (8,))
     n, dev = rays.shape[0], rays.device
@@ -334,7 +346,7 @@ class RenderContext:
         except Exception:
             pass
 
-    STAGES = ('sampler_kernel', 'refine_input_kernel', 'refine_kernel', 'nerf_kernel')
+    STAGES = ('sampler_kernel', 'refine_kernel', 'nerf_kernel')
 
     def profile_begin(self, max_frames=64):
         """Record per-stage events on the next ``max_frames`` render_rays calls (pnrf_ctx_profile_begin)."""
@@ -342,7 +354,7 @@ class RenderContext:
 
     def profile_end(self):
         """-> ({stage: mean ms}, frames recorded); waits for the last recorded call."""
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * len(self.STAGES))()
         frames = C.c_int()
         check(_lib.load().pnrf_ctx_profile_end(self.handle, ms, C.byref(frames)), 'pnrf_ctx_profile_end')
         return dict(zip(self.STAGES, (float(v) for v in ms))), frames.value

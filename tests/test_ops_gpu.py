@@ -206,6 +206,33 @@ def test_refine_input_stage(dev):
             assert 0.02 < frac0 < 0.98         # the case exercises out-of-image taps
 
 
+def test_refine_with_projection_in_the_kernel(dev):
+    """pnrf_refine_project_fwd (the refine stage of the fused path: projection + colour fetch + sample Pluecker in the head of the refine
+    kernel) against pnrf_refine_input_fwd + pnrf_refine_fwd (the [n,144] intermediate in memory) and against the oracle.  The in-kernel
+    projection uses the linear form p(z) = A + z B and v_rcp_f32 (pnrf_geom.h): pixel coordinates differ by fp32 ulps, colours by ~1e-4 of the
+    local texel difference, which is below the bf16 rounding of the MLP input — so the two paths agree to bf16 noise, not bit for bit."""
+    from pronerf_amd import ops
+    for seed, H, W, Hf, Wf, sig in ((0, 30, 41, 30, 41, 0.05), (2, 20, 28, 48, 64, 0.05), (3, 16, 24, 16, 24, 0.6)):      # the last: out-of-image taps
+        w, mlps = _packed(dev, seed, 'trained')
+        scene = synth.make_scene(seed, H=H, W=W, Hf=Hf, Wf=Wf, rotate=True, sigma_t=sig)
+        fr = orc.frame_setup(scene)
+        o = orc.render_rays_infer(w, fr['rays'], fr['or_rays'], fr['images'], fr['proj'])
+        rays, orr, ds = cu(fr['rays'], dev), cu(fr['or_rays'], dev), cu(o['depth_sorted'], dev)
+        img4, proj = ops.images_pack(cu(fr['images'], dev)), cu(fr['proj'], dev)
+        z1, p1 = ops.refine_fwd(mlps['refine'], ops.refine_input(rays, orr, ds, img4, proj), rays, ds)
+        z2, p2 = ops.refine_project_fwd(mlps['refine'], rays, orr, ds, img4, proj)
+        # a bf16 input that flips by one unit (2^-8 relative) moves z by ~1e-3 at most; typically the two paths are identical
+        np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), rtol=0, atol=2e-3)
+        np.testing.assert_allclose(p2.cpu().numpy(), p1.cpu().numpy(), rtol=0, atol=3e-3)
+        assert relrms(z2.cpu(), z1.cpu()) < 3e-4
+        np.testing.assert_allclose(z2.cpu().numpy(), o['z'].numpy(), rtol=0, atol=3e-3)
+        np.testing.assert_allclose(p2.cpu().numpy(), o['pts'].numpy(), rtol=0, atol=5e-3)
+        assert relrms(z2.cpu(), o['z']) < 2e-3
+        # ragged prefix: same rays, smaller call
+        z3, _ = ops.refine_project_fwd(mlps['refine'], rays[:77].contiguous(), orr[:77].contiguous(), ds[:77].contiguous(), img4, proj)
+        assert torch.equal(z3, z2[:77])
+
+
 def test_refine_and_nerf_stages(dev):
     from pronerf_amd import ops
     w, mlps = _packed(dev, 0, 'trained')

@@ -107,7 +107,7 @@ def test_empty_and_ragged(dev):
 
 
 def test_stage_timing_of_the_fused_path(dev):
-    """pnrf_ctx_profile_begin / _end: events around the four kernels of the next calls; results untouched, bounded by the wall clock."""
+    """pnrf_ctx_profile_begin / _end: events around the three kernels of the next calls; results untouched, bounded by the wall clock."""
     import time
     from pronerf_amd.ops import PnrfError
     from pronerf_amd.render import Renderer
@@ -126,7 +126,7 @@ def test_stage_timing_of_the_fused_path(dev):
     ms, frames = rend.ctx.profile_end()
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
-    assert frames == 3 and list(ms) == ['sampler_kernel', 'refine_input_kernel', 'refine_kernel', 'nerf_kernel']
+    assert frames == 3 and list(ms) == ['sampler_kernel', 'refine_kernel', 'nerf_kernel']
     assert all(v > 0 for v in ms.values()) and 3 * sum(ms.values()) < wall_ms
     assert torch.equal(out, ref)
     rend.ctx.profile_begin(2)                            # re-arm with a smaller window; nothing rendered -> zero frames
@@ -134,7 +134,8 @@ def test_stage_timing_of_the_fused_path(dev):
 
 
 def test_ray_counts_past_two_gib_of_workspace(dev):
-    """4.2 M rays in one call: the refine-input workspace alone is 2.4 GB, so every per-ray byte offset passes 2^31.  The rays are a
+    """4.2 M rays in one call: the per-ray workspace is 0.94 GB and the int64 index output 0.27 GB; ray-indexed byte offsets pass 2^31 in the
+    operator-level refine_in buffer checked below (2.4 GB).  The rays are a
     756 x 1008 frame repeated; each repetition must equal the single frame bit for bit, and a ragged tail must equal its prefix."""
     from pronerf_amd.render import Renderer
     H, W = 756, 1008
@@ -150,6 +151,13 @@ def test_ray_counts_past_two_gib_of_workspace(dev):
     big_o = torch.cat([orr] * reps + [orr[:tail]]).contiguous()
     assert big_r.shape[0] == 4_200_000 and big_r.shape[0] * 144 * 4 > 2 ** 31
     out, idx = rend.render_rays(big_r, big_o, want_idx=True)
+    # the operator-level projection writes refine_in [n,144] (2.4 GB): its last rows must equal the rows of the single frame
+    from pronerf_amd import ops
+    depth = ops.sampler_fwd(rend.sampler, big_r, want_idx=False, want_rgb=False)[0]
+    rin = ops.refine_input(big_r, big_o, depth, rend.img4, rend.proj)
+    d1 = ops.sampler_fwd(rend.sampler, rays, want_idx=False, want_rgb=False)[0]
+    assert torch.equal(rin[reps * n:], ops.refine_input(rays, orr, d1, rend.img4, rend.proj)[:tail])
+    del rin, depth
     for k in range(reps):
         assert torch.equal(out[k * n:(k + 1) * n], one[0]) and torch.equal(idx[k * n:(k + 1) * n], one[1]), k
     assert torch.equal(out[reps * n:], one[0][:tail]) and torch.equal(idx[reps * n:], one[1][:tail])

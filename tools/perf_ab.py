@@ -7,7 +7,9 @@ A config selects a library build (lib=<name> -> pronerf_amd/lib/libpronerf_hip_<
 `python -m pronerf_amd.build --variant <name> [flags]`) and the kernel variants of its handles (pnrf_mlp_set_variant: sampler=
 default | sampler_f32 | sampler_f32_full, bf16= default | bf16_32x32) — explicit configuration, the library reads no environment.
 Every round renders `--frames` frames per config through pnrf_render_rays_fwd with the context's per-kernel events
-(pnrf_ctx_profile_begin / _end); reports median / min over the rounds per stage kernel on the bench workload (one 1008x756 frame)."""
+(pnrf_ctx_profile_begin / _end); reports median / min over the rounds per stage kernel on the bench workload (one 1008x756 frame).
+path=ops times the operator-level sequence instead (sampler, refine_input, refine on refine_in, NeRF: four kernels with the [n,144]
+intermediate in HBM), frames back to back with torch events per stage."""
 import argparse
 import ctypes as C
 import os
@@ -18,7 +20,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pronerf_amd import _lib, synthetic         # noqa: E402
+from pronerf_amd import _lib, ops, synthetic    # noqa: E402
 from pronerf_amd.render import Renderer         # noqa: E402
 
 H, W = 756, 1008
@@ -62,11 +64,27 @@ def main():
         for i, c in enumerate(cfgs):
             _lib._lib = libs[c.get('lib', '')]
             rend = rends[i]
-            rend.ctx.profile_begin(a.frames)
-            for _ in range(a.frames):
-                rend.render_rays(rays, or_rays)
-            ms, _ = rend.ctx.profile_end()
-            torch.cuda.synchronize()
+            if c.get('path') == 'ops':
+                ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.frames)]
+                for e in ev:
+                    e[0].record()
+                    depth, _, add, mul, _, _ = ops.sampler_fwd(rend.sampler, rays, want_idx=False, want_rgb=False)
+                    e[1].record()
+                    rin = ops.refine_input(rays, or_rays, depth, rend.img4, rend.proj)
+                    e[2].record()
+                    z, pts = ops.refine_fwd(rend.refine, rin, rays, depth)
+                    e[3].record()
+                    ops.nerf_fwd(rend.nerf, pts, rays, z, add, mul)
+                    e[4].record()
+                torch.cuda.synchronize()
+                names = ('sampler_kernel', 'refine_input_kernel', 'refine_kernel', 'nerf_kernel')
+                ms = {k: sum(e[i].elapsed_time(e[i + 1]) for e in ev) / a.frames for i, k in enumerate(names)}
+            else:
+                rend.ctx.profile_begin(a.frames)
+                for _ in range(a.frames):
+                    rend.render_rays(rays, or_rays)
+                ms, _ = rend.ctx.profile_end()
+                torch.cuda.synchronize()
             if r == 0:
                 continue
             for k, v in ms.items():
