@@ -377,7 +377,13 @@ template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + 
 #ifndef PNRF_H16_ATSTEP
 #define PNRF_H16_ATSTEP 2
 #endif
-constexpr int H16_PIECES = 4;             // deferred epilogue pieces per tile pair: piece pc = registers 2(pc&1), 2(pc&1)+1 of tile pc>>1
+#ifndef PNRF_H16_PIECES
+#define PNRF_H16_PIECES 8
+#endif
+// deferred epilogue pieces per tile pair.  4: piece pc = registers 2(pc&1), 2(pc&1)+1 of tile pc>>1, one every second k-step;
+// 8: piece pc = register pc&3 of tile pc>>2, one per k-step (the even one leaves its activation in the accumulator register for the odd one,
+// which packs the pair)
+constexpr int H16_PIECES = PNRF_H16_PIECES;
 constexpr float H16_LO_SCALE = 2048.f;
 template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1,
@@ -425,7 +431,9 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
       }
 #pragma unroll
       for (int pc = 0; pc < H16_PIECES; ++pc) {
-        const int at = KS >= 8 ? (tp == 0 ? 1 + pc : PNRF_H16_AT0 + pc * PNRF_H16_ATSTEP) : KS - 1;
+        const int at = KS < 8 ? KS - 1
+                       : H16_PIECES == 8 ? (tp == 0 ? (pc < 6 ? pc : 6) : pc)       // first pair of a layer: done before k-step 7 reads the result
+                                         : (tp == 0 ? 1 + pc : PNRF_H16_AT0 + pc * PNRF_H16_ATSTEP);
         if (ks == (at < KS ? at : KS - 1)) {
           if (tp == 0) pre1(pc);
           else epi1(tp - 1, pc, pm, pc_);

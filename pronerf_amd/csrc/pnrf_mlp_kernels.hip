@@ -311,14 +311,24 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
     // activations ping-pong between X and Y: per 32-feature k-step one hi and one lo plane
     f16x8 Xh[SH_KS_H], Xl[SH_KS_H], Yh[SH_KS_H], Yl[SH_KS_H];
     f32x4 pm[2], pc[2];                   // pending (deferred) tile pair of the previous layer
-    // piece pcx (0..3) of tile pair tp: registers 2p, 2p+1 (p = pcx & 1) of tile t = pcx >> 1 -> dword 2t + p of k-step tp of the next layer's
+    // pair (t, p) of tile pair tp: registers 2p, 2p+1 of tile t -> dword 2t + p of k-step tp of the next layer's
     // planes.  Per activation: combine (v_fma), ELU on the log2(e) scale (v_exp, v_fma, v_med3), then per PAIR one v_cvt_pk_f16_f32 for the
     // high plane and per value v_mul (x 2^11) + v_fma_mix{lo,hi}_f16 for the low plane ((v - hi) 2^11 in one fused step: hi 2^11 and v 2^11 are
     // exact).  Written with the instructions spelled out: left to the compiler this came out as v_cvt_f32_f16 round trips and SLP-packed
     // v_pk_*_f32, which cost more beside MFMAs than the scalar forms (MI355X_MICROARCH.md, issue-cost table).
     auto store_piece = [&](f16x8(&dh)[SH_KS_H], f16x8(&dl)[SH_KS_H], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
-      const int t = pcx >> 1, p = pcx & 1;
-      const float v0 = elu_scaled(fmaf(cr[t][2 * p], INV, mn[t][2 * p])), v1 = elu_scaled(fmaf(cr[t][2 * p + 1], INV, mn[t][2 * p + 1]));
+      int t, p;
+      float v0, v1;
+      if constexpr (H16_PIECES == 8) {          // one activation per piece: the even one waits, activated, in its accumulator register
+        t = pcx >> 2; p = (pcx >> 1) & 1;
+        const int r = pcx & 3;
+        const float v = elu_scaled(fmaf(cr[t][r], INV, mn[t][r]));
+        if (!(r & 1)) { mn[t][r] = v; return; }
+        v0 = mn[t][r - 1]; v1 = v;
+      } else {
+        t = pcx >> 1; p = pcx & 1;
+        v0 = elu_scaled(fmaf(cr[t][2 * p], INV, mn[t][2 * p])); v1 = elu_scaled(fmaf(cr[t][2 * p + 1], INV, mn[t][2 * p + 1]));
+      }
       int hi, lo;
       asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
       const float s0 = v0 * H16_LO_SCALE, s1 = v1 * H16_LO_SCALE, sc = H16_LO_SCALE;
@@ -502,12 +512,16 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         e_d0[cb] = *(const float4*)(a.depth_sorted + rr * 8); e_d1[cb] = *(const float4*)(a.depth_sorted + rr * 8 + 4);
       }
       if constexpr (HEAD == 0) {
+        // refine_in0: a lane's 72 inputs are two contiguous runs of the natural row — the colours of its two views [48 + 48h, 96 + 48h) and
+        // the Pluecker values of its four samples [24h, 24h + 24): 18 aligned 16-byte loads
         const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN;
+        static_assert(refine_in0(0, 1, 0) == 96 && refine_in0(5, 1, 7) == 143 && refine_in0(6, 1, 0) == 24 && refine_in0(8, 0, 7) == 23, "runs of refine_in0");
+        const float4* xc = (const float4*)(xr + 48 + 48 * h);
+        const float4* xp = (const float4*)(xr + 24 * h);
 #pragma unroll
         for (int ks = 0; ks < R_KS0; ++ks) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = xr[h ? refine_in0(ks, 1, j) : refine_in0(ks, 0, j)];
+          const float4 lo = ks < 6 ? xc[2 * ks] : xp[2 * (ks - 6)], hi = ks < 6 ? xc[2 * ks + 1] : xp[2 * (ks - 6) + 1];
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           Bo[cb][ks] = pack_bf16(v);
         }
       } else {
