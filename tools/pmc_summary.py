@@ -7,7 +7,8 @@ Each pass directory holds rocprofv3's *_counter_collection.csv (one counter set 
 --kernel-trace only, as MI355X_MICROARCH.md prescribes).  Per kernel (mean over its launches, copy kernels
 dropped):  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB  — gfx950 reports half of a wide coalesced
 read stream in FETCH_SIZE;  clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration;  mfma_busy_frac =
-SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8).  bench.py reads hbm_bytes_per_launch as
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8);  valu_per_mfma = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA — SQ_INSTS_VALU
+counts the MFMAs themselves as well (checked against the static instruction mix of the kernels' steady-state loops, tools/isa_table.py).  bench.py reads hbm_bytes_per_launch as
 roofline.traffic.  The raw CSVs are copied next to the summary."""
 import csv
 import glob
@@ -61,15 +62,17 @@ for k, c in acc.items():
         e['clock_GHz'] = round(cyc / durs[0], 3)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
             e['mfma_busy_frac'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc), 3)
+    if m.get('SQ_INSTS_MFMA', 0) > 0 and 'SQ_INSTS_VALU' in m:
+        e['valu_per_mfma'] = round((m['SQ_INSTS_VALU'] - m['SQ_INSTS_MFMA']) / m['SQ_INSTS_MFMA'], 3)
     per[k] = e
 summary = {
     'round': tag,
     'command': 'rocprofv3 --pmc <C> --kernel-trace --output-format csv -d <pass dir> -- python3 bench.py --steps 3 --warmup 1 '
-               '--no-cpu-baseline   (tools/profile_round.sh: one pass per counter set)',
+               '--no-cpu-baseline --no-gpu-eager-baseline   (tools/profile_round.sh: one pass per counter set)',
     'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over launches); see tools/pmc_summary.py for the derived fields',
     'per_kernel': per,
 }
 path = os.path.join(out_dir, f'{tag}_pmc_summary.json')
 json.dump(summary, open(path, 'w'), indent=1)
 print(path)
-print(json.dumps({k: {n: v for n, v in e.items() if n in ('hbm_bytes_per_launch', 'clock_GHz', 'mfma_busy_frac')} for k, e in per.items()}, indent=1))
+print(json.dumps({k: {n: v for n, v in e.items() if n in ('hbm_bytes_per_launch', 'clock_GHz', 'mfma_busy_frac', 'valu_per_mfma')} for k, e in per.items()}, indent=1))
