@@ -228,12 +228,14 @@ int pnrf_ctx_profile_begin(pnrf_ctx_t* ctx, int max_frames);
 int pnrf_ctx_profile_end(pnrf_ctx_t* ctx, float* ms, int* frames);
 
 /* ---- stage-2 training step --------------------------------------------------
- * fp32 throughout, like the reference's training.  Layer products are rocBLAS GEMMs inside the library; every other
- * stage (heads, sort, interval refinement, jitter, encodings, compositing, losses, Adam) is a kernel of this library. */
+ * fp32 throughout, like the reference's training.  Every stage is a kernel of this library: the layer products run on
+ * v_mfma_f32_16x16x4_f32 with bias + activation (forward) and the activation derivative of the layer below (backward) fused into
+ * their epilogues; heads, sort, interval refinement, jitter, encodings, compositing, losses and Adam are per-ray kernels. */
 
 /* Operator-level backward passes (each mirrors what torch.autograd derives for the forward it names). */
 /* raw2outputs backward for d rgb_map [n,3]: arguments as pnrf_composite_fwd; outputs d_raw dev [n,s,4], d_z dev [n,s] (NULL to
- * skip), d_add / d_mul dev [n,s] (NULL to skip).  s <= 64.  (run_S_eS_eN_alter_base_refine2.py:475-522) */
+ * skip), d_add / d_mul dev [n,s] (NULL to skip).  Any s >= 1 (two passes per ray, O(1) registers; d_raw doubles as scratch between
+ * them).  (run_S_eS_eN_alter_base_refine2.py:475-522) */
 int pnrf_composite_bwd(const float* raw, const float* z, const float* rays_d, int d_stride, const float* add,
                        const float* mul, const float* noise, float clamp, int white_bkgd, const float* d_rgb,
                        float* d_raw, float* d_z, float* d_add, float* d_mul, int64_t n, int s, void* stream);
@@ -267,6 +269,10 @@ int pnrf_refine_head_bwd(const float* y, const float* rays, const float* depth_s
 int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim,
                         int n_layers, int64_t max_rays, int max_samples, pnrf_trainer_t** out);
 int pnrf_trainer_free(pnrf_trainer_t* t);
+/* Weight-gradient kernel of the square layers: tile 0 = chosen by shape and row count (default), 64 / 128 = forced where the shape allows;
+ * min_rows_128 = row count from which the 128 x 128-tile kernel is used (0 = default).  Configuration, not on the step path. */
+int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t min_rows_128);
+
 /* kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment of the joint optimizer, 4 / 5 those of the NeRF-only
  * optimizer; W, b: host or device (NULL to skip). */
 int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, float* W, float* b, void* stream);

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libpronerf_hip.so')
 SOURCES = ['pnrf_pack.hip', 'pnrf_ops.hip', 'pnrf_mlp_kernels.hip', 'pnrf_train.hip']
-LINK = ['-lrocblas']          # layer products of the training step (plain library GEMMs)
+LINK = []                    # no library dependencies: every kernel, the training step's layer products included, is in csrc/
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
 

@@ -12,8 +12,6 @@
 // Pluecker moment does not depend on the depth along the ray, so no gradient reaches refine_in or mm_input and the first
 // layers of the sampler / refine nets need no dX.  A trainer owns parameters, gradients, Adam moments and workspaces;
 // nothing is allocated per step and every launch goes to the caller's stream.
-#include <rocblas/rocblas.h>
-
 #include "pnrf_common.h"
 
 using namespace pnrf;
@@ -29,58 +27,141 @@ inline int grid_for(int64_t work, int per_block = TPB) {
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 enum { T_ACT_NONE = 0, T_ACT_RELU = 1, T_ACT_ELU = 2 };
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-// ------------------------------------------------------------------------------------------ dense-layer pieces
-// Y[r, j] = act(Y[r, j] + b[j]) in place; Y has row stride ld.
-__global__ void bias_act_kernel(float* __restrict__ Y, int ld, const float* __restrict__ b, int64_t R, int out, int act) {
-  const int64_t total = R * out;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / out;
-    const int j = (int)(i - r * out);
-    float v = Y[r * ld + j] + b[j];
-    if (act == T_ACT_RELU) v = fmaxf(v, 0.f);
-    else if (act == T_ACT_ELU) v = v > 0.f ? v : expm1f(v);           // F.elu, alpha = 1
-    Y[r * ld + j] = v;
+// ------------------------------------------------------------------------------------------ layer products with fused epilogues
+// The forward product Y = act(X W^T + b) and the input gradient dX = (dZ W [+ dX]) * act'(H_prev) of a Linear layer as ONE kernel each, on
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation: the reference trains in fp32).  They replace a rocBLAS sgemm + a
+// bias/activation pass (forward) and a sgemm + the activation-backward pass of the layer below (backward): the activation derivative of
+// the PREVIOUS layer is applied in the epilogue of the product that creates its output gradient, so every gradient buffer is written once,
+// already as dL/dZ, and no separate elementwise pass runs over [rows, 256] activations.
+//
+// Register-direct operands, no LDS: lane l = (m = l & 15, g = l >> 4) loads 16 bytes along k — A[row m][16 j + 4 g .. + 3] — and the four
+// MFMAs of a 16-deep step use element e of every lane's vector, i.e. contract over k = {16 j + 4 g + e : g}.  Both operands are loaded with
+// the same permutation of k, so the sum is the same.  A wave owns a (16 MI) x (16 NI) tile, a workgroup 2 x 2 waves; the next step's
+// fragments are fetched while the current step's MI NI 4 MFMAs (32 cycles each) run.
+//   MODE_NT: B = W [N, K], k contiguous (forward: N = out, K = in);  MODE_NN: B = W [K, N], n contiguous (backward: K = out, N = in).
+// ALIGNED: K % 16 == 0, lda / ldb % 4 == 0 and 16-byte aligned bases -> vector loads without bounds checks along k.
+enum { MODE_NT = 0, MODE_NN = 1 };
+struct GemmArgs {
+  const float* A; int lda;              // [M, K]
+  const float* B; int ldb;              // MODE_NT: [N, K]; MODE_NN: [K, N]
+  float* C; int ldc;                    // [M, N]
+  int64_t M; int N, K;
+  const float* bias;                    // forward: [N] or NULL
+  int act;                              // forward: activation of this layer; backward: activation of the layer whose output gradient C is
+  const float* H; int ldh;              // backward: saved output of that layer (act'(H)), applied to columns >= act_col0
+  int act_col0;
+  float beta;                           // backward: C = beta C + A B   (0 or 1)
+};
+template <int MI, int NI, int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m16 = lane & 15, g = lane >> 4;
+  const int tiles_n = (a.N + 32 * NI - 1) / (32 * NI);
+  const int64_t tm = blockIdx.x / tiles_n;
+  const int tn = (int)(blockIdx.x - tm * tiles_n);
+  const int64_t row0 = tm * (32 * MI) + (wave >> 1) * (16 * MI);
+  const int col0 = tn * (32 * NI) + (wave & 1) * (16 * NI);
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const float* ap[MI];
+  bool aok[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t r = row0 + 16 * i + m16;
+    aok[i] = r < a.M;
+    ap[i] = a.A + (aok[i] ? r : 0) * a.lda + 4 * g;
   }
-}
-
-// dZ = dH * act'(H) in place (H = saved post-activation output) and partial column sums for the bias gradient.
-// grid (ceil(out/64), NCHUNK); block 256 = 64 columns x 4 row lanes.  part[chunk][out].
-constexpr int DB_CHUNKS = 256;
-__global__ void act_bwd_colsum_kernel(float* __restrict__ dH, int ldd, const float* __restrict__ H, int ldh, int64_t R, int out, int act,
-                                      float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c;
-  const int64_t rows_per = (R + DB_CHUNKS - 1) / DB_CHUNKS;
-  const int64_t r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
-  float s = 0.f;
-  if (j < out) {
-    // 4 independent rows per trip: the loads of a trip are all in flight before the first is consumed
-    for (int64_t r = r0 + rl; r < r1; r += 16) {
-      float g[4], h[4];
+  const float* bp[NI];
+  bool bok[NI];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t ru = r + 4 * u;
-        g[u] = ru < r1 ? dH[ru * ldd + j] : 0.f;
-        h[u] = (act != T_ACT_NONE && ru < r1) ? H[ru * ldh + j] : 1.f;
+  for (int j = 0; j < NI; ++j) {
+    const int c = col0 + 16 * j + m16;
+    bok[j] = c < a.N;
+    bp[j] = MODE == MODE_NT ? a.B + (size_t)(bok[j] ? c : 0) * a.ldb + 4 * g : a.B + (size_t)(4 * g) * a.ldb + (bok[j] ? c : 0);
+  }
+  auto load_a = [&](int i, int k0) {
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (ALIGNED) {
+      if (aok[i]) v = *(const f32x4_t*)(ap[i] + k0);
+    } else if (aok[i]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (k0 + 4 * g + e < a.K) ? ap[i][k0 + e] : 0.f;
+    }
+    return v;
+  };
+  auto load_b = [&](int j, int k0) {
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_NT) {
+      if (ALIGNED) {
+        if (bok[j]) v = *(const f32x4_t*)(bp[j] + k0);
+      } else if (bok[j]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k0 + 4 * g + e < a.K) ? bp[j][k0 + e] : 0.f;
       }
+    } else if (bok[j]) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t ru = r + 4 * u;
-        float gv = g[u];
-        if (act == T_ACT_RELU) gv = h[u] > 0.f ? gv : 0.f;
-        else if (act == T_ACT_ELU) gv = h[u] > 0.f ? gv : gv * (h[u] + 1.f);            // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
-        if (act != T_ACT_NONE && ru < r1) dH[ru * ldd + j] = gv;
-        s += gv;
+      for (int e = 0; e < 4; ++e) v[e] = (ALIGNED || k0 + 4 * g + e < a.K) ? bp[j][(size_t)(k0 + e) * a.ldb] : 0.f;
+    }
+    return v;
+  };
+  f32x4_t fa[MI], fb[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) fa[i] = load_a(i, 0);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) fb[j] = load_b(j, 0);
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+    f32x4_t na[MI], nb[NI];
+    const bool more = k0 + 16 < a.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) na[i] = more ? load_a(i, k0 + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NI; ++j) nb[j] = more ? load_b(j, k0 + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = na[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) fb[j] = nb[j];
+  }
+  // epilogue: D register e of lane (m16, g) = C[row 4 g + e][col m16] of its 16 x 16 tile
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int c = col0 + 16 * j + m16;
+      if (c >= a.N) continue;
+      const float bv = (MODE == MODE_NT && a.bias) ? a.bias[c] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t r = row0 + 16 * i + 4 * g + e;
+        if (r >= a.M) continue;
+        float v = acc[i][j][e];
+        float* dst = a.C + r * a.ldc + c;
+        if (MODE == MODE_NT) {
+          v += bv;
+          if (a.act == T_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == T_ACT_ELU) v = v > 0.f ? v : expm1f(v);            // F.elu, alpha = 1
+        } else {
+          if (a.beta != 0.f) v += *dst;
+          if (a.act != T_ACT_NONE && c >= a.act_col0) {
+            const float h = a.H[r * a.ldh + (c - a.act_col0)];
+            if (a.act == T_ACT_RELU) v = h > 0.f ? v : 0.f;
+            else v = h > 0.f ? v : v * (h + 1.f);                               // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
+          }
+        }
+        *dst = v;
       }
     }
-  }
-  red[rl][c] = s;
-  __syncthreads();
-  if (rl == 0 && j < out) part[blockIdx.y * out + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
-
 
 // ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
 // dW[out, in] = dZ^T[out, R] X[R, in] with R = rays or ray-samples (4096 .. 32768) and out, in <= 319: a tiny output with a
@@ -92,10 +173,11 @@ __global__ void act_bwd_colsum_kernel(float* __restrict__ dH, int ldd, const flo
 //   MFMA operands: A[m][k] = dZ[row k][out m], B[k][n] = X[row k][in n]; lane l supplies (m or n) = l&15, k = l>>4;
 //   rows are staged 32 at a time through LDS with a row stride of 80 floats: the 4 k-rows a wave reads per MFMA then fall
 //   into disjoint bank groups (ds_read_b32: 32 banks, conflicts within each 32-lane half).
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int DW_TILE = 64, DW_ROWS = 32, DW_LDS_STRIDE = 80, DW_MAX_SPLITS = 64;
+constexpr int DB_MAX_OUT = 512;          // widest layer output the bias-partial buffer is sized for
 __global__ __launch_bounds__(256) void dw_splitk_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
-                                                        float* __restrict__ part, int out, int in, int64_t R, int64_t rows_per_split) {
+                                                        float* __restrict__ part, int out, int in, int64_t R, int64_t rows_per_split,
+                                                        float* __restrict__ db_part) {
   __shared__ float sA[DW_ROWS * DW_LDS_STRIDE];
   __shared__ float sB[DW_ROWS * DW_LDS_STRIDE];
   const int tiles_n = (in + DW_TILE - 1) / DW_TILE;
@@ -125,11 +207,13 @@ __global__ __launch_bounds__(256) void dw_splitk_kernel(const float* __restrict_
     }
   };
   fetch(r_begin);
+  float colsum = 0.f;            // bias gradient: column sums of dZ over this split's rows (the loader touches every element once)
   for (int64_t r0 = r_begin; r0 < r_end; r0 += DW_ROWS) {
 #pragma unroll
     for (int k = 0; k < DW_ROWS / 4; ++k) {
       sA[(lr + 4 * k) * DW_LDS_STRIDE + lc] = pa[k];
       sB[(lr + 4 * k) * DW_LDS_STRIDE + lc] = pb[k];
+      colsum += pa[k];
     }
     __syncthreads();
     if (r0 + DW_ROWS < r_end) fetch(r0 + DW_ROWS);
@@ -155,6 +239,11 @@ __global__ __launch_bounds__(256) void dw_splitk_kernel(const float* __restrict_
         const int m = tm * DW_TILE + wm * 32 + 16 * i + 4 * q + e, n = tn * DW_TILE + wn * 32 + 16 * j + c16;      // D reg e = row 4q+e, col l&15
         if (m < out && n < in) p[(size_t)m * in + n] = acc[i][j][e];
       }
+  if (db_part && tn == 0) {      // the tiles of the first column block carry the bias partials of their 64 output rows
+    sA[lr * 64 + lc] = colsum;   // (the last row block's barrier has passed: sA is free)
+    __syncthreads();
+    if (lr == 0 && gm < out) db_part[(size_t)blockIdx.y * out + gm] = (sA[lc] + sA[64 + lc]) + (sA[128 + lc] + sA[192 + lc]);
+  }
 }
 // 128 x 128 tiles for the square hidden layers: each workgroup reads its row range of dZ and X half as often as with 64 x 64 tiles
 // (the kernel is bound by those reads: 16 FLOP per byte at 64 x 64), and an operand fetch is one ds_read_b128 per four MFMAs.
@@ -163,7 +252,8 @@ __global__ __launch_bounds__(256) void dw_splitk_kernel(const float* __restrict_
 // Requires out, in multiples of 128 and 16-byte aligned rows (ldz, ldx multiples of 4).
 constexpr int DW128_ROWS = 32, DW128_MAX_SPLITS = 128;
 __global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
-                                                           float* __restrict__ part, int out, int in, int64_t R, int64_t rows_per_split) {
+                                                           float* __restrict__ part, int out, int in, int64_t R, int64_t rows_per_split,
+                                                           float* __restrict__ db_part) {
   __shared__ __attribute__((aligned(16))) float sAB[2][2][DW128_ROWS * 128];     // [buffer][A | B]: double buffered, one barrier per row block
   const int tiles_n = in / 128;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
@@ -197,18 +287,21 @@ __global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restri
     }
   };
   fetch(r_begin);
+  f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};      // bias gradient partials of this thread's four dZ columns
   int buf = 0;
   for (int64_t r0 = r_begin; r0 < r_end; r0 += DW128_ROWS, buf ^= 1) {
     // the block before last was read from this buffer; every wave has passed the barrier of the last block since, so it is free
     float* sA = sAB[buf][0];
     float* sB = sAB[buf][1];
 #pragma unroll
-    for (int k = 0; k < DW128_ROWS / 8; ++k)
+    for (int k = 0; k < DW128_ROWS / 8; ++k) {
+      colsum += pa[k];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         sA[(lr + 8 * k) * 128 + lpos + 4 * e] = pa[k][e];
         sB[(lr + 8 * k) * 128 + lpos + 4 * e] = pb[k][e];
       }
+    }
     __syncthreads();
     if (r0 + DW128_ROWS < r_end) fetch(r0 + DW128_ROWS);
 #pragma unroll
@@ -231,9 +324,22 @@ __global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restri
         const int m = tm * 128 + wm * 64 + 16 * i + 4 * q + e, n = tn * 128 + wn * 64 + 16 * j + c16;
         p[(size_t)m * in + n] = acc[i][j][e];
       }
+  if (db_part && tn == 0) {
+    __syncthreads();                                        // every wave is done reading the staging buffers
+    float* red = sAB[0][0];                                 // [8 row lanes][128 columns]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[lr * 128 + lcol + e] = colsum[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r * 128 + threadIdx.x];
+      db_part[(size_t)blockIdx.y * out + tm * 128 + threadIdx.x] = sum;
+    }
+  }
 }
 // Adds the split-K partials of dW in a fixed order; the last `db_blocks` workgroups of the grid do the same for the bias gradient's
-// column-sum partials of act_bwd_colsum_kernel (one launch per layer instead of two: the iteration is launch-bound at 4096 rays).
+// column-sum partials, which the weight-gradient kernels' loaders produce on the way (one per split).
 __global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int64_t numel, float* __restrict__ dW, int db_blocks,
                                  const float* __restrict__ db_part, int out, float* __restrict__ db) {
   const int dw_blocks = (int)gridDim.x - db_blocks;
@@ -241,7 +347,7 @@ __global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int
     const int j = ((int)blockIdx.x - dw_blocks) * (int)blockDim.x + (int)threadIdx.x;
     if (j < out) {
       float s = 0.f;
-      for (int k = 0; k < DB_CHUNKS; ++k) s += db_part[k * out + j];
+      for (int k = 0; k < splits; ++k) s += db_part[(size_t)k * out + j];
       db[j] = s;
     }
     return;
@@ -496,9 +602,11 @@ __global__ void refine_head_bwd_kernel(const float* __restrict__ y, const float*
 
 // ------------------------------------------------------------------------------------------ compositing backward
 // raw2outputs (refine2.py:475-522) backward for d rgb_map [n,3]: d raw [n,S,4], d z [n,S], d add / d mul [n,S] (NULL to skip).
-// The derivative of the transmittance products is accumulated with explicit suffix products (S <= 64), never dividing by
-// a factor 1 - alpha + 1e-10 that can be 1e-10.
-constexpr int CB_MAXS = 64;
+// Any S (a runtime value; the reference's exploration goes to 64, BASELINE.json's stress bound is 256): two passes per ray with O(1)
+// registers.  Pass 1 (ascending) leaves alpha_s and the exclusive transmittance T_s = prod_{k<s} x_k, x_k = 1 - alpha_k + 1e-10, in the first
+// two channels of d_raw (scratch, overwritten by pass 2).  Pass 2 (descending) carries Q_s = sum_{j>s} dw_j alpha_j prod_{s<k<j} x_k through
+// the recurrence Q_{s-1} = dw_s alpha_s + x_s Q_s, so that  d alpha_s = T_s (dw_s - Q_s)  — the derivative of the transmittance products
+// without ever dividing by a factor x_k that can be 1e-10.
 __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
                                      const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
                                      int white_bkgd, const float* __restrict__ d_rgb, float* __restrict__ d_raw, float* __restrict__ d_z,
@@ -507,50 +615,48 @@ __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float*
     const float* d = rays_d + i * d_stride;
     const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     const float g0 = d_rgb[i * 3], g1 = d_rgb[i * 3 + 1], g2 = d_rgb[i * 3 + 2];
-    float x[CB_MAXS], al[CB_MAXS], dw[CB_MAXS];
-    // pass 1: forward quantities
+    const float gsum = white_bkgd ? (g0 + g1 + g2) : 0.f;                       // rgb_map += 1 - sum_s w_s
+    const bool clamped = clampv > 0.f;
+    auto sigma_of = [&](int64_t e, float& r3) {
+      r3 = raw[e * 4 + 3];
+      if (clamped) r3 = fminf(fmaxf(r3, -clampv), clampv);
+      float sg = r3;
+      if (noise) sg += noise[e];
+      if (add) sg += add[e];
+      return sg;
+    };
+    // pass 1
     float T = 1.f;
     for (int s = 0; s < S; ++s) {
       const int64_t e = i * S + s;
-      float r0 = raw[e * 4], r1 = raw[e * 4 + 1], r2 = raw[e * 4 + 2], r3 = raw[e * 4 + 3];
-      if (clampv > 0.f) { r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv); r2 = fminf(fmaxf(r2, -clampv), clampv); r3 = fminf(fmaxf(r3, -clampv), clampv); }
+      float r3;
+      const float sg = sigma_of(e, r3);
       const float dist = ((s + 1 < S) ? (z[e + 1] - z[e]) : 1e10f) * dn;
-      float sg = r3;
-      if (noise) sg += noise[e];
-      if (add) sg += add[e];
       const float a = 1.f - expf(-fmaxf(sg, 0.f) * dist);
-      al[s] = mul ? a * fmaxf(mul[e], 0.f) : a;
-      x[s] = 1.f - al[s] + 1e-10f;
-      const float w = al[s] * T;
-      T *= x[s];
+      const float al = mul ? a * fmaxf(mul[e], 0.f) : a;
+      d_raw[e * 4] = T; d_raw[e * 4 + 1] = al;
+      T *= 1.f - al + 1e-10f;
+    }
+    // pass 2
+    float Q = 0.f, dd_next = 0.f;
+    for (int s = S - 1; s >= 0; --s) {
+      const int64_t e = i * S + s;
+      const float Tpre = d_raw[e * 4], al = d_raw[e * 4 + 1];
+      float r0 = raw[e * 4], r1 = raw[e * 4 + 1], r2 = raw[e * 4 + 2];
+      const bool in0 = !clamped || fabsf(r0) <= clampv, in1 = !clamped || fabsf(r1) <= clampv, in2 = !clamped || fabsf(r2) <= clampv;
+      if (clamped) { r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv); r2 = fminf(fmaxf(r2, -clampv), clampv); }
       const float c0 = sigmoid_f(r0), c1 = sigmoid_f(r1), c2 = sigmoid_f(r2);
-      dw[s] = g0 * c0 + g1 * c1 + g2 * c2 - (white_bkgd ? (g0 + g1 + g2) : 0.f);     // rgb_map += 1 - sum_s w_s
-      const bool in0 = !(clampv > 0.f) || fabsf(raw[e * 4]) <= clampv, in1 = !(clampv > 0.f) || fabsf(raw[e * 4 + 1]) <= clampv,
-                 in2 = !(clampv > 0.f) || fabsf(raw[e * 4 + 2]) <= clampv;
+      const float dws = g0 * c0 + g1 * c1 + g2 * c2 - gsum;
+      const float dal = Tpre * (dws - Q);
+      Q = dws * al + (1.f - al + 1e-10f) * Q;
+      const float w = al * Tpre;
       d_raw[e * 4] = in0 ? g0 * w * c0 * (1.f - c0) : 0.f;
       d_raw[e * 4 + 1] = in1 ? g1 * w * c1 * (1.f - c1) : 0.f;
       d_raw[e * 4 + 2] = in2 ? g2 * w * c2 * (1.f - c2) : 0.f;
-    }
-    // pass 2: d alpha_s = dw_s T_s - sum_{j>s} dw_j alpha_j prod_{k<j, k!=s} x_k
-    float gz_next = 0.f;       // contribution of dist_{s} to z_{s+1}, carried backwards is awkward: do it forwards below
-    float Tpre = 1.f;          // prod_{k<s} x_k
-    float carry = 0.f;         // d z contribution from the previous interval (d dist_{s-1} * dn)
-    for (int s = 0; s < S; ++s) {
-      const int64_t e = i * S + s;
-      float tail = 0.f, P = Tpre;                                       // P = prod_{k<j, k != s} x_k, starts at j = s+1 with prod_{k<s}
-      for (int j = s + 1; j < S; ++j) {
-        tail += dw[j] * al[j] * P;
-        P *= x[j];
-      }
-      const float dal = dw[s] * Tpre - tail;
-      Tpre *= x[s];
       // alpha = a * relu(mul); a = 1 - exp(-relu(sig) dist)
-      float r3 = raw[e * 4 + 3];
-      const bool in3 = !(clampv > 0.f) || fabsf(r3) <= clampv;
-      if (clampv > 0.f) r3 = fminf(fmaxf(r3, -clampv), clampv);
-      float sg = r3;
-      if (noise) sg += noise[e];
-      if (add) sg += add[e];
+      float r3;
+      const float sg = sigma_of(e, r3);
+      const bool in3 = !clamped || fabsf(raw[e * 4 + 3]) <= clampv;
       const float dist = ((s + 1 < S) ? (z[e + 1] - z[e]) : 1e10f) * dn;
       const float ee = fmaxf(sg, 0.f);
       const float ex = expf(-ee * dist);
@@ -562,10 +668,12 @@ __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float*
       d_raw[e * 4 + 3] = in3 ? dsg : 0.f;
       if (d_add) d_add[e] = add ? dsg : 0.f;
       const float ddist = (s + 1 < S) ? da * ee * ex * dn : 0.f;          // the last interval (1e10) does not depend on z
-      if (d_z) d_z[e] = carry - ddist;
-      carry = ddist;
+      if (d_z) {                                                          // d z_s = d dist_{s-1} dn - d dist_s dn
+        if (s + 1 < S) d_z[e + 1] = ddist - dd_next;
+        if (s == 0) d_z[e] = -ddist;
+      }
+      dd_next = ddist;
     }
-    (void)gz_next;
   }
 }
 
@@ -620,7 +728,8 @@ struct pnrf_trainer {
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
   float *M2 = nullptr, *V2 = nullptr;            // second Adam state over the NeRF layers only (stage 1: `optimizer` next to `s_optimizer`)
   int64_t step = 0, step2 = 0;
-  rocblas_handle blas = nullptr;
+  int dw_tile = 0;                               // 0: by shape and row count; 64 / 128: force that weight-gradient kernel where it applies
+  int64_t dw128_min_rows = 65536;
   std::vector<void*> allocs;
   // workspaces
   float *mm_input, *s_h[6], *s_y, *depth_sorted, *add_s, *mul_s, *mm_rgb;
@@ -643,31 +752,34 @@ int dev_alloc(pnrf_trainer* t, T** p, size_t count) {
   return 0;
 }
 #define T_ALLOC(ptr, count) do { int rc_ = dev_alloc(t, &(ptr), (size_t)(count)); if (rc_) return rc_; } while (0)
-#define T_BLAS(expr)                                                                                   \
-  do {                                                                                                 \
-    rocblas_status st_ = (expr);                                                                       \
-    if (st_ != rocblas_status_success) { set_error("%s failed: rocblas status %d", #expr, (int)st_); return 1000 + (int)st_; } \
-  } while (0)
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// Y[R,out] (row stride ldy) = X[R,in] (row stride ldx) W^T, W row-major [out,in]
-int gemm_fwd(pnrf_trainer* t, const float* X, int ldx, const float* W, int in, int out, float* Y, int ldy, int64_t R) {
-  const float one = 1.f, zero = 0.f;
-  T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_transpose, rocblas_operation_none, out, (int)R, in, &one, W, in, X, ldx, &zero, Y, ldy));
+template <int MODE>
+int launch_tgemm(const GemmArgs& a, hipStream_t s) {
+  const bool al = a.K % 16 == 0 && a.lda % 4 == 0 && aligned16(a.A) && (MODE == MODE_NN || (a.ldb % 4 == 0 && aligned16(a.B)));
+  // 128 x 128 workgroup tiles when that still gives every CU a workgroup, 64 x 128 below (the 4096-row layers of the sampler / refine nets)
+  const int tiles_n = (a.N + 127) / 128;
+  const bool big = ((a.M + 127) / 128) * tiles_n >= 256;
+  const int64_t tiles_m = big ? (a.M + 127) / 128 : (a.M + 63) / 64;
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
+  if (big) {
+    if (al) hipLaunchKernelGGL((tgemm_kernel<4, 4, MODE, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tgemm_kernel<4, 4, MODE, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (al) hipLaunchKernelGGL((tgemm_kernel<2, 4, MODE, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tgemm_kernel<2, 4, MODE, false>), grid, dim3(256), 0, s, a);
+  }
+  PNRF_LAUNCH_CHECK();
   return 0;
 }
-// dX[R,in] = beta dX + dY[R,out] W
-int gemm_dx(pnrf_trainer* t, const float* dY, int ldy, const float* W, int in, int out, float* dX, int ldx, int64_t R, float beta) {
-  const float one = 1.f;
-  T_BLAS(rocblas_sgemm(t->blas, rocblas_operation_none, rocblas_operation_none, in, (int)R, out, &one, W, in, dY, ldy, &beta, dX, ldx));
-  return 0;
-}
-// dW[out,in] = dY^T X  (dw_splitk_kernel + dw_reduce_kernel)
-int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, float* dW, int in, int out, int64_t R, hipStream_t s,
-            const float* db_part = nullptr, float* db = nullptr) {
-  const int db_blocks = db ? (out + TPB - 1) / TPB : 0;
-  static const int use128 = [] { const char* e = getenv("PNRF_DW_TILE"); return (e && atoi(e) == 64) ? 0 : 1; }();
-  static const int64_t dw128_min_rows = [] { const char* e = getenv("PNRF_DW128_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)65536; }();
-  if (use128 && out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)dY & 15) == 0 && R >= dw128_min_rows) {
+
+// dW[out,in] = dZ^T X and db[out] = column sums of dZ  (dw_splitk*_kernel + dw_reduce_kernel)
+int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, float* dW, float* db, int in, int out, int64_t R, hipStream_t s) {
+  PNRF_REQUIRE(out <= DB_MAX_OUT, PNRF_E_SHAPE, "pnrf_trainer: layer output %d wider than the bias-partial buffer (%d)", out, DB_MAX_OUT);
+  const int db_blocks = (out + TPB - 1) / TPB;
+  const int64_t numel = (int64_t)out * in;
+  const bool can128 = out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldz % 4 == 0 && aligned16(X) && aligned16(dZ);
+  if (can128 && t->dw_tile != 64 && R >= t->dw128_min_rows) {
     const int tiles = (out / 128) * (in / 128);
     int64_t splits = (512 + tiles - 1) / tiles;                 // two workgroups per CU
     const int64_t by_rows = R / 256;
@@ -677,10 +789,9 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, 
     int64_t rows_per = (R + splits - 1) / splits;
     rows_per = (rows_per + DW128_ROWS - 1) / DW128_ROWS * DW128_ROWS;
     splits = (R + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dY, ldy, X, ldx, t->dw_part, out, in, R, rows_per);
+    hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, t->dw_part, out, in, R, rows_per, t->part);
     PNRF_LAUNCH_CHECK();
-    const int64_t numel = (int64_t)out * in;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, db_part, out, db);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, t->part, out, db);
     PNRF_LAUNCH_CHECK();
     return 0;
   }
@@ -694,33 +805,33 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dY, int ldy, 
   int64_t rows_per = (R + splits - 1) / splits;
   rows_per = (rows_per + DW_ROWS - 1) / DW_ROWS * DW_ROWS;
   splits = (R + rows_per - 1) / rows_per;
-  hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dY, ldy, X, ldx, t->dw_part, out, in, R, rows_per);
+  hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, t->dw_part, out, in, R, rows_per, t->part);
   PNRF_LAUNCH_CHECK();
-  const int64_t numel = (int64_t)out * in;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, db_part, out, db);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, t->part, out, db);
   PNRF_LAUNCH_CHECK();
   return 0;
 }
 
+// Y = act(X W^T + b): one kernel
 int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, hipStream_t s) {
   const TLin& l = t->L[li];
-  int rc = gemm_fwd(t, X, ldx, t->P + l.w, l.in, l.out, Y, ldy, R);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for(R * l.out)), dim3(TPB), 0, s, Y, ldy, t->P + l.b, R, l.out, act);
-  PNRF_LAUNCH_CHECK();
-  return 0;
+  GemmArgs a = {};
+  a.A = X; a.lda = ldx; a.B = t->P + l.w; a.ldb = l.in; a.C = Y; a.ldc = ldy; a.M = R; a.N = l.out; a.K = l.in;
+  a.bias = t->P + l.b; a.act = act;
+  return launch_tgemm<MODE_NT>(a, s);
 }
-// dH (row stride ldd) holds dL/dH on entry and dL/dZ on exit; H = saved output of the layer; X = saved input.
-// dX == nullptr: no input gradient wanted.
-int layer_bwd(pnrf_trainer* t, int li, float* dH, int ldd, const float* H, int ldh, const float* X, int ldx, float* dX, int lddx, float beta,
-              int64_t R, int act, hipStream_t s) {
+// dZ (row stride ldz) = dL/dZ of layer li (its activation derivative was applied by whoever produced it); X = the layer's saved input.
+// Accumulates the weight / bias gradients and, unless dX == nullptr, writes dX = (beta dX + dZ W) * act'(Hprev) — Hprev = saved output of
+// the layer (activation prev_act) that produced the columns >= act_col0 of X — i.e. dL/dZ of that layer, ready for its own layer_bwd.
+int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* X, int ldx, float* dX, int lddx, float beta, int64_t R, int prev_act,
+              const float* Hprev, int ldh, int act_col0, hipStream_t s) {
   const TLin& l = t->L[li];
-  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((l.out + 63) / 64, DB_CHUNKS), dim3(256), 0, s, dH, ldd, H, ldh, R, l.out, act, t->part);
-  PNRF_LAUNCH_CHECK();
-  int rc = gemm_dw(t, X, ldx, dH, ldd, t->G + l.w, l.in, l.out, R, s, t->part, t->G + l.b);      // + the bias gradient's final column sums
-  if (rc) return rc;
-  if (dX) rc = gemm_dx(t, dH, ldd, t->P + l.w, l.in, l.out, dX, lddx, R, beta);
-  return rc;
+  int rc = gemm_dw(t, X, ldx, dZ, ldz, t->G + l.w, t->G + l.b, l.in, l.out, R, s);
+  if (rc || !dX) return rc;
+  GemmArgs a = {};
+  a.A = dZ; a.lda = ldz; a.B = t->P + l.w; a.ldb = l.in; a.C = dX; a.ldc = lddx; a.M = R; a.N = l.in; a.K = l.out;
+  a.act = prev_act; a.H = Hprev; a.ldh = ldh; a.act_col0 = act_col0; a.beta = beta;
+  return launch_tgemm<MODE_NN>(a, s);
 }
 
 constexpr int L_S = 0, L_R = 7, L_N = 14, L_FEAT = 22, L_ALPHA = 23, L_VIEWS = 24, L_RGB = 25, N_LAYERS = 26;
@@ -731,7 +842,7 @@ constexpr int L_S = 0, L_R = 7, L_N = 14, L_FEAT = 22, L_ALPHA = 23, L_VIEWS = 2
 extern "C" int pnrf_composite_bwd(const float* raw, const float* z, const float* rays_d, int d_stride, const float* add, const float* mul,
                                   const float* noise, float clampv, int white_bkgd, const float* d_rgb, float* d_raw, float* d_z, float* d_add,
                                   float* d_mul, int64_t n, int s, void* stream) {
-  PNRF_REQUIRE(n >= 0 && s >= 1 && s <= CB_MAXS && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_bwd: bad sizes (1 <= s <= %d)", CB_MAXS);
+  PNRF_REQUIRE(n >= 0 && s >= 1 && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_bwd: bad sizes");
   if (n == 0) return 0;
   PNRF_REQUIRE(raw && z && rays_d && d_rgb && d_raw, PNRF_E_ARG, "pnrf_composite_bwd: null pointer");
   PNRF_REQUIRE((add == nullptr) == (mul == nullptr), PNRF_E_ARG, "pnrf_composite_bwd: add and mul go together");
@@ -836,8 +947,6 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     PNRF_HIP(hipMemcpy(t->P + t->L[i].w, W[i], (size_t)t->L[i].in * t->L[i].out * 4, hipMemcpyDefault));
     PNRF_HIP(hipMemcpy(t->P + t->L[i].b, b[i], (size_t)t->L[i].out * 4, hipMemcpyDefault));
   }
-  if (rocblas_create_handle(&t->blas) != rocblas_status_success) { set_error("pnrf_trainer_create: rocblas_create_handle failed"); return 1; }
-  rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
   const int64_t N = max_rays, R = (int64_t)max_samples * max_rays;
   T_ALLOC(t->mm_input, N * 288);
   for (int k = 0; k < 6; ++k) { T_ALLOC(t->s_h[k], N * 256); T_ALLOC(t->r_h[k], N * 256); }
@@ -852,14 +961,13 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
-  T_ALLOC(t->part, DB_CHUNKS * 512); T_ALLOC(t->dw_part, std::max((size_t)DW_MAX_SPLITS * 256 * 320, (size_t)DW128_MAX_SPLITS * 256 * 256)); T_ALLOC(t->loss, 4);
+  T_ALLOC(t->part, (size_t)DW128_MAX_SPLITS * DB_MAX_OUT); T_ALLOC(t->dw_part, std::max((size_t)DW_MAX_SPLITS * 256 * 320, (size_t)DW128_MAX_SPLITS * 256 * 256)); T_ALLOC(t->loss, 4);
   return 0;
 }
 
 extern "C" int pnrf_trainer_free(pnrf_trainer_t* t) {
   if (!t) return 0;
   for (void* p : t->allocs) (void)hipFree(p);
-  if (t->blas) rocblas_destroy_handle(t->blas);
   delete t;
   return 0;
 }
@@ -890,6 +998,16 @@ extern "C" int pnrf_trainer_flat(pnrf_trainer_t* t, int kind, float** ptr, int64
   PNRF_REQUIRE(t && ptr && count && kind >= 0 && kind <= 5, PNRF_E_ARG, "pnrf_trainer_flat: bad arguments");
   *ptr = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   *count = (int64_t)t->nparam;
+  return 0;
+}
+
+// Which weight-gradient kernel the square layers use: tile 0 = by shape and row count (128 x 128 tiles from min_rows_128 rows on, the default:
+// 65 536), 64 / 128 = force that tile where the shape allows it.  A configuration step, like pnrf_mlp_set_variant: the library reads no
+// environment.  (The two kernels differ in fp32 summation order only; tests/test_train_gpu.py runs the same batch through both.)
+extern "C" int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t min_rows_128) {
+  PNRF_REQUIRE(t && (tile == 0 || tile == 64 || tile == 128) && min_rows_128 >= 0, PNRF_E_ARG, "pnrf_trainer_set_dw_kernel: tile must be 0, 64 or 128");
+  t->dw_tile = tile;
+  t->dw128_min_rows = tile == 128 ? (min_rows_128 > 0 ? min_rows_128 : 256) : (min_rows_128 > 0 ? min_rows_128 : 65536);
   return 0;
 }
 
@@ -963,26 +1081,42 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   return 0;
 }
 
-// t->d_raw [R,4] -> gradients of the 12 NeRF layers; want_dpts: also d pts [R,3] into t->d_pts
+// t->d_raw [R,4] -> gradients of the 12 NeRF layers; want_dpts: also d pts [R,3] into t->d_pts.  Every buffer handed to layer_bwd holds
+// dL/dZ of its layer: the input-gradient product of the layer above applied the activation derivative in its epilogue.
 int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
-  // rgb head: d_raw[:, 0:3] -> d_hv ; views layer -> d_cv ; feature -> d_a (beta 0) ; alpha: d_raw[:, 3] -> d_a (beta 1)
-  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, nullptr, 0, t->n_hv, 128, t->d_hv, 128, 0.f, R, T_ACT_NONE, s));
-  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, t->n_hv, 128, t->n_cv, 283, t->d_cv, 283, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, nullptr, 0, t->n_a7, 256, t->d_a, 256, 0.f, R, T_ACT_NONE, s));
-  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, nullptr, 0, t->n_a7, 256, t->d_a, 256, 1.f, R, T_ACT_NONE, s));
-  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, t->n_a7, 256, t->n_a6, 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, t->n_a6, 256, t->n_a5, 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, t->n_a5, 256, t->n_c5, 319, t->d_c5, 319, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + 63, 319, t->n_c5 + 63, 319, t->n_a[3], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, t->n_a[3], 256, t->n_a[2], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, t->n_a[2], 256, t->n_a[1], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, t->n_a[1], 256, t->n_a[0], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, s));
-  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, t->n_a[0], 256, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, 0.f, R, T_ACT_RELU, s));
+  const float* none = nullptr;
+  // rgb head: d_raw[:, 0:3] -> d_hv (x relu'(n_hv): the views layer) ; views layer -> d_cv = [d feature | d view embedding] (no activation) ;
+  // feature -> d_a ; alpha: d_raw[:, 3] -> d_a += ..., then x relu'(n_a7)
+  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, t->n_hv, 128, t->d_hv, 128, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
+  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, t->n_cv, 283, t->d_cv, 283, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, t->n_a7, 256, t->d_a, 256, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, t->n_a7, 256, t->d_a, 256, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, t->n_a6, 256, t->d_b, 256, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, t->n_a5, 256, t->d_a, 256, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
+  // layer 5 reads cat[embedding(63), h4(256)]: the activation derivative of layer 4 applies to the columns from 63 on
+  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, t->n_c5, 319, t->d_c5, 319, 0.f, R, T_ACT_RELU, t->n_c5 + 63, 319, 63, s));
+  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + 63, 319, t->n_a[3], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, t->n_a[2], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, t->n_a[1], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, t->n_a[0], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   if (want_dpts) {
     hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, 319, t->d_pts, R, 10);
     PNRF_LAUNCH_CHECK();
   }
   return 0;
+}
+
+// output-layer gradient dy [N, out_last] -> gradients of a 7-layer ELU net (sampler: first = L_S, refine: first = L_R); no gradient reaches the
+// net's input (the Pluecker moment is depth-independent; the projection is under no_grad in the reference)
+int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, float* const* h, const float* x0, int in0, int64_t N, hipStream_t s) {
+  T_RC(layer_bwd(t, first + 6, dy, out_last, h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
+  float* dA = t->d_h0; float* dB = t->d_h1;
+  for (int k = 5; k >= 1; --k) {
+    T_RC(layer_bwd(t, first + k, dA, 256, h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
+    float* tmp = dA; dA = dB; dB = tmp;
+  }
+  return layer_bwd(t, first + 0, dA, 256, x0, in0, nullptr, 0, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
 }
 
 int check_batch(const pnrf_trainer* t, const pnrf_train_batch_t* bt, const float* loss, int S, const char* who) {
@@ -1007,7 +1141,6 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
   T_RC(check_batch(t, bt, loss, 8, "pnrf_train_stage2_fwd_bwd"));
   const int64_t N = bt->n, R = 8 * bt->n;
   hipStream_t s = (hipStream_t)stream;
-  T_BLAS(rocblas_set_stream(t->blas, s));
   // ---------------- forward
   T_RC(sampler_refine_forward(t, bt, s));
   T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, bt->jitter, bt->jitter_dir, t->z_pre, t->z, t->pts, t->rgb0, N, stream));   // :635-668
@@ -1029,25 +1162,9 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
   T_RC(nerf_backward(t, R, true, s));
   T_RC(pnrf_refine_head_bwd(t->r_y, bt->rays, t->depth_sorted, t->z_pre, bt->jitter, bt->jitter_dir, t->d_pts, t->d_z, aux ? t->d_rgb0 : nullptr, t->d_ry,
                             t->d_depth, N, stream));
-  {   // refine net: no gradient reaches refine_in (Pluecker moment is depth-independent; the projection is under no_grad)
-    T_RC(layer_bwd(t, L_R + 6, t->d_ry, 35, nullptr, 0, t->r_h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_NONE, s));
-    float* dA = t->d_h0; float* dB = t->d_h1;
-    for (int k = 5; k >= 1; --k) {
-      T_RC(layer_bwd(t, L_R + k, dA, 256, t->r_h[k], 256, t->r_h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, s));
-      float* tmp = dA; dA = dB; dB = tmp;
-    }
-    T_RC(layer_bwd(t, L_R + 0, dA, 256, t->r_h[0], 256, t->refine_in, 144, nullptr, 0, 0.f, N, T_ACT_ELU, s));
-  }
+  T_RC(elu_net_backward(t, L_R, t->d_ry, 35, t->r_h, t->refine_in, 144, N, s));
   T_RC(pnrf_sampler_head_bwd(t->s_y, bt->rays, t->sort_idx, t->d_depth, t->d_add, t->d_mul, aux ? t->d_mmrgb : nullptr, t->d_sy, N, stream));
-  {
-    T_RC(layer_bwd(t, L_S + 6, t->d_sy, 27, nullptr, 0, t->s_h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_NONE, s));
-    float* dA = t->d_h0; float* dB = t->d_h1;
-    for (int k = 5; k >= 1; --k) {
-      T_RC(layer_bwd(t, L_S + k, dA, 256, t->s_h[k], 256, t->s_h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, s));
-      float* tmp = dA; dA = dB; dB = tmp;
-    }
-    T_RC(layer_bwd(t, L_S + 0, dA, 256, t->s_h[0], 256, t->mm_input, 288, nullptr, 0, 0.f, N, T_ACT_ELU, s));
-  }
+  T_RC(elu_net_backward(t, L_S, t->d_sy, 27, t->s_h, t->mm_input, 288, N, s));
   return 0;
 }
 
@@ -1063,7 +1180,6 @@ extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_ba
   PNRF_REQUIRE(bt->jitter, PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: the exploration jitter [n, 8 n_mult] is required");
   const int64_t N = bt->n, R = (int64_t)S * bt->n;
   hipStream_t s = (hipStream_t)stream;
-  T_BLAS(rocblas_set_stream(t->blas, s));
   T_RC(sampler_refine_forward(t, bt, s));
   T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, nullptr, 1, t->z_pre, t->z, t->pts, t->rgb0, N, stream));     // z_pre = refined depths
   T_RC(pnrf_explore_fwd(t->z_pre, bt->rays, bt->jitter, n_mult, dir1, bt->jitter_dir, t->z, t->pts, N, stream));            // base.py:689-729

@@ -507,6 +507,10 @@ class Trainer:
         t._pnrf_owner = self                             # keep the trainer alive as long as the view is
         return t
 
+    def set_dw_kernel(self, tile=0, min_rows_128=0):
+        """Weight-gradient kernel of the square layers: 0 = by shape and row count, 64 / 128 = forced (pnrf_trainer_set_dw_kernel)."""
+        check(_lib.load().pnrf_trainer_set_dw_kernel(self.handle, int(tile), int(min_rows_128)), 'pnrf_trainer_set_dw_kernel')
+
     def set_step(self, step, step_nerf=0):
         check(_lib.load().pnrf_trainer_set_step(self.handle, int(step), int(step_nerf)), 'pnrf_trainer_set_step')
 

@@ -1,5 +1,5 @@
 """Worker of test_train_gpu.py::test_weight_gradient_kernels_agree: one stage-2 forward + backward on a fixed batch, gradients to an
-.npz.  The weight-gradient kernel is chosen per process by PNRF_DW_TILE / PNRF_DW128_MIN_ROWS (read once by the library)."""
+.npz.  argv[2] = weight-gradient tile to force (64 | 128) through Trainer.set_dw_kernel."""
 import os
 import sys
 
@@ -17,6 +17,7 @@ dev = torch.device('cuda:0')
 b = T._batch(0, 16, 24, 7)                                    # 384 rays -> 3072 rows in the NeRF layers
 layers = orc.trainer_layers(b['w'])
 tr = ops.Trainer([W for W, _ in layers], [x for _, x in layers], max_rays=b['N'], device=dev)
+tr.set_dw_kernel(int(sys.argv[2]), 1024)
 img4 = ops.images_pack(T.cu(b['images'], dev))
 tr.fwd_bwd(T.cu(b['rays'], dev), T.cu(b['or_rays'], dev), T.cu(b['target'], dev), img4, T.cu(b['poses'], dev), T.cu(b['K'], dev),
            b['ref_nos'].to(dev).contiguous(), jitter=T.cu(b['jitter'], dev), jitter_dir=1, raw_noise=T.cu(b['noise'], dev), want_rgb=False)

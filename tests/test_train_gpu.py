@@ -497,9 +497,9 @@ def test_weight_gradient_kernels_agree(dev, tmp_path):
     import subprocess
     worker = os.path.join(os.path.dirname(__file__), 'dw_tile_worker.py')
     outs = []
-    for name, extra in (('t64', {'PNRF_DW_TILE': '64'}), ('t128', {'PNRF_DW_TILE': '128', 'PNRF_DW128_MIN_ROWS': '1024'})):
+    for name, tile in (('t64', '64'), ('t128', '128')):
         out = str(tmp_path / f'{name}.npz')
-        r = subprocess.run([sys.executable, worker, out], env={**os.environ, **extra}, capture_output=True, text=True, timeout=240)
+        r = subprocess.run([sys.executable, worker, out, tile], capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(dict(np.load(out)))
     a, b = outs
