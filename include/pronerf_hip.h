@@ -314,6 +314,11 @@ int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* batch
  * loss = img2mse(rgb_map1); gradients for the 12 NeRF layers only. */
 int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* batch, int n_mult, int dir1, float* loss,
                                float* rgb_map1, void* stream);
+/* Both iteration entry points copy the batch into buffers of the trainer with one launch; with pnrf_trainer_set_graph(t, 1) they then replay
+ * their ~100-kernel launch sequence as a hipGraph (captured from the given stream — the legacy default stream is served through a stream of
+ * the trainer's own — the first time a configuration (ray count, views, flags, stream) is seen; up to 8 configurations are kept).  Default
+ * 0: the kernels are launched one by one (same results bit for bit; measured slightly faster). */
+int pnrf_trainer_set_graph(pnrf_trainer_t* t, int enable);
 /* optimizer.step() of torch.optim.Adam (L2 weight decay added to the gradient).  which 0: the joint optimizer over all
  * parameters (run_S_eS_eN_alter_base_refine2.py:394, 869; stage 1 s_optimizer); which 1: the NeRF-only optimizer of stage 1
  * (run_S_eS_eN_alter_base.py:398-421, 940) with its own moments and step count. */

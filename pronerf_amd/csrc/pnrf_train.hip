@@ -12,6 +12,10 @@
 // Pluecker moment does not depend on the depth along the ray, so no gradient reaches refine_in or mm_input and the first
 // layers of the sampler / refine nets need no dX.  A trainer owns parameters, gradients, Adam moments and workspaces;
 // nothing is allocated per step and every launch goes to the caller's stream.
+#include <string.h>
+
+#include <type_traits>
+
 #include "pnrf_common.h"
 
 using namespace pnrf;
@@ -36,12 +40,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // the PREVIOUS layer is applied in the epilogue of the product that creates its output gradient, so every gradient buffer is written once,
 // already as dL/dZ, and no separate elementwise pass runs over [rows, 256] activations.
 //
-// Register-direct operands, no LDS: lane l = (m = l & 15, g = l >> 4) loads 16 bytes along k — A[row m][16 j + 4 g .. + 3] — and the four
-// MFMAs of a 16-deep step use element e of every lane's vector, i.e. contract over k = {16 j + 4 g + e : g}.  Both operands are loaded with
-// the same permutation of k, so the sum is the same.  A wave owns a (16 MI) x (16 NI) tile, a workgroup 2 x 2 waves; the next step's
-// fragments are fetched while the current step's MI NI 4 MFMAs (32 cycles each) run.
-//   MODE_NT: B = W [N, K], k contiguous (forward: N = out, K = in);  MODE_NN: B = W [K, N], n contiguous (backward: K = out, N = in).
-// ALIGNED: K % 16 == 0, lda / ldb % 4 == 0 and 16-byte aligned bases -> vector loads without bounds checks along k.
+// Shape of the problem: M = rows (rays or ray samples, 4 096 .. 1 M), N, K <= 319.  A [M, K] streams from HBM once, C [M, N] goes back once,
+// B (the weights, <= 320 KB) stays in L2: 64 FLOP per HBM byte, next to the crossover of the fp32 MFMA roofline — HBM efficiency decides.
+//   * Workgroup = 4 waves on a tile of 16 MI rows x 256 columns (wave w: columns 64 w .. 64 w + 63), so a row of A is fetched by exactly one
+//     workgroup.  A goes through LDS in chunks of 64 k: 256 threads fetch 16 MI rows x 256 contiguous bytes (a first, register-direct version
+//     read 64-byte pieces of 16 rows per instruction and spent as long in HBM as in the MFMA pipe: 45 % pipe occupancy with 6 % wait
+//     cycles), double buffered, one barrier per chunk (256 MFMAs per wave).  Row stride 68 floats: the ds_read_b128 of lane (m, g) — row m, k
+//     = 16 s + 4 g — starts at bank 4 (m + g) mod 32, evenly spread.
+//   * MFMA operands: lane l = (m = l & 15, g = l >> 4) holds 16 bytes along k — [row m][16 s + 4 g .. + 3] — of both operands, and the four
+//     MFMAs of a 16-deep step use element e of every lane's vector, i.e. contract over k = {16 s + 4 g + e : g}: the same permutation of k
+//     on both sides, the same sum.  The weight fragment is the MFMA's A operand (C^T = W X^T): D register e of lane (m, g) = C[row m][col 4 g + e].
+//   * B fragments come straight from global memory (L2), one 16-deep step ahead.  MODE_NT: B = W [N, K], k contiguous (forward: N = out, K =
+//     in); MODE_NN: B = W [K, N], n contiguous (backward: K = out, N = in).
+//   * Epilogue through LDS (the A buffers, two halves of the tile): the accumulators are written [row][column], then every thread handles 16
+//     contiguous bytes of a row — bias, activation, the saved activation's derivative, the running sum (beta) and the store are all full
+//     256..1024-byte row segments.
 enum { MODE_NT = 0, MODE_NN = 1 };
 struct GemmArgs {
   const float* A; int lda;              // [M, K]
@@ -54,113 +67,196 @@ struct GemmArgs {
   int act_col0;
   float beta;                           // backward: C = beta C + A B   (0 or 1)
 };
-template <int MI, int NI, int MODE, bool ALIGNED>
+constexpr int TG_KC = 64;               // k per LDS chunk
+constexpr int TG_LDA = TG_KC + 4;       // LDS row stride of the A chunk (floats)
+constexpr int TG_LDC = 256 + 4;         // LDS row stride of the C staging tile (floats)
+// MI: 16-row MFMA tiles per wave (4: 64-row workgroup tile; 2 / 1: 32 / 16 rows, for the 4 096-row layers of the sampler / refine nets).  VEC: K % 4 == 0 and 16-byte aligned rows
+// of A (and of B in MODE_NT): 16-byte loads along k.
+template <int MI, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
+  constexpr int ROWS = 16 * MI, NI = 4;
+  // A chunks: 2 x ROWS x 68 floats; the epilogue reuses the space as [ROWS / 2][260]
+  constexpr int HALVES = MI >= 2 ? 2 : 1;                      // the epilogue stages the tile through LDS in this many pieces
+  __shared__ __attribute__((aligned(16))) float smem[(2 * ROWS * TG_LDA > (ROWS / HALVES) * TG_LDC) ? 2 * ROWS * TG_LDA : (ROWS / HALVES) * TG_LDC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m16 = lane & 15, g = lane >> 4;
-  const int tiles_n = (a.N + 32 * NI - 1) / (32 * NI);
+  const int tiles_n = (a.N + 255) / 256;
   const int64_t tm = blockIdx.x / tiles_n;
   const int tn = (int)(blockIdx.x - tm * tiles_n);
-  const int64_t row0 = tm * (32 * MI) + (wave >> 1) * (16 * MI);
-  const int col0 = tn * (32 * NI) + (wave & 1) * (16 * NI);
+  const int64_t row0 = tm * ROWS;
+  const int col0 = tn * 256 + wave * 64;
+  const bool wave_on = col0 < a.N;                             // waves past the last column only help with the A chunks
   f32x4_t acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const float* ap[MI];
-  bool aok[MI];
+
+  // ---- A chunk loader: thread t -> 16 bytes at k-offset 4 (t & 15) of rows (t >> 4) + 16 pass
+  const int lc4 = 4 * (threadIdx.x & 15), lrow = threadIdx.x >> 4;
+  constexpr int PASSES = ROWS / 16;
+  const float* arow[PASSES];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int64_t r = row0 + 16 * i + m16;
-    aok[i] = r < a.M;
-    ap[i] = a.A + (aok[i] ? r : 0) * a.lda + 4 * g;
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int64_t r = row0 + lrow + 16 * ps;
+    arow[ps] = a.A + (r < a.M ? r : a.M - 1) * a.lda;         // rows past the edge: clamped, computed, never stored
   }
+  // Loads never feed a select: k past the edge is read from a clamped address and the A tile is zeroed when it is written to LDS (a zero in A
+  // makes the matching B value irrelevant), so nothing depends on a fetched register before its planned use and the compiler's vmcnt waits
+  // sit where the data is consumed.
+  f32x4_t stage[PASSES];
+  auto fetch_a = [&](int kc) {
+    const int k = kc * TG_KC + lc4;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      if (VEC) {
+        stage[ps] = *(const f32x4_t*)(arow[ps] + (k + 3 < a.K ? k : a.K - 4));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stage[ps][e] = arow[ps][k + e < a.K ? k + e : a.K - 1];
+      }
+    }
+  };
+  auto store_a = [&](int buf, int kc) {
+    float* dst = smem + buf * (ROWS * TG_LDA);
+    const int k = kc * TG_KC + lc4;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      f32x4_t v = stage[ps];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = k + e < a.K ? v[e] : 0.f;
+      *(f32x4_t*)(dst + (lrow + 16 * ps) * TG_LDA + lc4) = v;
+    }
+  };
+  // ---- B fragments of a 16-deep step, straight from global memory (L2)
   const float* bp[NI];
-  bool bok[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int c = col0 + 16 * j + m16;
-    bok[j] = c < a.N;
-    bp[j] = MODE == MODE_NT ? a.B + (size_t)(bok[j] ? c : 0) * a.ldb + 4 * g : a.B + (size_t)(4 * g) * a.ldb + (bok[j] ? c : 0);
+    const int cc = c < a.N ? c : a.N - 1;
+    bp[j] = MODE == MODE_NT ? a.B + (size_t)cc * a.ldb : a.B + cc;
   }
-  auto load_a = [&](int i, int k0) {
-    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-    if (ALIGNED) {
-      if (aok[i]) v = *(const f32x4_t*)(ap[i] + k0);
-    } else if (aok[i]) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (k0 + 4 * g + e < a.K) ? ap[i][k0 + e] : 0.f;
-    }
-    return v;
-  };
   auto load_b = [&](int j, int k0) {
-    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == MODE_NT) {
-      if (ALIGNED) {
-        if (bok[j]) v = *(const f32x4_t*)(bp[j] + k0);
-      } else if (bok[j]) {
+    const int k = k0 + 4 * g;
+    if (MODE == MODE_NT && VEC) return *(const f32x4_t*)(bp[j] + (k + 3 < a.K ? k : a.K - 4));
+    f32x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (k0 + 4 * g + e < a.K) ? bp[j][k0 + e] : 0.f;
-      }
-    } else if (bok[j]) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (ALIGNED || k0 + 4 * g + e < a.K) ? bp[j][(size_t)(k0 + e) * a.ldb] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + e < a.K ? k + e : a.K - 1;
+      v[e] = MODE == MODE_NT ? bp[j][kk] : bp[j][(size_t)kk * a.ldb];
     }
     return v;
   };
-  f32x4_t fa[MI], fb[NI];
+
+  // Per chunk (4 steps of 64 MFMAs per wave) two fetch groups, each consumed two steps after it is issued:
+  //   G1, before step 0: the next chunk's A rows (-> stage) and this chunk's B fragments of steps 2, 3 (into the registers steps 2, 3 of the
+  //       previous chunk have just freed);   G2, before step 2: the next chunk's B fragments of steps 0, 1.
+  // vmcnt counts in issue order, so a fetch issued right before a wait would be waited for with it; here every wait only covers fetches that
+  // are at least 128 MFMAs old.  One B buffer (64 registers): two waves per SIMD.
+  const int chunks = (a.K + TG_KC - 1) / TG_KC;
+  f32x4_t fb[TG_KC / 16][NI];
+  fetch_a(0);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) fa[i] = load_a(i, 0);
+  for (int j = 0; j < NI; ++j) { fb[0][j] = load_b(j, 0); fb[1][j] = load_b(j, 16); }
+  store_a(0, 0);
+  __syncthreads();
+  for (int kc = 0; kc < chunks; ++kc) {
+    const float* sA = smem + (kc & 1) * (ROWS * TG_LDA);
+    const int kn = kc + 1 < chunks ? kc + 1 : kc;              // past the last chunk: harmless re-fetch of the last one
+    fetch_a(kn);
 #pragma unroll
-  for (int j = 0; j < NI; ++j) fb[j] = load_b(j, 0);
-  for (int k0 = 0; k0 < a.K; k0 += 16) {
-    f32x4_t na[MI], nb[NI];
-    const bool more = k0 + 16 < a.K;
+    for (int j = 0; j < NI; ++j) { fb[2][j] = load_b(j, kc * TG_KC + 32); fb[3][j] = load_b(j, kc * TG_KC + 48); }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) na[i] = more ? load_a(i, k0 + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < TG_KC / 16; ++st) {
+      if (st == 2) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) nb[j] = more ? load_b(j, k0 + 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) { fb[0][j] = load_b(j, kn * TG_KC); fb[1][j] = load_b(j, kn * TG_KC + 16); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4_t fa[MI];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int i = 0; i < MI; ++i) fa[i] = *(const f32x4_t*)(sA + (16 * i + m16) * TG_LDA + 16 * st + 4 * g);
+      if (wave_on) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) fa[i] = na[i];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) fb[j] = nb[j];
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[st][j][e], fa[i][e], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kc + 1 < chunks) store_a((kc + 1) & 1, kc + 1);        // that buffer was last read in chunk kc - 1: every wave has passed its barrier
+    __syncthreads();
   }
-  // epilogue: D register e of lane (m16, g) = C[row 4 g + e][col m16] of its 16 x 16 tile
+
+  // ---- epilogue, two halves of the tile through LDS
+  float* sC = smem;
+  const bool cvec = a.ldc % 4 == 0 && (((uintptr_t)a.C) & 15) == 0 && a.N % 4 == 0 && (((uintptr_t)a.bias) & 15) == 0 &&
+                    (MODE == MODE_NT || a.act == T_ACT_NONE || (a.ldh % 4 == 0 && (((uintptr_t)a.H) & 15) == 0 && a.act_col0 % 4 == 0));
+  const bool use_h = MODE == MODE_NN && a.act != T_ACT_NONE, use_c = MODE == MODE_NN && a.beta != 0.f;
+  constexpr int HROWS = ROWS / HALVES, HI = MI / HALVES;
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int half = 0; half < HALVES; ++half) {
+    if (wave_on) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int c = col0 + 16 * j + m16;
-      if (c >= a.N) continue;
-      const float bv = (MODE == MODE_NT && a.bias) ? a.bias[c] : 0.f;
+      for (int ii = 0; ii < HI; ++ii)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t r = row0 + 16 * i + 4 * g + e;
-        if (r >= a.M) continue;
-        float v = acc[i][j][e];
-        float* dst = a.C + r * a.ldc + c;
+        for (int j = 0; j < NI; ++j) *(f32x4_t*)(sC + (16 * ii + m16) * TG_LDC + wave * 64 + 16 * j + 4 * g) = acc[half * HI + ii][j];
+    }
+    __syncthreads();
+    // thread t: 16 bytes at column 4 (t & 63) of rows (t >> 6) + 4 q
+    const int cl = 4 * (threadIdx.x & 63), c = tn * 256 + cl;
+#pragma unroll
+    for (int q = 0; q < HROWS / 4; ++q) {
+      const int rl = (threadIdx.x >> 6) + 4 * q;
+      const int64_t r = row0 + half * HROWS + rl;
+      if (r >= a.M || c >= a.N) continue;
+      f32x4_t v = *(const f32x4_t*)(sC + rl * TG_LDC + cl);
+      float* dst = a.C + r * a.ldc + c;
+      if (cvec) {                                               // N % 4 == 0: the four columns are inside together
         if (MODE == MODE_NT) {
-          v += bv;
-          if (a.act == T_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == T_ACT_ELU) v = v > 0.f ? v : expm1f(v);            // F.elu, alpha = 1
+          if (a.bias) v += *(const f32x4_t*)(a.bias + c);
         } else {
-          if (a.beta != 0.f) v += *dst;
-          if (a.act != T_ACT_NONE && c >= a.act_col0) {
-            const float h = a.H[r * a.ldh + (c - a.act_col0)];
-            if (a.act == T_ACT_RELU) v = h > 0.f ? v : 0.f;
-            else v = h > 0.f ? v : v * (h + 1.f);                               // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
+          if (use_c) v += *(const f32x4_t*)dst;
+        }
+        f32x4_t h = {1.f, 1.f, 1.f, 1.f};
+        if (use_h && c >= a.act_col0) h = *(const f32x4_t*)(a.H + r * a.ldh + (c - a.act_col0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (MODE == MODE_NT) {
+            if (a.act == T_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            else if (a.act == T_ACT_ELU) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);          // F.elu, alpha = 1
+          } else if (use_h && c >= a.act_col0) {
+            if (a.act == T_ACT_RELU) v[e] = h[e] > 0.f ? v[e] : 0.f;
+            else v[e] = h[e] > 0.f ? v[e] : v[e] * (h[e] + 1.f);                           // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
           }
         }
-        *dst = v;
+        *(f32x4_t*)dst = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (c + e >= a.N) break;
+          float x = v[e];
+          if (MODE == MODE_NT) {
+            if (a.bias) x += a.bias[c + e];
+            if (a.act == T_ACT_RELU) x = fmaxf(x, 0.f);
+            else if (a.act == T_ACT_ELU) x = x > 0.f ? x : expm1f(x);
+          } else {
+            if (use_c) x += dst[e];
+            if (use_h && c + e >= a.act_col0) {
+              const float h = a.H[r * a.ldh + (c + e - a.act_col0)];
+              if (a.act == T_ACT_RELU) x = h > 0.f ? x : 0.f;
+              else x = h > 0.f ? x : x * (h + 1.f);
+            }
+          }
+          dst[e] = x;
+        }
       }
     }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
@@ -714,6 +810,21 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// one launch copies a batch into the trainer's staging buffers (n rays; S = samples per ray of jitter / noise; either may be absent)
+struct StageArgs {
+  const float *rays, *or_rays, *target, *jitter, *noise; const int64_t* ref_nos;
+  float *d_rays, *d_or_rays, *d_target, *d_jitter, *d_noise; int64_t* d_ref_nos;
+  int64_t n; int S;
+};
+__global__ void stage_batch_kernel(StageArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < a.n * 11; i += stride) { a.d_rays[i] = a.rays[i]; a.d_or_rays[i] = a.or_rays[i]; }
+  for (int64_t i = t0; i < a.n * 3; i += stride) a.d_target[i] = a.target[i];
+  for (int64_t i = t0; i < a.n * 4; i += stride) a.d_ref_nos[i] = a.ref_nos[i];
+  if (a.jitter) for (int64_t i = t0; i < a.n * a.S; i += stride) a.d_jitter[i] = a.jitter[i];
+  if (a.noise) for (int64_t i = t0; i < a.n * a.S; i += stride) a.d_noise[i] = a.noise[i];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ trainer object
@@ -730,6 +841,22 @@ struct pnrf_trainer {
   int64_t step = 0, step2 = 0;
   int dw_tile = 0;                               // 0: by shape and row count; 64 / 128: force that weight-gradient kernel where it applies
   int64_t dw128_min_rows = 65536;
+  // hipGraph replay of an iteration (pnrf_trainer_set_graph): the batch is copied into the trainer's own staging buffers by one kernel, so
+  // every pointer and scalar argument inside the captured launch sequence is fixed; one instantiated graph per configuration key
+  struct GraphKey {
+    int kind, n_mult, dir1, jitter_dir, white_bkgd, layout, nv, Hf, Wf, has_jitter, has_noise;
+    int64_t n;
+    float eps, a_mmrgb, clamp;
+    const void *img4, *poses, *K;
+    hipStream_t stream;
+  };
+  struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+  bool use_graph = false;                        // measured on one MI355X, 4096-ray stage-2 iteration: 2.98 ms kernel by kernel, 3.13 ms replayed
+  hipStream_t own_stream = nullptr;              // the legacy default stream cannot be captured: iterations submitted on it run on this one,
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;  // ordered against the caller's stream by two events
+  float *st_rays = nullptr, *st_or_rays = nullptr, *st_target = nullptr, *st_jitter = nullptr, *st_noise = nullptr;
+  int64_t* st_ref_nos = nullptr;
   std::vector<void*> allocs;
   // workspaces
   float *mm_input, *s_h[6], *s_y, *depth_sorted, *add_s, *mul_s, *mm_rgb;
@@ -756,19 +883,17 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int MODE>
 int launch_tgemm(const GemmArgs& a, hipStream_t s) {
-  const bool al = a.K % 16 == 0 && a.lda % 4 == 0 && aligned16(a.A) && (MODE == MODE_NN || (a.ldb % 4 == 0 && aligned16(a.B)));
-  // 128 x 128 workgroup tiles when that still gives every CU a workgroup, 64 x 128 below (the 4096-row layers of the sampler / refine nets)
-  const int tiles_n = (a.N + 127) / 128;
-  const bool big = ((a.M + 127) / 128) * tiles_n >= 256;
-  const int64_t tiles_m = big ? (a.M + 127) / 128 : (a.M + 63) / 64;
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
-  if (big) {
-    if (al) hipLaunchKernelGGL((tgemm_kernel<4, 4, MODE, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((tgemm_kernel<4, 4, MODE, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (al) hipLaunchKernelGGL((tgemm_kernel<2, 4, MODE, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((tgemm_kernel<2, 4, MODE, false>), grid, dim3(256), 0, s, a);
-  }
+  const bool vec = a.lda % 4 == 0 && aligned16(a.A) && a.K % 4 == 0 && (MODE == MODE_NN || (a.ldb % 4 == 0 && aligned16(a.B)));
+  const int tiles_n = (a.N + 255) / 256;
+  // 64-row tiles when that still gives every CU a workgroup; below that 32-row and, for the 4 096-row layers of the sampler / refine nets,
+  // 16-row tiles (256 workgroups: these products are latency-bound, more workgroups in flight is what helps)
+  const int64_t t64 = ((a.M + 63) / 64) * tiles_n, t32 = ((a.M + 31) / 32) * tiles_n;
+  const int mi = t64 >= 256 ? 4 : (t32 >= 256 ? 2 : 1);
+  const dim3 grid((unsigned)(((a.M + 16 * mi - 1) / (16 * mi)) * tiles_n));
+#define PNRF_TG(MI_) do { if (vec) hipLaunchKernelGGL((tgemm_kernel<MI_, MODE, true>), grid, dim3(256), 0, s, a); \
+                          else hipLaunchKernelGGL((tgemm_kernel<MI_, MODE, false>), grid, dim3(256), 0, s, a); } while (0)
+  if (mi == 4) PNRF_TG(4); else if (mi == 2) PNRF_TG(2); else PNRF_TG(1);
+#undef PNRF_TG
   PNRF_LAUNCH_CHECK();
   return 0;
 }
@@ -961,12 +1086,25 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
+  T_ALLOC(t->st_rays, N * 11); T_ALLOC(t->st_or_rays, N * 11); T_ALLOC(t->st_target, N * 3); T_ALLOC(t->st_ref_nos, N * 4); T_ALLOC(t->st_jitter, R); T_ALLOC(t->st_noise, R);
   T_ALLOC(t->part, (size_t)DW128_MAX_SPLITS * DB_MAX_OUT); T_ALLOC(t->dw_part, std::max((size_t)DW_MAX_SPLITS * 256 * 320, (size_t)DW128_MAX_SPLITS * 256 * 256)); T_ALLOC(t->loss, 4);
+  PNRF_HIP(hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking));
+  PNRF_HIP(hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming));
+  PNRF_HIP(hipEventCreateWithFlags(&t->ev_out, hipEventDisableTiming));
+  {   // pnrf_ray_encode_fwd allocates its table of ray points on first use: do that now, not inside a stream capture
+    int rc = pnrf_ray_encode_fwd(t->st_rays, t->mm_input, 1, 48, nullptr);
+    if (rc) return rc;
+    PNRF_HIP(hipDeviceSynchronize());
+  }
   return 0;
 }
 
 extern "C" int pnrf_trainer_free(pnrf_trainer_t* t) {
   if (!t) return 0;
+  for (auto& g : t->graphs) (void)hipGraphExecDestroy(g.exec);
+  if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
+  if (t->ev_in) (void)hipEventDestroy(t->ev_in);
+  if (t->ev_out) (void)hipEventDestroy(t->ev_out);
   for (void* p : t->allocs) (void)hipFree(p);
   delete t;
   return 0;
@@ -1137,17 +1275,15 @@ int check_batch(const pnrf_trainer* t, const pnrf_train_batch_t* bt, const float
 // iterations (base.py:554-761 with train_sampler=True, :941-958): layout 1, eps 1e-6, clamp 10, no jitter / noise, a_mmrgb 1.
 // Gradients of all 26 layers are left in the trainer (pnrf_trainer_read kind 1); loss dev [4] = {total, mse(rgb_map1),
 // mse(rgb_map0), mse(mm_rgb)}; rgb_out dev [n,3] or NULL.
-extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, float* loss, float* rgb_out, void* stream) {
-  T_RC(check_batch(t, bt, loss, 8, "pnrf_train_stage2_fwd_bwd"));
+static int stage2_body(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, hipStream_t s) {
+  void* stream = (void*)s;
   const int64_t N = bt->n, R = 8 * bt->n;
-  hipStream_t s = (hipStream_t)stream;
   // ---------------- forward
   T_RC(sampler_refine_forward(t, bt, s));
   T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, bt->jitter, bt->jitter_dir, t->z_pre, t->z, t->pts, t->rgb0, N, stream));   // :635-668
   T_RC(nerf_forward(t, bt, 8, s));
   T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, bt->clamp, bt->white_bkgd, t->rgb_map, nullptr, nullptr,
                           t->wts, nullptr, N, 8, stream));                                                            // :674
-  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
   // ---------------- losses (:861-866)
   const bool aux = bt->a_mmrgb > 0.f;
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
@@ -1155,7 +1291,6 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, bt->a_mmrgb, t->loss + 3, aux ? t->d_mmrgb : (float*)nullptr);
   hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, aux ? bt->a_mmrgb : 0.f);
   PNRF_LAUNCH_CHECK();
-  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
   // ---------------- backward
   T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, bt->clamp, bt->white_bkgd, t->d_rgb_map, t->d_raw, t->d_z,
                           t->d_add, t->d_mul, N, 8, stream));
@@ -1172,30 +1307,105 @@ extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_bat
 // the refined depths are explored into S = 8 n_mult samples (pnrf_explore_fwd: replicate toward dir1, sort, jitter toward
 // jitter_dir with batch->jitter dev [n, S]), query points carry no learned offsets, compositing without add / mul and with
 // batch->raw_noise dev [n, S]; loss = img2mse(rgb_map1); only the 12 NeRF layers get gradients (the others are left untouched).
-extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int n_mult, int dir1, float* loss, float* rgb_out,
-                                          void* stream) {
-  PNRF_REQUIRE(n_mult >= 1 && n_mult <= 32 && (dir1 == 1 || dir1 == -1), PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: n_mult 1..32, dir1 +-1");
+static int explore_body(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int n_mult, int dir1, hipStream_t s) {
+  void* stream = (void*)s;
   const int S = 8 * n_mult;
-  T_RC(check_batch(t, bt, loss, S, "pnrf_train_explore_fwd_bwd"));
-  PNRF_REQUIRE(bt->jitter, PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: the exploration jitter [n, 8 n_mult] is required");
   const int64_t N = bt->n, R = (int64_t)S * bt->n;
-  hipStream_t s = (hipStream_t)stream;
   T_RC(sampler_refine_forward(t, bt, s));
   T_RC(pnrf_refine_head_fwd(t->r_y, bt->rays, t->depth_sorted, nullptr, 1, t->z_pre, t->z, t->pts, t->rgb0, N, stream));     // z_pre = refined depths
   T_RC(pnrf_explore_fwd(t->z_pre, bt->rays, bt->jitter, n_mult, dir1, bt->jitter_dir, t->z, t->pts, N, stream));            // base.py:689-729
   T_RC(nerf_forward(t, bt, S, s));
   T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, nullptr, nullptr, bt->raw_noise, bt->clamp, bt->white_bkgd, t->rgb_map, nullptr, nullptr, t->wts,
                           nullptr, N, S, stream));
-  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, 0.f, t->loss + 2, (float*)nullptr);
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, 0.f, t->loss + 3, (float*)nullptr);
   hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, 0.f);
   PNRF_LAUNCH_CHECK();
-  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
   T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, nullptr, nullptr, bt->raw_noise, bt->clamp, bt->white_bkgd, t->d_rgb_map, t->d_raw, nullptr, nullptr,
                           nullptr, N, S, stream));
   T_RC(nerf_backward(t, R, false, s));
+  return 0;
+}
+// Runs one iteration: the batch goes into the trainer's staging buffers (one launch), then the launch sequence of `body` — ~100 kernels whose
+// pointer and scalar arguments are now all fixed for a given configuration — is replayed as a hipGraph (captured from this very stream the
+// first time a configuration is seen), then loss / rgb are copied out.  Off by default (pnrf_trainer_set_graph): with ~100 kernels of 10-60 us
+// each the iteration is bound by its kernels, not by the gaps between dependent launches — replayed it measured 5 % slower than launched
+// kernel by kernel from a host that runs ahead of the GPU (2.98 vs 3.13 ms at 4096 rays, default stream, i.e. through the owned-stream hop).
+template <class Body>
+static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int kind, int n_mult, int dir1, int S, float* loss, float* rgb_out,
+                         hipStream_t caller, Body body) {
+  const int64_t N = bt->n;
+  hipStream_t s = caller;
+  const bool hop = t->use_graph && caller == nullptr;          // the legacy default stream cannot be captured
+  if (hop) {
+    s = t->own_stream;
+    PNRF_HIP(hipEventRecord(t->ev_in, caller));
+    PNRF_HIP(hipStreamWaitEvent(s, t->ev_in, 0));
+  }
+  StageArgs sa = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
+                  t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S};
+  hipLaunchKernelGGL(stage_batch_kernel, dim3(grid_for(N * 11)), dim3(TPB), 0, s, sa);
+  PNRF_LAUNCH_CHECK();
+  pnrf_train_batch_t b = *bt;
+  b.rays = t->st_rays; b.or_rays = t->st_or_rays; b.target = t->st_target; b.ref_nos = t->st_ref_nos;
+  b.jitter = bt->jitter ? t->st_jitter : nullptr; b.raw_noise = bt->raw_noise ? t->st_noise : nullptr;
+  if (!t->use_graph) {
+    T_RC(body(&b, s));
+  } else {
+    pnrf_trainer::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = kind; key.n_mult = n_mult; key.dir1 = dir1; key.jitter_dir = b.jitter_dir; key.white_bkgd = b.white_bkgd; key.layout = b.layout;
+    key.nv = b.nv; key.Hf = b.Hf; key.Wf = b.Wf; key.has_jitter = b.jitter != nullptr; key.has_noise = b.raw_noise != nullptr; key.n = N;
+    key.eps = b.eps; key.a_mmrgb = b.a_mmrgb; key.clamp = b.clamp; key.img4 = b.img4; key.poses = b.poses; key.K = b.K; key.stream = s;
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : t->graphs)
+      if (memcmp(&g.key, &key, sizeof(key)) == 0) exec = g.exec;
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      PNRF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int rc = body(&b, s);
+      const hipError_t e = hipStreamEndCapture(s, &graph);
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) { set_error("pnrf_trainer: stream capture of the iteration failed: %s", hipGetErrorString(e)); return (int)e; }
+      const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ei != hipSuccess) { set_error("pnrf_trainer: hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return (int)ei; }
+      if (t->graphs.size() >= 8) { (void)hipGraphExecDestroy(t->graphs.front().exec); t->graphs.erase(t->graphs.begin()); }
+      t->graphs.push_back({key, exec});
+    }
+    PNRF_HIP(hipGraphLaunch(exec, s));
+  }
+  PNRF_HIP(hipMemcpyAsync(loss, t->loss, 16, hipMemcpyDeviceToDevice, s));
+  if (rgb_out) PNRF_HIP(hipMemcpyAsync(rgb_out, t->rgb_map, N * 3 * 4, hipMemcpyDeviceToDevice, s));
+  if (hop) {
+    PNRF_HIP(hipEventRecord(t->ev_out, s));
+    PNRF_HIP(hipStreamWaitEvent(caller, t->ev_out, 0));
+  }
+  return 0;
+}
+
+extern "C" int pnrf_train_stage2_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, float* loss, float* rgb_out, void* stream) {
+  T_RC(check_batch(t, bt, loss, 8, "pnrf_train_stage2_fwd_bwd"));
+  hipStream_t s = (hipStream_t)stream;
+  return run_iteration(t, bt, 0, 1, 1, 8, loss, rgb_out, s, [&](const pnrf_train_batch_t* b, hipStream_t st) { return stage2_body(t, b, st); });
+}
+
+extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int n_mult, int dir1, float* loss, float* rgb_out,
+                                          void* stream) {
+  PNRF_REQUIRE(n_mult >= 1 && n_mult <= 32 && (dir1 == 1 || dir1 == -1), PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: n_mult 1..32, dir1 +-1");
+  const int S = 8 * n_mult;
+  T_RC(check_batch(t, bt, loss, S, "pnrf_train_explore_fwd_bwd"));
+  PNRF_REQUIRE(bt->jitter, PNRF_E_ARG, "pnrf_train_explore_fwd_bwd: the exploration jitter [n, 8 n_mult] is required");
+  hipStream_t s = (hipStream_t)stream;
+  return run_iteration(t, bt, 1, n_mult, dir1, S, loss, rgb_out, s,
+                       [&](const pnrf_train_batch_t* b, hipStream_t st) { return explore_body(t, b, n_mult, dir1, st); });
+}
+
+// 1: replay every iteration as a hipGraph; 0 (default): launch its kernels one by one
+extern "C" int pnrf_trainer_set_graph(pnrf_trainer_t* t, int enable) {
+  PNRF_REQUIRE(t, PNRF_E_ARG, "pnrf_trainer_set_graph: null trainer");
+  t->use_graph = enable != 0;
   return 0;
 }
 #undef T_RC

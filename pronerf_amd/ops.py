@@ -511,6 +511,10 @@ class Trainer:
         """Weight-gradient kernel of the square layers: 0 = by shape and row count, 64 / 128 = forced (pnrf_trainer_set_dw_kernel)."""
         check(_lib.load().pnrf_trainer_set_dw_kernel(self.handle, int(tile), int(min_rows_128)), 'pnrf_trainer_set_dw_kernel')
 
+    def set_graph(self, enable=True):
+        """Replay the iterations as hipGraphs, or (default) launch their kernels one by one (pnrf_trainer_set_graph)."""
+        check(_lib.load().pnrf_trainer_set_graph(self.handle, int(bool(enable))), 'pnrf_trainer_set_graph')
+
     def set_step(self, step, step_nerf=0):
         check(_lib.load().pnrf_trainer_set_step(self.handle, int(step), int(step_nerf)), 'pnrf_trainer_set_step')
 

@@ -15,7 +15,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import pronerf_oracle as orc   # noqa: E402  (baseline leg only)
-from pronerf_amd import ops, synthetic     # noqa: E402
+from pronerf_amd import _lib, ops, synthetic     # noqa: E402
+
+if '--lib' in sys.argv:                     # time another build: pronerf_amd/lib/libpronerf_hip_<name>.so (python -m pronerf_amd.build --variant <name> ...)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libpronerf_hip_' + sys.argv[sys.argv.index('--lib') + 1] + '.so')
 
 dev = torch.device('cuda:0')
 HIP_ONLY = '--hip-only' in sys.argv        # skip the eager legs (for rocprofv3 runs)
