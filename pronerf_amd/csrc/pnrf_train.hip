@@ -434,24 +434,34 @@ __global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restri
     }
   }
 }
-// Adds the split-K partials of dW in a fixed order; the last `db_blocks` workgroups of the grid do the same for the bias gradient's
-// column-sum partials, which the weight-gradient kernels' loaders produce on the way (one per split).
-__global__ void dw_reduce_kernel(const float* __restrict__ part, int splits, int64_t numel, float* __restrict__ dW, int db_blocks,
-                                 const float* __restrict__ db_part, int out, float* __restrict__ db) {
-  const int dw_blocks = (int)gridDim.x - db_blocks;
-  if ((int)blockIdx.x >= dw_blocks) {
-    const int j = ((int)blockIdx.x - dw_blocks) * (int)blockDim.x + (int)threadIdx.x;
-    if (j < out) {
+// Adds the split-K partials of every weight gradient of the iteration in a fixed order, in ONE launch at the end of the backward pass (26
+// layers: 26 launches of ~16 us each were 0.4 ms of a 3 ms iteration).  Each layer's weight-gradient kernel wrote its partials into its own
+// slice of the trainer's pool; a job names that slice, and the workgroups [block0, block0 + blocks) belong to it: the first `blocks - db_blocks`
+// of them sum dW, the rest the bias gradient's column-sum partials that the weight-gradient kernels' loaders produce on the way.
+struct DwJob {
+  const float* part; const float* db_part; float* dW; float* db;
+  int numel, splits, out, block0, blocks, db_blocks;
+};
+constexpr int DW_MAX_JOBS = 32;
+struct DwJobs { DwJob j[DW_MAX_JOBS]; int n; };
+__global__ void dw_reduce_kernel(const DwJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const DwJob& J = jobs.j[k];
+  const int b = (int)blockIdx.x - J.block0, dw_blocks = J.blocks - J.db_blocks;
+  if (b >= dw_blocks) {
+    const int j = (b - dw_blocks) * (int)blockDim.x + (int)threadIdx.x;
+    if (j < J.out) {
       float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += db_part[(size_t)k * out + j];
-      db[j] = s;
+      for (int q = 0; q < J.splits; ++q) s += J.db_part[(size_t)q * J.out + j];
+      J.db[j] = s;
     }
     return;
   }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)dw_blocks * blockDim.x) {
+  for (int i = b * (int)blockDim.x + (int)threadIdx.x; i < J.numel; i += dw_blocks * (int)blockDim.x) {
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * numel + i];
-    dW[i] = s;
+    for (int q = 0; q < J.splits; ++q) s += J.part[(size_t)q * J.numel + i];
+    J.dW[i] = s;
   }
 }
 
@@ -864,7 +874,9 @@ struct pnrf_trainer {
   float *refine_in, *r_h[6], *r_y, *z_pre, *z, *pts, *rgb0;
   float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
   float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
-      *d_h0, *d_h1, *part, *dw_part, *loss;
+      *d_h0, *d_h1, *dw_pool, *loss;
+  size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
+  DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
 };
 
 namespace {
@@ -898,42 +910,61 @@ int launch_tgemm(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-// dW[out,in] = dZ^T X and db[out] = column sums of dZ  (dw_splitk*_kernel + dw_reduce_kernel)
+// dW[out,in] = dZ^T X and db[out] = column sums of dZ: dw_splitk*_kernel writes the split-K partials into a fresh slice of the pool and
+// queues their summation; flush_dw_reduce() at the end of the backward pass does all of them in one launch.
 int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, float* dW, float* db, int in, int out, int64_t R, hipStream_t s) {
   PNRF_REQUIRE(out <= DB_MAX_OUT, PNRF_E_SHAPE, "pnrf_trainer: layer output %d wider than the bias-partial buffer (%d)", out, DB_MAX_OUT);
-  const int db_blocks = (out + TPB - 1) / TPB;
-  const int64_t numel = (int64_t)out * in;
+  PNRF_REQUIRE(t->jobs.n < DW_MAX_JOBS, PNRF_E_STATE, "pnrf_trainer: more than %d weight gradients in one iteration", DW_MAX_JOBS);
+  const int numel = out * in;
   const bool can128 = out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldz % 4 == 0 && aligned16(X) && aligned16(dZ);
-  if (can128 && t->dw_tile != 64 && R >= t->dw128_min_rows) {
-    const int tiles = (out / 128) * (in / 128);
-    int64_t splits = (512 + tiles - 1) / tiles;                 // two workgroups per CU
+  const bool use128 = can128 && t->dw_tile != 64 && R >= t->dw128_min_rows;
+  int tiles;
+  int64_t splits, rows_per;
+  if (use128) {
+    tiles = (out / 128) * (in / 128);
+    splits = (512 + tiles - 1) / tiles;                         // two workgroups per CU
     const int64_t by_rows = R / 256;
     if (splits > by_rows) splits = by_rows;
     if (splits > DW128_MAX_SPLITS) splits = DW128_MAX_SPLITS;
-    if (splits < 1) splits = 1;
-    int64_t rows_per = (R + splits - 1) / splits;
-    rows_per = (rows_per + DW128_ROWS - 1) / DW128_ROWS * DW128_ROWS;
-    splits = (R + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, t->dw_part, out, in, R, rows_per, t->part);
-    PNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, t->part, out, db);
-    PNRF_LAUNCH_CHECK();
-    return 0;
+  } else {
+    tiles = ((out + DW_TILE - 1) / DW_TILE) * ((in + DW_TILE - 1) / DW_TILE);
+    // enough workgroups for 4 per CU (they hide each other's load latency), at least 128 rows per split, at most DW_MAX_SPLITS partials
+    splits = (1024 + tiles - 1) / tiles;
+    const int64_t by_rows = (R + 127) / 128;
+    if (splits > by_rows) splits = by_rows;
+    if (splits > DW_MAX_SPLITS) splits = DW_MAX_SPLITS;
   }
-  const int tiles = ((out + DW_TILE - 1) / DW_TILE) * ((in + DW_TILE - 1) / DW_TILE);
-  // enough workgroups for 4 per CU (they hide each other's load latency), at least 128 rows per split, at most DW_MAX_SPLITS partials
-  int64_t splits = (1024 + tiles - 1) / tiles;
-  const int64_t by_rows = (R + 127) / 128;
-  if (splits > by_rows) splits = by_rows;
-  if (splits > DW_MAX_SPLITS) splits = DW_MAX_SPLITS;
   if (splits < 1) splits = 1;
-  int64_t rows_per = (R + splits - 1) / splits;
-  rows_per = (rows_per + DW_ROWS - 1) / DW_ROWS * DW_ROWS;
+  const int rows_q = use128 ? DW128_ROWS : DW_ROWS;
+  rows_per = (R + splits - 1) / splits;
+  rows_per = (rows_per + rows_q - 1) / rows_q * rows_q;
   splits = (R + rows_per - 1) / rows_per;
-  hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, t->dw_part, out, in, R, rows_per, t->part);
+  const size_t need = (size_t)splits * ((size_t)numel + out);
+  PNRF_REQUIRE(t->pool_used + need <= t->pool_cap, PNRF_E_STATE, "pnrf_trainer: weight-gradient partials exceed their pool (%zu + %zu > %zu floats)",
+               t->pool_used, need, t->pool_cap);
+  float* part = t->dw_pool + t->pool_used;
+  float* db_part = part + (size_t)splits * numel;
+  t->pool_used += (need + 3) & ~(size_t)3;                      // slices stay 16-byte aligned
+  if (use128)
+    hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, part, out, in, R, rows_per, db_part);
+  else
+    hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, part, out, in, R, rows_per, db_part);
   PNRF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(numel) + db_blocks), dim3(TPB), 0, s, t->dw_part, (int)splits, numel, dW, db_blocks, t->part, out, db);
+  DwJob& J = t->jobs.j[t->jobs.n];
+  J.part = part; J.db_part = db_part; J.dW = dW; J.db = db; J.numel = numel; J.splits = (int)splits; J.out = out;
+  J.db_blocks = (out + TPB - 1) / TPB;
+  J.blocks = grid_for(numel) + J.db_blocks;
+  J.block0 = t->jobs.n ? t->jobs.j[t->jobs.n - 1].block0 + t->jobs.j[t->jobs.n - 1].blocks : 0;
+  ++t->jobs.n;
+  return 0;
+}
+void begin_dw(pnrf_trainer* t) { t->jobs.n = 0; t->pool_used = 0; }
+int flush_dw_reduce(pnrf_trainer* t, hipStream_t s) {
+  if (!t->jobs.n) return 0;
+  const DwJob& last = t->jobs.j[t->jobs.n - 1];
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)(last.block0 + last.blocks)), dim3(TPB), 0, s, t->jobs);
   PNRF_LAUNCH_CHECK();
+  begin_dw(t);
   return 0;
 }
 
@@ -1087,7 +1118,17 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
   T_ALLOC(t->st_rays, N * 11); T_ALLOC(t->st_or_rays, N * 11); T_ALLOC(t->st_target, N * 3); T_ALLOC(t->st_ref_nos, N * 4); T_ALLOC(t->st_jitter, R); T_ALLOC(t->st_noise, R);
-  T_ALLOC(t->part, (size_t)DW128_MAX_SPLITS * DB_MAX_OUT); T_ALLOC(t->dw_part, std::max((size_t)DW_MAX_SPLITS * 256 * 320, (size_t)DW128_MAX_SPLITS * 256 * 256)); T_ALLOC(t->loss, 4);
+  T_ALLOC(t->loss, 4);
+  {   // one slice of split-K partials per layer and iteration, each at its largest
+    size_t cap = 0;
+    for (int li = 0; li < N_LAYERS; ++li) {
+      const TLin& l = t->L[li];
+      const size_t sp = (l.out % 128 == 0 && l.in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;
+      cap += sp * ((size_t)l.out * l.in + l.out) + 4;
+    }
+    t->pool_cap = cap;
+    T_ALLOC(t->dw_pool, cap);
+  }
   PNRF_HIP(hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking));
   PNRF_HIP(hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming));
   PNRF_HIP(hipEventCreateWithFlags(&t->ev_out, hipEventDisableTiming));
@@ -1116,18 +1157,20 @@ extern "C" int pnrf_trainer_read(const pnrf_trainer_t* t, int kind, int layer, f
   PNRF_REQUIRE(t && kind >= 0 && kind <= 5 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_read: bad kind / layer");
   const float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   const TLin& l = t->L[layer];
+  // on the caller's stream and complete on return (a plain hipMemcpy between device buffers runs on the null stream and may still be in
+  // flight when it returns: a caller working on a non-blocking stream would race with it)
+  if (W) PNRF_HIP(hipMemcpyAsync(W, base + l.w, (size_t)l.in * l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
+  if (b) PNRF_HIP(hipMemcpyAsync(b, base + l.b, (size_t)l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
   PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (W) PNRF_HIP(hipMemcpy(W, base + l.w, (size_t)l.in * l.out * 4, hipMemcpyDefault));
-  if (b) PNRF_HIP(hipMemcpy(b, base + l.b, (size_t)l.out * 4, hipMemcpyDefault));
   return 0;
 }
 extern "C" int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const float* W, const float* b, void* stream) {
   PNRF_REQUIRE(t && kind >= 0 && kind <= 5 && layer >= 0 && layer < N_LAYERS, PNRF_E_ARG, "pnrf_trainer_write: bad kind / layer");
   float* base = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   const TLin& l = t->L[layer];
+  if (W) PNRF_HIP(hipMemcpyAsync(base + l.w, W, (size_t)l.in * l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
+  if (b) PNRF_HIP(hipMemcpyAsync(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
   PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (W) PNRF_HIP(hipMemcpy(base + l.w, W, (size_t)l.in * l.out * 4, hipMemcpyDefault));
-  if (b) PNRF_HIP(hipMemcpy(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault));
   return 0;
 }
 // Device address and element count of one of the flat arrays (kind as pnrf_trainer_read) — e.g. to all-reduce the gradients of
@@ -1334,7 +1377,7 @@ static int explore_body(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int n_m
 // kernel by kernel from a host that runs ahead of the GPU (2.98 vs 3.13 ms at 4096 rays, default stream, i.e. through the owned-stream hop).
 template <class Body>
 static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int kind, int n_mult, int dir1, int S, float* loss, float* rgb_out,
-                         hipStream_t caller, Body body) {
+                         hipStream_t caller, Body body_) {
   const int64_t N = bt->n;
   hipStream_t s = caller;
   const bool hop = t->use_graph && caller == nullptr;          // the legacy default stream cannot be captured
@@ -1350,6 +1393,11 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
   pnrf_train_batch_t b = *bt;
   b.rays = t->st_rays; b.or_rays = t->st_or_rays; b.target = t->st_target; b.ref_nos = t->st_ref_nos;
   b.jitter = bt->jitter ? t->st_jitter : nullptr; b.raw_noise = bt->raw_noise ? t->st_noise : nullptr;
+  auto body = [&](const pnrf_train_batch_t* bb, hipStream_t st) -> int {
+    begin_dw(t);
+    int rc = body_(bb, st);
+    return rc ? rc : flush_dw_reduce(t, st);
+  };
   if (!t->use_graph) {
     T_RC(body(&b, s));
   } else {

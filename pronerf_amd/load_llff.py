@@ -79,118 +79,134 @@ def _load_data(basedir, factor=None, load_imgs=True):
 
 
 # ------------------------------------------------------------------------------------------ pose algebra
+# Everything below is built on two batched helpers: `_frames` (camera frames from look directions) and `_homog` (3x4 -> 4x4).  The public
+# names are the reference's (its drivers import them); paths are generated for all angles at once rather than camera by camera.
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64) if not isinstance(v, np.ndarray) else v
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def _frames(back, up, origin):
+    """Camera-to-world frames [..., 3, 4] with columns (right, true up, backwards, origin): `back` is the direction the camera's +z axis
+    points along, `up` an approximate up vector; all broadcast over leading dimensions."""
+    zc = _unit(back)
+    xc = _unit(np.cross(np.broadcast_to(up, zc.shape), zc))
+    yc = _unit(np.cross(zc, xc))
+    return np.stack([xc, yc, zc, np.broadcast_to(origin, zc.shape)], axis=-1)
+
+
+def _homog(m34):
+    """[..., 3, 4] -> [..., 4, 4] by appending the row (0, 0, 0, 1)."""
+    m34 = np.asarray(m34)
+    out = np.zeros(m34.shape[:-2] + (4, 4), dtype=m34.dtype)
+    out[..., :3, :] = m34
+    out[..., 3, 3] = 1
+    return out
+
+
+def _with_hwf(frames, hwf):
+    """Append the [H, W, focal] column to every frame: [..., 3, 4] -> [..., 3, 5]."""
+    return np.concatenate([frames, np.broadcast_to(hwf, frames.shape[:-1] + (1,))], axis=-1)
+
+
 def normalize(x):
     return x / np.linalg.norm(x)
 
 
 def viewmatrix(z, up, pos):
-    vec2 = normalize(z)
-    vec0 = normalize(np.cross(up, vec2))
-    vec1 = normalize(np.cross(vec2, vec0))
-    return np.stack([vec0, vec1, vec2, pos], 1)
+    return _frames(np.asarray(z), np.asarray(up), np.asarray(pos))
 
 
 def poses_avg(poses):
     """Average camera [3,5]: mean centre, summed z axis, summed y axis as up (load_llff.py:163-172)."""
-    hwf = poses[0, :3, -1:]
-    center = poses[:, :3, 3].mean(0)
-    vec2 = normalize(poses[:, :3, 2].sum(0))
-    up = poses[:, :3, 1].sum(0)
-    return np.concatenate([viewmatrix(vec2, up, center), hwf], 1)
+    rot = poses[:, :3, :3].sum(0)
+    return _with_hwf(_frames(rot[:, 2], rot[:, 1], poses[:, :3, 3].mean(0)), poses[0, :3, 4:5])
 
 
 def recenter_poses(poses):
     """Express all poses in the frame of the average camera (load_llff.py:189-203)."""
-    out = poses + 0
-    bottom = np.reshape([0, 0, 0, 1.], [1, 4])
-    c2w = np.concatenate([poses_avg(poses)[:3, :4], bottom], -2)
-    p44 = np.concatenate([poses[:, :3, :4], np.tile(bottom[None], [poses.shape[0], 1, 1])], -2)
-    p44 = np.linalg.inv(c2w) @ p44
-    out[:, :3, :4] = p44[:, :3, :4]
+    out = poses.copy()
+    out[:, :3, :4] = (np.linalg.inv(_homog(poses_avg(poses)[:, :4])) @ _homog(poses[:, :3, :4]))[:, :3, :4]
     return out
 
 
 def render_path_spiral(c2w, up, rads, focal, zdelta, zrate, rots, N):
-    """Spiral of N cameras around the average pose looking at depth ``focal`` (load_llff.py:176-185)."""
-    out = []
-    rads = np.array(list(rads) + [1.])
-    hwf = c2w[:, 4:5]
-    for theta in np.linspace(0., 2. * np.pi * rots, int(N) + 1)[:-1]:
-        c = np.dot(c2w[:3, :4], np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads)
-        z = normalize(c - np.dot(c2w[:3, :4], np.array([0, 0, -focal, 1.])))
-        out.append(np.concatenate([viewmatrix(z, up, c), hwf], 1))
-    return out
+    """Spiral of N cameras around the average pose looking at depth ``focal`` (load_llff.py:176-185; ``zdelta`` is unused there too)."""
+    th = np.linspace(0., 2. * np.pi * rots, int(N) + 1)[:-1]
+    local = np.stack([np.cos(th), -np.sin(th), -np.sin(th * zrate), np.ones_like(th)], -1) * np.append(np.asarray(rads, dtype=np.float64), 1.)
+    m = c2w[:3, :4]
+    eye = local @ m.T                                              # [N, 3] camera centres in world coordinates
+    target = m @ np.array([0, 0, -focal, 1.])
+    return list(_with_hwf(_frames(eye - target, up, eye), c2w[:, 4:5]))
 
 
 def spherify_poses(poses, bds):
     """360-degree captures: recentre on the point closest to all optical axes, unit mean radius, circular path
     (load_llff.py:207-262)."""
-    def p44(p):
-        return np.concatenate([p, np.tile(np.reshape(np.eye(4)[-1, :], [1, 1, 4]), [p.shape[0], 1, 1])], 1)
-
-    rays_d, rays_o = poses[:, :3, 2:3], poses[:, :3, 3:4]
-    A = np.eye(3) - rays_d * np.transpose(rays_d, [0, 2, 1])
-    b = -A @ rays_o
-    center = np.squeeze(-np.linalg.inv((np.transpose(A, [0, 2, 1]) @ A).mean(0)) @ b.mean(0))
-    up = (poses[:, :3, 3] - center).mean(0)
-    vec0 = normalize(up)
-    vec1 = normalize(np.cross([.1, .2, .3], vec0))
-    vec2 = normalize(np.cross(vec0, vec1))
-    c2w = np.stack([vec1, vec2, vec0, center], 1)
-    reset = np.linalg.inv(p44(c2w[None])) @ p44(poses[:, :3, :4])
-    rad = np.sqrt(np.mean(np.sum(np.square(reset[:, :3, 3]), -1)))
-    sc = 1. / rad
-    reset[:, :3, 3] *= sc
-    bds *= sc
-    rad *= sc
-    zh = np.mean(reset[:, :3, 3], 0)[2]
-    radcircle = np.sqrt(rad ** 2 - zh ** 2)
-    path = []
-    for th in np.linspace(0., 2. * np.pi, 120):
-        cam = np.array([radcircle * np.cos(th), radcircle * np.sin(th), zh])
-        v2 = normalize(cam)
-        v0 = normalize(np.cross(v2, np.array([0, 0, -1.])))
-        v1 = normalize(np.cross(v2, v0))
-        path.append(np.stack([v0, v1, v2, cam], 1))
-    path = np.stack(path, 0)
-    path = np.concatenate([path, np.broadcast_to(poses[0, :3, -1:], path[:, :3, -1:].shape)], -1)
-    reset = np.concatenate([reset[:, :3, :4], np.broadcast_to(poses[0, :3, -1:], reset[:, :3, -1:].shape)], -1)
-    return reset, path, bds
+    hwf = poses[0, :3, 4:5]
+    d, o = poses[:, :3, 2], poses[:, :3, 3]
+    # least squares: the point minimising the summed squared distance to the optical axes o + t d
+    P = np.eye(3) - d[:, :, None] * d[:, None, :]
+    centre = np.linalg.inv((np.swapaxes(P, 1, 2) @ P).mean(0)) @ (P @ o[:, :, None]).mean(0)[:, 0]
+    e_up = _unit((o - centre).mean(0))
+    e_1 = _unit(np.cross([.1, .2, .3], e_up))
+    e_2 = _unit(np.cross(e_up, e_1))
+    world = np.stack([e_1, e_2, e_up, centre], 1)
+    moved = np.linalg.inv(_homog(world)) @ _homog(poses[:, :3, :4])
+    scale = 1. / np.sqrt(np.mean(np.sum(np.square(moved[:, :3, 3]), -1)))
+    moved[:, :3, 3] *= scale
+    bds *= scale                                                   # in place, as the reference does
+    height = moved[:, 2, 3].mean()
+    ring = np.sqrt(1. - height ** 2)                               # mean radius is 1 after scaling
+    th = np.linspace(0., 2. * np.pi, 120)
+    eye = np.stack([ring * np.cos(th), ring * np.sin(th), np.full_like(th, height)], -1)
+    zc = _unit(eye)
+    xc = _unit(np.cross(zc, np.array([0, 0, -1.])))
+    yc = _unit(np.cross(zc, xc))
+    path = _with_hwf(np.stack([xc, yc, zc, eye], -1), hwf)
+    return _with_hwf(moved[:, :3, :4], hwf), path, bds
 
 
 # ------------------------------------------------------------------------------------------ scene assembly
+def _llff_to_nerf_axes(poses):
+    """LLFF stores camera axes as [down, right, backwards]; NeRF wants [right, up, backwards] (load_llff.py:354-356).  [3,5,N] -> [N,3,5]"""
+    return np.moveaxis(np.concatenate([poses[:, 1:2], -poses[:, 0:1], poses[:, 2:]], 1), -1, 0).astype(np.float32)
+
+
+def _forward_facing_path(poses, bds, path_zflat, n_views=120):
+    """The reference's spiral for forward-facing captures (load_llff.py:376-407): focus at the 1/4-3/4 mix of the near and far disparities,
+    radii = 90th percentile of the camera offsets, two turns (one flat half-length turn with ``path_zflat``)."""
+    mean_cam = poses_avg(poses)
+    up = _unit(poses[:, :3, 1].sum(0))
+    near, far = bds.min() * .9, bds.max() * 5.
+    focus = 1. / (.25 / near + .75 / far)
+    radii = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+    turns = 2
+    if path_zflat:
+        mean_cam[:3, 3] += -near * .1 * mean_cam[:3, 2]
+        radii[2] = 0.
+        turns, n_views = 1, n_views / 2
+    return render_path_spiral(mean_cam, up, radii, focus, near * .2, zrate=.5, rots=turns, N=n_views)
+
+
 def _assemble(basedir, factor, recenter, bd_factor, spherify, path_zflat):
-    poses, bds, imgs = _load_data(basedir, factor=factor)
-    # LLFF stores [down, right, backwards]; NeRF wants [right, up, backwards] (load_llff.py:354-356)
-    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)
-    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    raw_poses, raw_bds, imgs = _load_data(basedir, factor=factor)
+    poses = _llff_to_nerf_axes(raw_poses)
     images = np.moveaxis(imgs, -1, 0).astype(np.float32)
-    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
-    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)          # nearest bound -> 1/bd_factor
-    poses[:, :3, 3] *= sc
-    bds *= sc
+    bds = np.moveaxis(raw_bds, -1, 0).astype(np.float32)
+    if bd_factor is not None:                                               # nearest bound -> 1/bd_factor
+        rescale = 1. / (bds.min() * bd_factor)
+        poses[:, :3, 3] *= rescale
+        bds *= rescale
     if recenter:
         poses = recenter_poses(poses)
     if spherify:
         poses, render_poses, bds = spherify_poses(poses, bds)
     else:
-        c2w = poses_avg(poses)
-        up = normalize(poses[:, :3, 1].sum(0))
-        close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
-        dt = .75
-        focal = 1. / ((1. - dt) / close_depth + dt / inf_depth)            # focus depth of the spiral
-        zdelta = close_depth * .2
-        rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
-        n_views, n_rots = 120, 2
-        if path_zflat:
-            c2w[:3, 3] = c2w[:3, 3] + (-close_depth * .1) * c2w[:3, 2]
-            rads[2] = 0.
-            n_rots, n_views = 1, n_views / 2
-        render_poses = render_path_spiral(c2w, up, rads, focal, zdelta, zrate=.5, rots=n_rots, N=n_views)
-    render_poses = np.array(render_poses).astype(np.float32)
-    c2w = poses_avg(poses)
-    i_test = np.argmin(np.sum(np.square(c2w[:3, 3] - poses[:, :3, 3]), -1))   # view closest to the average pose
-    return images.astype(np.float32), poses.astype(np.float32), bds, render_poses, i_test
+        render_poses = _forward_facing_path(poses, bds, path_zflat)
+    render_poses = np.asarray(render_poses, dtype=np.float32)
+    dist2 = np.sum(np.square(poses_avg(poses)[:3, 3] - poses[:, :3, 3]), -1)
+    return images, poses.astype(np.float32), bds, render_poses, np.argmin(dist2)   # hold-out = view closest to the average pose
 
 
 def load_llff_data(basedir, factor=8, recenter=True, bd_factor=.75, spherify=False, path_zflat=False):

@@ -211,8 +211,8 @@ def test_graph_replay_equals_kernel_by_kernel(dev):
     ref = run(False)
     for got in (run(True), run(True, torch.cuda.Stream(device=dev))):
         assert len(got) == len(ref)
-        for x, y in zip(got, ref):
-            assert torch.equal(x, y)
+        for k, (x, y) in enumerate(zip(got, ref)):
+            assert torch.equal(x, y), (k, tuple(x.shape), float((x - y).abs().max()), float(y.abs().max()))
 
 
 def test_adam_step_matches_torch_optim(dev):
