@@ -75,6 +75,7 @@ SIGNATURES = {
     'pnrf_trainer_set_step': (_i, [_p, _i64, _i64]),
     'pnrf_trainer_set_dw_kernel': (_i, [_p, _i, _i64]),
     'pnrf_trainer_set_graph': (_i, [_p, _i]),
+    'pnrf_trainer_set_products': (_i, [_p, _i]),
     'pnrf_trainer_flat': (_i, [_p, _i, C.POINTER(_p), C.POINTER(_i64)]),
     'pnrf_train_stage2_fwd_bwd': (_i, [_p, _p, _p, _p, _p]),
     'pnrf_train_explore_fwd_bwd': (_i, [_p, _p, _i, _i, _p, _p, _p]),

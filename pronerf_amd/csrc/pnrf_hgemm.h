@@ -1,0 +1,350 @@
+// Split-fp16 layer products for the trainer (included by pnrf_train.hip inside its anonymous namespace).
+//
+// Y = act(X W^T + b) and dX = (dZ W [+ dX]) * act'(H) with fp32-grade results at 3/16 of the fp32 MFMA cycles: both operands are split
+//   x = x_hi + 2^-11 x_lo',  x_hi = fp16(x),  x_lo' = fp16((x - x_hi) 2^11)          (22 significand bits per operand)
+// and the product is accumulated in fp32 as   main += W_hi x_hi ;  cross += W_hi x_lo' + W_lo' x_hi ;  C = main + 2^-11 cross
+// (the dropped W_lo x_lo term is 2^-22 relative) — the scheme of the inference sampler (pnrf_engine.h layer_h16x2), three
+// v_mfma_f32_16x16x32_f16 per 32-deep step instead of eight v_mfma_f32_16x16x4_f32 of twice the duration.
+//
+// Operand ranges.  Weights and forward activations are O(1).  Gradients are not (1e-9 .. 1e-3): the A operand of a backward product is
+// multiplied by a power of two s chosen from max |A| — which the kernel that produced A left in a device slot with one atomicMax per wave —
+// so that s max|A| lies in [2^11, 2^12); the result is multiplied by 1 / s.  Elements more than 2^36 below the tensor's maximum flush to
+// zero: 2^-12 of an fp32 ulp of the largest term of their dot product.
+//
+// Layout.  Workgroup = 8 waves on tiles of 16 MI rows x 256 columns; wave w owns columns 32 w .. 32 w + 31 (two 16-column MFMA tiles) of all
+// rows.  The kernel is persistent: workgroup b of G works on row tiles b, b + G, ... as ONE software pipeline over all their 64-k chunks, so
+// the fetches of a tile's first chunks overlap the previous tile's last MFMAs and its epilogue (a product with K = 256 has only four chunks:
+// started afresh per tile, every tile paid an HBM and an L2 round trip with the MFMA pipe idle — 36 us instead of 21 us per 32 768 x 256 x 256
+// product in the probe build without weight fetches, tools/hgemm_probe.hip).
+//   * A [M, K] fp32 streams from HBM once: 512 threads fetch a chunk (16 bytes each, whole 256-byte row segments) two chunks ahead into
+//     registers, split it one chunk ahead and write the two fp16 planes [row][64 + 8] to LDS (double buffered; row stride 144 bytes: the
+//     ds_read_b128 of the 16 rows of a fragment cover all 64 banks once).
+//   * The weight planes are stored fragment-major (split_weights_kernel): the 16 columns x 32 k block that one MFMA consumes is one contiguous
+//     KiB in lane order, so a fragment fetch is a single fully coalesced 16-byte-per-lane load from L2.  Fragments are fetched per 32-deep step,
+//     three steps ahead, into four rotating register sets.  Two orientations are kept: [out][in] for the forward product, [in][out] for dX.
+//   * Every fetch inside the loop is a buffer load — resource in scalar registers, a per-lane offset that never changes, a scalar offset per
+//     chunk — so the loop writes no vector register for addressing.  (With 64-bit vector address arithmetic per iteration the register
+//     allocator put address temporaries into destination registers of loads still in flight: a write-after-write dependency that made every
+//     chunk wait for vmcnt(0) before it could issue its own fetches.)  The range check of the resource returns zeros for rows past M and for
+//     column tiles past the padded planes.
+//   * As in tgemm_kernel the weight fragment is the MFMA's A operand (C^T = W X^T), so D register e of lane (m, g) is C[row m][column 4 g + e],
+//     and the epilogue goes through LDS to row-contiguous 16-byte accesses for bias / activation / act'(H) / beta / store.
+#pragma once
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+struct HGemmArgs {
+  const float* A; int lda;                     // [M, K] fp32
+  const _Float16 *Bh, *Bl; int ldb, n_pad;     // weight planes [n_pad][ldb], zero padded (n_pad, ldb multiples of 64, ldb >= K)
+  float* C; int ldc;                           // [M, N]
+  int64_t M; int N, K;
+  int bwd;                                     // 0: Y = act(A B^T + bias); 1: C = (beta C + A B^T) * act'(H)
+  const float* bias; int act;
+  const float* H; int ldh; int act_col0; float beta;
+  const float* a_amax;                         // device scalar max |A| or NULL (A used as it is)
+  float* c_amax;                               // device scalar, atomic max |C| or NULL
+};
+constexpr int HG_KC = 64, HG_LDS_ROW = HG_KC + 8, HG_LDC = 256 + 4;
+constexpr float HG_LO_SCALE = 2048.f, HG_LO_INV = 1.f / 2048.f;
+constexpr int HG_BUF_FLAGS = 0x00020000;       // raw buffer, 32-bit elements (gfx9 resource word 3)
+
+// power of two s with s * mx in [2^11, 2^12) (mx = 0 or non-finite: 1)
+__device__ __forceinline__ float hg_scale_for(float mx) {
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
+  int ex;
+  (void)frexpf(mx, &ex);                       // mx = f 2^ex, f in [0.5, 1)
+  int sh = 12 - ex;
+  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+  return ldexpf(1.f, sh);
+}
+// offset (in halfs) of weight element (row n, k) in a fragment-major plane with k padded to kp (a multiple of 64): blocks of 16 rows x 32 k,
+// inside a block lane (n & 15) + 16 ((k & 31) >> 3) holds 8 consecutive k
+__host__ __device__ inline size_t hg_plane_index(int n, int k, int kp) {
+  return ((size_t)(n >> 4) * (kp >> 5) + (k >> 5)) * 512 + (size_t)(((n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
+}
+
+template <int MI, int PROBE = 0>
+__global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
+  constexpr int ROWS = 16 * MI, NI = 2;
+  constexpr int PLANE = ROWS * HG_LDS_ROW;                     // halfs per plane of one chunk
+  constexpr int A_BYTES = 2 * 2 * PLANE * 2, C_BYTES = ROWS * HG_LDC * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_a[A_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_c[C_BYTES];
+  _Float16* const sA = (_Float16*)smem_a;                      // [buffer][plane hi / lo][row][72]
+  float* const sC = (float*)smem_c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m16 = lane & 15, g = lane >> 4;
+  const int tn = blockIdx.y;
+  const int col0 = tn * 256 + wave * 32;
+  const bool wave_on = col0 < a.N;
+  const float a_scale = a.a_amax ? hg_scale_for(*a.a_amax) : 1.f;
+  const float inv_scale = 1.f / a_scale;
+  const int chunks = (a.K + HG_KC - 1) / HG_KC;
+  const int64_t ntiles = (a.M + ROWS - 1) / ROWS;
+  const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);   // >= 1: the grid has at most ntiles workgroups
+  const int total = my_tiles * chunks;                                                // chunks in this workgroup's pipeline
+
+  f32x4_t accm[MI][NI], accx[MI][NI];
+  auto zero_acc = [&] {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { accm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  };
+  zero_acc();
+
+  // ---- A chunk loader: thread t -> 16 bytes at k-offset 4 (t & 15) of rows (t >> 4) + 32 pass.  k past the end of a row reads the floats that
+  // follow (zeros past the end of the buffer) and is zeroed when the chunk is written to LDS.  Rows need 4-byte alignment only.
+  const int lc4 = 4 * (threadIdx.x & 15), lrow = threadIdx.x >> 4;
+  constexpr int PASSES = (ROWS + 31) / 32;
+  const bool loader_on = ROWS >= 32 || lrow < ROWS;
+  const int64_t a_bytes = ((a.M - 1) * (int64_t)a.lda + a.K) * 4;                      // launch_hgemm refuses operands of 4 GiB and more
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)(unsigned)a_bytes, HG_BUF_FLAGS);
+  unsigned a_off[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) a_off[ps] = (unsigned)(((lrow + 32 * ps) * a.lda + lc4) * 4);
+  const unsigned tile_bytes = (unsigned)(ROWS * a.lda * 4), tile_step = tile_bytes * gridDim.x;
+  // fetch cursor: (byte offset of the tile's first row, chunk in the tile) of the next chunk to request — runs two chunks ahead of the MFMAs,
+  // past this workgroup's last tile it points behind the buffer (zeros)
+  unsigned f_row = (unsigned)(blockIdx.x * (size_t)tile_bytes);
+  int f_kc = 0, f_left = total;
+  auto fetch_a = [&](f32x4_t (&st)[PASSES]) {
+    const unsigned soff = f_left > 0 ? f_row + (unsigned)f_kc * (HG_KC * 4) : 0xfffffff0u;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      if (!(PROBE & 4)) st[ps] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[ps], soff, 0));
+      else st[ps] = f32x4_t{1.f, 2.f, 3.f, (float)f_kc};
+    }
+    --f_left;
+    if (++f_kc == chunks) { f_kc = 0; f_row += tile_step; }
+  };
+  auto store_a = [&](const f32x4_t (&st)[PASSES], int buf, int kc) {
+    _Float16* hi = sA + buf * (2 * PLANE);
+    _Float16* lo = hi + PLANE;
+    const int k = kc * HG_KC + lc4;
+    if (!loader_on) return;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = k + e < a.K ? st[ps][e] * a_scale : 0.f;
+        const _Float16 xh = (_Float16)x;
+        h[e] = xh;
+        l[e] = (_Float16)((x - (float)xh) * HG_LO_SCALE);
+      }
+      const int off = (lrow + 32 * ps) * HG_LDS_ROW + lc4;
+      *(f16x4_t*)(hi + off) = h;
+      *(f16x4_t*)(lo + off) = l;
+    }
+  };
+  // ---- weight fragments of one 32-deep step (NI tiles x 2 planes), fragment-major planes: lane l reads bytes 16 l of its block
+  const int ksteps = a.ldb >> 5;                                                        // 32-k blocks per 16-row block of the plane
+  const int plane_bytes = a.n_pad * a.ldb * 2;
+  const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.Bh, 0, plane_bytes, HG_BUF_FLAGS);
+  const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.Bl, 0, plane_bytes, HG_BUF_FLAGS);
+  unsigned b_off[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) b_off[j] = (unsigned)(((col0 >> 4) + j) * ksteps * 1024 + lane * 16);   // tiles past n_pad: out of range, zeros
+  struct WFrag { f16x8_t h[NI], l[NI]; };
+  int w_ks = 0;                                                                          // step of the next fragment request, cyclic over the tile's steps
+  auto load_w = [&](WFrag& w) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (PROBE & 8) { for (int e = 0; e < 8; ++e) { w.h[j][e] = (_Float16)(float)(w_ks + e); w.l[j][e] = (_Float16)(float)(w_ks - e); } continue; }
+      w.h[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, b_off[j], w_ks * 1024, 0));
+      w.l[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, b_off[j], w_ks * 1024, 0));
+    }
+    if (++w_ks == 2 * chunks) w_ks = 0;
+  };
+  // activation fragments of one 32-deep step: read from LDS one step before their MFMAs (two register sets)
+  struct XFrag { f16x8_t h[MI], l[MI]; };
+  auto read_x = [&](XFrag& x, int buf, int st) {
+    const _Float16* hi = sA + buf * (2 * PLANE);
+    const _Float16* lo = hi + PLANE;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int off = (16 * i + m16) * HG_LDS_ROW + 32 * st + 8 * g;
+      x.h[i] = *(const f16x8_t*)(hi + off);
+      x.l[i] = *(const f16x8_t*)(lo + off);
+    }
+  };
+  auto mma_step = [&](const WFrag& w, const XFrag& x) {
+    if (wave_on && !(PROBE & 1)) {
+      // three sweeps over the tiles, so that the two MFMAs that accumulate into the same cross registers are MI NI MFMAs apart
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[j], x.l[i], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[j], x.h[i], accm[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[j], x.h[i], accx[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- epilogue of one tile, through LDS (its own region: the A buffers keep being filled for the next tile).  launch_hgemm only takes
+  // products whose C / H / bias rows are 16-byte aligned and whose N is a multiple of 4.
+  // gfx9 has ONE counter for vector-memory loads and stores, and loads and stores may complete out of order with respect to each other: with a
+  // store in flight every wait for a load has to be vmcnt(0), i.e. wait for the store's round trip as well (one exposed round trip per stored
+  // row was 3.3 us per tile).  So: (1) at the start all prefetches are drained — they are at least a step old — and the compiler's scoreboard
+  // learns it from the explicit s_waitcnt; (2) everything the epilogue reads from global memory is requested and waited for before its first
+  // store; (3) the stores go out back to back, and the first wait after them belongs to a fetch issued after them, whole steps later.
+  const bool use_h = a.bwd && a.act != T_ACT_NONE, use_c = a.bwd && a.beta != 0.f;
+  constexpr int QN = ROWS / 8 > 0 ? ROWS / 8 : 1;              // rows per thread: (t >> 6) + 8 q
+  const int cl = 4 * (threadIdx.x & 63), c = tn * 256 + cl;
+  const bool col_on = c < a.N;
+  const int cc = col_on ? c : 0;
+  const bool h_on = use_h && c >= a.act_col0;
+  float amax = 0.f;
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (!a.bwd && a.bias) bias4 = *(const f32x4_t*)(a.bias + cc);
+  auto epilogue = [&](int64_t row0) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
+    if (wave_on) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const f32x4_t v = (accm[i][j] + accx[i][j] * HG_LO_INV) * inv_scale;
+          *(f32x4_t*)(sC + (16 * i + m16) * HG_LDC + wave * 32 + 16 * j + 4 * g) = v;
+        }
+    }
+    zero_acc();
+    __syncthreads();
+    f32x4_t hv[QN], cv[QN];
+    const float* hp[QN]; float* cp[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int rl = (threadIdx.x >> 6) + 8 * q;
+      int64_t r = row0 + rl;
+      r = r < a.M ? r : a.M - 1;                               // clamped: loads are unconditional, stores are masked
+      cp[q] = a.C + r * a.ldc + cc;
+      hp[q] = a.H + r * a.ldh + (h_on ? c - a.act_col0 : 0);
+    }
+    if (use_h) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) hv[q] = *(const f32x4_t*)hp[q];
+    }
+    if (use_c) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) cv[q] = *(const f32x4_t*)cp[q];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): before the first store
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int rl = (threadIdx.x >> 6) + 8 * q;
+      f32x4_t v = *(const f32x4_t*)(sC + (rl < ROWS ? rl : 0) * HG_LDC + cl);
+      if (!a.bwd) {
+        v += bias4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (a.act == T_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+          else if (a.act == T_ACT_ELU) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);            // F.elu, alpha = 1
+        }
+      } else {
+        if (use_c) v += cv[q];
+        if (h_on) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (a.act == T_ACT_RELU) v[e] = hv[q][e] > 0.f ? v[e] : 0.f;
+            else v[e] = hv[q][e] > 0.f ? v[e] : v[e] * (hv[q][e] + 1.f);                     // elu'(z) = elu(z) + 1 for z <= 0
+          }
+        }
+      }
+      const bool on = rl < ROWS && row0 + rl < a.M && col_on && !((PROBE & 2) && a.K != 12345);
+      if (on) {
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        *(f32x4_t*)cp[q] = v;
+      }
+    }
+  };
+
+  // ---- the pipeline.  Chunk q of this workgroup (tile q / chunks, chunk q % chunks of it) has its A planes in LDS buffer q & 1 and the weight
+  // fragments of its two steps in register sets 2 q & 3, (2 q + 1) & 3.  Distances, all in flight while MFMAs run:
+  //   A rows: requested two chunks ahead (right after the register set is freed in the middle of chunk q - 2), split and written to LDS in the
+  //           middle of chunk q - 1, behind that chunk's step-0 MFMAs; ONE barrier per chunk, after that write;
+  //   activation fragments: read from LDS one step ahead (step 0 of chunk q during step 1 of chunk q - 1, i.e. right behind the barrier);
+  //   weight fragments: requested three steps ahead into the set freed by the previous step.
+  // Why one barrier is enough: buffer (q + 1) & 1 is written in the middle of chunk q; its last readers issued their reads in step 0 of chunk
+  // q - 1, before they arrived at that chunk's barrier, which the writer has passed.  Unrolled by two chunks: every index is static.
+  f32x4_t stg0[PASSES], stg1[PASSES];
+  WFrag w0, w1, w2, w3;
+  XFrag x0, x1;
+  fetch_a(stg0);
+  fetch_a(stg1);
+  load_w(w0); load_w(w1); load_w(w2);
+  store_a(stg0, 0, 0);
+  fetch_a(stg0);                                               // chunk 2
+  __syncthreads();
+  read_x(x0, 0, 0);
+  int64_t q_row0 = (int64_t)blockIdx.x * ROWS;                 // first row of the tile chunk q belongs to
+  int q_kc = 0;
+  auto next_kc = [&](int kc) { return kc + 1 == chunks ? 0 : kc + 1; };
+  auto finish_chunk = [&] {                                     // after the MFMAs of chunk q: the tile's epilogue if that was its last chunk
+    if (q_kc + 1 == chunks) { epilogue(q_row0); q_row0 += (int64_t)gridDim.x * ROWS; q_kc = 0; }
+    else ++q_kc;
+  };
+  for (int q = 0; q < total; q += 2) {
+    // even chunk: A in buffer 0, weight sets 0, 1; chunk q + 1 is in stg1, chunk q + 2 on its way into stg0
+    read_x(x1, 0, 1);
+    load_w(w3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(w0, x0);
+    store_a(stg1, 1, next_kc(q_kc));
+    fetch_a(stg1);                                             // chunk q + 3
+    __syncthreads();
+    read_x(x0, 1, 0);
+    load_w(w0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(w1, x1);
+    finish_chunk();
+    if (q + 1 >= total) break;
+    // odd chunk: A in buffer 1, weight sets 2, 3
+    read_x(x1, 1, 1);
+    load_w(w1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(w2, x0);
+    store_a(stg0, 0, next_kc(q_kc));
+    fetch_a(stg0);                                             // chunk q + 4
+    __syncthreads();
+    read_x(x0, 0, 0);
+    load_w(w2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(w3, x1);
+    finish_chunk();
+  }
+  if (a.c_amax) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0 && amax > 0.f) atomicMax((unsigned int*)a.c_amax, __float_as_uint(amax));   // non-negative floats order like their bits
+  }
+}
+
+// Splits the fp32 parameters of every layer into the fp16 planes hgemm_kernel reads (fragment-major, hg_plane_index): forward orientation
+// [out padded][in padded] and backward orientation [in padded][out padded], hi and lo' each; the padding stays zero from the allocation.
+// One thread per weight.
+struct SplitLayer { size_t w; int in, out; size_t fwd, bwd; int ld_fwd, ld_bwd; size_t plane_fwd, plane_bwd; };   // offsets in floats (w) / halfs
+struct SplitArgs { SplitLayer l[26]; int n; const float* P; _Float16* planes; size_t total; };
+__global__ void split_weights_kernel(SplitArgs a) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.total; i += stride) {
+    int li = 0;
+    while (li + 1 < a.n && i >= a.l[li + 1].w) ++li;
+    const SplitLayer& L = a.l[li];
+    const size_t e = i - L.w;
+    if (e >= (size_t)L.in * L.out) continue;                   // bias / padding
+    const int o = (int)(e / L.in), k = (int)(e - (size_t)o * L.in);
+    const float x = a.P[i];
+    const _Float16 h = (_Float16)x, l = (_Float16)((x - (float)h) * HG_LO_SCALE);
+    const size_t f = L.fwd + hg_plane_index(o, k, L.ld_fwd), b = L.bwd + hg_plane_index(k, o, L.ld_bwd);
+    a.planes[f] = h; a.planes[f + L.plane_fwd] = l;
+    a.planes[b] = h; a.planes[b + L.plane_bwd] = l;
+  }
+}

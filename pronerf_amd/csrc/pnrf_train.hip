@@ -32,6 +32,9 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 
 enum { T_ACT_NONE = 0, T_ACT_RELU = 1, T_ACT_ELU = 2 };
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+}  // namespace
+namespace {
+#include "pnrf_hgemm.h"
 
 // ------------------------------------------------------------------------------------------ layer products with fused epilogues
 // The forward product Y = act(X W^T + b) and the input gradient dX = (dZ W [+ dX]) * act'(H_prev) of a Linear layer as ONE kernel each, on
@@ -66,6 +69,7 @@ struct GemmArgs {
   const float* H; int ldh;              // backward: saved output of that layer (act'(H)), applied to columns >= act_col0
   int act_col0;
   float beta;                           // backward: C = beta C + A B   (0 or 1)
+  float* c_amax;                        // device scalar, atomic max |C| (for a split-fp16 product that reads C next), or NULL
 };
 constexpr int TG_KC = 64;               // k per LDS chunk
 constexpr int TG_LDA = TG_KC + 4;       // LDS row stride of the A chunk (floats)
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
                     (MODE == MODE_NT || a.act == T_ACT_NONE || (a.ldh % 4 == 0 && (((uintptr_t)a.H) & 15) == 0 && a.act_col0 % 4 == 0));
   const bool use_h = MODE == MODE_NN && a.act != T_ACT_NONE, use_c = MODE == MODE_NN && a.beta != 0.f;
   constexpr int HROWS = ROWS / HALVES, HI = MI / HALVES;
+  float amax = 0.f;
 #pragma unroll
   for (int half = 0; half < HALVES; ++half) {
     if (wave_on) {
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
             if (a.act == T_ACT_RELU) v[e] = h[e] > 0.f ? v[e] : 0.f;
             else v[e] = h[e] > 0.f ? v[e] : v[e] * (h[e] + 1.f);                           // elu'(z) = exp(z) = elu(z) + 1 for z <= 0
           }
+          amax = fmaxf(amax, fabsf(v[e]));
         }
         *(f32x4_t*)dst = v;
       } else {
@@ -251,11 +257,17 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
               else x = h > 0.f ? x : x * (h + 1.f);
             }
           }
+          amax = fmaxf(amax, fabsf(x));
           dst[e] = x;
         }
       }
     }
     __syncthreads();
+  }
+  if (a.c_amax) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0 && amax > 0.f) atomicMax((unsigned int*)a.c_amax, __float_as_uint(amax));
   }
 }
 
@@ -825,9 +837,11 @@ struct StageArgs {
   const float *rays, *or_rays, *target, *jitter, *noise; const int64_t* ref_nos;
   float *d_rays, *d_or_rays, *d_target, *d_jitter, *d_noise; int64_t* d_ref_nos;
   int64_t n; int S;
+  float* amax; int n_amax;              // the iteration's max-|gradient| slots (hgemm_kernel operand scaling): cleared here
 };
 __global__ void stage_batch_kernel(StageArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t0 < a.n_amax) a.amax[t0] = 0.f;
   for (int64_t i = t0; i < a.n * 11; i += stride) { a.d_rays[i] = a.rays[i]; a.d_or_rays[i] = a.or_rays[i]; }
   for (int64_t i = t0; i < a.n * 3; i += stride) a.d_target[i] = a.target[i];
   for (int64_t i = t0; i < a.n * 4; i += stride) a.d_ref_nos[i] = a.ref_nos[i];
@@ -838,6 +852,7 @@ __global__ void stage_batch_kernel(StageArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ trainer object
+constexpr int N_AMAX = 64;
 struct TLin { int in, out; size_t w, b; };       // offsets into the flat parameter array
 
 struct pnrf_trainer {
@@ -875,6 +890,11 @@ struct pnrf_trainer {
   float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
   float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
       *d_h0, *d_h1, *dw_pool, *loss;
+  _Float16* planes = nullptr;                    // fp16 hi / lo planes of every layer's weights, both orientations (pnrf_hgemm.h)
+  SplitArgs split;
+  bool planes_stale = true;                      // parameters changed since the planes were last written
+  bool use_f16 = true;                           // split-fp16 layer products (default) or the exact-fp32 MFMA kernels throughout
+  float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
   size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
   DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
 };
@@ -968,9 +988,39 @@ int flush_dw_reduce(pnrf_trainer* t, hipStream_t s) {
   return 0;
 }
 
+int launch_hgemm(const HGemmArgs& a, hipStream_t s) {
+  const int tiles_n = (a.N + 255) / 256;
+  // 64-row tiles while they give every CU a workgroup, else 32 / 16 rows (the 4 096-row layers of the sampler / refine nets); one persistent
+  // workgroup per CU, each taking every G-th row tile
+  const int64_t t64 = (a.M + 63) / 64, t32 = (a.M + 31) / 32;
+  const int mi = t64 * tiles_n >= 256 ? 4 : (t32 * tiles_n >= 256 ? 2 : 1);
+  const int64_t ntiles = (a.M + 16 * mi - 1) / (16 * mi);
+  const int per_col = 256 / tiles_n > 0 ? 256 / tiles_n : 1;
+  const dim3 grid((unsigned)(ntiles < per_col ? ntiles : per_col), (unsigned)tiles_n);
+  if (mi == 4) hipLaunchKernelGGL((hgemm_kernel<4>), grid, dim3(512), 0, s, a);
+  else if (mi == 2) hipLaunchKernelGGL((hgemm_kernel<2>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((hgemm_kernel<1>), grid, dim3(512), 0, s, a);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+// which product kernel: the split-fp16 one wherever the tile shape fits (>= 64 output columns, a contraction of >= 32), the exact-fp32 one
+// for the narrow heads and, in the backward pass, for gradients whose magnitude nobody recorded
+inline bool hgemm_fits(const pnrf_trainer* t, int n, int k, int64_t rows, int ld, const float* C, int ldc, const float* H, int ldh, int act_col0) {
+  // the kernel addresses its row operand with 32-bit byte offsets and reads / writes C, H, bias as aligned float4
+  return t->use_f16 && n >= 64 && k >= 32 && rows * (int64_t)ld * 4 < ((int64_t)1 << 32) && n % 4 == 0 && ldc % 4 == 0 && aligned16(C) &&
+         (!H || (ldh % 4 == 0 && aligned16(H) && act_col0 % 4 == 0));
+}
+
 // Y = act(X W^T + b): one kernel
 int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, hipStream_t s) {
   const TLin& l = t->L[li];
+  if (hgemm_fits(t, l.out, l.in, R, ldx, Y, ldy, nullptr, 0, 0) && aligned16(t->P + l.b)) {
+    const SplitLayer& sl = t->split.l[li];
+    HGemmArgs h = {};
+    h.A = X; h.lda = ldx; h.Bh = t->planes + sl.fwd; h.Bl = h.Bh + sl.plane_fwd; h.ldb = sl.ld_fwd; h.n_pad = (l.out + 63) / 64 * 64;
+    h.C = Y; h.ldc = ldy; h.M = R; h.N = l.out; h.K = l.in; h.bwd = 0; h.bias = t->P + l.b; h.act = act;
+    return launch_hgemm(h, s);
+  }
   GemmArgs a = {};
   a.A = X; a.lda = ldx; a.B = t->P + l.w; a.ldb = l.in; a.C = Y; a.ldc = ldy; a.M = R; a.N = l.out; a.K = l.in;
   a.bias = t->P + l.b; a.act = act;
@@ -979,17 +1029,25 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
 // dZ (row stride ldz) = dL/dZ of layer li (its activation derivative was applied by whoever produced it); X = the layer's saved input.
 // Accumulates the weight / bias gradients and, unless dX == nullptr, writes dX = (beta dX + dZ W) * act'(Hprev) — Hprev = saved output of
 // the layer (activation prev_act) that produced the columns >= act_col0 of X — i.e. dL/dZ of that layer, ready for its own layer_bwd.
-int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* X, int ldx, float* dX, int lddx, float beta, int64_t R, int prev_act,
-              const float* Hprev, int ldh, int act_col0, hipStream_t s) {
+// dz_amax: device scalar holding max |dZ| (left there by the product that wrote dZ) or NULL if unknown; dx_amax: where to leave max |dX|.
+int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz_amax, const float* X, int ldx, float* dX, int lddx, float* dx_amax,
+              float beta, int64_t R, int prev_act, const float* Hprev, int ldh, int act_col0, hipStream_t s) {
   const TLin& l = t->L[li];
   int rc = gemm_dw(t, X, ldx, dZ, ldz, t->G + l.w, t->G + l.b, l.in, l.out, R, s);
   if (rc || !dX) return rc;
+  if (dz_amax && hgemm_fits(t, l.in, l.out, R, ldz, dX, lddx, prev_act != T_ACT_NONE ? Hprev : nullptr, ldh, act_col0)) {
+    const SplitLayer& sl = t->split.l[li];
+    HGemmArgs h = {};
+    h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd; h.n_pad = (l.in + 63) / 64 * 64;
+    h.C = dX; h.ldc = lddx; h.M = R; h.N = l.in; h.K = l.out; h.bwd = 1;
+    h.act = prev_act; h.H = Hprev; h.ldh = ldh; h.act_col0 = act_col0; h.beta = beta; h.a_amax = dz_amax; h.c_amax = dx_amax;
+    return launch_hgemm(h, s);
+  }
   GemmArgs a = {};
   a.A = dZ; a.lda = ldz; a.B = t->P + l.w; a.ldb = l.in; a.C = dX; a.ldc = lddx; a.M = R; a.N = l.in; a.K = l.out;
-  a.act = prev_act; a.H = Hprev; a.ldh = ldh; a.act_col0 = act_col0; a.beta = beta;
+  a.act = prev_act; a.H = Hprev; a.ldh = ldh; a.act_col0 = act_col0; a.beta = beta; a.c_amax = dx_amax;
   return launch_tgemm<MODE_NN>(a, s);
 }
-
 constexpr int L_S = 0, L_R = 7, L_N = 14, L_FEAT = 22, L_ALPHA = 23, L_VIEWS = 24, L_RGB = 25, N_LAYERS = 26;
 
 }  // namespace
@@ -1103,6 +1161,26 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     PNRF_HIP(hipMemcpy(t->P + t->L[i].w, W[i], (size_t)t->L[i].in * t->L[i].out * 4, hipMemcpyDefault));
     PNRF_HIP(hipMemcpy(t->P + t->L[i].b, b[i], (size_t)t->L[i].out * 4, hipMemcpyDefault));
   }
+  {   // fp16 planes of the weights for the split-fp16 products: per layer [out64][in64] (forward) and [in64][out64] (backward), hi and lo each
+    size_t halfs = 0;
+    memset(&t->split, 0, sizeof(t->split));
+    for (int i = 0; i < N_LAYERS; ++i) {
+      const TLin& l = t->L[i];
+      SplitLayer& sl = t->split.l[i];
+      const int in64 = (l.in + 63) / 64 * 64, out64 = (l.out + 63) / 64 * 64;
+      sl.w = l.w; sl.in = l.in; sl.out = l.out;
+      sl.ld_fwd = in64; sl.ld_bwd = out64;
+      sl.plane_fwd = sl.plane_bwd = (size_t)in64 * out64;
+      sl.fwd = halfs; halfs += 2 * sl.plane_fwd;
+      sl.bwd = halfs; halfs += 2 * sl.plane_bwd;
+    }
+    T_ALLOC(t->planes, halfs);
+    PNRF_HIP(hipMemset(t->planes, 0, halfs * sizeof(_Float16)));
+    t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam;
+    t->planes_stale = true;
+    T_ALLOC(t->amax, N_AMAX);
+    PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * 4));
+  }
   const int64_t N = max_rays, R = (int64_t)max_samples * max_rays;
   T_ALLOC(t->mm_input, N * 288);
   for (int k = 0; k < 6; ++k) { T_ALLOC(t->s_h[k], N * 256); T_ALLOC(t->r_h[k], N * 256); }
@@ -1171,6 +1249,7 @@ extern "C" int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const 
   if (W) PNRF_HIP(hipMemcpyAsync(base + l.w, W, (size_t)l.in * l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
   if (b) PNRF_HIP(hipMemcpyAsync(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
   PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (kind == 0) t->planes_stale = true;
   return 0;
 }
 // Device address and element count of one of the flat arrays (kind as pnrf_trainer_read) — e.g. to all-reduce the gradients of
@@ -1179,6 +1258,7 @@ extern "C" int pnrf_trainer_flat(pnrf_trainer_t* t, int kind, float** ptr, int64
   PNRF_REQUIRE(t && ptr && count && kind >= 0 && kind <= 5, PNRF_E_ARG, "pnrf_trainer_flat: bad arguments");
   *ptr = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   *count = (int64_t)t->nparam;
+  if (kind == 0) t->planes_stale = true;        // the caller may write the parameters through this pointer (before the next iteration is submitted)
   return 0;
 }
 
@@ -1211,6 +1291,7 @@ extern "C" int pnrf_trainer_adam_step(pnrf_trainer_t* t, int which, float lr, fl
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(TPB), 0, (hipStream_t)stream, t->P + first, t->G + first, (which == 0 ? t->M : t->M2) + first,
                      (which == 0 ? t->V : t->V2) + first, count, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   PNRF_LAUNCH_CHECK();
+  t->planes_stale = true;
   return 0;
 }
 
@@ -1266,21 +1347,24 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
 // dL/dZ of its layer: the input-gradient product of the layer above applied the activation derivative in its epilogue.
 int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   const float* none = nullptr;
+  constexpr int slot0 = 0;
   // rgb head: d_raw[:, 0:3] -> d_hv (x relu'(n_hv): the views layer) ; views layer -> d_cv = [d feature | d view embedding] (no activation) ;
   // feature -> d_a ; alpha: d_raw[:, 3] -> d_a += ..., then x relu'(n_a7)
-  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, t->n_hv, 128, t->d_hv, 128, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
-  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, t->n_cv, 283, t->d_cv, 283, 0.f, R, T_ACT_NONE, none, 0, 0, s));
-  T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, t->n_a7, 256, t->d_a, 256, 0.f, R, T_ACT_NONE, none, 0, 0, s));
-  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, t->n_a7, 256, t->d_a, 256, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, t->n_a6, 256, t->d_b, 256, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, t->n_a5, 256, t->d_a, 256, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
+  // one max-|gradient| slot per gradient buffer write (the two products that add up d_a share one)
+  float* m = t->amax + slot0;
+  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
+  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0, t->n_cv, 283, t->d_cv, 283, m + 1, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, m + 1, t->n_a7, 256, t->d_a, 256, m + 2, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, t->d_a, 256, m + 2, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, m + 2, t->n_a6, 256, t->d_b, 256, m + 3, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, m + 3, t->n_a5, 256, t->d_a, 256, m + 4, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
   // layer 5 reads cat[embedding(63), h4(256)]: the activation derivative of layer 4 applies to the columns from 63 on
-  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, t->n_c5, 319, t->d_c5, 319, 0.f, R, T_ACT_RELU, t->n_c5 + 63, 319, 63, s));
-  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + 63, 319, t->n_a[3], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, t->n_a[2], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, t->n_a[1], 256, t->d_a, 256, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, t->n_a[0], 256, t->d_b, 256, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4, t->n_c5, 319, t->d_c5, 319, m + 5, 0.f, R, T_ACT_RELU, t->n_c5 + 63, 319, 63, s));
+  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + 63, 319, m + 5, t->n_a[3], 256, t->d_a, 256, m + 6, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6, t->n_a[2], 256, t->d_b, 256, m + 7, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7, t->n_a[1], 256, t->d_a, 256, m + 8, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, m + 8, t->n_a[0], 256, t->d_b, 256, m + 9, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   if (want_dpts) {
     hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, 319, t->d_pts, R, 10);
     PNRF_LAUNCH_CHECK();
@@ -1291,13 +1375,15 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
 // output-layer gradient dy [N, out_last] -> gradients of a 7-layer ELU net (sampler: first = L_S, refine: first = L_R); no gradient reaches the
 // net's input (the Pluecker moment is depth-independent; the projection is under no_grad in the reference)
 int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, float* const* h, const float* x0, int in0, int64_t N, hipStream_t s) {
-  T_RC(layer_bwd(t, first + 6, dy, out_last, h[5], 256, t->d_h0, 256, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
+  float* m = t->amax + (first == L_S ? 16 : 24);                // max-|gradient| slots of this net's six hidden gradients
+  T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, t->d_h0, 256, m, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
   float* dA = t->d_h0; float* dB = t->d_h1;
   for (int k = 5; k >= 1; --k) {
-    T_RC(layer_bwd(t, first + k, dA, 256, h[k - 1], 256, dB, 256, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
+    T_RC(layer_bwd(t, first + k, dA, 256, m, h[k - 1], 256, dB, 256, m + 1, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
     float* tmp = dA; dA = dB; dB = tmp;
+    ++m;
   }
-  return layer_bwd(t, first + 0, dA, 256, x0, in0, nullptr, 0, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
+  return layer_bwd(t, first + 0, dA, 256, m, x0, in0, nullptr, 0, nullptr, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
 }
 
 int check_batch(const pnrf_trainer* t, const pnrf_train_batch_t* bt, const float* loss, int S, const char* who) {
@@ -1386,8 +1472,13 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     PNRF_HIP(hipEventRecord(t->ev_in, caller));
     PNRF_HIP(hipStreamWaitEvent(s, t->ev_in, 0));
   }
+  if (t->planes_stale && t->use_f16) {
+    hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, s, t->split);
+    PNRF_LAUNCH_CHECK();
+    t->planes_stale = false;
+  }
   StageArgs sa = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
-                  t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S};
+                  t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S, t->amax, N_AMAX};
   hipLaunchKernelGGL(stage_batch_kernel, dim3(grid_for(N * 11)), dim3(TPB), 0, s, sa);
   PNRF_LAUNCH_CHECK();
   pnrf_train_batch_t b = *bt;
@@ -1448,6 +1539,15 @@ extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_ba
   hipStream_t s = (hipStream_t)stream;
   return run_iteration(t, bt, 1, n_mult, dir1, S, loss, rgb_out, s,
                        [&](const pnrf_train_batch_t* b, hipStream_t st) { return explore_body(t, b, n_mult, dir1, st); });
+}
+
+// How the layer products are computed.  0 (default): split-fp16 MFMA (pnrf_hgemm.h: fp32-grade, 22 significand bits per operand, fp32
+// accumulation) wherever the shape fits; 1: exact-fp32 MFMA everywhere.
+extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
+  PNRF_REQUIRE(t && (kind == 0 || kind == 1), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16) or 1 (fp32)");
+  t->use_f16 = kind == 0;
+  if (t->use_f16) t->planes_stale = true;
+  return 0;
 }
 
 // 1: replay every iteration as a hipGraph; 0 (default): launch its kernels one by one

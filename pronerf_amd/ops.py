@@ -515,6 +515,11 @@ class Trainer:
         """Replay the iterations as hipGraphs, or (default) launch their kernels one by one (pnrf_trainer_set_graph)."""
         check(_lib.load().pnrf_trainer_set_graph(self.handle, int(bool(enable))), 'pnrf_trainer_set_graph')
 
+    def set_products(self, kind):
+        """'f16x2' (default): split-fp16 MFMA layer products (fp32-grade); 'f32': exact-fp32 MFMA products (pnrf_trainer_set_products)."""
+        k = {'f16x2': 0, 'f32': 1}[kind]
+        check(_lib.load().pnrf_trainer_set_products(self.handle, k), 'pnrf_trainer_set_products')
+
     def set_step(self, step, step_nerf=0):
         check(_lib.load().pnrf_trainer_set_step(self.handle, int(step), int(step_nerf)), 'pnrf_trainer_set_step')
 
