@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
   const int cl = 4 * (threadIdx.x & 63), c = tn * 256 + cl;
   const bool col_on = c < a.N;
   const int cc = col_on ? c : 0;
-  const bool h_on = use_h && c >= a.act_col0;
+  const bool h_on = use_h && col_on && c >= a.act_col0;         // (columns past N must not form an address: the loads are unconditional)
   float amax = 0.f;
   f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
   if (!a.bwd && a.bias) bias4 = *(const f32x4_t*)(a.bias + cc);
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
 // Splits the fp32 parameters of every layer into the fp16 planes hgemm_kernel reads (fragment-major, hg_plane_index): forward orientation
 // [out padded][in padded] and backward orientation [in padded][out padded], hi and lo' each; the padding stays zero from the allocation.
 // One thread per weight.
-struct SplitLayer { size_t w; int in, out; size_t fwd, bwd; int ld_fwd, ld_bwd; size_t plane_fwd, plane_bwd; };   // offsets in floats (w) / halfs
-struct SplitArgs { SplitLayer l[26]; int n; const float* P; _Float16* planes; size_t total; };
+struct SplitLayer { size_t w; int in, out, gap; size_t fwd, bwd; int ld_fwd, ld_bwd; size_t plane_fwd, plane_bwd; };   // offsets in floats (w) / halfs
+struct SplitArgs { SplitLayer l[26]; int n; const float* P; _Float16* planes; size_t total; float* gapped; };
 __global__ void split_weights_kernel(SplitArgs a) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.total; i += stride) {
@@ -340,11 +340,172 @@ __global__ void split_weights_kernel(SplitArgs a) {
     const SplitLayer& L = a.l[li];
     const size_t e = i - L.w;
     if (e >= (size_t)L.in * L.out) continue;                   // bias / padding
-    const int o = (int)(e / L.in), k = (int)(e - (size_t)o * L.in);
+    const int o = (int)(e / L.in);
+    int k = (int)(e - (size_t)o * L.in);
     const float x = a.P[i];
+    if (L.gap >= 0) {                                          // the layer's input rows carry a zero column at `gap`: input index k sits one further
+      if (k >= L.gap) ++k;
+      a.gapped[(size_t)o * (L.in + 1) + k] = x;                // fp32 copy in that layout for the exact-fp32 kernels
+    }
     const _Float16 h = (_Float16)x, l = (_Float16)((x - (float)h) * HG_LO_SCALE);
     const size_t f = L.fwd + hg_plane_index(o, k, L.ld_fwd), b = L.bwd + hg_plane_index(k, o, L.ld_bwd);
     a.planes[f] = h; a.planes[f + L.plane_fwd] = l;
     a.planes[b] = h; a.planes[b + L.plane_bwd] = l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient, split fp16
+// dW[out, in] = dZ^T X over R rows as split-K partials, on the same split-fp16 arithmetic: both operands are activations here (dZ scaled by
+// the power of two from its recorded maximum), the contraction runs over rows, so both MFMA operands need 8 consecutive ROWS of one column per
+// lane — a transposition of the row-major inputs.  It happens in registers on the way to LDS: a thread fetches the same four columns of four
+// consecutive rows (each fetch instruction of a wave still reads whole 512-byte row segments), splits them, and writes one 8-byte column
+// piece per column and plane; LDS holds [column][32 rows + 8] fp16 (column stride 80 bytes: the fragment reads of 16 columns cover all banks
+// once).
+// Workgroup = 8 waves on a 128 x 128 output tile (wave: 64 out x 32 in = 4 x 2 MFMA tiles, two accumulators each) over its split's rows in
+// 32-row chunks (one MFMA step), fetched two chunks ahead, LDS double buffered, one barrier per chunk; blockIdx.y = split.  The loaders' column
+// sums of dZ are the bias-gradient partials, as in dw_splitk_kernel.
+struct DwhArgs {
+  const float* dZ; int ldz; const float* X; int ldx;
+  float* part; float* db_part;
+  int out, in; int64_t R, rows_per;
+  const float* dz_amax;                        // device scalar max |dZ| or NULL
+};
+constexpr int DH_KC = 32, DH_COL = DH_KC + 8;  // rows per chunk; halfs per column in LDS
+__global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
+  constexpr int PLANE = 128 * DH_COL;          // halfs
+  __shared__ __attribute__((aligned(16))) _Float16 sm[2 * 2 * 2 * PLANE];      // [buffer][operand dZ / X][plane hi / lo][column][row]
+  const int tiles_n = (a.in + 127) / 128;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int64_t r_begin = blockIdx.y * a.rows_per;
+  const int64_t r_end = r_begin + a.rows_per < a.R ? r_begin + a.rows_per : a.R;
+  const int chunks = (int)((r_end - r_begin + DH_KC - 1) / DH_KC);
+  const float z_scale = a.dz_amax ? hg_scale_for(*a.dz_amax) : 1.f;
+
+  f32x4_t accm[4][2], accx[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { accm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  // ---- loader: thread -> operand op, rows 4 rg .. 4 rg + 3 of the chunk, columns 4 cq .. 4 cq + 3 of the tile
+  const int op = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));     // uniform per wave: the buffer resource below must live in scalar registers
+  const int rg = (threadIdx.x >> 5) & 7, cq = threadIdx.x & 31;
+  const float* src = op == 0 ? a.dZ : a.X;
+  const int ld = op == 0 ? a.ldz : a.ldx, width = op == 0 ? a.out : a.in;
+  const int col = (op == 0 ? tm : tn) * 128 + 4 * cq;
+  const float scale = op == 0 ? z_scale : 1.f;
+  const int64_t span = ((r_end - r_begin - 1) * (int64_t)ld + width) * 4;                 // bytes of this split's rows: past them the fetches return zeros
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(src + r_begin * ld), 0, (int)(unsigned)(span < 0xffffffffll ? span : 0xffffffffll), HG_BUF_FLAGS);
+  const unsigned voff = (unsigned)((4 * rg * ld + col) * 4);                              // the thread's first row; rows + 1 .. + 3 through the scalar offset
+  const unsigned chunk_bytes = (unsigned)(DH_KC * ld * 4), row_bytes = (unsigned)(ld * 4);
+  bool col_on[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) col_on[e] = col + e < width;
+  auto fetch = [&](f32x4_t (&st)[4], int kc) {
+    const unsigned soff = kc < chunks ? (unsigned)kc * chunk_bytes : 0xffff0000u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + k * row_bytes, 0));
+  };
+  f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
+  // 4-row pieces of a column are stored at position rg ^ 2 ((column >> 4) & 3): the 32 lanes that write the same rows of 32 column quads then
+  // spread over 16 bank pairs instead of 4 (an even swizzle: the two pieces of a fragment's 16 bytes stay adjacent and in order)
+  const int sm_off = 4 * cq * DH_COL + 4 * (rg ^ (2 * ((cq >> 2) & 3)));
+  auto store = [&](const f32x4_t (&st)[4], int buf) {
+    _Float16* hi = sm + ((buf * 2 + op) * 2) * PLANE + sm_off;
+    _Float16* lo = hi + PLANE;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f16x4_t h, l;
+      float cs = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float raw = col_on[e] ? st[k][e] : 0.f;
+        cs += raw;
+        const float x = raw * scale;
+        const _Float16 xh = (_Float16)x;
+        h[k] = xh;
+        l[k] = (_Float16)((x - (float)xh) * HG_LO_SCALE);
+      }
+      colsum[e] += cs;
+      *(f16x4_t*)(hi + e * DH_COL) = h;
+      *(f16x4_t*)(lo + e * DH_COL) = l;
+    }
+  };
+  // fragment of 16 consecutive columns starting at a multiple of 16: all share the swizzle; rows 8 g .. 8 g + 7 = pieces 2 g, 2 g + 1
+  auto frag_off = [&](int col0) { return (col0 + c16) * DH_COL + 8 * (g ^ ((col0 >> 4) & 3)); };
+  auto mma_chunk = [&](int buf) {
+    const _Float16* zh = sm + ((buf * 2 + 0) * 2) * PLANE;
+    const _Float16* zl = zh + PLANE;
+    const _Float16* xh = sm + ((buf * 2 + 1) * 2) * PLANE;
+    const _Float16* xl = xh + PLANE;
+    f16x8_t ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int o = frag_off(wm * 64 + 16 * i); ah[i] = *(const f16x8_t*)(zh + o); al[i] = *(const f16x8_t*)(zl + o); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int o = frag_off(wn * 32 + 16 * j); bh[j] = *(const f16x8_t*)(xh + o); bl[j] = *(const f16x8_t*)(xl + o); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // chunk q in LDS buffer q & 1; chunk q + 1 in one register set, chunk q + 2 on its way into the other (cf. hgemm_kernel)
+  f32x4_t stg0[4], stg1[4];
+  fetch(stg0, 0);
+  fetch(stg1, 1);
+  store(stg0, 0);
+  fetch(stg0, 2);
+  __syncthreads();
+  for (int q = 0; q < chunks; q += 2) {
+    mma_chunk(0);
+    store(stg1, 1);                                            // past the last chunk: zeros
+    fetch(stg1, q + 3);
+    __syncthreads();
+    if (q + 1 >= chunks) break;
+    mma_chunk(1);
+    store(stg0, 0);
+    fetch(stg0, q + 4);
+    __syncthreads();
+  }
+
+  // ---- partial tile: D register e of lane (c16, g) = dW[out 4 g + e][in c16] of its MFMA tile
+  const float inv = HG_LO_INV, unscale = 1.f / z_scale;
+  float* p = a.part + (size_t)blockIdx.y * a.out * a.in;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = tm * 128 + wm * 64 + 16 * i + 4 * g + e, n = tn * 128 + wn * 32 + 16 * j + c16;
+        if (m < a.out && n < a.in) p[(size_t)m * a.in + n] = (accm[i][j][e] + accx[i][j][e] * inv) * unscale;
+      }
+  if (a.db_part && tn == 0) {
+    __syncthreads();                                           // every wave is done reading the staging buffers
+    float* red = (float*)sm;                                   // [8 row groups][128 columns]
+    if (op == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[rg * 128 + 4 * cq + e] = colsum[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128 && tm * 128 + (int)threadIdx.x < a.out) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r * 128 + threadIdx.x];
+      a.db_part[(size_t)blockIdx.y * a.out + tm * 128 + threadIdx.x] = sum;
+    }
   }
 }

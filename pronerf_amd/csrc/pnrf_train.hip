@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256) void dw_splitk128_kernel(const float* __restri
 // of them sum dW, the rest the bias gradient's column-sum partials that the weight-gradient kernels' loaders produce on the way.
 struct DwJob {
   const float* part; const float* db_part; float* dW; float* db;
-  int numel, splits, out, block0, blocks, db_blocks;
+  int numel, splits, out, block0, blocks, db_blocks;   // numel = out x in_src: elements of one partial
+  int in_src, in_dst, gap;                             // partial rows have in_src columns; column `gap` of them (if >= 0) is not part of dW
 };
 constexpr int DW_MAX_JOBS = 32;
 struct DwJobs { DwJob j[DW_MAX_JOBS]; int n; };
@@ -473,7 +474,9 @@ __global__ void dw_reduce_kernel(const DwJobs jobs) {
   for (int i = b * (int)blockDim.x + (int)threadIdx.x; i < J.numel; i += dw_blocks * (int)blockDim.x) {
     float s = 0.f;
     for (int q = 0; q < J.splits; ++q) s += J.part[(size_t)q * J.numel + i];
-    J.dW[i] = s;
+    if (J.gap < 0) { J.dW[i] = s; continue; }
+    const int o = i / J.in_src, c = i - o * J.in_src;
+    if (c != J.gap) J.dW[o * J.in_dst + (c < J.gap ? c : c - 1)] = s;
   }
 }
 
@@ -853,7 +856,13 @@ __global__ void stage_batch_kernel(StageArgs a) {
 
 // ------------------------------------------------------------------------------------------ trainer object
 constexpr int N_AMAX = 64;
-struct TLin { int in, out; size_t w, b; };       // offsets into the flat parameter array
+struct TLin {
+  int in, out; size_t w, b;                      // offsets into the flat parameter array
+  int gap = -1;                                  // >= 0: the layer's input buffer has one extra (zero) column at this index (the skip layer reads
+  int in_x() const { return gap >= 0 ? in + 1 : in; }   // cat[embedding 63, pad, h 256]: the hidden part then starts 16-byte aligned)
+};
+constexpr int LD_C5 = 320, C5_H = 64;            // skip-layer input / gradient rows: [embedding 63 | 0 | h 256]
+constexpr int LD_CV = 288;                       // views-layer input / gradient rows: [feature 256 | view embedding 27 | 5 x 0]
 
 struct pnrf_trainer {
   int device = 0;
@@ -890,6 +899,7 @@ struct pnrf_trainer {
   float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
   float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
       *d_h0, *d_h1, *dw_pool, *loss;
+  float* w_gapped = nullptr;                     // fp32 copy [out][in + 1] of the skip layer's weights with the zero column of its input layout
   _Float16* planes = nullptr;                    // fp16 hi / lo planes of every layer's weights, both orientations (pnrf_hgemm.h)
   SplitArgs split;
   bool planes_stale = true;                      // parameters changed since the planes were last written
@@ -932,19 +942,35 @@ int launch_tgemm(const GemmArgs& a, hipStream_t s) {
 
 // dW[out,in] = dZ^T X and db[out] = column sums of dZ: dw_splitk*_kernel writes the split-K partials into a fresh slice of the pool and
 // queues their summation; flush_dw_reduce() at the end of the backward pass does all of them in one launch.
-int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, float* dW, float* db, int in, int out, int64_t R, hipStream_t s) {
+// `in` counts the columns of X; with gap >= 0 column `gap` of X is padding and dW has in - 1 columns
+int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, const float* dz_amax, float* dW, float* db, int in, int gap, int out,
+            int64_t R, hipStream_t s) {
   PNRF_REQUIRE(out <= DB_MAX_OUT, PNRF_E_SHAPE, "pnrf_trainer: layer output %d wider than the bias-partial buffer (%d)", out, DB_MAX_OUT);
   PNRF_REQUIRE(t->jobs.n < DW_MAX_JOBS, PNRF_E_STATE, "pnrf_trainer: more than %d weight gradients in one iteration", DW_MAX_JOBS);
   const int numel = out * in;
   const bool can128 = out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldz % 4 == 0 && aligned16(X) && aligned16(dZ);
-  const bool use128 = can128 && t->dw_tile != 64 && R >= t->dw128_min_rows;
+  // split-fp16 kernel (128 x 128 tiles, 64-row chunks) wherever the gradient's magnitude is on record and the output is not a narrow head
+  const bool use_h = t->use_f16 && dz_amax && out >= 64 && in >= 32 && t->dw_tile == 0;
+  const bool use128 = !use_h && can128 && t->dw_tile != 64 && R >= t->dw128_min_rows;
+  const int max_splits = (out % 128 == 0 && in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;   // what the pool was sized for
   int tiles;
   int64_t splits, rows_per;
-  if (use128) {
+  // the partials are written and then read again by the reduction: hold them to a quarter of the operand bytes (26 layers x 64 .. 128 splits
+  // were 1 GB per iteration, the reduction kernel alone 0.22 ms of 2.5)
+  const int64_t by_traffic = R * (in + out) / (4 * (int64_t)numel) > 1 ? R * (in + out) / (4 * (int64_t)numel) : 1;
+  if (use_h) {
+    tiles = ((out + 127) / 128) * ((in + 127) / 128);
+    splits = (256 + tiles - 1) / tiles;                         // one workgroup per CU ...
+    if (splits > by_traffic) splits = by_traffic;               // ... unless the partials would outweigh the operands
+    const int64_t by_rows = (R + DH_KC - 1) / DH_KC;
+    if (splits > by_rows) splits = by_rows;
+    if (splits > max_splits) splits = max_splits;
+  } else if (use128) {
     tiles = (out / 128) * (in / 128);
     splits = (512 + tiles - 1) / tiles;                         // two workgroups per CU
     const int64_t by_rows = R / 256;
     if (splits > by_rows) splits = by_rows;
+    if (splits > by_traffic) splits = by_traffic;
     if (splits > DW128_MAX_SPLITS) splits = DW128_MAX_SPLITS;
   } else {
     tiles = ((out + DW_TILE - 1) / DW_TILE) * ((in + DW_TILE - 1) / DW_TILE);
@@ -952,10 +978,11 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
     splits = (1024 + tiles - 1) / tiles;
     const int64_t by_rows = (R + 127) / 128;
     if (splits > by_rows) splits = by_rows;
+    if (splits > 2 * by_traffic) splits = 2 * by_traffic;       // (64 x 64 tiles: four times the workgroups per split)
     if (splits > DW_MAX_SPLITS) splits = DW_MAX_SPLITS;
   }
   if (splits < 1) splits = 1;
-  const int rows_q = use128 ? DW128_ROWS : DW_ROWS;
+  const int rows_q = use_h ? DH_KC : (use128 ? DW128_ROWS : DW_ROWS);
   rows_per = (R + splits - 1) / splits;
   rows_per = (rows_per + rows_q - 1) / rows_q * rows_q;
   splits = (R + rows_per - 1) / rows_per;
@@ -965,13 +992,17 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   float* part = t->dw_pool + t->pool_used;
   float* db_part = part + (size_t)splits * numel;
   t->pool_used += (need + 3) & ~(size_t)3;                      // slices stay 16-byte aligned
-  if (use128)
+  if (use_h) {
+    DwhArgs h = {dZ, ldz, X, ldx, part, db_part, out, in, R, rows_per, dz_amax};
+    hipLaunchKernelGGL(dwh_kernel, dim3(tiles, (unsigned)splits), dim3(512), 0, s, h);
+  } else if (use128)
     hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, part, out, in, R, rows_per, db_part);
   else
     hipLaunchKernelGGL(dw_splitk_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, part, out, in, R, rows_per, db_part);
   PNRF_LAUNCH_CHECK();
   DwJob& J = t->jobs.j[t->jobs.n];
   J.part = part; J.db_part = db_part; J.dW = dW; J.db = db; J.numel = numel; J.splits = (int)splits; J.out = out;
+  J.in_src = in; J.in_dst = gap >= 0 ? in - 1 : in; J.gap = gap;
   J.db_blocks = (out + TPB - 1) / TPB;
   J.blocks = grid_for(numel) + J.db_blocks;
   J.block0 = t->jobs.n ? t->jobs.j[t->jobs.n - 1].block0 + t->jobs.j[t->jobs.n - 1].blocks : 0;
@@ -1014,15 +1045,16 @@ inline bool hgemm_fits(const pnrf_trainer* t, int n, int k, int64_t rows, int ld
 // Y = act(X W^T + b): one kernel
 int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, hipStream_t s) {
   const TLin& l = t->L[li];
-  if (hgemm_fits(t, l.out, l.in, R, ldx, Y, ldy, nullptr, 0, 0) && aligned16(t->P + l.b)) {
+  const int K = l.in_x();
+  if (hgemm_fits(t, l.out, K, R, ldx, Y, ldy, nullptr, 0, 0) && aligned16(t->P + l.b)) {
     const SplitLayer& sl = t->split.l[li];
     HGemmArgs h = {};
     h.A = X; h.lda = ldx; h.Bh = t->planes + sl.fwd; h.Bl = h.Bh + sl.plane_fwd; h.ldb = sl.ld_fwd; h.n_pad = (l.out + 63) / 64 * 64;
-    h.C = Y; h.ldc = ldy; h.M = R; h.N = l.out; h.K = l.in; h.bwd = 0; h.bias = t->P + l.b; h.act = act;
+    h.C = Y; h.ldc = ldy; h.M = R; h.N = l.out; h.K = K; h.bwd = 0; h.bias = t->P + l.b; h.act = act;
     return launch_hgemm(h, s);
   }
   GemmArgs a = {};
-  a.A = X; a.lda = ldx; a.B = t->P + l.w; a.ldb = l.in; a.C = Y; a.ldc = ldy; a.M = R; a.N = l.out; a.K = l.in;
+  a.A = X; a.lda = ldx; a.B = l.gap >= 0 ? t->w_gapped : t->P + l.w; a.ldb = K; a.C = Y; a.ldc = ldy; a.M = R; a.N = l.out; a.K = K;
   a.bias = t->P + l.b; a.act = act;
   return launch_tgemm<MODE_NT>(a, s);
 }
@@ -1033,18 +1065,20 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
 int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz_amax, const float* X, int ldx, float* dX, int lddx, float* dx_amax,
               float beta, int64_t R, int prev_act, const float* Hprev, int ldh, int act_col0, hipStream_t s) {
   const TLin& l = t->L[li];
-  int rc = gemm_dw(t, X, ldx, dZ, ldz, t->G + l.w, t->G + l.b, l.in, l.out, R, s);
+  int rc = gemm_dw(t, X, ldx, dZ, ldz, dz_amax, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s);
   if (rc || !dX) return rc;
-  if (dz_amax && hgemm_fits(t, l.in, l.out, R, ldz, dX, lddx, prev_act != T_ACT_NONE ? Hprev : nullptr, ldh, act_col0)) {
+  const int N = l.in_x();
+  const int N4 = (N + 3) & ~3;                                  // the split-fp16 kernel stores whole float4s: the row padding of dX takes the rest (zeros)
+  if (dz_amax && N4 <= lddx && hgemm_fits(t, N4, l.out, R, ldz, dX, lddx, prev_act != T_ACT_NONE ? Hprev : nullptr, ldh, act_col0)) {
     const SplitLayer& sl = t->split.l[li];
     HGemmArgs h = {};
-    h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd; h.n_pad = (l.in + 63) / 64 * 64;
-    h.C = dX; h.ldc = lddx; h.M = R; h.N = l.in; h.K = l.out; h.bwd = 1;
+    h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd; h.n_pad = (N + 63) / 64 * 64;
+    h.C = dX; h.ldc = lddx; h.M = R; h.N = N4; h.K = l.out; h.bwd = 1;
     h.act = prev_act; h.H = Hprev; h.ldh = ldh; h.act_col0 = act_col0; h.beta = beta; h.a_amax = dz_amax; h.c_amax = dx_amax;
     return launch_hgemm(h, s);
   }
   GemmArgs a = {};
-  a.A = dZ; a.lda = ldz; a.B = t->P + l.w; a.ldb = l.in; a.C = dX; a.ldc = lddx; a.M = R; a.N = l.in; a.K = l.out;
+  a.A = dZ; a.lda = ldz; a.B = l.gap >= 0 ? t->w_gapped : t->P + l.w; a.ldb = N; a.C = dX; a.ldc = lddx; a.M = R; a.N = N; a.K = l.out;
   a.act = prev_act; a.H = Hprev; a.ldh = ldh; a.act_col0 = act_col0; a.beta = beta; a.c_amax = dx_amax;
   return launch_tgemm<MODE_NN>(a, s);
 }
@@ -1161,14 +1195,15 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     PNRF_HIP(hipMemcpy(t->P + t->L[i].w, W[i], (size_t)t->L[i].in * t->L[i].out * 4, hipMemcpyDefault));
     PNRF_HIP(hipMemcpy(t->P + t->L[i].b, b[i], (size_t)t->L[i].out * 4, hipMemcpyDefault));
   }
+  t->L[L_N + 5].gap = 63;                          // its input is cat[embedding 63 | 0 | h 256] (LD_C5, C5_H)
   {   // fp16 planes of the weights for the split-fp16 products: per layer [out64][in64] (forward) and [in64][out64] (backward), hi and lo each
     size_t halfs = 0;
     memset(&t->split, 0, sizeof(t->split));
     for (int i = 0; i < N_LAYERS; ++i) {
       const TLin& l = t->L[i];
       SplitLayer& sl = t->split.l[i];
-      const int in64 = (l.in + 63) / 64 * 64, out64 = (l.out + 63) / 64 * 64;
-      sl.w = l.w; sl.in = l.in; sl.out = l.out;
+      const int in64 = (l.in_x() + 63) / 64 * 64, out64 = (l.out + 63) / 64 * 64;
+      sl.w = l.w; sl.in = l.in; sl.out = l.out; sl.gap = l.gap;
       sl.ld_fwd = in64; sl.ld_bwd = out64;
       sl.plane_fwd = sl.plane_bwd = (size_t)in64 * out64;
       sl.fwd = halfs; halfs += 2 * sl.plane_fwd;
@@ -1176,7 +1211,10 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     }
     T_ALLOC(t->planes, halfs);
     PNRF_HIP(hipMemset(t->planes, 0, halfs * sizeof(_Float16)));
-    t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam;
+    const TLin& g = t->L[L_N + 5];
+    T_ALLOC(t->w_gapped, (size_t)g.out * g.in_x());
+    PNRF_HIP(hipMemset(t->w_gapped, 0, (size_t)g.out * g.in_x() * 4));
+    t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam; t->split.gapped = t->w_gapped;
     t->planes_stale = true;
     T_ALLOC(t->amax, N_AMAX);
     PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * 4));
@@ -1189,20 +1227,23 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->refine_in, N * 144); T_ALLOC(t->r_y, N * 35); T_ALLOC(t->z_pre, N * 8); T_ALLOC(t->z, R); T_ALLOC(t->pts, R * 3); T_ALLOC(t->rgb0, N * 3);
   T_ALLOC(t->emb, R * 90);
   for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], R * 256);
-  T_ALLOC(t->n_c5, R * 319); T_ALLOC(t->n_a5, R * 256); T_ALLOC(t->n_a6, R * 256); T_ALLOC(t->n_a7, R * 256);
-  T_ALLOC(t->n_cv, R * 283); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
-  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * 283); T_ALLOC(t->d_a, R * 256);
-  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * 319); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
+  T_ALLOC(t->n_c5, R * LD_C5); T_ALLOC(t->n_a5, R * 256); T_ALLOC(t->n_a6, R * 256); T_ALLOC(t->n_a7, R * 256);
+  T_ALLOC(t->n_cv, R * LD_CV); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
+  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, R * 256);
+  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * LD_C5); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
+  // padding columns of the concatenated rows are zero and stay zero (the kernels write the payload columns only, or zeros)
+  PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)R * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)R * LD_C5 * 4));
+  PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)R * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)R * LD_CV * 4));
   T_ALLOC(t->st_rays, N * 11); T_ALLOC(t->st_or_rays, N * 11); T_ALLOC(t->st_target, N * 3); T_ALLOC(t->st_ref_nos, N * 4); T_ALLOC(t->st_jitter, R); T_ALLOC(t->st_noise, R);
   T_ALLOC(t->loss, 4);
   {   // one slice of split-K partials per layer and iteration, each at its largest
     size_t cap = 0;
     for (int li = 0; li < N_LAYERS; ++li) {
       const TLin& l = t->L[li];
-      const size_t sp = (l.out % 128 == 0 && l.in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;
-      cap += sp * ((size_t)l.out * l.in + l.out) + 4;
+      const size_t sp = (l.out % 128 == 0 && l.in_x() % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;
+      cap += sp * ((size_t)l.out * l.in_x() + l.out) + 4;
     }
     t->pool_cap = cap;
     T_ALLOC(t->dw_pool, cap);
@@ -1328,17 +1369,17 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   PNRF_LAUNCH_CHECK();
   T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
   for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
-  T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + 63, 319, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 63)), dim3(TPB), 0, s, t->emb, 90, 0, t->n_c5, 319, 0, R, 63);
+  T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + C5_H, LD_C5, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 63)), dim3(TPB), 0, s, t->emb, 90, 0, t->n_c5, LD_C5, 0, R, 63);
   PNRF_LAUNCH_CHECK();
-  T_RC(layer_fwd(t, L_N + 5, t->n_c5, 319, t->n_a5, 256, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_N + 6, t->n_a5, 256, t->n_a6, 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_N + 7, t->n_a6, 256, t->n_a7, 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
-  T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, 283, R, T_ACT_NONE, s));
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 27)), dim3(TPB), 0, s, t->emb, 90, 63, t->n_cv, 283, 256, R, 27);
+  T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, LD_CV, R, T_ACT_NONE, s));
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 27)), dim3(TPB), 0, s, t->emb, 90, 63, t->n_cv, LD_CV, 256, R, 27);
   PNRF_LAUNCH_CHECK();
-  T_RC(layer_fwd(t, L_VIEWS, t->n_cv, 283, t->n_hv, 128, R, T_ACT_RELU, s));
+  T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
   return 0;
 }
@@ -1353,20 +1394,20 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   // one max-|gradient| slot per gradient buffer write (the two products that add up d_a share one)
   float* m = t->amax + slot0;
   T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
-  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0, t->n_cv, 283, t->d_cv, 283, m + 1, 0.f, R, T_ACT_NONE, none, 0, 0, s));
-  T_RC(layer_bwd(t, L_FEAT, t->d_cv, 283, m + 1, t->n_a7, 256, t->d_a, 256, m + 2, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_FEAT, t->d_cv, LD_CV, m + 1, t->n_a7, 256, t->d_a, 256, m + 2, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, t->d_a, 256, m + 2, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
   T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, m + 2, t->n_a6, 256, t->d_b, 256, m + 3, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
   T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, m + 3, t->n_a5, 256, t->d_a, 256, m + 4, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
-  // layer 5 reads cat[embedding(63), h4(256)]: the activation derivative of layer 4 applies to the columns from 63 on
-  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4, t->n_c5, 319, t->d_c5, 319, m + 5, 0.f, R, T_ACT_RELU, t->n_c5 + 63, 319, 63, s));
-  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + 63, 319, m + 5, t->n_a[3], 256, t->d_a, 256, m + 6, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
+  // layer 5 reads cat[embedding(63), 0, h4(256)]: the activation derivative of layer 4 applies to the columns from 64 on
+  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4, t->n_c5, LD_C5, t->d_c5, LD_C5, m + 5, 0.f, R, T_ACT_RELU, t->n_c5 + C5_H, LD_C5, C5_H, s));
+  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + C5_H, LD_C5, m + 5, t->n_a[3], 256, t->d_a, 256, m + 6, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6, t->n_a[2], 256, t->d_b, 256, m + 7, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7, t->n_a[1], 256, t->d_a, 256, m + 8, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, m + 8, t->n_a[0], 256, t->d_b, 256, m + 9, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   if (want_dpts) {
-    hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, 319, t->d_pts, R, 10);
+    hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, LD_C5, t->d_pts, R, 10);
     PNRF_LAUNCH_CHECK();
   }
   return 0;
@@ -1472,7 +1513,7 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     PNRF_HIP(hipEventRecord(t->ev_in, caller));
     PNRF_HIP(hipStreamWaitEvent(s, t->ev_in, 0));
   }
-  if (t->planes_stale && t->use_f16) {
+  if (t->planes_stale) {
     hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, s, t->split);
     PNRF_LAUNCH_CHECK();
     t->planes_stale = false;
