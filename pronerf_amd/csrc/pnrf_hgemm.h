@@ -42,8 +42,8 @@ struct HGemmArgs {
   int bwd;                                     // 0: Y = act(A B^T + bias); 1: C = (beta C + A B^T) * act'(H)
   const float* bias; int act;
   const float* H; int ldh; int act_col0; float beta;
-  const float* a_amax;                         // device scalar max |A| or NULL (A used as it is)
-  float* c_amax;                               // device scalar, atomic max |C| or NULL
+  const float* a_amax;                         // max |A| slot (HG_SLOT floats, hg_slot_read) or NULL (A used as it is)
+  float* c_amax;                               // slot that receives max |C| (hg_slot_write) or NULL
 };
 constexpr int HG_KC = 64, HG_LDS_ROW = HG_KC + 8, HG_LDC = 256 + 4;
 constexpr float HG_LO_SCALE = 2048.f, HG_LO_INV = 1.f / 2048.f;
@@ -57,6 +57,34 @@ __device__ __forceinline__ float hg_scale_for(float mx) {
   int sh = 12 - ex;
   sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
   return ldexpf(1.f, sh);
+}
+// A gradient's recorded maximum is HG_SLOT floats (one per workgroup index mod HG_SLOT: thousands of waves hammering one address with atomicMax
+// cost 20 us per product).  Writer: one atomicMax per workgroup after a reduction through LDS; reader: the first HG_SLOT threads fetch one
+// entry each.  Both need `red` = 16 floats of LDS and are called by every thread of the workgroup.
+constexpr int HG_SLOT = 256;
+__device__ __forceinline__ void hg_slot_write(float* slot, float m, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __syncthreads();
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+    const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (m > 0.f) atomicMax((unsigned int*)slot + (wg & (HG_SLOT - 1)), __float_as_uint(m));   // non-negative floats order like their bits
+  }
+}
+__device__ __forceinline__ float hg_slot_read(const float* slot, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = threadIdx.x < HG_SLOT ? slot[threadIdx.x] : 0.f;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0 && wave < HG_SLOT / 64) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return m;
 }
 // offset (in halfs) of weight element (row n, k) in a fragment-major plane with k padded to kp (a multiple of 64): blocks of 16 rows x 32 k,
 // inside a block lane (n & 15) + 16 ((k & 31) >> 3) holds 8 consecutive k
@@ -78,7 +106,8 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
   const int tn = blockIdx.y;
   const int col0 = tn * 256 + wave * 32;
   const bool wave_on = col0 < a.N;
-  const float a_scale = a.a_amax ? hg_scale_for(*a.a_amax) : 1.f;
+  __shared__ float s_red[16];
+  const float a_scale = a.a_amax ? hg_scale_for(hg_slot_read(a.a_amax, s_red)) : 1.f;
   const float inv_scale = 1.f / a_scale;
   const int chunks = (a.K + HG_KC - 1) / HG_KC;
   const int64_t ntiles = (a.M + ROWS - 1) / ROWS;
@@ -320,11 +349,7 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
     mma_step(w3, x1);
     finish_chunk();
   }
-  if (a.c_amax) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (lane == 0 && amax > 0.f) atomicMax((unsigned int*)a.c_amax, __float_as_uint(amax));   // non-negative floats order like their bits
-  }
+  if (a.c_amax) hg_slot_write(a.c_amax, amax, s_red);
 }
 
 // Splits the fp32 parameters of every layer into the fp16 planes hgemm_kernel reads (fragment-major, hg_plane_index): forward orientation
@@ -368,7 +393,7 @@ struct DwhArgs {
   const float* dZ; int ldz; const float* X; int ldx;
   float* part; float* db_part;
   int out, in; int64_t R, rows_per;
-  const float* dz_amax;                        // device scalar max |dZ| or NULL
+  const float* dz_amax;                        // max |dZ| slot (HG_SLOT floats) or NULL
 };
 constexpr int DH_KC = 32, DH_COL = DH_KC + 8;  // rows per chunk; halfs per column in LDS
 __global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
@@ -382,7 +407,8 @@ __global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
   const int64_t r_begin = blockIdx.y * a.rows_per;
   const int64_t r_end = r_begin + a.rows_per < a.R ? r_begin + a.rows_per : a.R;
   const int chunks = (int)((r_end - r_begin + DH_KC - 1) / DH_KC);
-  const float z_scale = a.dz_amax ? hg_scale_for(*a.dz_amax) : 1.f;
+  __shared__ float s_red[16];
+  const float z_scale = a.dz_amax ? hg_scale_for(hg_slot_read(a.dz_amax, s_red)) : 1.f;
 
   f32x4_t accm[4][2], accx[4][2];
 #pragma unroll

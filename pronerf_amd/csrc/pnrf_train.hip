@@ -69,7 +69,7 @@ struct GemmArgs {
   const float* H; int ldh;              // backward: saved output of that layer (act'(H)), applied to columns >= act_col0
   int act_col0;
   float beta;                           // backward: C = beta C + A B   (0 or 1)
-  float* c_amax;                        // device scalar, atomic max |C| (for a split-fp16 product that reads C next), or NULL
+  float* c_amax;                        // slot that receives max |C| (hg_slot_write; for a split-fp16 product that reads C next), or NULL
 };
 constexpr int TG_KC = 64;               // k per LDS chunk
 constexpr int TG_LDA = TG_KC + 4;       // LDS row stride of the A chunk (floats)
@@ -264,11 +264,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
     }
     __syncthreads();
   }
-  if (a.c_amax) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (lane == 0 && amax > 0.f) atomicMax((unsigned int*)a.c_amax, __float_as_uint(amax));
-  }
+  if (a.c_amax) hg_slot_write(a.c_amax, amax, smem);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
@@ -844,7 +840,7 @@ struct StageArgs {
 };
 __global__ void stage_batch_kernel(StageArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t0 < a.n_amax) a.amax[t0] = 0.f;
+  for (int64_t i = t0; i < a.n_amax; i += stride) a.amax[i] = 0.f;
   for (int64_t i = t0; i < a.n * 11; i += stride) { a.d_rays[i] = a.rays[i]; a.d_or_rays[i] = a.or_rays[i]; }
   for (int64_t i = t0; i < a.n * 3; i += stride) a.d_target[i] = a.target[i];
   for (int64_t i = t0; i < a.n * 4; i += stride) a.d_ref_nos[i] = a.ref_nos[i];
@@ -955,9 +951,9 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   const int max_splits = (out % 128 == 0 && in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;   // what the pool was sized for
   int tiles;
   int64_t splits, rows_per;
-  // the partials are written and then read again by the reduction: hold them to a quarter of the operand bytes (26 layers x 64 .. 128 splits
+  // the partials are written and then read again by the reduction: hold them to half of the operand bytes (26 layers x 64 .. 128 splits
   // were 1 GB per iteration, the reduction kernel alone 0.22 ms of 2.5)
-  const int64_t by_traffic = R * (in + out) / (4 * (int64_t)numel) > 1 ? R * (in + out) / (4 * (int64_t)numel) : 1;
+  const int64_t by_traffic = R * (in + out) / (2 * (int64_t)numel) > 1 ? R * (in + out) / (2 * (int64_t)numel) : 1;
   if (use_h) {
     tiles = ((out + 127) / 128) * ((in + 127) / 128);
     splits = (256 + tiles - 1) / tiles;                         // one workgroup per CU ...
@@ -1216,8 +1212,8 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     PNRF_HIP(hipMemset(t->w_gapped, 0, (size_t)g.out * g.in_x() * 4));
     t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam; t->split.gapped = t->w_gapped;
     t->planes_stale = true;
-    T_ALLOC(t->amax, N_AMAX);
-    PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * 4));
+    T_ALLOC(t->amax, N_AMAX * HG_SLOT);
+    PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * HG_SLOT * 4));
   }
   const int64_t N = max_rays, R = (int64_t)max_samples * max_rays;
   T_ALLOC(t->mm_input, N * 288);
@@ -1392,20 +1388,20 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   // rgb head: d_raw[:, 0:3] -> d_hv (x relu'(n_hv): the views layer) ; views layer -> d_cv = [d feature | d view embedding] (no activation) ;
   // feature -> d_a ; alpha: d_raw[:, 3] -> d_a += ..., then x relu'(n_a7)
   // one max-|gradient| slot per gradient buffer write (the two products that add up d_a share one)
-  float* m = t->amax + slot0;
-  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
-  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1, 0.f, R, T_ACT_NONE, none, 0, 0, s));
-  T_RC(layer_bwd(t, L_FEAT, t->d_cv, LD_CV, m + 1, t->n_a7, 256, t->d_a, 256, m + 2, 0.f, R, T_ACT_NONE, none, 0, 0, s));
-  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, t->d_a, 256, m + 2, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, m + 2, t->n_a6, 256, t->d_b, 256, m + 3, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, m + 3, t->n_a5, 256, t->d_a, 256, m + 4, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
+  float* m = t->amax + slot0 * HG_SLOT;
+  T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
+  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0 * HG_SLOT, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_FEAT, t->d_cv, LD_CV, m + 1 * HG_SLOT, t->n_a7, 256, t->d_a, 256, m + 2 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, t->d_a, 256, m + 2 * HG_SLOT, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, m + 2 * HG_SLOT, t->n_a6, 256, t->d_b, 256, m + 3 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, m + 3 * HG_SLOT, t->n_a5, 256, t->d_a, 256, m + 4 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
   // layer 5 reads cat[embedding(63), 0, h4(256)]: the activation derivative of layer 4 applies to the columns from 64 on
-  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4, t->n_c5, LD_C5, t->d_c5, LD_C5, m + 5, 0.f, R, T_ACT_RELU, t->n_c5 + C5_H, LD_C5, C5_H, s));
-  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + C5_H, LD_C5, m + 5, t->n_a[3], 256, t->d_a, 256, m + 6, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6, t->n_a[2], 256, t->d_b, 256, m + 7, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7, t->n_a[1], 256, t->d_a, 256, m + 8, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, m + 8, t->n_a[0], 256, t->d_b, 256, m + 9, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4 * HG_SLOT, t->n_c5, LD_C5, t->d_c5, LD_C5, m + 5 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_c5 + C5_H, LD_C5, C5_H, s));
+  T_RC(layer_bwd(t, L_N + 4, t->d_c5 + C5_H, LD_C5, m + 5 * HG_SLOT, t->n_a[3], 256, t->d_a, 256, m + 6 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6 * HG_SLOT, t->n_a[2], 256, t->d_b, 256, m + 7 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7 * HG_SLOT, t->n_a[1], 256, t->d_a, 256, m + 8 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, m + 8 * HG_SLOT, t->n_a[0], 256, t->d_b, 256, m + 9 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9 * HG_SLOT, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   if (want_dpts) {
     hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, LD_C5, t->d_pts, R, 10);
     PNRF_LAUNCH_CHECK();
@@ -1416,13 +1412,13 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
 // output-layer gradient dy [N, out_last] -> gradients of a 7-layer ELU net (sampler: first = L_S, refine: first = L_R); no gradient reaches the
 // net's input (the Pluecker moment is depth-independent; the projection is under no_grad in the reference)
 int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, float* const* h, const float* x0, int in0, int64_t N, hipStream_t s) {
-  float* m = t->amax + (first == L_S ? 16 : 24);                // max-|gradient| slots of this net's six hidden gradients
+  float* m = t->amax + (first == L_S ? 16 : 24) * HG_SLOT;                // max-|gradient| slots of this net's six hidden gradients
   T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, t->d_h0, 256, m, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
   float* dA = t->d_h0; float* dB = t->d_h1;
   for (int k = 5; k >= 1; --k) {
-    T_RC(layer_bwd(t, first + k, dA, 256, m, h[k - 1], 256, dB, 256, m + 1, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
+    T_RC(layer_bwd(t, first + k, dA, 256, m, h[k - 1], 256, dB, 256, m + HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
     float* tmp = dA; dA = dB; dB = tmp;
-    ++m;
+    m += HG_SLOT;
   }
   return layer_bwd(t, first + 0, dA, 256, m, x0, in0, nullptr, 0, nullptr, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
 }
@@ -1519,7 +1515,7 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     t->planes_stale = false;
   }
   StageArgs sa = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
-                  t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S, t->amax, N_AMAX};
+                  t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S, t->amax, N_AMAX * HG_SLOT};
   hipLaunchKernelGGL(stage_batch_kernel, dim3(grid_for(N * 11)), dim3(TPB), 0, s, sa);
   PNRF_LAUNCH_CHECK();
   pnrf_train_batch_t b = *bt;

@@ -86,7 +86,7 @@ eager_ms, eager_wall = timed(eager_step, 10, 2) if not HIP_ONLY else (float('nan
 torch.set_default_device('cpu')
 explore = {}
 opt_n = torch.optim.Adam([p for pair in tl[14:] for p in pair], lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-8)
-for n_mult in (1, 4, 8):
+for n_mult in (() if '--stage2-only' in sys.argv else (1, 4, 8)):          # --stage2-only: a clean kernel trace of the joint iteration
     S = 8 * n_mult
     jit = torch.from_numpy(np.minimum(np.abs(rs.randn(N, S)) / 5, 0.99).astype(np.float32))
     tr_x = ops.Trainer([W_ for W_, _ in layers], [b for _, b in layers], max_rays=N, device=dev, max_samples=S)
