@@ -92,6 +92,13 @@ __host__ __device__ inline size_t hg_plane_index(int n, int k, int kp) {
   return ((size_t)(n >> 4) * (kp >> 5) + (k >> 5)) * 512 + (size_t)(((n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
 }
 
+// PNRF_HG_PROBE (defined by tools/hgemm_probe.hip only): timing builds without the MFMAs (1), the epilogue's stores (2), the A fetches (4), the
+// weight fetches (8).  In the library HG_PROBE(x) is the constant false and the parameter has no effect.
+#ifdef PNRF_HG_PROBE
+#define HG_PROBE(bit) ((PROBE & (bit)) != 0)
+#else
+#define HG_PROBE(bit) false
+#endif
 template <int MI, int PROBE = 0>
 __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
   constexpr int ROWS = 16 * MI, NI = 2;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
     const unsigned soff = f_left > 0 ? f_row + (unsigned)f_kc * (HG_KC * 4) : 0xfffffff0u;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      if (!(PROBE & 4)) st[ps] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[ps], soff, 0));
+      if (!HG_PROBE(4)) st[ps] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[ps], soff, 0));
       else st[ps] = f32x4_t{1.f, 2.f, 3.f, (float)f_kc};
     }
     --f_left;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
   auto load_w = [&](WFrag& w) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      if (PROBE & 8) { for (int e = 0; e < 8; ++e) { w.h[j][e] = (_Float16)(float)(w_ks + e); w.l[j][e] = (_Float16)(float)(w_ks - e); } continue; }
+      if (HG_PROBE(8)) { for (int e = 0; e < 8; ++e) { w.h[j][e] = (_Float16)(float)(w_ks + e); w.l[j][e] = (_Float16)(float)(w_ks - e); } continue; }
       w.h[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, b_off[j], w_ks * 1024, 0));
       w.l[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, b_off[j], w_ks * 1024, 0));
     }
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
     }
   };
   auto mma_step = [&](const WFrag& w, const XFrag& x) {
-    if (wave_on && !(PROBE & 1)) {
+    if (wave_on && !HG_PROBE(1)) {
       // three sweeps over the tiles, so that the two MFMAs that accumulate into the same cross registers are MI NI MFMAs apart
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
           }
         }
       }
-      const bool on = rl < ROWS && row0 + rl < a.M && col_on && !((PROBE & 2) && a.K != 12345);
+      const bool on = rl < ROWS && row0 + rl < a.M && col_on && !(HG_PROBE(2) && a.K != 12345);
       if (on) {
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         *(f32x4_t*)cp[q] = v;

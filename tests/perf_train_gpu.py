@@ -64,6 +64,9 @@ def hip_step():
 
 
 hip_ms, hip_wall = timed(hip_step, 50, 5)
+tr.set_products('f32')                      # the same iteration on the exact-fp32 MFMA products
+f32_ms, f32_wall = timed(hip_step, 30, 5)
+tr.set_products('f16x2')
 
 g = lambda x: x.to(dev)
 tl = [(torch.tensor(W_, device=dev, requires_grad=True), torch.tensor(b, device=dev, requires_grad=True)) for W_, b in layers]
@@ -111,6 +114,7 @@ for n_mult in (() if '--stage2-only' in sys.argv else (1, 4, 8)):          # --s
     explore[S] = {'hip_ms': round(hx_wall, 3), 'eager_ms': round(ex_wall, 3), 'speedup': round(ex_wall / hx_wall, 2)}
     del tr_x
 print(json.dumps({'workload': 'stage-2 training iteration, 4096 rays, 17 views 756x1008, 8 samples, NeRF-class fine net, fp32',
-                  'hip_trainer_ms': round(hip_ms, 3), 'hip_trainer_wall_ms': round(hip_wall, 3), 'eager_torch_gpu_ms': round(eager_ms, 3),
+                  'products': 'split fp16 (default); fp32_products_ms: exact-fp32 MFMA products',
+                  'hip_trainer_ms': round(hip_ms, 3), 'hip_trainer_wall_ms': round(hip_wall, 3), 'fp32_products_ms': round(f32_ms, 3), 'eager_torch_gpu_ms': round(eager_ms, 3),
                   'eager_torch_gpu_wall_ms': round(eager_wall, 3), 'speedup': round(eager_wall / hip_wall, 2),
                   'rays_per_s_hip': round(N / (hip_wall * 1e-3)), 'stage1_explore_by_samples_per_ray': explore}))

@@ -150,9 +150,10 @@ def _oracle_grads(b, jdir, white, a_mmrgb, dtype):
     return float(loss.detach()), float(img_loss.detach()), o, [(W.grad, x.grad) for W, x in layers]
 
 
+@pytest.mark.parametrize('products', ['f16x2', 'f32'])
 @pytest.mark.parametrize('jdir,white,a_mmrgb', [(1, False, 0.0), (-1, True, 1.0)])
-def test_stage2_step_gradients_vs_oracle_autograd(dev, jdir, white, a_mmrgb):
-    """Gradients of all 26 Linear layers.  Arbiter = the oracle run in fp64: its own fp32 run differs from it by 1.3e-3 ..
+def test_stage2_step_gradients_vs_oracle_autograd(dev, jdir, white, a_mmrgb, products):
+    """Gradients of all 26 Linear layers, with the split-fp16 layer products (the default) and with the exact-fp32 ones.  Arbiter = the oracle run in fp64: its own fp32 run differs from it by 1.3e-3 ..
     2.5e-3 per tensor on this batch (2^9 positional frequencies and the 1e10 last interval amplify round-off), so two
     correct fp32 implementations agree to ~1e-3, not 1e-6.  Bounds: relative to the CPU fp32 run's own distance from fp64 (per tensor and
     in the median); an absolute cap only to catch a wrong formula."""
@@ -162,6 +163,7 @@ def test_stage2_step_gradients_vs_oracle_autograd(dev, jdir, white, a_mmrgb):
     _, _, _, g32 = _oracle_grads(b, jdir, white, a_mmrgb, torch.float32)
     layers = orc.trainer_layers(b['w'])
     tr = ops.Trainer([W for W, _ in layers], [x for _, x in layers], max_rays=b['N'], device=dev)
+    tr.set_products(products)
     img4 = ops.images_pack(cu(b['images'], dev))
     L, rgb = tr.fwd_bwd(cu(b['rays'], dev), cu(b['or_rays'], dev), cu(b['target'], dev), img4, cu(b['poses'], dev), cu(b['K'], dev),
                         b['ref_nos'].to(dev).contiguous(), jitter=cu(b['jitter'], dev), jitter_dir=jdir, raw_noise=cu(b['noise'], dev), white_bkgd=white,
@@ -213,6 +215,36 @@ def test_graph_replay_equals_kernel_by_kernel(dev):
         assert len(got) == len(ref)
         for k, (x, y) in enumerate(zip(got, ref)):
             assert torch.equal(x, y), (k, tuple(x.shape), float((x - y).abs().max()), float(y.abs().max()))
+
+
+def test_split_fp16_products_keep_tiny_gradients(dev):
+    """The split-fp16 products scale each gradient tensor by a power of two taken from its recorded maximum before splitting it into fp16
+    pairs.  A batch whose target is the rendered image itself plus 1e-4 noise has layer gradients of 1e-9 .. 1e-6 — below the fp16 range: without
+    the scaling the weight gradients would flush to zero.  Here they agree with the exact-fp32 products' as well as two fp32 runs agree."""
+    from pronerf_amd import ops
+    b = _batch(0, 12, 16, 7)
+    layers = orc.trainer_layers(b['w'])
+    img4 = ops.images_pack(cu(b['images'], dev))
+    args = lambda target: (cu(b['rays'], dev), cu(b['or_rays'], dev), target, img4, cu(b['poses'], dev), cu(b['K'], dev), b['ref_nos'].to(dev).contiguous())
+    kw = dict(jitter=cu(b['jitter'], dev), jitter_dir=1, raw_noise=cu(b['noise'], dev))
+    grads = {}
+    target = None
+    for products in ('f32', 'f16x2'):
+        tr = ops.Trainer([W for W, _ in layers], [x for _, x in layers], max_rays=b['N'], device=dev)
+        tr.set_products(products)
+        if target is None:
+            _, rgb = tr.fwd_bwd(*args(cu(b['target'], dev)), **kw)
+            g = torch.Generator(device='cpu').manual_seed(3)
+            target = (rgb + 1e-4 * torch.randn(rgb.shape, generator=g).to(dev)).contiguous()
+        L, _ = tr.fwd_bwd(*args(target), **kw)
+        assert float(L[1]) < 1e-7                                             # mse of a 1e-4 residual
+        grads[products] = [tr.read('grad', i) for i in range(26)]
+    worst = 0.0
+    for li in range(14, 26):                                                  # the NeRF layers carry all of the loss here (a_mmrgb = 0)
+        for x, y in zip(grads['f16x2'][li], grads['f32'][li]):
+            assert 0 < float(y.abs().max()) < 1e-3, (li, float(y.abs().max()))
+            worst = max(worst, rel(x, y))
+    assert worst < 3e-2, worst                                                # (flushed to zero: 1.0)
 
 
 def test_adam_step_matches_torch_optim(dev):

@@ -6,6 +6,7 @@
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 enum { T_ACT_NONE = 0, T_ACT_RELU = 1, T_ACT_ELU = 2 };
+#define PNRF_HG_PROBE 1
 #include "pnrf_hgemm.h"
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 32768;
