@@ -62,7 +62,7 @@ __device__ __forceinline__ float hg_scale_for(float mx) {
 // cost 20 us per product).  Writer: one atomicMax per workgroup after a reduction through LDS; reader: the first HG_SLOT threads fetch one
 // entry each.  Both need `red` = 16 floats of LDS and are called by every thread of the workgroup.
 constexpr int HG_SLOT = 256;
-__device__ __forceinline__ void hg_slot_write(float* slot, float m, float* red) {
+__device__ __forceinline__ void hg_slot_write(float* slot, float m, float* red, unsigned wg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -71,7 +71,6 @@ __device__ __forceinline__ void hg_slot_write(float* slot, float m, float* red) 
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
-    const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
     if (m > 0.f) atomicMax((unsigned int*)slot + (wg & (HG_SLOT - 1)), __float_as_uint(m));   // non-negative floats order like their bits
   }
 }
@@ -99,26 +98,30 @@ __host__ __device__ inline size_t hg_plane_index(int n, int k, int kp) {
 #else
 #define HG_PROBE(bit) false
 #endif
+// Shared-memory needs of the product body for 16 MI rows per tile
+template <int MI> struct HgShape {
+  static constexpr int ROWS = 16 * MI, PLANE = ROWS * HG_LDS_ROW;
+  static constexpr int A_BYTES = 2 * 2 * PLANE * 2, C_BYTES = ROWS * HG_LDC * 4, BYTES = A_BYTES + C_BYTES;
+};
+// bx of gx workgroups share the row tiles of column block by (the launch's grid, or a slice of it when the launch also carries other work)
 template <int MI, int PROBE = 0>
-__global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
+__device__ __forceinline__ void hgemm_body(const HGemmArgs& a, const int bx, const int by, const int gx, unsigned char* smem, float* s_red) {
   constexpr int ROWS = 16 * MI, NI = 2;
   constexpr int PLANE = ROWS * HG_LDS_ROW;                     // halfs per plane of one chunk
-  constexpr int A_BYTES = 2 * 2 * PLANE * 2, C_BYTES = ROWS * HG_LDC * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_a[A_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char smem_c[C_BYTES];
+  unsigned char* const smem_a = smem;
+  unsigned char* const smem_c = smem + HgShape<MI>::A_BYTES;
   _Float16* const sA = (_Float16*)smem_a;                      // [buffer][plane hi / lo][row][72]
   float* const sC = (float*)smem_c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m16 = lane & 15, g = lane >> 4;
-  const int tn = blockIdx.y;
+  const int tn = by;
   const int col0 = tn * 256 + wave * 32;
   const bool wave_on = col0 < a.N;
-  __shared__ float s_red[16];
   const float a_scale = a.a_amax ? hg_scale_for(hg_slot_read(a.a_amax, s_red)) : 1.f;
   const float inv_scale = 1.f / a_scale;
   const int chunks = (a.K + HG_KC - 1) / HG_KC;
   const int64_t ntiles = (a.M + ROWS - 1) / ROWS;
-  const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);   // >= 1: the grid has at most ntiles workgroups
+  const int my_tiles = (int)((ntiles - bx + gx - 1) / gx);   // >= 1: the grid has at most ntiles workgroups
   const int total = my_tiles * chunks;                                                // chunks in this workgroup's pipeline
 
   f32x4_t accm[MI][NI], accx[MI][NI];
@@ -140,10 +143,10 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
   unsigned a_off[PASSES];
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) a_off[ps] = (unsigned)(((lrow + 32 * ps) * a.lda + lc4) * 4);
-  const unsigned tile_bytes = (unsigned)(ROWS * a.lda * 4), tile_step = tile_bytes * gridDim.x;
+  const unsigned tile_bytes = (unsigned)(ROWS * a.lda * 4), tile_step = tile_bytes * (unsigned)gx;
   // fetch cursor: (byte offset of the tile's first row, chunk in the tile) of the next chunk to request — runs two chunks ahead of the MFMAs,
   // past this workgroup's last tile it points behind the buffer (zeros)
-  unsigned f_row = (unsigned)(blockIdx.x * (size_t)tile_bytes);
+  unsigned f_row = (unsigned)(bx * (size_t)tile_bytes);
   int f_kc = 0, f_left = total;
   auto fetch_a = [&](f32x4_t (&st)[PASSES]) {
     const unsigned soff = f_left > 0 ? f_row + (unsigned)f_kc * (HG_KC * 4) : 0xfffffff0u;
@@ -320,11 +323,11 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
   fetch_a(stg0);                                               // chunk 2
   __syncthreads();
   read_x(x0, 0, 0);
-  int64_t q_row0 = (int64_t)blockIdx.x * ROWS;                 // first row of the tile chunk q belongs to
+  int64_t q_row0 = (int64_t)bx * ROWS;                 // first row of the tile chunk q belongs to
   int q_kc = 0;
   auto next_kc = [&](int kc) { return kc + 1 == chunks ? 0 : kc + 1; };
   auto finish_chunk = [&] {                                     // after the MFMAs of chunk q: the tile's epilogue if that was its last chunk
-    if (q_kc + 1 == chunks) { epilogue(q_row0); q_row0 += (int64_t)gridDim.x * ROWS; q_kc = 0; }
+    if (q_kc + 1 == chunks) { epilogue(q_row0); q_row0 += (int64_t)gx * ROWS; q_kc = 0; }
     else ++q_kc;
   };
   for (int q = 0; q < total; q += 2) {
@@ -356,7 +359,13 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
     mma_step(w3, x1);
     finish_chunk();
   }
-  if (a.c_amax) hg_slot_write(a.c_amax, amax, s_red);
+  if (a.c_amax) hg_slot_write(a.c_amax, amax, s_red, (unsigned)(bx + gx * by));
+}
+template <int MI, int PROBE = 0>
+__global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<MI>::BYTES];
+  __shared__ float s_red[16];
+  hgemm_body<MI, PROBE>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, smem, s_red);
 }
 
 // Splits the fp32 parameters of every layer into the fp16 planes hgemm_kernel reads (fragment-major, hg_plane_index): forward orientation
@@ -403,18 +412,19 @@ struct DwhArgs {
   const float* dz_amax;                        // max |dZ| slot (HG_SLOT floats) or NULL
 };
 constexpr int DH_KC = 32, DH_COL = DH_KC + 8;  // rows per chunk; halfs per column in LDS
-__global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
+constexpr int DH_BYTES = 2 * 2 * 2 * 128 * DH_COL * 2;      // LDS of the weight-gradient body
+// workgroup (tile bx, split by) of the weight gradient
+__device__ __forceinline__ void dwh_body(const DwhArgs& a, const int bx, const int by, unsigned char* smem, float* s_red) {
   constexpr int PLANE = 128 * DH_COL;          // halfs
-  __shared__ __attribute__((aligned(16))) _Float16 sm[2 * 2 * 2 * PLANE];      // [buffer][operand dZ / X][plane hi / lo][column][row]
+  _Float16* const sm = (_Float16*)smem;        // [buffer][operand dZ / X][plane hi / lo][column][row]
   const int tiles_n = (a.in + 127) / 128;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int c16 = lane & 15, g = lane >> 4;
-  const int64_t r_begin = blockIdx.y * a.rows_per;
+  const int64_t r_begin = by * a.rows_per;
   const int64_t r_end = r_begin + a.rows_per < a.R ? r_begin + a.rows_per : a.R;
   const int chunks = (int)((r_end - r_begin + DH_KC - 1) / DH_KC);
-  __shared__ float s_red[16];
   const float z_scale = a.dz_amax ? hg_scale_for(hg_slot_read(a.dz_amax, s_red)) : 1.f;
 
   f32x4_t accm[4][2], accx[4][2];
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
 
   // ---- partial tile: D register e of lane (c16, g) = dW[out 4 g + e][in c16] of its MFMA tile
   const float inv = HG_LO_INV, unscale = 1.f / z_scale;
-  float* p = a.part + (size_t)blockIdx.y * a.out * a.in;
+  float* p = a.part + (size_t)by * a.out * a.in;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -538,7 +548,29 @@ __global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) sum += red[r * 128 + threadIdx.x];
-      a.db_part[(size_t)blockIdx.y * a.out + tm * 128 + threadIdx.x] = sum;
+      a.db_part[(size_t)by * a.out + tm * 128 + threadIdx.x] = sum;
     }
+  }
+}
+__global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DH_BYTES];
+  __shared__ float s_red[16];
+  dwh_body(a, (int)blockIdx.x, (int)blockIdx.y, smem, s_red);
+}
+
+// One launch for a layer's backward pass: the first n_dx workgroups form the persistent grid (gx x gy) of the input-gradient product, the
+// others are the (tile, split) workgroups of the weight gradient.  The two read the same dZ and are independent: dispatched together, the
+// weight gradient fills the CUs the product leaves idle (the 4096-row nets: 13 + 10 us as two launches).
+template <int MI>
+__global__ __launch_bounds__(512) void layer_bwd_kernel(HGemmArgs g, DwhArgs d, int gx, int gy, int dw_tiles) {
+  constexpr int BYTES = HgShape<MI>::BYTES > DH_BYTES ? HgShape<MI>::BYTES : DH_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
+  __shared__ float s_red[16];
+  const int b = (int)blockIdx.x, n_dx = gx * gy;
+  if (b < n_dx) {
+    hgemm_body<MI, 0>(g, b % gx, b / gx, gx, smem, s_red);
+  } else {
+    const int w = b - n_dx;
+    dwh_body(d, w % dw_tiles, w / dw_tiles, smem, s_red);
   }
 }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
     }
     __syncthreads();
   }
-  if (a.c_amax) hg_slot_write(a.c_amax, amax, smem);
+  if (a.c_amax) hg_slot_write(a.c_amax, amax, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
@@ -939,8 +939,11 @@ int launch_tgemm(const GemmArgs& a, hipStream_t s) {
 // dW[out,in] = dZ^T X and db[out] = column sums of dZ: dw_splitk*_kernel writes the split-K partials into a fresh slice of the pool and
 // queues their summation; flush_dw_reduce() at the end of the backward pass does all of them in one launch.
 // `in` counts the columns of X; with gap >= 0 column `gap` of X is padding and dW has in - 1 columns
+// defer != NULL: if the split-fp16 kernel is the one to use, its arguments and grid go to *defer instead of a launch (layer_bwd dispatches it
+// together with the layer's input-gradient product)
+struct DwDefer { DwhArgs args; int tiles, splits; bool set; };
 int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, const float* dz_amax, float* dW, float* db, int in, int gap, int out,
-            int64_t R, hipStream_t s) {
+            int64_t R, hipStream_t s, DwDefer* defer = nullptr) {
   PNRF_REQUIRE(out <= DB_MAX_OUT, PNRF_E_SHAPE, "pnrf_trainer: layer output %d wider than the bias-partial buffer (%d)", out, DB_MAX_OUT);
   PNRF_REQUIRE(t->jobs.n < DW_MAX_JOBS, PNRF_E_STATE, "pnrf_trainer: more than %d weight gradients in one iteration", DW_MAX_JOBS);
   const int numel = out * in;
@@ -956,7 +959,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   const int64_t by_traffic = R * (in + out) / (2 * (int64_t)numel) > 1 ? R * (in + out) / (2 * (int64_t)numel) : 1;
   if (use_h) {
     tiles = ((out + 127) / 128) * ((in + 127) / 128);
-    splits = (256 + tiles - 1) / tiles;                         // one workgroup per CU ...
+    splits = ((defer ? 128 : 256) + tiles - 1) / tiles;         // one workgroup per CU (half of the CUs when the launch is shared with the dX product) ...
     if (splits > by_traffic) splits = by_traffic;               // ... unless the partials would outweigh the operands
     const int64_t by_rows = (R + DH_KC - 1) / DH_KC;
     if (splits > by_rows) splits = by_rows;
@@ -988,9 +991,11 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   float* part = t->dw_pool + t->pool_used;
   float* db_part = part + (size_t)splits * numel;
   t->pool_used += (need + 3) & ~(size_t)3;                      // slices stay 16-byte aligned
+  if (defer) defer->set = false;
   if (use_h) {
     DwhArgs h = {dZ, ldz, X, ldx, part, db_part, out, in, R, rows_per, dz_amax};
-    hipLaunchKernelGGL(dwh_kernel, dim3(tiles, (unsigned)splits), dim3(512), 0, s, h);
+    if (defer) { defer->args = h; defer->tiles = tiles; defer->splits = (int)splits; defer->set = true; }
+    else hipLaunchKernelGGL(dwh_kernel, dim3(tiles, (unsigned)splits), dim3(512), 0, s, h);
   } else if (use128)
     hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, part, out, in, R, rows_per, db_part);
   else
@@ -1015,18 +1020,44 @@ int flush_dw_reduce(pnrf_trainer* t, hipStream_t s) {
   return 0;
 }
 
-int launch_hgemm(const HGemmArgs& a, hipStream_t s) {
+// 64-row tiles while they give every CU a workgroup, else 32 / 16 rows (the 4 096-row layers of the sampler / refine nets); one persistent
+// workgroup per CU, each taking every gx-th row tile of its column block
+void hgemm_grid(const HGemmArgs& a, int* mi, int* gx, int* gy) {
   const int tiles_n = (a.N + 255) / 256;
-  // 64-row tiles while they give every CU a workgroup, else 32 / 16 rows (the 4 096-row layers of the sampler / refine nets); one persistent
-  // workgroup per CU, each taking every G-th row tile
   const int64_t t64 = (a.M + 63) / 64, t32 = (a.M + 31) / 32;
-  const int mi = t64 * tiles_n >= 256 ? 4 : (t32 * tiles_n >= 256 ? 2 : 1);
-  const int64_t ntiles = (a.M + 16 * mi - 1) / (16 * mi);
+  *mi = t64 * tiles_n >= 256 ? 4 : (t32 * tiles_n >= 256 ? 2 : 1);
+  const int64_t ntiles = (a.M + 16 * *mi - 1) / (16 * *mi);
   const int per_col = 256 / tiles_n > 0 ? 256 / tiles_n : 1;
-  const dim3 grid((unsigned)(ntiles < per_col ? ntiles : per_col), (unsigned)tiles_n);
+  *gx = (int)(ntiles < per_col ? ntiles : per_col);
+  *gy = tiles_n;
+}
+int launch_hgemm(const HGemmArgs& a, hipStream_t s) {
+  int mi, gx, gy;
+  hgemm_grid(a, &mi, &gx, &gy);
+  const dim3 grid((unsigned)gx, (unsigned)gy);
   if (mi == 4) hipLaunchKernelGGL((hgemm_kernel<4>), grid, dim3(512), 0, s, a);
   else if (mi == 2) hipLaunchKernelGGL((hgemm_kernel<2>), grid, dim3(512), 0, s, a);
   else hipLaunchKernelGGL((hgemm_kernel<1>), grid, dim3(512), 0, s, a);
+  PNRF_LAUNCH_CHECK();
+  return 0;
+}
+// the layer's input-gradient product and its weight gradient as one launch
+int launch_layer_bwd(const HGemmArgs& a, const DwDefer& d, hipStream_t s) {
+  int mi, gx, gy;
+  hgemm_grid(a, &mi, &gx, &gy);
+  // both parts in ONE wave of workgroups (a CU holds one of either kind): the product's persistent grid shrinks to the CUs the weight gradient
+  // leaves free, with larger row tiles if that keeps every workgroup at >= 1 tile
+  const int dw_wgs = d.tiles * d.splits, room = 256 - dw_wgs;
+  if (room >= 64 * gy && gx * gy > room) {
+    gx = room / gy;
+    while (mi < 4 && (a.M + 16 * mi - 1) / (16 * mi) > 2 * (int64_t)gx) mi *= 2;       // few workgroups: take more rows per tile
+    const int64_t ntiles = (a.M + 16 * mi - 1) / (16 * mi);
+    if (gx > ntiles) gx = (int)ntiles;
+  }
+  const dim3 grid((unsigned)(gx * gy + d.tiles * d.splits));
+  if (mi == 4) hipLaunchKernelGGL((layer_bwd_kernel<4>), grid, dim3(512), 0, s, a, d.args, gx, gy, d.tiles);
+  else if (mi == 2) hipLaunchKernelGGL((layer_bwd_kernel<2>), grid, dim3(512), 0, s, a, d.args, gx, gy, d.tiles);
+  else hipLaunchKernelGGL((layer_bwd_kernel<1>), grid, dim3(512), 0, s, a, d.args, gx, gy, d.tiles);
   PNRF_LAUNCH_CHECK();
   return 0;
 }
@@ -1061,17 +1092,21 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
 int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz_amax, const float* X, int ldx, float* dX, int lddx, float* dx_amax,
               float beta, int64_t R, int prev_act, const float* Hprev, int ldh, int act_col0, hipStream_t s) {
   const TLin& l = t->L[li];
-  int rc = gemm_dw(t, X, ldx, dZ, ldz, dz_amax, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s);
-  if (rc || !dX) return rc;
   const int N = l.in_x();
   const int N4 = (N + 3) & ~3;                                  // the split-fp16 kernel stores whole float4s: the row padding of dX takes the rest (zeros)
-  if (dz_amax && N4 <= lddx && hgemm_fits(t, N4, l.out, R, ldz, dX, lddx, prev_act != T_ACT_NONE ? Hprev : nullptr, ldh, act_col0)) {
+  const bool dx_h = dX && dz_amax && N4 <= lddx &&
+                    hgemm_fits(t, N4, l.out, R, ldz, dX, lddx, prev_act != T_ACT_NONE ? Hprev : nullptr, ldh, act_col0);
+  DwDefer dw;
+  dw.set = false;
+  int rc = gemm_dw(t, X, ldx, dZ, ldz, dz_amax, t->G + l.w, t->G + l.b, N, l.gap, l.out, R, s, dx_h ? &dw : nullptr);
+  if (rc || !dX) return rc;
+  if (dx_h) {
     const SplitLayer& sl = t->split.l[li];
     HGemmArgs h = {};
     h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd; h.n_pad = (N + 63) / 64 * 64;
     h.C = dX; h.ldc = lddx; h.M = R; h.N = N4; h.K = l.out; h.bwd = 1;
     h.act = prev_act; h.H = Hprev; h.ldh = ldh; h.act_col0 = act_col0; h.beta = beta; h.a_amax = dz_amax; h.c_amax = dx_amax;
-    return launch_hgemm(h, s);
+    return dw.set ? launch_layer_bwd(h, dw, s) : launch_hgemm(h, s);
   }
   GemmArgs a = {};
   a.A = dZ; a.lda = ldz; a.B = l.gap >= 0 ? t->w_gapped : t->P + l.w; a.ldb = N; a.C = dX; a.ldc = lddx; a.M = R; a.N = N; a.K = l.out;

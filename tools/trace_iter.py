@@ -20,7 +20,8 @@ def main():
     f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if 'stage_batch' in r['Kernel_Name']]
-    a, b = idx[which], idx[which + 1] if which + 1 < 0 else len(rows)
+    nxt = which + 1
+    a, b = idx[which], (idx[nxt] if nxt != 0 and nxt < len(idx) else len(rows))
     prev, tot, gaps = None, 0.0, 0.0
     per = collections.defaultdict(lambda: [0, 0.0])
     for r in rows[a:b]:
