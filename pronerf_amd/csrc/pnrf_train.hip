@@ -267,6 +267,117 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs a) {
   if (a.c_amax) hg_slot_write(a.c_amax, amax, smem, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------ the 1 .. 4-wide heads
+// The rgb (128 -> 3) and alpha (256 -> 1) heads of the NeRF are 32 768 .. 1 M rows of a few dot products: streaming kernels, fp32 FMA.  On the
+// MFMA tile kernels they cost as much as a 256-wide layer (a 16-column tile for 1 .. 3 columns, thousands of workgroups for the atomics).
+constexpr int HEAD_MAX = 4, HEAD_MAX_SPLITS = 256;
+struct HeadArgs {
+  const float* X; int ldx;              // [M, K]   K = 4 x (32 | 64)
+  const float* W; const float* bias;    // [n, K], [n]
+  float* Y; int ldy;                    // forward: [M, n]
+  const float* dZ; int ldz;             // backward: [M, n]
+  float* dX; int lddx; const float* H; int ldh; int act; float beta; float* dx_amax;   // backward: dX = (beta dX + dZ W) * act'(H)
+  float* part; float* db_part; int64_t rows_per;                                       // weight gradient: partials [split][n x K], [split][n]
+  int64_t M; int n, K;
+};
+// Y[r, 0..n) = X[r] . W^T + b: K / 4 lanes per row, 16 bytes each; butterfly sums
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+  const int L = a.K >> 2, rows_w = 64 / L;                     // lanes per row, rows per wave and step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane % L, rw = lane / L;
+  f32x4_t w[HEAD_MAX];
+#pragma unroll
+  for (int j = 0; j < HEAD_MAX; ++j) w[j] = j < a.n ? *(const f32x4_t*)(a.W + (size_t)j * a.K + 4 * lr) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int64_t step = (int64_t)gridDim.x * 4 * rows_w;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_w; r0 < a.M; r0 += step) {
+    const int64_t r = r0 + rw;
+    const f32x4_t x = r < a.M ? *(const f32x4_t*)(a.X + r * a.ldx + 4 * lr) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float acc[HEAD_MAX];
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX; ++j) acc[j] = (x[0] * w[j][0] + x[1] * w[j][1]) + (x[2] * w[j][2] + x[3] * w[j][3]);
+    for (int o = L >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int j = 0; j < HEAD_MAX; ++j) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (lr == 0 && r < a.M) {
+#pragma unroll
+      for (int j = 0; j < HEAD_MAX; ++j)
+        if (j < a.n) a.Y[r * a.ldy + j] = acc[j] + a.bias[j];
+    }
+  }
+}
+// dX[r, c..c+3] = (beta dX + sum_j dZ[r, j] W[j, c..c+3]) * act'(H): a thread keeps its four columns of W in registers and walks down the rows
+__global__ __launch_bounds__(256) void head_dx_kernel(HeadArgs a) {
+  __shared__ float red[16];
+  const int Q = a.K >> 2;                                      // column quads per row (32 | 64)
+  const int cq = threadIdx.x % Q, rl = threadIdx.x / Q, rows_b = 256 / Q;
+  f32x4_t w[HEAD_MAX];
+#pragma unroll
+  for (int j = 0; j < HEAD_MAX; ++j) w[j] = j < a.n ? *(const f32x4_t*)(a.W + (size_t)j * a.K + 4 * cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * rows_b + rl; r < a.M; r += (int64_t)gridDim.x * rows_b) {
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX; ++j)
+      if (j < a.n) v += a.dZ[r * a.ldz + j] * w[j];
+    float* dst = a.dX + r * a.lddx + 4 * cq;
+    if (a.beta != 0.f) v += *(const f32x4_t*)dst;
+    if (a.act != T_ACT_NONE) {
+      const f32x4_t h = *(const f32x4_t*)(a.H + r * a.ldh + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.act == T_ACT_RELU) v[e] = h[e] > 0.f ? v[e] : 0.f;
+        else v[e] = h[e] > 0.f ? v[e] : v[e] * (h[e] + 1.f);
+      }
+    }
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    *(f32x4_t*)dst = v;
+  }
+  if (a.dx_amax) hg_slot_write(a.dx_amax, amax, red, blockIdx.x);
+}
+// partial dW[j, c..c+3] and db[j] over the rows of split blockIdx.x: a thread accumulates its four columns for the n outputs over every
+// (256 / quads)-th row, the row lanes are summed through LDS
+__global__ __launch_bounds__(256) void head_dw_kernel(HeadArgs a) {
+  __shared__ float red[8 * HEAD_MAX * 256];                   // [row lane][j][column]
+  const int Q = a.K >> 2, rows_b = 256 / Q;
+  const int cq = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int64_t r_begin = blockIdx.x * a.rows_per, r_end = r_begin + a.rows_per < a.M ? r_begin + a.rows_per : a.M;
+  f32x4_t acc[HEAD_MAX];
+  float sz[HEAD_MAX];
+#pragma unroll
+  for (int j = 0; j < HEAD_MAX; ++j) { acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; sz[j] = 0.f; }
+  for (int64_t r = r_begin + rl; r < r_end; r += rows_b) {
+    const f32x4_t x = *(const f32x4_t*)(a.X + r * a.ldx + 4 * cq);
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX; ++j)
+      if (j < a.n) { const float z = a.dZ[r * a.ldz + j]; acc[j] += z * x; sz[j] += z; }
+  }
+#pragma unroll
+  for (int j = 0; j < HEAD_MAX; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(rl * HEAD_MAX + j) * 256 + 4 * cq + e] = acc[j][e];
+  __syncthreads();
+  float* p = a.part + (size_t)blockIdx.x * a.n * a.K;
+  for (int i = threadIdx.x; i < a.n * a.K; i += 256) {
+    const int j = i / a.K, c = i - j * a.K;
+    float s = 0.f;
+    for (int q = 0; q < rows_b; ++q) s += red[(q * HEAD_MAX + j) * 256 + c];
+    p[i] = s;
+  }
+  __syncthreads();
+  // bias partials: the threads of column quad 0 hold the row sums of dZ of their row lane
+  if (cq == 0) {
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX; ++j) red[rl * HEAD_MAX + j] = sz[j];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.n) {
+    float s = 0.f;
+    for (int q = 0; q < rows_b; ++q) s += red[q * HEAD_MAX + threadIdx.x];
+    a.db_part[(size_t)blockIdx.x * a.n + threadIdx.x] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient: split-K MFMA GEMM
 // dW[out, in] = dZ^T[out, R] X[R, in] with R = rays or ray-samples (4096 .. 32768) and out, in <= 319: a tiny output with a
 // very long contraction.  rocBLAS runs the 256x256 cases as four 128x128 macro-tiles without splitting K (4 workgroups on
@@ -950,14 +1061,19 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   const bool can128 = out % 128 == 0 && in % 128 == 0 && ldx % 4 == 0 && ldz % 4 == 0 && aligned16(X) && aligned16(dZ);
   // split-fp16 kernel (128 x 128 tiles, 64-row chunks) wherever the gradient's magnitude is on record and the output is not a narrow head
   const bool use_h = t->use_f16 && dz_amax && out >= 64 && in >= 32 && t->dw_tile == 0;
-  const bool use128 = !use_h && can128 && t->dw_tile != 64 && R >= t->dw128_min_rows;
-  const int max_splits = (out % 128 == 0 && in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;   // what the pool was sized for
+  // the 1 .. 4-wide heads: streaming kernel, one workgroup per split
+  const bool use_head = out <= HEAD_MAX && gap < 0 && (in == 128 || in == 256) && ldx % 4 == 0 && aligned16(X);
+  const bool use128 = !use_h && !use_head && can128 && t->dw_tile != 64 && R >= t->dw128_min_rows;
+  const int max_splits = out <= HEAD_MAX ? HEAD_MAX_SPLITS : (out % 128 == 0 && in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;   // what the pool was sized for
   int tiles;
   int64_t splits, rows_per;
   // the partials are written and then read again by the reduction: hold them to half of the operand bytes (26 layers x 64 .. 128 splits
   // were 1 GB per iteration, the reduction kernel alone 0.22 ms of 2.5)
   const int64_t by_traffic = R * (in + out) / (2 * (int64_t)numel) > 1 ? R * (in + out) / (2 * (int64_t)numel) : 1;
-  if (use_h) {
+  if (use_head) {
+    tiles = 1;
+    splits = R / 128 < HEAD_MAX_SPLITS ? R / 128 : HEAD_MAX_SPLITS;      // partials are a few KB each: as many workgroups as there are CUs
+  } else if (use_h) {
     tiles = ((out + 127) / 128) * ((in + 127) / 128);
     splits = ((defer ? 128 : 256) + tiles - 1) / tiles;         // one workgroup per CU (half of the CUs when the launch is shared with the dX product) ...
     if (splits > by_traffic) splits = by_traffic;               // ... unless the partials would outweigh the operands
@@ -981,7 +1097,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
     if (splits > DW_MAX_SPLITS) splits = DW_MAX_SPLITS;
   }
   if (splits < 1) splits = 1;
-  const int rows_q = use_h ? DH_KC : (use128 ? DW128_ROWS : DW_ROWS);
+  const int rows_q = use_head ? 8 : use_h ? DH_KC : (use128 ? DW128_ROWS : DW_ROWS);
   rows_per = (R + splits - 1) / splits;
   rows_per = (rows_per + rows_q - 1) / rows_q * rows_q;
   splits = (R + rows_per - 1) / rows_per;
@@ -992,7 +1108,11 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   float* db_part = part + (size_t)splits * numel;
   t->pool_used += (need + 3) & ~(size_t)3;                      // slices stay 16-byte aligned
   if (defer) defer->set = false;
-  if (use_h) {
+  if (use_head) {
+    HeadArgs h = {};
+    h.X = X; h.ldx = ldx; h.dZ = dZ; h.ldz = ldz; h.part = part; h.db_part = db_part; h.rows_per = rows_per; h.M = R; h.n = out; h.K = in;
+    hipLaunchKernelGGL(head_dw_kernel, dim3((unsigned)splits), dim3(256), 0, s, h);
+  } else if (use_h) {
     DwhArgs h = {dZ, ldz, X, ldx, part, db_part, out, in, R, rows_per, dz_amax};
     if (defer) { defer->args = h; defer->tiles = tiles; defer->splits = (int)splits; defer->set = true; }
     else hipLaunchKernelGGL(dwh_kernel, dim3(tiles, (unsigned)splits), dim3(512), 0, s, h);
@@ -1073,6 +1193,15 @@ inline bool hgemm_fits(const pnrf_trainer* t, int n, int k, int64_t rows, int ld
 int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, hipStream_t s) {
   const TLin& l = t->L[li];
   const int K = l.in_x();
+  if (l.out <= HEAD_MAX && l.gap < 0 && (K == 128 || K == 256) && ldx % 4 == 0 && aligned16(X)) {
+    HeadArgs h = {};
+    h.X = X; h.ldx = ldx; h.W = t->P + l.w; h.bias = t->P + l.b; h.Y = Y; h.ldy = ldy; h.M = R; h.n = l.out; h.K = K;
+    PNRF_REQUIRE(act == T_ACT_NONE, PNRF_E_STATE, "pnrf_trainer: the narrow heads have no activation");
+    const int64_t wgs = (R + 4 * (256 / K) - 1) / (4 * (256 / K));
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), 0, s, h);
+    PNRF_LAUNCH_CHECK();
+    return 0;
+  }
   if (hgemm_fits(t, l.out, K, R, ldx, Y, ldy, nullptr, 0, 0) && aligned16(t->P + l.b)) {
     const SplitLayer& sl = t->split.l[li];
     HGemmArgs h = {};
@@ -1100,6 +1229,16 @@ int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz
   dw.set = false;
   int rc = gemm_dw(t, X, ldx, dZ, ldz, dz_amax, t->G + l.w, t->G + l.b, N, l.gap, l.out, R, s, dx_h ? &dw : nullptr);
   if (rc || !dX) return rc;
+  if (l.out <= HEAD_MAX && l.gap < 0 && (N == 128 || N == 256) && lddx % 4 == 0 && aligned16(dX) &&
+      (prev_act == T_ACT_NONE || (ldh % 4 == 0 && aligned16(Hprev) && act_col0 == 0))) {
+    HeadArgs h = {};
+    h.W = t->P + l.w; h.dZ = dZ; h.ldz = ldz; h.dX = dX; h.lddx = lddx; h.H = Hprev; h.ldh = ldh; h.act = prev_act; h.beta = beta; h.dx_amax = dx_amax;
+    h.M = R; h.n = l.out; h.K = N;
+    const int64_t wgs = (R + 256 / (N / 4) - 1) / (256 / (N / 4));
+    hipLaunchKernelGGL(head_dx_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), 0, s, h);
+    PNRF_LAUNCH_CHECK();
+    return 0;
+  }
   if (dx_h) {
     const SplitLayer& sl = t->split.l[li];
     HGemmArgs h = {};
@@ -1261,7 +1400,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->n_c5, R * LD_C5); T_ALLOC(t->n_a5, R * 256); T_ALLOC(t->n_a6, R * 256); T_ALLOC(t->n_a7, R * 256);
   T_ALLOC(t->n_cv, R * LD_CV); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
   T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, R * 256);
-  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * LD_C5); T_ALLOC(t->d_e0, N * 8 * 63); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
+  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * LD_C5); T_ALLOC(t->d_e0, N * 8 * 64); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
   // padding columns of the concatenated rows are zero and stay zero (the kernels write the payload columns only, or zeros)
@@ -1273,7 +1412,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     size_t cap = 0;
     for (int li = 0; li < N_LAYERS; ++li) {
       const TLin& l = t->L[li];
-      const size_t sp = (l.out % 128 == 0 && l.in_x() % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;
+      const size_t sp = l.out <= HEAD_MAX ? HEAD_MAX_SPLITS : (l.out % 128 == 0 && l.in_x() % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;
       cap += sp * ((size_t)l.out * l.in_x() + l.out) + 4;
     }
     t->pool_cap = cap;
@@ -1436,9 +1575,9 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6 * HG_SLOT, t->n_a[2], 256, t->d_b, 256, m + 7 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7 * HG_SLOT, t->n_a[1], 256, t->d_a, 256, m + 8 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, m + 8 * HG_SLOT, t->n_a[0], 256, t->d_b, 256, m + 9 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9 * HG_SLOT, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 63, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9 * HG_SLOT, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 64, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));   // 63 columns in rows of 64
   if (want_dpts) {
-    hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 63, t->d_c5, LD_C5, t->d_pts, R, 10);
+    hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 64, t->d_c5, LD_C5, t->d_pts, R, 10);
     PNRF_LAUNCH_CHECK();
   }
   return 0;
