@@ -588,21 +588,34 @@ __global__ void dw_reduce_kernel(const DwJobs jobs) {
 }
 
 // ------------------------------------------------------------------------------------------ positional encoding
-// out[row, col_off + ...] = [x, sin(2^k x), cos(2^k x)]_k with row stride ld; the input row is row / rep (view directions are
-// shared by the `rep` samples of a ray), x has row stride xs.   (run_nerf_helpers.py:666-671)
-__global__ void posenc_strided_kernel(const float* __restrict__ x, int xs, int rep, float* __restrict__ out, int ld, int col_off, int64_t rows,
-                                      int n_freq) {
+// The NeRF's inputs in one launch: gamma(x) (10 octaves, 63 values) into the first layer's input rows AND into the head of the skip layer's
+// concatenated rows, gamma(v) (4 octaves, 27 values; the direction of ray row / rep) behind the feature columns of the views layer's rows.
+__global__ void nerf_inputs_kernel(const float* __restrict__ pts, const float* __restrict__ dirs, int dir_stride, int rep, float* __restrict__ emb,
+                                   int ld_emb, float* __restrict__ c5, int ld_c5, float* __restrict__ cv, int ld_cv, int cv_col, int64_t rows) {
   const int64_t total = rows * 3;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / 3;
     const int c = (int)(i - row * 3);
-    const float v = x[(row / rep) * xs + c];
-    float* o = out + row * ld + col_off;
-    o[c] = v;
-    for (int k = 0; k < n_freq; ++k) {
-      const float arg = v * (float)(1u << k);
-      o[3 + 6 * k + c] = sinf(arg);
-      o[3 + 6 * k + 3 + c] = cosf(arg);
+    {
+      const float v = pts[i];
+      float* o = emb + row * ld_emb;
+      float* o2 = c5 + row * ld_c5;
+      o[c] = v; o2[c] = v;
+      for (int k = 0; k < 10; ++k) {
+        const float arg = v * (float)(1u << k), sn = sinf(arg), cs = cosf(arg);
+        o[3 + 6 * k + c] = sn; o2[3 + 6 * k + c] = sn;
+        o[3 + 6 * k + 3 + c] = cs; o2[3 + 6 * k + 3 + c] = cs;
+      }
+    }
+    {
+      const float v = dirs[(row / rep) * dir_stride + c];
+      float* o = cv + row * ld_cv + cv_col;
+      o[c] = v;
+      for (int k = 0; k < 4; ++k) {
+        const float arg = v * (float)(1u << k);
+        o[3 + 6 * k + c] = sinf(arg);
+        o[3 + 6 * k + 3 + c] = cosf(arg);
+      }
     }
   }
 }
@@ -626,15 +639,6 @@ __global__ void posenc_bwd_kernel(const float* __restrict__ x, const float* __re
       }
     }
     dx[i] = g;
-  }
-}
-// copy a column block: dst[r, dcol + j] = src[r, scol + j], j < w
-__global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, int scol, float* __restrict__ dst, int ldd, int dcol, int64_t R, int w) {
-  const int64_t total = R * w;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / w;
-    const int j = (int)(i - r * w);
-    dst[r * ldd + dcol + j] = src[r * lds_ + scol + j];
   }
 }
 
@@ -906,14 +910,24 @@ __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float*
 }
 
 // ------------------------------------------------------------------------------------------ losses, Adam
-// loss[k] = mean((pred - target)^2), d_pred = scale * 2 (pred - target) / numel.  One block (deterministic).
-__global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t numel, float scale,
-                                   float* __restrict__ loss_out, float* __restrict__ d_pred) {
+// The three image losses of an iteration in one launch: block k computes loss[1 + k] = mean((pred_k - target)^2) and, if asked, d_pred_k =
+// scale_k * 2 (pred_k - target) / numel (one block per loss: a fixed summation order); the block that finishes last adds them up,
+// loss[0] = loss[1] + a_total (loss[2] + loss[3]), and re-arms the counter.
+struct LossArgs {
+  const float* pred[3]; float* d_pred[3]; float scale[3];
+  const float* target; int64_t numel;
+  float* loss; unsigned* counter; float a_total;
+};
+__global__ __launch_bounds__(1024) void losses_kernel(LossArgs a) {
   __shared__ float red[1024];
+  const int k = blockIdx.x;
+  const float* pred = a.pred[k];
+  float* d_pred = a.d_pred[k];
+  const float scale = a.scale[k];
   float s = 0.f;
-  const float inv = 1.f / (float)numel;
-  for (int64_t i = threadIdx.x; i < numel; i += blockDim.x) {
-    const float e = pred[i] - target[i];
+  const float inv = 1.f / (float)a.numel;
+  for (int64_t i = threadIdx.x; i < a.numel; i += blockDim.x) {
+    const float e = pred[i] - a.target[i];
     s += e * e;
     if (d_pred) d_pred[i] = scale * 2.f * e * inv;
   }
@@ -923,9 +937,19 @@ __global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, const float* 
     if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *loss_out = red[0] * inv;
+  if (threadIdx.x == 0) {
+    __atomic_store_n((unsigned*)a.loss + 1 + k, __float_as_uint(red[0] * inv), __ATOMIC_RELAXED);
+    __threadfence();
+    if (atomicAdd(a.counter, 1u) == gridDim.x - 1) {             // every block's loss is visible now
+      __threadfence();
+      const unsigned* lu = (const unsigned*)a.loss;             // (device-scope loads: the other blocks' stores went to L2)
+      const float l1 = __uint_as_float(__atomic_load_n(lu + 1, __ATOMIC_RELAXED)), l2 = __uint_as_float(__atomic_load_n(lu + 2, __ATOMIC_RELAXED)),
+                  l3 = __uint_as_float(__atomic_load_n(lu + 3, __ATOMIC_RELAXED));
+      a.loss[0] = l1 + a.a_total * (l2 + l3);
+      *a.counter = 0;
+    }
+  }
 }
-__global__ void total_loss_kernel(float* loss, float a_mmrgb) { loss[0] = loss[1] + a_mmrgb * (loss[2] + loss[3]); }
 
 // torch.optim.Adam (no amsgrad): g += wd p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
@@ -1407,7 +1431,8 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)R * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)R * LD_C5 * 4));
   PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)R * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)R * LD_CV * 4));
   T_ALLOC(t->st_rays, N * 11); T_ALLOC(t->st_or_rays, N * 11); T_ALLOC(t->st_target, N * 3); T_ALLOC(t->st_ref_nos, N * 4); T_ALLOC(t->st_jitter, R); T_ALLOC(t->st_noise, R);
-  T_ALLOC(t->loss, 4);
+  T_ALLOC(t->loss, 8);                              // [total, mse x 3, completion counter of losses_kernel]
+  PNRF_HIP(hipMemset(t->loss, 0, 32));
   {   // one slice of split-K partials per layer and iteration, each at its largest
     size_t cap = 0;
     for (int li = 0; li < N_LAYERS; ++li) {
@@ -1534,21 +1559,16 @@ int sampler_refine_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, hipStr
 // query points t->pts [N*S,3] + view directions -> raw [N*S,4]  (NeRF class, run_nerf_helpers.py:824-847)
 int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream_t s) {
   const int64_t R = bt->n * S;
-  hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, 3, 1, t->emb, 90, 0, R, 10);
-  hipLaunchKernelGGL(posenc_strided_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, bt->rays + 8, 11, S, t->emb, 90, 63, R, 4);
+  hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->emb, 90, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
   PNRF_LAUNCH_CHECK();
   T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
   for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + C5_H, LD_C5, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 63)), dim3(TPB), 0, s, t->emb, 90, 0, t->n_c5, LD_C5, 0, R, 63);
-  PNRF_LAUNCH_CHECK();
   T_RC(layer_fwd(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_N + 6, t->n_a5, 256, t->n_a6, 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_N + 7, t->n_a6, 256, t->n_a7, 256, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
   T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, LD_CV, R, T_ACT_NONE, s));
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(R * 27)), dim3(TPB), 0, s, t->emb, 90, 63, t->n_cv, LD_CV, 256, R, 27);
-  PNRF_LAUNCH_CHECK();
   T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
   return 0;
@@ -1626,10 +1646,11 @@ static int stage2_body(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, hipStrea
                           t->wts, nullptr, N, 8, stream));                                                            // :674
   // ---------------- losses (:861-866)
   const bool aux = bt->a_mmrgb > 0.f;
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, bt->a_mmrgb, t->loss + 2, aux ? t->d_rgb0 : (float*)nullptr);
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, bt->a_mmrgb, t->loss + 3, aux ? t->d_mmrgb : (float*)nullptr);
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, aux ? bt->a_mmrgb : 0.f);
+  {
+    LossArgs la = {{t->rgb_map, t->rgb0, t->mm_rgb}, {t->d_rgb_map, aux ? t->d_rgb0 : nullptr, aux ? t->d_mmrgb : nullptr}, {1.f, bt->a_mmrgb, bt->a_mmrgb},
+                   bt->target, N * 3, t->loss, (unsigned*)(t->loss + 4), aux ? bt->a_mmrgb : 0.f};
+    hipLaunchKernelGGL(losses_kernel, dim3(3), dim3(1024), 0, s, la);
+  }
   PNRF_LAUNCH_CHECK();
   // ---------------- backward
   T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, t->add_s, t->mul_s, bt->raw_noise, bt->clamp, bt->white_bkgd, t->d_rgb_map, t->d_raw, t->d_z,
@@ -1657,10 +1678,11 @@ static int explore_body(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int n_m
   T_RC(nerf_forward(t, bt, S, s));
   T_RC(pnrf_composite_fwd(t->raw, t->z, bt->rays + 3, 11, nullptr, nullptr, bt->raw_noise, bt->clamp, bt->white_bkgd, t->rgb_map, nullptr, nullptr, t->wts,
                           nullptr, N, S, stream));
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb_map, bt->target, N * 3, 1.f, t->loss + 1, t->d_rgb_map);
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->rgb0, bt->target, N * 3, 0.f, t->loss + 2, (float*)nullptr);
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, t->mm_rgb, bt->target, N * 3, 0.f, t->loss + 3, (float*)nullptr);
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, t->loss, 0.f);
+  {
+    LossArgs la = {{t->rgb_map, t->rgb0, t->mm_rgb}, {t->d_rgb_map, nullptr, nullptr}, {1.f, 0.f, 0.f}, bt->target, N * 3, t->loss,
+                   (unsigned*)(t->loss + 4), 0.f};
+    hipLaunchKernelGGL(losses_kernel, dim3(3), dim3(1024), 0, s, la);
+  }
   PNRF_LAUNCH_CHECK();
   T_RC(pnrf_composite_bwd(t->raw, t->z, bt->rays + 3, 11, nullptr, nullptr, bt->raw_noise, bt->clamp, bt->white_bkgd, t->d_rgb_map, t->d_raw, nullptr, nullptr,
                           nullptr, N, S, stream));
