@@ -1258,16 +1258,18 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
 // Accumulates the weight / bias gradients and, unless dX == nullptr, writes dX = (beta dX + dZ W) * act'(Hprev) — Hprev = saved output of
 // the layer (activation prev_act) that produced the columns >= act_col0 of X — i.e. dL/dZ of that layer, ready for its own layer_bwd.
 // dz_amax: device scalar holding max |dZ| (left there by the product that wrote dZ) or NULL if unknown; dx_amax: where to leave max |dX|.
+// n_first (a multiple of 16): the input gradient is only wanted from that input column on — dX, Hprev and act_col0 then refer to column n_first
+// (the skip layer without a position gradient: the 64 leading columns of its input are the embedding, whose gradient nobody reads)
 int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz_amax, const float* X, int ldx, float* dX, int lddx, float* dx_amax,
-              float beta, int64_t R, int prev_act, const float* Hprev, int ldh, int act_col0, hipStream_t s) {
+              float beta, int64_t R, int prev_act, const float* Hprev, int ldh, int act_col0, hipStream_t s, int n_first = 0) {
   const TLin& l = t->L[li];
-  const int N = l.in_x();
+  const int N = l.in_x() - n_first;
   const int N4 = (N + 3) & ~3;                                  // the split-fp16 kernel stores whole float4s: the row padding of dX takes the rest (zeros)
   const bool dx_h = dX && dz_amax && N4 <= lddx &&
                     hgemm_fits(t, N4, l.out, R, ldz, dX, lddx, prev_act != T_ACT_NONE ? Hprev : nullptr, ldh, act_col0);
   DwDefer dw;
   dw.set = false;
-  int rc = gemm_dw(t, X, ldx, dZ, ldz, dz_amax, t->G + l.w, t->G + l.b, N, l.gap, l.out, R, s, dx_h ? &dw : nullptr);
+  int rc = gemm_dw(t, X, ldx, dZ, ldz, dz_amax, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s, dx_h ? &dw : nullptr);
   if (rc || !dX) return rc;
   if (l.out <= HEAD_MAX && l.gap < 0 && (N == 128 || N == 256) && lddx % 4 == 0 && aligned16(dX) &&
       (prev_act == T_ACT_NONE || (ldh % 4 == 0 && aligned16(Hprev) && act_col0 == 0))) {
@@ -1282,13 +1284,15 @@ int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz
   if (dx_h) {
     const SplitLayer& sl = t->split.l[li];
     HGemmArgs h = {};
-    h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd; h.n_pad = (N + 63) / 64 * 64;
+    // fragment-major plane: input column n_first starts (n_first / 16) blocks of 16 rows x ld_bwd in
+    h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd + (size_t)(n_first >> 4) * 16 * sl.ld_bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd;
+    h.n_pad = (N + 63) / 64 * 64;
     h.C = dX; h.ldc = lddx; h.M = R; h.N = N4; h.K = l.out; h.bwd = 1;
     h.act = prev_act; h.H = Hprev; h.ldh = ldh; h.act_col0 = act_col0; h.beta = beta; h.a_amax = dz_amax; h.c_amax = dx_amax;
     return dw.set ? launch_layer_bwd(h, dw, s) : launch_hgemm(h, s);
   }
   GemmArgs a = {};
-  a.A = dZ; a.lda = ldz; a.B = l.gap >= 0 ? t->w_gapped : t->P + l.w; a.ldb = N; a.C = dX; a.ldc = lddx; a.M = R; a.N = N; a.K = l.out;
+  a.A = dZ; a.lda = ldz; a.B = (l.gap >= 0 ? t->w_gapped : t->P + l.w) + n_first; a.ldb = l.in_x(); a.C = dX; a.ldc = lddx; a.M = R; a.N = N; a.K = l.out;
   a.act = prev_act; a.H = Hprev; a.ldh = ldh; a.act_col0 = act_col0; a.beta = beta; a.c_amax = dx_amax;
   return launch_tgemm<MODE_NN>(a, s);
 }
@@ -1606,7 +1610,12 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, m + 2 * HG_SLOT, t->n_a6, 256, t->d_b, 256, m + 3 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
   T_RC(layer_bwd(t, L_N + 6, t->d_b, 256, m + 3 * HG_SLOT, t->n_a5, 256, t->d_a, 256, m + 4 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a5, 256, 0, s));
   // layer 5 reads cat[embedding(63), 0, h4(256)]: the activation derivative of layer 4 applies to the columns from 64 on
-  T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4 * HG_SLOT, t->n_c5, LD_C5, t->d_c5, LD_C5, m + 5 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_c5 + C5_H, LD_C5, C5_H, s));
+  if (want_dpts) {
+    T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4 * HG_SLOT, t->n_c5, LD_C5, t->d_c5, LD_C5, m + 5 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_c5 + C5_H, LD_C5, C5_H, s));
+  } else {   // no position gradient: only the 256 hidden columns of the skip layer's input gradient are needed (one column block instead of two)
+    T_RC(layer_bwd(t, L_N + 5, t->d_a, 256, m + 4 * HG_SLOT, t->n_c5, LD_C5, t->d_c5 + C5_H, LD_C5, m + 5 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_c5 + C5_H, LD_C5, 0, s,
+                   C5_H));
+  }
   T_RC(layer_bwd(t, L_N + 4, t->d_c5 + C5_H, LD_C5, m + 5 * HG_SLOT, t->n_a[3], 256, t->d_a, 256, m + 6 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[3], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6 * HG_SLOT, t->n_a[2], 256, t->d_b, 256, m + 7 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7 * HG_SLOT, t->n_a[1], 256, t->d_a, 256, m + 8 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
