@@ -137,6 +137,23 @@ def gpu_eager_baseline(weights, scene, dev, reps=5):
             'torch': torch.__version__}, rgb
 
 
+def sustained_mfma_peak():
+    """TFLOP/s of a pure v_mfma_f32_16x16x32_bf16 loop (no LDS, no VALU, no barrier; 2 waves per SIMD on every CU) on THIS GPU with random and
+    with constant operand bits — tools/mfma_ceiling.hip, built by pronerf_amd.build into pronerf_amd/lib/mfma_ceiling.  A separate process,
+    outside the timed region; None if the binary is not there.  `roofline.peak` stays the spec figure."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pronerf_amd', 'lib', 'mfma_ceiling')
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[-1]
+        d = json.loads(out)
+        d['what'] = 'pure MFMA loop, measured in this run by tools/mfma_ceiling.hip: what the pipes sustain at the power limit'
+        return d
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (profiles/r<round>_v<version>_pmc_summary.json,
     newest = highest (round, version), not lexicographic: v9 < v11): separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2
@@ -283,6 +300,9 @@ def main():
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
                                'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
             res['kernels'] = kern
+            sus = sustained_mfma_peak()
+            if sus:                            # context for `frac`: the spec peak is not reachable at this chip's power limit with real operand bits
+                res['roofline']['sustained'] = dict(sus, frac_of_sustained=kern[dom]['achieved_tflops'] / sus['random_operands_tflops'])
             if not args.no_gpu_eager_baseline:
                 last = outs[0][:count, :3].clone() if not pipeline else None
                 eager, eager_rgb = gpu_eager_baseline(weights, scene, dev, args.eager_reps)

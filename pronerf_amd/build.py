@@ -84,6 +84,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+CEILING_SRC = os.path.join(os.path.dirname(HERE), 'tools', 'mfma_ceiling.hip')
+CEILING_BIN = os.path.join(LIBDIR, 'mfma_ceiling')
+
+
+def build_ceiling_probe(force: bool = False) -> str:
+    """tools/mfma_ceiling.hip -> pronerf_amd/lib/mfma_ceiling: the pure-MFMA loop bench.py runs to report what the pipes sustain at the chip's
+    power limit (roofline.sustained).  Not part of the product."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not os.path.exists(CEILING_SRC):
+        return ''
+    if force or not os.path.exists(CEILING_BIN) or os.path.getmtime(CEILING_BIN) < os.path.getmtime(CEILING_SRC):
+        subprocess.run([_hipcc(), '-O3', f'--offload-arch={ARCH}', CEILING_SRC, '-o', CEILING_BIN], check=True)
+    return CEILING_BIN
+
+
 def build_variant(name: str, extra_flags=(), csrc: str = CSRC, include: str = INCLUDE) -> str:
     """Build pronerf_amd/lib/libpronerf_hip_<name>.so with extra compiler flags (A/B timing, diagnostics)."""
     os.makedirs(LIBDIR, exist_ok=True)
@@ -99,3 +114,4 @@ if __name__ == '__main__':
         print(build_variant(sys.argv[2], sys.argv[3:]))
     else:
         print(build(force='--force' in sys.argv))
+        print(build_ceiling_probe(force='--force' in sys.argv))
