@@ -228,9 +228,12 @@ int pnrf_ctx_profile_begin(pnrf_ctx_t* ctx, int max_frames);
 int pnrf_ctx_profile_end(pnrf_ctx_t* ctx, float* ms, int* frames);
 
 /* ---- stage-2 training step --------------------------------------------------
- * fp32 throughout, like the reference's training.  Every stage is a kernel of this library: the layer products run on
- * v_mfma_f32_16x16x4_f32 with bias + activation (forward) and the activation derivative of the layer below (backward) fused into
- * their epilogues; heads, sort, interval refinement, jitter, encodings, compositing, losses and Adam are per-ray kernels. */
+ * fp32 storage and accumulation throughout, like the reference's training.  Every stage is a kernel of this library: the layer
+ * products carry bias + activation (forward) and the activation derivative of the layer below (backward) in their epilogues and
+ * multiply either in split fp16 (default: both operands as hi + 2^-11 lo fp16 pairs, 22 significand bits, three fp16 MFMAs per
+ * block, gradients scaled by a power of two from their recorded maximum) or in exact fp32 on v_mfma_f32_16x16x4_f32
+ * (pnrf_trainer_set_products); a layer's input-gradient product and weight gradient are one launch; the 1-4 wide heads, sort,
+ * interval refinement, jitter, encodings, compositing, losses and Adam are per-ray / streaming kernels. */
 
 /* Operator-level backward passes (each mirrors what torch.autograd derives for the forward it names). */
 /* raw2outputs backward for d rgb_map [n,3]: arguments as pnrf_composite_fwd; outputs d_raw dev [n,s,4], d_z dev [n,s] (NULL to
@@ -264,7 +267,7 @@ int pnrf_refine_head_bwd(const float* y, const float* rays, const float* depth_s
  * rays.  26 Linear layers in this order: sampler fc_backbone.0..5, fc_output (MinMaxRay_Net, 288 -> 27); refine net
  * likewise (144 -> 35); fine net of class NeRF: pts_linears.0..7, feature_linear, alpha_linear, views_linears.0, rgb_linear.
  * W[i]: [out_dim[i], in_dim[i]] row-major (torch layout), host or device.  max_samples: samples per ray the NeRF-side
- * workspaces are sized for (8; stage-1 exploration: up to 64).
+ * workspaces are sized for (8; stage-1 exploration: up to 256).
  * Replaces create_nerf's modules + torch.optim.Adam (run_S_eS_eN_alter_base_refine2.py:337-395). */
 int pnrf_trainer_create(const float* const* W, const float* const* b, const int* in_dim, const int* out_dim,
                         int n_layers, int64_t max_rays, int max_samples, pnrf_trainer_t** out);
