@@ -44,6 +44,7 @@ struct HGemmArgs {
   const float* H; int ldh; int act_col0; float beta;
   const float* a_amax;                         // max |A| slot (HG_SLOT floats, hg_slot_read) or NULL (A used as it is)
   float* c_amax;                               // slot that receives max |C| (hg_slot_write) or NULL
+  int tile_max;                                // 1: the body returns max |C| of the workgroup's rows even without a slot (layer chains)
 };
 constexpr int HG_KC = 64, HG_LDS_ROW = HG_KC + 8, HG_LDC = 256 + 4;
 constexpr float HG_LO_SCALE = 2048.f, HG_LO_INV = 1.f / 2048.f;
@@ -62,17 +63,19 @@ __device__ __forceinline__ float hg_scale_for(float mx) {
 // cost 20 us per product).  Writer: one atomicMax per workgroup after a reduction through LDS; reader: the first HG_SLOT threads fetch one
 // entry each.  Both need `red` = 16 floats of LDS and are called by every thread of the workgroup.
 constexpr int HG_SLOT = 256;
-__device__ __forceinline__ void hg_slot_write(float* slot, float m, float* red, unsigned wg) {
+// returns the workgroup's maximum to every thread; slot may be NULL (only the reduction)
+__device__ __forceinline__ float hg_slot_write(float* slot, float m, float* red, unsigned wg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   __syncthreads();
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
-    if (m > 0.f) atomicMax((unsigned int*)slot + (wg & (HG_SLOT - 1)), __float_as_uint(m));   // non-negative floats order like their bits
-  }
+  for (int w = 0; w < nw; ++w) m = fmaxf(m, red[w]);
+  if (threadIdx.x == 0 && slot && m > 0.f)
+    atomicMax((unsigned int*)slot + (wg & (HG_SLOT - 1)), __float_as_uint(m));                 // non-negative floats order like their bits
+  __syncthreads();
+  return m;
 }
 __device__ __forceinline__ float hg_slot_read(const float* slot, float* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,8 +107,11 @@ template <int MI> struct HgShape {
   static constexpr int A_BYTES = 2 * 2 * PLANE * 2, C_BYTES = ROWS * HG_LDC * 4, BYTES = A_BYTES + C_BYTES;
 };
 // bx of gx workgroups share the row tiles of column block by (the launch's grid, or a slice of it when the launch also carries other work)
+// a_max_local >= 0: max |A| over this workgroup's rows is already known (the previous layer of a chain left it): no slot is read.
+// Returns max |C| over what this workgroup stored.
 template <int MI, int PROBE = 0>
-__device__ __forceinline__ void hgemm_body(const HGemmArgs& a, const int bx, const int by, const int gx, unsigned char* smem, float* s_red) {
+__device__ __forceinline__ float hgemm_body(const HGemmArgs& a, const int bx, const int by, const int gx, unsigned char* smem, float* s_red,
+                                            const float a_max_local = -1.f) {
   constexpr int ROWS = 16 * MI, NI = 2;
   constexpr int PLANE = ROWS * HG_LDS_ROW;                     // halfs per plane of one chunk
   unsigned char* const smem_a = smem;
@@ -117,7 +123,7 @@ __device__ __forceinline__ void hgemm_body(const HGemmArgs& a, const int bx, con
   const int tn = by;
   const int col0 = tn * 256 + wave * 32;
   const bool wave_on = col0 < a.N;
-  const float a_scale = a.a_amax ? hg_scale_for(hg_slot_read(a.a_amax, s_red)) : 1.f;
+  const float a_scale = a_max_local >= 0.f ? hg_scale_for(a_max_local) : a.a_amax ? hg_scale_for(hg_slot_read(a.a_amax, s_red)) : 1.f;
   const float inv_scale = 1.f / a_scale;
   const int chunks = (a.K + HG_KC - 1) / HG_KC;
   const int64_t ntiles = (a.M + ROWS - 1) / ROWS;
@@ -359,7 +365,7 @@ __device__ __forceinline__ void hgemm_body(const HGemmArgs& a, const int bx, con
     mma_step(w3, x1);
     finish_chunk();
   }
-  if (a.c_amax) hg_slot_write(a.c_amax, amax, s_red, (unsigned)(bx + gx * by));
+  return a.c_amax || a.tile_max ? hg_slot_write(a.c_amax, amax, s_red, (unsigned)(bx + gx * by)) : 0.f;
 }
 template <int MI, int PROBE = 0>
 __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
@@ -573,4 +579,38 @@ __global__ __launch_bounds__(512) void layer_bwd_kernel(HGemmArgs g, DwhArgs d, 
     const int w = b - n_dx;
     dwh_body(d, w % dw_tiles, w / dw_tiles, smem, s_red);
   }
+}
+
+// ------------------------------------------------------------------------------------------ layer chains of the 4096-row nets
+// The sampler / refine nets see one batch of rays (4096 rows): a layer product is 4 MB in, 4 MB out, and a launch costs 3.7 us before its
+// first useful instruction plus the exposed latencies of a pipeline that is only four chunks long — 7.6 us per layer.  Rows are independent
+// through the layers, so one launch walks a whole chain: workgroup b owns rows 16 b .. 16 b + 15 in every layer (grid = number of 16-row
+// tiles), waits for its own stores between layers, and reads back what it wrote (same CU, same L1: no other workgroup is involved).
+//   forward: h_{l+1} = ELU(h_l W_l^T + b_l), six layers;   backward: dZ_{l-1} = (dZ_l W_l) * ELU'(h_{l-1}), five layers — there the power-of-two
+//   scale of the next product comes from the maximum over the workgroup's OWN rows (any per-row-block scale is exact: it is undone in the
+//   same workgroup's epilogue), while the global maxima still go to the slots for the weight-gradient kernel that follows the chain.
+constexpr int HG_CHAIN_MAX = 6;
+struct ChainArgs { HGemmArgs l[HG_CHAIN_MAX]; int n; int local_scale; };
+__global__ __launch_bounds__(512) void hgemm_chain_kernel(ChainArgs c) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<1>::BYTES];
+  __shared__ float s_red[16];
+  float tile_max = -1.f;
+  for (int i = 0; i < c.n; ++i) {
+    const float m = hgemm_body<1, 0>(c.l[i], (int)blockIdx.x, 0, (int)gridDim.x, smem, s_red, c.local_scale && i > 0 ? tile_max : -1.f);
+    tile_max = m;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this layer's rows are in L2 / this CU's L1 ...
+    __syncthreads();                                           // ... for every wave of the workgroup before the next layer fetches them
+  }
+}
+// The weight gradients of several layers in one launch (their dZ / X buffers must all still exist): blocks [first[j], first[j + 1]) belong to
+// job j as (tile, split) = (b % tiles, b / tiles).
+constexpr int DH_GROUP_MAX = 6;
+struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int tiles[DH_GROUP_MAX]; int n; };
+__global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DH_BYTES];
+  __shared__ float s_red[16];
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
+  const int b = (int)blockIdx.x - g.first[j];
+  dwh_body(g.j[j], b % g.tiles[j], b / g.tiles[j], smem, s_red);
 }

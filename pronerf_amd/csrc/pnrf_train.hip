@@ -1045,7 +1045,7 @@ struct pnrf_trainer {
   float *refine_in, *r_h[6], *r_y, *z_pre, *z, *pts, *rgb0;
   float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
   float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
-      *d_h0, *d_h1, *dw_pool, *loss;
+      *d_h0, *d_h1, *d_hk[6], *dw_pool, *loss;   // d_hk: one gradient buffer per hidden layer of an ELU net (layer chains); d_h0 / d_h1 = d_hk[0 / 1]
   float* w_gapped = nullptr;                     // fp32 copy [out][in + 1] of the skip layer's weights with the zero column of its input layout
   _Float16* planes = nullptr;                    // fp16 hi / lo planes of every layer's weights, both orientations (pnrf_hgemm.h)
   SplitArgs split;
@@ -1230,6 +1230,17 @@ inline bool hgemm_fits(const pnrf_trainer* t, int n, int k, int64_t rows, int ld
 }
 
 // Y = act(X W^T + b): one kernel
+// arguments of the split-fp16 forward product of layer li; false if the layer has to take another kernel
+bool fwd_hgemm_args(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, HGemmArgs* h) {
+  const TLin& l = t->L[li];
+  const int K = l.in_x();
+  if (!(hgemm_fits(t, l.out, K, R, ldx, Y, ldy, nullptr, 0, 0) && aligned16(t->P + l.b))) return false;
+  const SplitLayer& sl = t->split.l[li];
+  *h = HGemmArgs{};
+  h->A = X; h->lda = ldx; h->Bh = t->planes + sl.fwd; h->Bl = h->Bh + sl.plane_fwd; h->ldb = sl.ld_fwd; h->n_pad = (l.out + 63) / 64 * 64;
+  h->C = Y; h->ldc = ldy; h->M = R; h->N = l.out; h->K = K; h->bwd = 0; h->bias = t->P + l.b; h->act = act;
+  return true;
+}
 int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ldy, int64_t R, int act, hipStream_t s) {
   const TLin& l = t->L[li];
   const int K = l.in_x();
@@ -1242,22 +1253,50 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
     PNRF_LAUNCH_CHECK();
     return 0;
   }
-  if (hgemm_fits(t, l.out, K, R, ldx, Y, ldy, nullptr, 0, 0) && aligned16(t->P + l.b)) {
-    const SplitLayer& sl = t->split.l[li];
-    HGemmArgs h = {};
-    h.A = X; h.lda = ldx; h.Bh = t->planes + sl.fwd; h.Bl = h.Bh + sl.plane_fwd; h.ldb = sl.ld_fwd; h.n_pad = (l.out + 63) / 64 * 64;
-    h.C = Y; h.ldc = ldy; h.M = R; h.N = l.out; h.K = K; h.bwd = 0; h.bias = t->P + l.b; h.act = act;
-    return launch_hgemm(h, s);
-  }
+  HGemmArgs h;
+  if (fwd_hgemm_args(t, li, X, ldx, Y, ldy, R, act, &h)) return launch_hgemm(h, s);
   GemmArgs a = {};
   a.A = X; a.lda = ldx; a.B = l.gap >= 0 ? t->w_gapped : t->P + l.w; a.ldb = K; a.C = Y; a.ldc = ldy; a.M = R; a.N = l.out; a.K = K;
   a.bias = t->P + l.b; a.act = act;
   return launch_tgemm<MODE_NT>(a, s);
 }
+// rows few enough that a layer product is bound by launch and pipeline-fill latency: walk the layers in one launch (hgemm_chain_kernel)
+inline bool chain_rows(int64_t R) { return (R + 15) / 16 <= 512; }
+// the six hidden layers of an ELU net: h[k] = ELU(h[k - 1] W^T + b), h[-1] = x0
+int elu_net_forward(pnrf_trainer* t, int first, const float* x0, int in0, float* const* h, int64_t N, hipStream_t s) {
+  if (chain_rows(N)) {
+    ChainArgs c = {};
+    bool ok = true;
+    const float* x = x0; int ldx = in0;
+    for (int k = 0; k < 6 && ok; ++k) { ok = fwd_hgemm_args(t, first + k, x, ldx, h[k], 256, N, T_ACT_ELU, &c.l[k]); x = h[k]; ldx = 256; }
+    if (ok) {
+      c.n = 6; c.local_scale = 0;
+      hipLaunchKernelGGL(hgemm_chain_kernel, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
+      PNRF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  const float* x = x0; int ldx = in0;
+  for (int k = 0; k < 6; ++k) { int rc = layer_fwd(t, first + k, x, ldx, h[k], 256, N, T_ACT_ELU, s); if (rc) return rc; x = h[k]; ldx = 256; }
+  return 0;
+}
 // dZ (row stride ldz) = dL/dZ of layer li (its activation derivative was applied by whoever produced it); X = the layer's saved input.
 // Accumulates the weight / bias gradients and, unless dX == nullptr, writes dX = (beta dX + dZ W) * act'(Hprev) — Hprev = saved output of
 // the layer (activation prev_act) that produced the columns >= act_col0 of X — i.e. dL/dZ of that layer, ready for its own layer_bwd.
 // dz_amax: device scalar holding max |dZ| (left there by the product that wrote dZ) or NULL if unknown; dx_amax: where to leave max |dX|.
+// arguments of the split-fp16 input-gradient product of layer li (the caller has checked hgemm_fits)
+void bwd_hgemm_args(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz_amax, float* dX, int lddx, float* dx_amax, float beta, int64_t R,
+                    int prev_act, const float* Hprev, int ldh, int act_col0, int n_first, HGemmArgs* h) {
+  const TLin& l = t->L[li];
+  const SplitLayer& sl = t->split.l[li];
+  const int N = l.in_x() - n_first;
+  *h = HGemmArgs{};
+  // fragment-major plane: input column n_first starts (n_first / 16) blocks of 16 rows x ld_bwd in
+  h->A = dZ; h->lda = ldz; h->Bh = t->planes + sl.bwd + (size_t)(n_first >> 4) * 16 * sl.ld_bwd; h->Bl = h->Bh + sl.plane_bwd; h->ldb = sl.ld_bwd;
+  h->n_pad = (N + 63) / 64 * 64;
+  h->C = dX; h->ldc = lddx; h->M = R; h->N = (N + 3) & ~3; h->K = l.out; h->bwd = 1;
+  h->act = prev_act; h->H = Hprev; h->ldh = ldh; h->act_col0 = act_col0; h->beta = beta; h->a_amax = dz_amax; h->c_amax = dx_amax;
+}
 // n_first (a multiple of 16): the input gradient is only wanted from that input column on — dX, Hprev and act_col0 then refer to column n_first
 // (the skip layer without a position gradient: the 64 leading columns of its input are the embedding, whose gradient nobody reads)
 int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz_amax, const float* X, int ldx, float* dX, int lddx, float* dx_amax,
@@ -1282,13 +1321,8 @@ int layer_bwd(pnrf_trainer* t, int li, const float* dZ, int ldz, const float* dz
     return 0;
   }
   if (dx_h) {
-    const SplitLayer& sl = t->split.l[li];
-    HGemmArgs h = {};
-    // fragment-major plane: input column n_first starts (n_first / 16) blocks of 16 rows x ld_bwd in
-    h.A = dZ; h.lda = ldz; h.Bh = t->planes + sl.bwd + (size_t)(n_first >> 4) * 16 * sl.ld_bwd; h.Bl = h.Bh + sl.plane_bwd; h.ldb = sl.ld_bwd;
-    h.n_pad = (N + 63) / 64 * 64;
-    h.C = dX; h.ldc = lddx; h.M = R; h.N = N4; h.K = l.out; h.bwd = 1;
-    h.act = prev_act; h.H = Hprev; h.ldh = ldh; h.act_col0 = act_col0; h.beta = beta; h.a_amax = dz_amax; h.c_amax = dx_amax;
+    HGemmArgs h;
+    bwd_hgemm_args(t, li, dZ, ldz, dz_amax, dX, lddx, dx_amax, beta, R, prev_act, Hprev, ldh, act_col0, n_first, &h);
     return dw.set ? launch_layer_bwd(h, dw, s) : launch_hgemm(h, s);
   }
   GemmArgs a = {};
@@ -1446,7 +1480,8 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, R * 256);
   T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * LD_C5); T_ALLOC(t->d_e0, N * 8 * 64); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
-  T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); T_ALLOC(t->d_h0, N * 256); T_ALLOC(t->d_h1, N * 256);
+  T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); for (int k = 0; k < 6; ++k) T_ALLOC(t->d_hk[k], N * 256);
+  t->d_h0 = t->d_hk[0]; t->d_h1 = t->d_hk[1];
   // padding columns of the concatenated rows are zero and stay zero (the kernels write the payload columns only, or zeros)
   PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)R * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)R * LD_C5 * 4));
   PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)R * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)R * LD_CV * 4));
@@ -1561,17 +1596,15 @@ int sampler_refine_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, hipStr
   const int64_t N = bt->n;
   T_RC(pnrf_ray_encode_fwd(bt->rays, t->mm_input, N, 48, stream));                                                    // refine2.py:551-556
   {
-    const float* x = t->mm_input; int ldx = 288;
-    for (int k = 0; k < 6; ++k) { T_RC(layer_fwd(t, L_S + k, x, ldx, t->s_h[k], 256, N, T_ACT_ELU, s)); x = t->s_h[k]; ldx = 256; }
-    T_RC(layer_fwd(t, L_S + 6, x, 256, t->s_y, 27, N, T_ACT_NONE, s));
+    T_RC(elu_net_forward(t, L_S, t->mm_input, 288, t->s_h, N, s));
+    T_RC(layer_fwd(t, L_S + 6, t->s_h[5], 256, t->s_y, 27, N, T_ACT_NONE, s));
   }
   T_RC(pnrf_sampler_head_fwd(t->s_y, bt->rays, t->depth_sorted, t->sort_idx, t->add_s, t->mul_s, t->mm_rgb, N, stream));     // :557-568
   T_RC(pnrf_refine_input_train_fwd(bt->rays, bt->or_rays, t->depth_sorted, bt->img4, bt->poses, bt->K, bt->ref_nos, bt->nv, 4, bt->Hf, bt->Wf, bt->eps,
                                    bt->layout, t->refine_in, N, stream));                                             // :570-634
   {
-    const float* x = t->refine_in; int ldx = 144;
-    for (int k = 0; k < 6; ++k) { T_RC(layer_fwd(t, L_R + k, x, ldx, t->r_h[k], 256, N, T_ACT_ELU, s)); x = t->r_h[k]; ldx = 256; }
-    T_RC(layer_fwd(t, L_R + 6, x, 256, t->r_y, 35, N, T_ACT_NONE, s));
+    T_RC(elu_net_forward(t, L_R, t->refine_in, 144, t->r_h, N, s));
+    T_RC(layer_fwd(t, L_R + 6, t->r_h[5], 256, t->r_y, 35, N, T_ACT_NONE, s));
   }
   return 0;
 }
@@ -1632,14 +1665,41 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
 // net's input (the Pluecker moment is depth-independent; the projection is under no_grad in the reference)
 int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, float* const* h, const float* x0, int in0, int64_t N, hipStream_t s) {
   float* m = t->amax + (first == L_S ? 16 : 24) * HG_SLOT;                // max-|gradient| slots of this net's six hidden gradients
-  T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, t->d_h0, 256, m, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
-  float* dA = t->d_h0; float* dB = t->d_h1;
-  for (int k = 5; k >= 1; --k) {
-    T_RC(layer_bwd(t, first + k, dA, 256, m, h[k - 1], 256, dB, 256, m + HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
-    float* tmp = dA; dA = dB; dB = tmp;
-    m += HG_SLOT;
+  // dZ of hidden layer k lives in d_hk[k]; the output layer's product writes d_hk[5]
+  T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, t->d_hk[5], 256, m + 5 * HG_SLOT, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
+  bool chain = chain_rows(N) && t->dw_tile == 0;
+  for (int k = 5; k >= 1 && chain; --k)
+    chain = hgemm_fits(t, 256, t->L[first + k].out, N, 256, t->d_hk[k - 1], 256, h[k - 1], 256, 0) && t->L[first + k].in == 256;
+  if (chain) {
+    // (1) the five input-gradient products in one launch, (2) the six weight gradients in one launch
+    ChainArgs c = {};
+    for (int k = 5; k >= 1; --k) {
+      bwd_hgemm_args(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0,
+                     &c.l[5 - k]);
+      c.l[5 - k].tile_max = 1;
+    }
+    c.n = 5; c.local_scale = 1;
+    hipLaunchKernelGGL(hgemm_chain_kernel, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
+    PNRF_LAUNCH_CHECK();
+    DwhGroupArgs g = {};
+    int blocks = 0;
+    for (int k = 5; k >= 0; --k) {
+      const TLin& l = t->L[first + k];
+      DwDefer d;
+      T_RC(gemm_dw(t, k ? h[k - 1] : x0, k ? 256 : in0, t->d_hk[k], 256, m + k * HG_SLOT, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, N, s, &d));
+      PNRF_REQUIRE(d.set, PNRF_E_STATE, "pnrf_trainer: a hidden layer of an ELU net did not take the split-fp16 weight-gradient kernel");
+      g.j[g.n] = d.args; g.first[g.n] = blocks; g.tiles[g.n] = d.tiles;
+      blocks += d.tiles * d.splits;
+      ++g.n;
+    }
+    g.first[g.n] = blocks;
+    hipLaunchKernelGGL(dwh_group_kernel, dim3((unsigned)blocks), dim3(512), 0, s, g);
+    PNRF_LAUNCH_CHECK();
+    return 0;
   }
-  return layer_bwd(t, first + 0, dA, 256, m, x0, in0, nullptr, 0, nullptr, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
+  for (int k = 5; k >= 1; --k)
+    T_RC(layer_bwd(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, h[k - 1], 256, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
+  return layer_bwd(t, first + 0, t->d_hk[0], 256, m, x0, in0, nullptr, 0, nullptr, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
 }
 
 int check_batch(const pnrf_trainer* t, const pnrf_train_batch_t* bt, const float* loss, int S, const char* who) {

@@ -34,5 +34,10 @@ int main(int argc, char** argv) {
   HGemmArgs b = a; b.bwd = 1; b.H = H; b.ldh = N; b.bias = nullptr;
 #define RUNB(P) run("backward (act'(H)), probe " #P, [&] { hipLaunchKernelGGL((hgemm_kernel<4, P>), grid, dim3(512), 0, 0, b); })
   RUNB(0); RUNB(2);
+  if (M <= 8192) {                                             // the 4096-row nets: 16-row tiles, one per workgroup
+    const dim3 g1((unsigned)((M + 15) / 16 < 256 ? (M + 15) / 16 : 256));
+#define RUN1(P) run("16-row tiles, forward, probe " #P, [&] { hipLaunchKernelGGL((hgemm_kernel<1, P>), g1, dim3(512), 0, 0, a); })
+    RUN1(0); RUN1(1); RUN1(2); RUN1(4); RUN1(8); RUN1(12); RUN1(14); RUN1(15);
+  }
   return 0;
 }
