@@ -44,7 +44,6 @@ struct HGemmArgs {
   const float* H; int ldh; int act_col0; float beta;
   const float* a_amax;                         // max |A| slot (HG_SLOT floats, hg_slot_read) or NULL (A used as it is)
   float* c_amax;                               // slot that receives max |C| (hg_slot_write) or NULL
-  int tile_max;                                // 1: the body returns max |C| of the workgroup's rows even without a slot (layer chains)
 };
 constexpr int HG_KC = 64, HG_LDS_ROW = HG_KC + 8, HG_LDC = 256 + 4;
 constexpr float HG_LO_SCALE = 2048.f, HG_LO_INV = 1.f / 2048.f;
@@ -107,11 +106,8 @@ template <int MI> struct HgShape {
   static constexpr int A_BYTES = 2 * 2 * PLANE * 2, C_BYTES = ROWS * HG_LDC * 4, BYTES = A_BYTES + C_BYTES;
 };
 // bx of gx workgroups share the row tiles of column block by (the launch's grid, or a slice of it when the launch also carries other work)
-// a_max_local >= 0: max |A| over this workgroup's rows is already known (the previous layer of a chain left it): no slot is read.
-// Returns max |C| over what this workgroup stored.
 template <int MI, int PROBE = 0>
-__device__ __forceinline__ float hgemm_body(const HGemmArgs& a, const int bx, const int by, const int gx, unsigned char* smem, float* s_red,
-                                            const float a_max_local = -1.f) {
+__device__ __forceinline__ void hgemm_body(const HGemmArgs& a, const int bx, const int by, const int gx, unsigned char* smem, float* s_red) {
   constexpr int ROWS = 16 * MI, NI = 2;
   constexpr int PLANE = ROWS * HG_LDS_ROW;                     // halfs per plane of one chunk
   unsigned char* const smem_a = smem;
@@ -123,7 +119,7 @@ __device__ __forceinline__ float hgemm_body(const HGemmArgs& a, const int bx, co
   const int tn = by;
   const int col0 = tn * 256 + wave * 32;
   const bool wave_on = col0 < a.N;
-  const float a_scale = a_max_local >= 0.f ? hg_scale_for(a_max_local) : a.a_amax ? hg_scale_for(hg_slot_read(a.a_amax, s_red)) : 1.f;
+  const float a_scale = a.a_amax ? hg_scale_for(hg_slot_read(a.a_amax, s_red)) : 1.f;
   const float inv_scale = 1.f / a_scale;
   const int chunks = (a.K + HG_KC - 1) / HG_KC;
   const int64_t ntiles = (a.M + ROWS - 1) / ROWS;
@@ -365,7 +361,7 @@ __device__ __forceinline__ float hgemm_body(const HGemmArgs& a, const int bx, co
     mma_step(w3, x1);
     finish_chunk();
   }
-  return a.c_amax || a.tile_max ? hg_slot_write(a.c_amax, amax, s_red, (unsigned)(bx + gx * by)) : 0.f;
+  if (a.c_amax) (void)hg_slot_write(a.c_amax, amax, s_red, (unsigned)(bx + gx * by));
 }
 template <int MI, int PROBE = 0>
 __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
@@ -581,27 +577,7 @@ __global__ __launch_bounds__(512) void layer_bwd_kernel(HGemmArgs g, DwhArgs d, 
   }
 }
 
-// ------------------------------------------------------------------------------------------ layer chains of the 4096-row nets
-// The sampler / refine nets see one batch of rays (4096 rows): a layer product is 4 MB in, 4 MB out, and a launch costs 3.7 us before its
-// first useful instruction plus the exposed latencies of a pipeline that is only four chunks long — 7.6 us per layer.  Rows are independent
-// through the layers, so one launch walks a whole chain: workgroup b owns rows 16 b .. 16 b + 15 in every layer (grid = number of 16-row
-// tiles), waits for its own stores between layers, and reads back what it wrote (same CU, same L1: no other workgroup is involved).
-//   forward: h_{l+1} = ELU(h_l W_l^T + b_l), six layers;   backward: dZ_{l-1} = (dZ_l W_l) * ELU'(h_{l-1}), five layers — there the power-of-two
-//   scale of the next product comes from the maximum over the workgroup's OWN rows (any per-row-block scale is exact: it is undone in the
-//   same workgroup's epilogue), while the global maxima still go to the slots for the weight-gradient kernel that follows the chain.
-constexpr int HG_CHAIN_MAX = 6;
-struct ChainArgs { HGemmArgs l[HG_CHAIN_MAX]; int n; int local_scale; };
-__global__ __launch_bounds__(512) void hgemm_chain_kernel(ChainArgs c) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<1>::BYTES];
-  __shared__ float s_red[16];
-  float tile_max = -1.f;
-  for (int i = 0; i < c.n; ++i) {
-    const float m = hgemm_body<1, 0>(c.l[i], (int)blockIdx.x, 0, (int)gridDim.x, smem, s_red, c.local_scale && i > 0 ? tile_max : -1.f);
-    tile_max = m;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this layer's rows are in L2 / this CU's L1 ...
-    __syncthreads();                                           // ... for every wave of the workgroup before the next layer fetches them
-  }
-}
+// ------------------------------------------------------------------------------------------ grouped weight gradients
 // The weight gradients of several layers in one launch (their dZ / X buffers must all still exist): blocks [first[j], first[j + 1]) belong to
 // job j as (tile, split) = (b % tiles, b / tiles).
 constexpr int DH_GROUP_MAX = 6;
@@ -613,4 +589,162 @@ __global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
   while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
   const int b = (int)blockIdx.x - g.first[j];
   dwh_body(g.j[j], b % g.tiles[j], b / g.tiles[j], smem, s_red);
+}
+
+// ------------------------------------------------------------------------------------------ layer chains of the 4096-row nets, handed over in LDS
+// The sampler / refine nets see one batch of rays (4096 rows): a layer product is 4 MB in, 4 MB out, and as a launch of its own it costs 7.6 us —
+// 3.7 us before the first useful instruction plus the exposed latencies of a pipeline that is only four chunks long.  Rows are independent
+// through the layers, so one launch walks a whole chain: workgroup b owns rows 16 b .. 16 b + 15 in every layer (grid = number of 16-row tiles).
+// Walking the layers with hgemm_body alone (stores drained, the output fetched back from L2, the weight pipeline restarted per layer) still
+// cost ~7 us per layer; for the 256 -> 256 layers the hand-over stays on chip instead: the epilogue that stores a layer's rows (they are
+// needed for the backward pass / the weight gradients) also splits them and writes the next layer's fp16 operand planes into LDS —
+// 16 rows x 256 k x 2 planes = 17 KB, two such regions — so a layer is: eight MFMA steps fed from LDS and from a weight stream that is
+// prefetched three steps ahead ACROSS the layer boundary, plus one epilogue.  An optional first layer of another input width runs through
+// hgemm_body and its output is fetched once.  Backward chains prefetch the rows of ELU'(h) at the start of each layer and take the scale of the
+// next product from the maximum over the workgroup's own 16 rows.
+constexpr int RC_LDX = 256 + 8;                                // halfs per row of a resident operand plane
+constexpr int HG_CHAIN_MAX = 6;
+struct RChainLayer { const _Float16 *Bh, *Bl; int ldb, n_pad; const float* bias; float* C; const float* H; float* c_amax; };
+struct RChainArgs {
+  HGemmArgs first; int has_first;                              // optional leading layer through hgemm_body (forward: 288 / 144 -> 256)
+  const float* X0; const float* x0_amax;                       // [M, 256] input rows of the first resident layer; its max-|.| slot or NULL
+  RChainLayer l[HG_CHAIN_MAX]; int n;
+  int64_t M; int bwd;                                          // forward: C = ELU(X W^T + bias); backward: C = (X W^T) * ELU'(H)
+};
+// MI: 16-row MFMA tiles per workgroup.  Every workgroup reads all 256 KB of a layer's weight planes from L2: with 16-row tiles (256 workgroups
+// for 4096 rows) that is 64 MB per layer — 6 us of L2 bandwidth; 32-row tiles halve it and still give half of the CUs a workgroup.
+template <int MI>
+__global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
+  constexpr int ROWS = 16 * MI, QN = 2 * MI;
+  constexpr int XPLANE = ROWS * RC_LDX;                        // halfs per plane
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<MI>::BYTES > 4 * XPLANE * 2 + ROWS * HG_LDC * 4 ? HgShape<MI>::BYTES : 4 * XPLANE * 2 + ROWS * HG_LDC * 4];
+  __shared__ float s_red[16];
+  _Float16* const sX = (_Float16*)smem;                        // [region][plane hi / lo][ROWS][RC_LDX]
+  float* const sC = (float*)(smem + 4 * XPLANE * 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m16 = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  if (c.has_first) {
+    hgemm_body<MI, 0>(c.first, (int)blockIdx.x, 0, (int)gridDim.x, smem, s_red);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+  // thread t <-> rows (t >> 6) + 8 q (q < QN), columns 4 (t & 63) .. + 3: the mapping of the hand-over and of the epilogue
+  const int cl = 4 * (threadIdx.x & 63), rl0 = threadIdx.x >> 6;
+  int64_t rr[QN];
+#pragma unroll
+  for (int q = 0; q < QN; ++q) { const int64_t r = row0 + rl0 + 8 * q; rr[q] = r < c.M ? r : c.M - 1; }
+  float in_scale = 1.f;
+  {
+    if (c.x0_amax) in_scale = hg_scale_for(hg_slot_read(c.x0_amax, s_red));
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const f32x4_t x = *(const f32x4_t*)(c.X0 + rr[q] * 256 + cl);
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = x[e] * in_scale; const _Float16 vh = (_Float16)v; h[e] = vh; l[e] = (_Float16)((v - (float)vh) * HG_LO_SCALE); }
+      const int off = (rl0 + 8 * q) * RC_LDX + cl;
+      *(f16x4_t*)(sX + off) = h;
+      *(f16x4_t*)(sX + XPLANE + off) = l;
+    }
+  }
+  // weight stream: step s of layer i = global step 8 i + s; four rotating register sets, three steps ahead
+  struct WFrag { f16x8_t h[2], l[2]; };
+  int w_layer = 0, w_ks = 0;
+  auto load_w = [&](WFrag& w) {
+    if (w_layer < c.n) {
+      const RChainLayer& L = c.l[w_layer];
+      const int plane_bytes = L.n_pad * L.ldb * 2;
+      const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc((void*)L.Bh, 0, plane_bytes, HG_BUF_FLAGS);
+      const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc((void*)L.Bl, 0, plane_bytes, HG_BUF_FLAGS);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned off = (unsigned)(((wave * 2 + j) * (L.ldb >> 5)) * 1024 + lane * 16);
+        w.h[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(hr, off, w_ks * 1024, 0));
+        w.l[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(lr, off, w_ks * 1024, 0));
+      }
+    }
+    if (++w_ks == 8) { w_ks = 0; ++w_layer; }
+  };
+  WFrag w0, w1, w2, w3;
+  load_w(w0); load_w(w1); load_w(w2);
+  __syncthreads();                                             // the first resident operand planes are complete
+  for (int i = 0; i < c.n; ++i) {
+    const RChainLayer& L = c.l[i];
+    const _Float16* xh = sX + (i & 1) * 2 * XPLANE;
+    const _Float16* xl = xh + XPLANE;
+    f32x4_t hv[QN];
+    if (c.bwd) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) hv[q] = *(const f32x4_t*)(L.H + rr[q] * 256 + cl);
+    }
+    f32x4_t accm[MI][2], accx[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { accm[mi][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accx[mi][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    auto step = [&](const WFrag& w, int s) {
+      f16x8_t ah[MI], al[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int off = (16 * mi + m16) * RC_LDX + 32 * s + 8 * g;
+        ah[mi] = *(const f16x8_t*)(xh + off); al[mi] = *(const f16x8_t*)(xl + off);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          accx[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[j], al[mi], accx[mi][j], 0, 0, 0);
+          accm[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[j], ah[mi], accm[mi][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[j], ah[mi], accx[mi][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    load_w(w3); step(w0, 0); load_w(w0); step(w1, 1); load_w(w1); step(w2, 2); load_w(w2); step(w3, 3);
+    load_w(w3); step(w0, 4); load_w(w0); step(w1, 5); load_w(w1); step(w2, 6); load_w(w2); step(w3, 7);
+    // ---- epilogue.  All fetches in flight (the next layer's first weight fragments, the rows of H) are drained before the first store
+    // (cf. hgemm_body: one counter for loads and stores).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const float inv = 1.f / in_scale;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *(f32x4_t*)(sC + (16 * mi + m16) * HG_LDC + wave * 32 + 16 * j + 4 * g) = (accm[mi][j] + accx[mi][j] * HG_LO_INV) * inv;
+    __syncthreads();
+    f32x4_t v[QN];
+    float amax = 0.f;
+    const f32x4_t b4 = !c.bwd && L.bias ? *(const f32x4_t*)(L.bias + cl) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      v[q] = *(const f32x4_t*)(sC + (rl0 + 8 * q) * HG_LDC + cl) + b4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!c.bwd) v[q][e] = v[q][e] > 0.f ? v[q][e] : expm1f(v[q][e]);
+        else v[q][e] = hv[q][e] > 0.f ? v[q][e] : v[q][e] * (hv[q][e] + 1.f);
+      }
+      if (row0 + rl0 + 8 * q < c.M) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[q][0]), fabsf(v[q][1]))), fmaxf(fabsf(v[q][2]), fabsf(v[q][3])));
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // (the bias fetch)
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+      if (row0 + rl0 + 8 * q < c.M) *(f32x4_t*)(L.C + rr[q] * 256 + cl) = v[q];
+    in_scale = 1.f;
+    if (c.bwd) in_scale = hg_scale_for(hg_slot_write(L.c_amax, amax, s_red, blockIdx.x));   // the workgroup's own maximum
+    if (i + 1 < c.n) {
+      _Float16* nh = sX + ((i + 1) & 1) * 2 * XPLANE;
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        f16x4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float x = v[q][e] * in_scale; const _Float16 xh_ = (_Float16)x; h[e] = xh_; l[e] = (_Float16)((x - (float)xh_) * HG_LO_SCALE); }
+        const int off = (rl0 + 8 * q) * RC_LDX + cl;
+        *(f16x4_t*)(nh + off) = h;
+        *(f16x4_t*)(nh + XPLANE + off) = l;
+      }
+    }
+    __syncthreads();
+  }
 }

@@ -1260,18 +1260,28 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
   a.bias = t->P + l.b; a.act = act;
   return launch_tgemm<MODE_NT>(a, s);
 }
-// rows few enough that a layer product is bound by launch and pipeline-fill latency: walk the layers in one launch (hgemm_chain_kernel)
+// 16-row tiles while they fit one wave of workgroups (4096 rows: 1.227 ms per iteration; with 32-row tiles 1.254 — the chain is bound by its
+// latencies, not by the weight planes every workgroup streams from L2), 32-row tiles beyond
+void launch_rchain(const RChainArgs& c, int64_t N, hipStream_t s) {
+  if (N > 4096) hipLaunchKernelGGL((hgemm_rchain_kernel<2>), dim3((unsigned)((N + 31) / 32)), dim3(512), 0, s, c);
+  else hipLaunchKernelGGL((hgemm_rchain_kernel<1>), dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
+}
+// rows few enough that a layer product is bound by launch and pipeline-fill latency: walk the layers in one launch (hgemm_rchain_kernel)
 inline bool chain_rows(int64_t R) { return (R + 15) / 16 <= 512; }
 // the six hidden layers of an ELU net: h[k] = ELU(h[k - 1] W^T + b), h[-1] = x0
 int elu_net_forward(pnrf_trainer* t, int first, const float* x0, int in0, float* const* h, int64_t N, hipStream_t s) {
   if (chain_rows(N)) {
-    ChainArgs c = {};
-    bool ok = true;
-    const float* x = x0; int ldx = in0;
-    for (int k = 0; k < 6 && ok; ++k) { ok = fwd_hgemm_args(t, first + k, x, ldx, h[k], 256, N, T_ACT_ELU, &c.l[k]); x = h[k]; ldx = 256; }
+    // layer 0 (288 / 144 -> 256) through the general product body, layers 1 .. 5 (256 -> 256) handed over in LDS: one launch
+    RChainArgs c = {};
+    bool ok = fwd_hgemm_args(t, first, x0, in0, h[0], 256, N, T_ACT_ELU, &c.first);
+    for (int k = 1; k < 6 && ok; ++k) {
+      HGemmArgs a;
+      ok = fwd_hgemm_args(t, first + k, h[k - 1], 256, h[k], 256, N, T_ACT_ELU, &a) && a.K == 256 && a.N == 256;
+      c.l[k - 1] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, h[k], nullptr, nullptr};
+    }
     if (ok) {
-      c.n = 6; c.local_scale = 0;
-      hipLaunchKernelGGL(hgemm_chain_kernel, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
+      c.has_first = 1; c.X0 = h[0]; c.x0_amax = nullptr; c.n = 5; c.M = N; c.bwd = 0;
+      launch_rchain(c, N, s);
       PNRF_LAUNCH_CHECK();
       return 0;
     }
@@ -1669,17 +1679,17 @@ int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, 
   T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, t->d_hk[5], 256, m + 5 * HG_SLOT, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
   bool chain = chain_rows(N) && t->dw_tile == 0;
   for (int k = 5; k >= 1 && chain; --k)
-    chain = hgemm_fits(t, 256, t->L[first + k].out, N, 256, t->d_hk[k - 1], 256, h[k - 1], 256, 0) && t->L[first + k].in == 256;
+    chain = hgemm_fits(t, 256, t->L[first + k].out, N, 256, t->d_hk[k - 1], 256, h[k - 1], 256, 0) && t->L[first + k].in == 256 && t->L[first + k].out == 256;
   if (chain) {
     // (1) the five input-gradient products in one launch, (2) the six weight gradients in one launch
-    ChainArgs c = {};
+    RChainArgs c = {};
     for (int k = 5; k >= 1; --k) {
-      bwd_hgemm_args(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0,
-                     &c.l[5 - k]);
-      c.l[5 - k].tile_max = 1;
+      HGemmArgs a;
+      bwd_hgemm_args(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0, &a);
+      c.l[5 - k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, nullptr, t->d_hk[k - 1], h[k - 1], m + (k - 1) * HG_SLOT};
     }
-    c.n = 5; c.local_scale = 1;
-    hipLaunchKernelGGL(hgemm_chain_kernel, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
+    c.has_first = 0; c.X0 = t->d_hk[5]; c.x0_amax = m + 5 * HG_SLOT; c.n = 5; c.M = N; c.bwd = 1;
+    launch_rchain(c, N, s);
     PNRF_LAUNCH_CHECK();
     DwhGroupArgs g = {};
     int blocks = 0;

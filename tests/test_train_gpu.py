@@ -247,6 +247,30 @@ def test_split_fp16_products_keep_tiny_gradients(dev):
     assert worst < 3e-2, worst                                                # (flushed to zero: 1.0)
 
 
+def test_larger_batch_takes_the_same_gradients_on_both_product_paths(dev):
+    """4 200 rays (not a multiple of any tile size): the ELU nets' layer chains then run on 32-row tiles and the NeRF layers on 33 600 rows with
+    ragged last tiles.  The exact-fp32 products use none of those kernels (no chains, no split-fp16 tiles), so the two runs are independent
+    implementations of the same iteration: same loss, gradients as close as two fp32 summation orders are on this ill-conditioned chain."""
+    from pronerf_amd import ops
+    b = _batch(1, 60, 70, 7)
+    assert b['N'] == 4200
+    layers = orc.trainer_layers(b['w'])
+    img4 = ops.images_pack(cu(b['images'], dev))
+    args = (cu(b['rays'], dev), cu(b['or_rays'], dev), cu(b['target'], dev), img4, cu(b['poses'], dev), cu(b['K'], dev), b['ref_nos'].to(dev).contiguous())
+    kw = dict(jitter=cu(b['jitter'], dev), jitter_dir=-1, raw_noise=cu(b['noise'], dev), a_mmrgb=1.0)
+    res = {}
+    for products in ('f32', 'f16x2'):
+        tr = ops.Trainer([W for W, _ in layers], [x for _, x in layers], max_rays=b['N'], device=dev)
+        tr.set_products(products)
+        L, rgb = tr.fwd_bwd(*args, **kw)
+        res[products] = (L.cpu().numpy(), rgb.cpu(), [tr.read('grad', i) for i in range(26)])
+    La, Lb = res['f32'][0], res['f16x2'][0]
+    assert np.all(np.abs(La - Lb) < 2e-6 * np.maximum(1.0, np.abs(La))), (La, Lb)
+    assert orc.psnr(res['f16x2'][1], res['f32'][1]) > 90.0
+    worst = max(rel(x, y) for li in range(26) for x, y in zip(res['f16x2'][2][li], res['f32'][2][li]))
+    assert worst < 2e-2, worst
+
+
 def test_adam_step_matches_torch_optim(dev):
     """optimizer.step(): identical gradients in, torch.optim.Adam's parameters out (three steps, weight decay, bias correction)."""
     from pronerf_amd import ops
