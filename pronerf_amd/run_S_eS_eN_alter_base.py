@@ -159,6 +159,8 @@ def train(argv=None, device='cuda'):
         dist.broadcast_object_list(box, src=0)
         sds = box[0]
     tr = ops.Trainer(*zip(*trainer_layer_list(*sds)), max_rays=n_local, device=dev, max_samples=8 * max_mult)
+    if os.environ.get('PNRF_TRAIN_PRODUCTS'):          # 'f32': exact-fp32 layer products instead of the split-fp16 default (Trainer.set_products)
+        tr.set_products(os.environ['PNRF_TRAIN_PRODUCTS'])
     if ck is not None:
         restore_optimizer(tr, ck, 1)
     adam_steps = [start - start // 2, start // 2] if ck is not None and 'pnrf_adam_steps' not in ck else ([0, 0] if ck is None else list(ck['pnrf_adam_steps']))

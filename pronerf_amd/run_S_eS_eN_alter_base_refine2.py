@@ -346,6 +346,8 @@ def train(argv=None, device='cuda'):
         fine_sd = ck['network_fine_state_dict']
         print('Reloading from', resume, 'at step', start)
     tr = ops.Trainer(*zip(*trainer_layer_list(ck['mmr_network_fn_state_dict'], ck['refine_net_state_dict'], fine_sd)), max_rays=n_local, device=dev)
+    if os.environ.get('PNRF_TRAIN_PRODUCTS'):          # 'f32': exact-fp32 layer products instead of the split-fp16 default (Trainer.set_products)
+        tr.set_products(os.environ['PNRF_TRAIN_PRODUCTS'])
     if resume is not None:
         restore_optimizer(tr, ck, 2)
     adam_steps = [start, 0]
