@@ -74,7 +74,9 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
  * on v_mfma_f32_16x16x32_bf16.  The others exist for parity tests and A/B timing (tools/perf_ab.py):
  *   SAMPLER_F32       sampler on the exact fp32 FMA chain (v_mfma_f32_16x16x4_f32), folded first layer;
  *   SAMPLER_F32_FULL  ... with the full K = 288 first layer on the 48 Pluecker points (no fold);
- *   BF16_32X32        refine / NeRF handles: the v_mfma_f32_32x32x16_bf16 engine.
+ *   BF16_32X32        refine / NeRF handles: the v_mfma_f32_32x32x16_bf16 engine;
+ *   NERF_4X64         NeRF handles: 4 waves of 64 columns per workgroup (one wave per SIMD) instead of 8 waves of 32 — same arithmetic,
+ *                     same packed stream, every weight fragment read from LDS feeds four MFMAs instead of two.
  * A variant is part of a handle's configuration, like its weights: set it right after pack / deserialize, before the handle is given to
  * a context or a stream (the call is not synchronised against launches that use the handle).  Nothing in the library reads the process
  * environment to pick kernels.  Returns PNRF_E_ARG for a variant the handle's net kind does not have. */
@@ -82,6 +84,7 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 #define PNRF_VARIANT_SAMPLER_F32 1
 #define PNRF_VARIANT_SAMPLER_F32_FULL 2
 #define PNRF_VARIANT_BF16_32X32 3
+#define PNRF_VARIANT_NERF_4X64 4
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear

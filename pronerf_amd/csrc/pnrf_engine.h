@@ -469,21 +469,24 @@ __host__ __device__ constexpr int hidden_feat_h16(int ks, int g, int j) { return
 #ifndef PNRF_B16_ATSTEP
 #define PNRF_B16_ATSTEP 2
 #endif
-template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
-__device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][2]) {
+// NCB: 16-column blocks per wave fed by every weight fragment (2 with 8 waves per workgroup, 4 with 4 waves: half the LDS fragment reads per MFMA)
+template <int KS, int NTP, int POS0, int NCB = 2, class ST, class BFn, class Epi1, class Pre1>
+__device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][NCB]) {
   constexpr int NF = NTP * KS * 2;
   constexpr int AHEAD = NF < PNRF_B16_AHEAD ? NF : PNRF_B16_AHEAD;
   auto frag_ptr = [&](int g) {
     return (const bf16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
-  f32x4 pend[2][2];
+  f32x4 pend[2][NCB];
   bf16x8 aq[AHEAD];
   f32x4 nbias[2] = {*(const f32x4*)biaslane, *(const f32x4*)(biaslane + 16)};
 #pragma unroll
   for (int tp = 0; tp < NTP; ++tp) {
-    f32x4 acc[2][2];
+    f32x4 acc[2][NCB];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { acc[t][0] = nbias[t]; acc[t][1] = nbias[t]; }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = nbias[t];
     if (tp + 1 < NTP) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) nbias[t] = *(const f32x4*)(biaslane + (2 * (tp + 1) + t) * 16);
@@ -501,25 +504,32 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
         }
         const bf16x8 a = aq[f % AHEAD];
         if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bf(0, ks), acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bf(1, ks), acc[t][1], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bf(cb, ks), acc[t][cb], 0, 0, 0);
         st.slot_issue(f % SLOT_FRAGS);
       }
+      // deferred epilogue of the previous pair in NCB pieces (tile pc, column blocks [cb0, cb0 + 2)): with one wave per SIMD (NCB = 4) nothing
+      // else fills the MFMA pipe while a piece's VALU burst runs, so the pieces are half as large and sit in four different k-steps
 #pragma unroll
-      for (int pc = 0; pc < 2; ++pc) {
-        const int at = KS >= 4 ? PNRF_B16_AT0 + pc * PNRF_B16_ATSTEP : KS - 1;
+      for (int pp = 0; pp < NCB; ++pp) {
+        const int pc = NCB == 2 ? pp : pp >> 1, cb0 = NCB == 2 ? 0 : 2 * (pp & 1);
+        const int at = KS >= 4 ? (NCB == 2 ? PNRF_B16_AT0 + pc * PNRF_B16_ATSTEP : 1 + pp) : KS - 1;
         if (ks == (at < KS ? at : KS - 1)) {
-          if (tp == 0) pre1(pc);
-          else epi1(tp - 1, pc, pend);
+          if (tp == 0) pre1(pc, cb0);
+          else epi1(tp - 1, pc, pend, cb0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { pend[t][0] = acc[t][0]; pend[t][1] = acc[t][1]; }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = acc[t][cb];
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) { last[t][0] = pend[t][0]; last[t][1] = pend[t][1]; }
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) last[t][cb] = pend[t][cb];
 }
 
 // Row of a 32x32 accumulator tile held in register g of a lane in half h (cdna guide §3).

@@ -1044,11 +1044,13 @@ __device__ __forceinline__ int relu_pack_bf16(float a, float b) {
   return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, pk), i16x2_t{0, 0}));
 #endif
 }
+template <int NCB>
 struct HiddenEpi16 {
-  bf16x8 (&Bn)[2][NB_KS_H];
-  __device__ __forceinline__ void operator()(int tp, int pc, f32x4 (&acc)[2][2]) const {
+  bf16x8 (&Bn)[NCB][NB_KS_H];
+  // column blocks cb0, cb0 + 1 of tile pc
+  __device__ __forceinline__ void operator()(int tp, int pc, f32x4 (&acc)[2][NCB], int cb0) const {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = cb0; cb < cb0 + 2; ++cb) {
       i32x4_t w = __builtin_bit_cast(i32x4_t, Bn[cb][tp]);
       w[2 * pc] = relu_pack_bf16(acc[pc][cb][0], acc[pc][cb][1]);
       w[2 * pc + 1] = relu_pack_bf16(acc[pc][cb][2], acc[pc][cb][3]);
@@ -1058,9 +1060,12 @@ struct HiddenEpi16 {
 };
 
 // CLS = false: DoNeRFTRT; CLS = true: the NeRF class (layer sequence as nerf_kernel<.., CLS>, feature_linear folded, alpha as a 9th tile)
-template <bool CLS>
-__global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
-  constexpr int TPB = 512, NW = 8;
+// NCB = 2: 8 waves of 32 columns, two waves per SIMD (the default).  NCB = 4: 4 waves of 64 columns, one wave per SIMD: every weight fragment read
+// from LDS feeds four MFMAs instead of two (tools/lds_mfma_probe.hip: 1.57 -> 1.81 PFLOP/s for the bare hidden-layer loop).
+template <bool CLS, int NCB = 2>
+__global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfArgs a) {
+  constexpr int NW = 16 / NCB, TPB = 64 * NW;
+  using Epi = HiddenEpi16<NCB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
@@ -1085,13 +1090,13 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
   const bool composite = a.S == 8 && a.rgbd;
 
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
-    int64_t row[2];
-    bool valid[2];
-    bf16x8 Bo[2][NB_KS_H], Bn[2][NB_KS_H], Bx[2];
-    float e_dn[2], e_z[2], e_add[2], e_mul[2], e_noise[2];
-    static_for<2>([&](auto cbc) {
+    int64_t row[NCB];
+    bool valid[NCB];
+    bf16x8 Bo[NCB][NB_KS_H], Bn[NCB][NB_KS_H], Bx[NCB];
+    float e_dn[NCB], e_z[NCB], e_add[NCB], e_mul[NCB], e_noise[NCB];
+    static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
-      row[cb] = (int64_t)batch * (NW * 32) + wave * 32 + cb * 16 + c16;
+      row[cb] = (int64_t)batch * (NW * 16 * NCB) + wave * (16 * NCB) + cb * 16 + c16;
       valid[cb] = row[cb] < nrows;
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       const float* pp = a.pts + rr * 3;
@@ -1129,71 +1134,77 @@ __global__ __launch_bounds__(512, 2) void nerf16_kernel(NerfArgs a) {
       }
       Bx[cb] = pack_bf16(fx);
     });
-    f32x4 fin[2][2], pend[2][2];
+    f32x4 fin[2][NCB], pend[2][NCB];
     if constexpr (!CLS) {
-      auto hidden = [&](bf16x8(&in)[2][NB_KS_H], bf16x8(&out)[2][NB_KS_H], int l) {
-        f32x4 np[2][2];
-        layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, HiddenEpi16{out},
-                                               [&](int pc) { HiddenEpi16{in}(NB_NTP_H - 1, pc, pend); }, np);
+      auto hidden = [&](bf16x8(&in)[NCB][NB_KS_H], bf16x8(&out)[NCB][NB_KS_H], int l) {
+        f32x4 np[2][NCB];
+        layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H, NCB>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
+                                               [&](int pc, int cb0) { Epi{in}(NB_NTP_H - 1, pc, pend, cb0); }, np);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
-      layer_b16<NB_KS0, NB_NTP_H, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, HiddenEpi16{Bn}, [](int) {}, pend);
+      layer_b16<NB_KS0, NB_NTP_H, 0, NCB>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
       static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
       for (int l = 0; l < N_NHID; l += 2) {
         hidden(Bn, Bo, l);
         hidden(Bo, Bn, l + 1);
       }
-      layer_b16<NB_KS_LAST, 1, NB_POS_LAST>(
+      layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB>(
           st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
-          [&](int, int, f32x4(&)[2][2]) {}, [&](int pc) { HiddenEpi16{Bn}(NB_NTP_H - 1, pc, pend); }, fin);
+          [&](int, int, f32x4(&)[2][NCB], int) {}, [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, fin);
 #pragma unroll
       for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
     } else {
       // E0 Bo->Bn | E1..E4 ping-pong (ends in Bn) | E5 [Bn, P]->Bo | E6 Bo->Bn | E7 Bn->Bo | E89 [Bo, Bx]->Bn (128 wide) + alpha | E10 Bn -> rgb
-      bf16x8 P[2][NB_KS0];                  // positional fragments, needed again by the skip connection at layer 5
+      bf16x8 P[NCB][NB_KS0];                  // positional fragments, needed again by the skip connection at layer 5
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int k = 0; k < NB_KS0; ++k) P[cb][k] = Bo[cb][k];
-      auto hidden = [&](bf16x8(&in)[2][NB_KS_H], bf16x8(&out)[2][NB_KS_H], int l, auto posc) {
+      auto hidden = [&](bf16x8(&in)[NCB][NB_KS_H], bf16x8(&out)[NCB][NB_KS_H], int l, auto posc) {
         constexpr int POS = decltype(posc)::value;
-        f32x4 np[2][2];
-        layer_b16<NB_KS_H, NB_NTP_H, POS>(st, ringlane, biaslane + l * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, HiddenEpi16{out},
-                                          [&](int pc) { HiddenEpi16{in}(NB_NTP_H - 1, pc, pend); }, np);
+        f32x4 np[2][NCB];
+        layer_b16<NB_KS_H, NB_NTP_H, POS, NCB>(st, ringlane, biaslane + l * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
+                                          [&](int pc, int cb0) { Epi{in}(NB_NTP_H - 1, pc, pend, cb0); }, np);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
-      layer_b16<NB_KS0, NB_NTP_H, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, HiddenEpi16{Bn}, [](int) {}, pend);
+      layer_b16<NB_KS0, NB_NTP_H, 0, NCB>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
       for (int l = 1; l < 5; l += 2) {        // E1..E4
         hidden(Bn, Bo, l, std::integral_constant<int, CB_POS_E1>{});
         hidden(Bo, Bn, l + 1, std::integral_constant<int, CB_POS_E1>{});
       }
       {                                       // E5: cat[pts, h] -> 256 (skip connection after layer 4)
-        f32x4 np[2][2];
-        layer_b16<CB_KS5, NB_NTP_H, CB_POS_E5>(
+        f32x4 np[2][NCB];
+        layer_b16<CB_KS5, NB_NTP_H, CB_POS_E5, NCB>(
             st, ringlane, biaslane + 5 * W_HID,
-            [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : P[cb][ks >= NB_KS_H ? ks - NB_KS_H : 0]; }, HiddenEpi16{Bo},
-            [&](int pc) { HiddenEpi16{Bn}(NB_NTP_H - 1, pc, pend); }, np);
+            [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : P[cb][ks >= NB_KS_H ? ks - NB_KS_H : 0]; }, Epi{Bo},
+            [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, np);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { pend[t][0] = np[t][0]; pend[t][1] = np[t][1]; }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       }
       hidden(Bo, Bn, 6, std::integral_constant<int, CB_POS_E6>{});
       hidden(Bn, Bo, 7, std::integral_constant<int, CB_POS_E6>{});
-      f32x4 al[2][2];                         // E89: view tiles (pairs 0..3, ReLU -> Bn k-steps 0..3) + alpha (pair 4, tile 0, row 0)
-      layer_b16<NB_KS_LAST, CB_NTP89, CB_POS_E89>(
-          st, ringlane, biaslane + CB_BIAS_E89, [&](int cb, int ks) { return ks < NB_KS_H ? Bo[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; }, HiddenEpi16{Bn},
-          [&](int pc) { HiddenEpi16{Bo}(NB_NTP_H - 1, pc, pend); }, al);
-      layer_b16<CB_KS10, 1, CB_POS_E10>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
-                                        [&](int, int, f32x4(&)[2][2]) {}, [](int) {}, fin);
+      f32x4 al[2][NCB];                         // E89: view tiles (pairs 0..3, ReLU -> Bn k-steps 0..3) + alpha (pair 4, tile 0, row 0)
+      layer_b16<NB_KS_LAST, CB_NTP89, CB_POS_E89, NCB>(
+          st, ringlane, biaslane + CB_BIAS_E89, [&](int cb, int ks) { return ks < NB_KS_H ? Bo[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; }, Epi{Bn},
+          [&](int pc, int cb0) { Epi{Bo}(NB_NTP_H - 1, pc, pend, cb0); }, al);
+      layer_b16<CB_KS10, 1, CB_POS_E10, NCB>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
+                                        [&](int, int, f32x4(&)[2][NCB], int) {}, [](int, int) {}, fin);
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) fin[0][cb][3] = al[0][cb][0];          // raw = [rgb, alpha] (helpers:851)
+      for (int cb = 0; cb < NCB; ++cb) fin[0][cb][3] = al[0][cb][0];          // raw = [rgb, alpha] (helpers:851)
 #pragma unroll
       for (int i = 0; i < CB_SLOTS_PAD; ++i) st.begin();
     }
 
     // ---- fused epilogue (as nerf_kernel): group 0 holds raw rgb-sigma of its column in regs 0-3 of tile 0
-    static_for<2>([&](auto cbc) {
+    static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       float r0 = fin[0][cb][0], r1 = fin[0][cb][1], r2 = fin[0][cb][2], r3 = fin[0][cb][3];
@@ -1376,13 +1387,17 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   if (h->net == PNRF_NET_NERFCLS) {
     if (b16) {
       a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
-      return launch_mlp(nerf16_kernel<true>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+      if (h->variant == PNRF_VARIANT_NERF_4X64)
+        return launch_mlp(nerf16_kernel<true, 4>, a, 256, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+      return launch_mlp(nerf16_kernel<true, 2>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
     }
     return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
   }
   if (b16) {
     a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
-    return launch_mlp(nerf16_kernel<false>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+    if (h->variant == PNRF_VARIANT_NERF_4X64)
+      return launch_mlp(nerf16_kernel<false, 4>, a, 256, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
+    return launch_mlp(nerf16_kernel<false, 2>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
   }
   return launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }

@@ -255,6 +255,35 @@ def test_refine_and_nerf_stages(dev):
     np.testing.assert_allclose(rgbd[:, 3].cpu().numpy(), r[4].numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize('net', ['nerf', 'nerfcls'])
+def test_nerf_stage_variants_agree(dev, net):
+    """PNRF_VARIANT_NERF_4X64 (4 waves of 64 columns) runs the same MFMAs on the same packed stream in the same accumulation order as the
+    default (8 waves of 32 columns): bit-identical raw outputs and composited pixels, ragged row counts included.  PNRF_VARIANT_BF16_32X32
+    (the 32x32x16 engine) contracts in another order: bf16-grade agreement."""
+    from pronerf_amd import ops
+    w = synth.make_weights(0, 'trained')
+    if net == 'nerf':
+        Ws, bs, kind = w['nerf']['W'], w['nerf']['b'], ops.NET_NERF
+    else:
+        wc = synth.make_nerfcls_weights(0, head_scale=0.3)
+        Ws = [w_ for w_, _ in wc['pts_linears']] + [wc['feature_linear'][0], wc['alpha_linear'][0], wc['views_linears'][0][0], wc['rgb_linear'][0]]
+        bs = [b_ for _, b_ in wc['pts_linears']] + [wc['feature_linear'][1], wc['alpha_linear'][1], wc['views_linears'][0][1], wc['rgb_linear'][1]]
+        kind = ops.NET_NERFCLS
+    rs = np.random.RandomState(3)
+    for n in (1, 37, 300):                                          # rays; 8 samples each: 8 .. 2400 columns, 256 per workgroup batch
+        rays = torch.from_numpy(rs.uniform(-1, 1, (n, 11)).astype(np.float32)); rays[:, 6] = 0; rays[:, 7] = 1
+        z = torch.sort(torch.from_numpy(rs.uniform(0.05, 0.95, (n, 8)).astype(np.float32)), -1)[0]
+        pts = torch.from_numpy(rs.uniform(-1, 1, (n, 8, 3)).astype(np.float32))
+        add = torch.from_numpy(rs.randn(n, 8).astype(np.float32)); mul = torch.from_numpy(rs.rand(n, 8).astype(np.float32))
+        outs = {}
+        for var in ('default', 'nerf_4x64', 'bf16_32x32'):
+            mlp = ops.PackedMLP(kind, Ws, bs, variant=var)
+            outs[var] = ops.nerf_fwd(mlp, cu(pts, dev), cu(rays, dev), cu(z, dev), cu(add, dev), cu(mul, dev), want_raw=True)
+        for a_, b_ in zip(outs['default'], outs['nerf_4x64']):
+            assert torch.equal(a_, b_), (net, n)
+        assert relrms(outs['bf16_32x32'][1].cpu(), outs['default'][1].cpu()) < 2e-2
+
+
 def test_nerf_class_network(dev, golden_dir):
     """The NeRF class (skip-concat, feature/alpha heads, view branch) — module-level forward against the oracle and
     the reference-generated fixture, and the fused render path with it as the fine net."""
