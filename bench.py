@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (rank 0, N=1)')
     ap.add_argument('--cpu-sample-rays', type=int, default=65536, help='SURVEY.md §8(d): >= 65 536 rays')
     ap.add_argument('--no-gpu-eager-baseline', action='store_true', help='skip the eager-PyTorch-on-GPU baseline (rank 0, N=1)')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the pure-MFMA ceiling probe (a child process; skipped under rocprofv3)')
     ap.add_argument('--eager-reps', type=int, default=5)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
                     'the multi-rank path with several ranks sharing one GPU)')
@@ -292,7 +293,7 @@ def main():
             dom = max(flops, key=lambda k: prof[k])
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
             symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_h16_kernel', 'refine_kernel': 'refine_kernel<1, 8, 1, 1>',
-                       'nerf_kernel': 'nerf16_kernel<false>'}
+                       'nerf_kernel': 'nerf16_kernel<false, 2>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
             res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
@@ -300,7 +301,7 @@ def main():
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
                                'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
             res['kernels'] = kern
-            sus = sustained_mfma_peak()
+            sus = None if args.no_sustained else sustained_mfma_peak()
             if sus:                            # context for `frac`: the spec peak is not reachable at this chip's power limit with real operand bits
                 res['roofline']['sustained'] = dict(sus, frac_of_sustained=kern[dom]['achieved_tflops'] / sus['random_operands_tflops'])
             if not args.no_gpu_eager_baseline:
