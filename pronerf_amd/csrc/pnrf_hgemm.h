@@ -1,4 +1,6 @@
-// Split-fp16 layer products for the trainer (included by pnrf_train.hip inside its anonymous namespace).
+// Split-fp16 kernels of the trainer (included by pnrf_train.hip inside its anonymous namespace): the layer products (hgemm_kernel), the weight
+// gradients (dwh_kernel), a layer's backward as one launch (layer_bwd_kernel), the layer chains of the 4096-row nets (hgemm_rchain_kernel) and
+// their grouped weight gradients (dwh_group_kernel), and the kernel that keeps the fp16 weight planes current (split_weights_kernel).
 //
 // Y = act(X W^T + b) and dX = (dZ W [+ dX]) * act'(H) with fp32-grade results at 3/16 of the fp32 MFMA cycles: both operands are split
 //   x = x_hi + 2^-11 x_lo',  x_hi = fp16(x),  x_lo' = fp16((x - x_hi) 2^11)          (22 significand bits per operand)
@@ -7,7 +9,7 @@
 // v_mfma_f32_16x16x32_f16 per 32-deep step instead of eight v_mfma_f32_16x16x4_f32 of twice the duration.
 //
 // Operand ranges.  Weights and forward activations are O(1).  Gradients are not (1e-9 .. 1e-3): the A operand of a backward product is
-// multiplied by a power of two s chosen from max |A| — which the kernel that produced A left in a device slot with one atomicMax per wave —
+// multiplied by a power of two s chosen from max |A| — which the kernel that produced A left in a device slot (hg_slot_write) —
 // so that s max|A| lies in [2^11, 2^12); the result is multiplied by 1 / s.  Elements more than 2^36 below the tensor's maximum flush to
 // zero: 2^-12 of an fp32 ulp of the largest term of their dot product.
 //
