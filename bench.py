@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--no-gpu-eager-baseline', action='store_true', help='skip the eager-PyTorch-on-GPU baseline (rank 0, N=1)')
     ap.add_argument('--no-sustained', action='store_true', help='skip the pure-MFMA ceiling probe (a child process; skipped under rocprofv3)')
     ap.add_argument('--eager-reps', type=int, default=5)
+    ap.add_argument('--launch-timeout', type=float, default=900.0, help='N>1 started without a launcher: seconds before the ranks are stopped')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
                     'the multi-rank path with several ranks sharing one GPU)')
     return ap.parse_args()
@@ -178,20 +179,95 @@ def dbg(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def under_profiler():
+    """True when a rocprofv3 / rocprofiler-sdk tool library is preloaded into this process: child GPU programs would inherit it."""
+    env = os.environ
+    if any('rocprof' in env.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB')):
+        return True
+    return any(k.startswith(('ROCPROF', 'ROCPROFILER_', 'ROCP_')) for k in env)
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set), relay rank 0's JSON line, and return non-zero if any rank
+    fails or the launch times out.  This parent never touches the GPU (torch.cuda.device_count() does not initialise it on this image) and
+    never execs: the ranks are fresh processes."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.backend == 'nccl':
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            print(f'bench.py: --gpus {n} with the nccl (RCCL) backend needs {n} visible GPUs, found {ndev} '
+                  f"(use --backend gloo to rehearse the multi-rank path with ranks sharing a GPU)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), PNRF_BENCH_CHILD='1')
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.monotonic() + args.launch_timeout
+    rc, out0 = 0, ''
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                if r == 0:                           # drain rank 0's pipe while waiting for it
+                    try:
+                        o, _ = procs[0].communicate(timeout=0.2)
+                        out0 += o or ''
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif procs[r].poll() is None:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    raise RuntimeError(f'rank {r} exited with code {procs[r].returncode}')
+            if time.monotonic() > deadline:
+                raise RuntimeError(f'launch timed out after {args.launch_timeout} s')
+            if pending and 0 not in pending:
+                time.sleep(0.05)
+    except RuntimeError as e:
+        print(f'bench.py: {e}; stopping the other ranks', file=sys.stderr)
+        rc = 1
+    finally:
+        for p in procs:                                  # exact PIDs of the children started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    lines = [l for l in out0.splitlines() if l.startswith('{')]
+    if rc == 0 and not lines:
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks')
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     ndev = torch.cuda.device_count()
-    if args.backend == 'nccl' and local_rank >= ndev:
-        raise SystemExit(f'LOCAL_RANK={local_rank} but only {ndev} GPU(s) are visible')
+    if args.backend == 'nccl' and world > 1 and (local_rank >= ndev or ndev < int(os.environ.get('LOCAL_WORLD_SIZE', world))):
+        raise SystemExit(f'the nccl (RCCL) backend needs one GPU per rank: LOCAL_RANK={local_rank}, {ndev} GPU(s) visible, {world} ranks '
+                         '(--backend gloo rehearses the multi-rank path with ranks sharing a GPU)')
     dev = torch.device('cuda', local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     import torch.distributed as dist
@@ -271,10 +347,16 @@ def main():
                                                                   'f16x2 (sampler MLP: split fp16 hi+lo operands, fp32 accumulate, fp32-grade)'),
             'data': 'synthetic',
             'backend': (args.backend if world > 1 else None),
+            'rccl_ranks': (dist.get_world_size() if world > 1 and args.backend == 'nccl' else None),
+            'ranks': world,
+            'launcher': ('self (bench.py started its own ranks)' if os.environ.get('PNRF_BENCH_CHILD') else
+                         'torch.distributed.run' if world > 1 else None),
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, 48 ray-encoding points, '
                                    'bf16 MLP; one pnrf_render_rays_fwd call renders the whole frame (the 1024-ray chunks of configs[1] = 4 of the '
                                    '256-column workgroup batches each persistent kernel walks inside its single launch)',
-                       'rays_per_step': n_total, 'rays_per_gpu': counts[0],
+                       'rays_per_step': n_total, 'rays_per_gpu': counts[0], 'rays_per_rank': counts,
+                       'gather_bytes_per_rank_per_frame': (fg.cmax * 4 * 4 if world > 1 else 0),
+                       'gather_bytes_per_frame': (fg.cmax * 4 * 4 * world if world > 1 else 0),
                        'gather_pipelined': bool(pipeline), 'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
             'outputs_finite': finite,
             'algorithmic_flop_per_ray': FLOP_PER_RAY,
@@ -301,7 +383,7 @@ def main():
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
                                'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
             res['kernels'] = kern
-            sus = None if args.no_sustained else sustained_mfma_peak()
+            sus = None if (args.no_sustained or under_profiler()) else sustained_mfma_peak()
             if sus:                            # context for `frac`: the spec peak is not reachable at this chip's power limit with real operand bits
                 res['roofline']['sustained'] = dict(sus, frac_of_sustained=kern[dom]['achieved_tflops'] / sus['random_operands_tflops'])
             if not args.no_gpu_eager_baseline:
