@@ -70,11 +70,13 @@ int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** out);
 int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int* out_dim);
 
 /* Kernel variant of a packed network.  PNRF_VARIANT_DEFAULT is what pack / deserialize produce and what every product path runs:
- * sampler in split fp16 (fp32-grade, three v_mfma_f32_16x16x32_f16 per product) with the folded first layer, refine and NeRF stages
- * on v_mfma_f32_16x16x32_bf16.  The others exist for parity tests and A/B timing (tools/perf_ab.py):
+ * sampler with the folded first layer in split fp16 (fp32-grade, three v_mfma_f32_16x16x32_f16 per product) — through pnrf_sampler_fwd_ws /
+ * pnrf_render_rays_fwd as the second of two passes, see there —, refine stage on v_mfma_f32_32x32x16_bf16, NeRF stage on
+ * v_mfma_f32_16x16x32_bf16.  The others exist for parity tests and A/B timing (tools/perf_ab.py):
  *   SAMPLER_F32       sampler on the exact fp32 FMA chain (v_mfma_f32_16x16x4_f32), folded first layer;
  *   SAMPLER_F32_FULL  ... with the full K = 288 first layer on the 48 Pluecker points (no fold);
- *   BF16_32X32        refine / NeRF handles: the v_mfma_f32_32x32x16_bf16 engine;
+ *   SAMPLER_SPLIT     the split-fp16 kernel for every ray, also where a workspace is given (single pass: the default of round 2);
+ *   BF16_32X32        NeRF handles: the v_mfma_f32_32x32x16_bf16 engine (the refine net has one engine);
  *   NERF_4X64         NeRF handles: 4 waves of 64 columns per workgroup (one wave per SIMD) instead of 8 waves of 32 — same arithmetic,
  *                     same packed stream, every weight fragment read from LDS feeds four MFMAs instead of two.
  * A variant is part of a handle's configuration, like its weights: set it right after pack / deserialize, before the handle is given to
@@ -85,6 +87,7 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 #define PNRF_VARIANT_SAMPLER_F32_FULL 2
 #define PNRF_VARIANT_BF16_32X32 3
 #define PNRF_VARIANT_NERF_4X64 4
+#define PNRF_VARIANT_SAMPLER_SPLIT 5
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear
@@ -166,12 +169,31 @@ int pnrf_composite_fwd(const float* raw, const float* z, const float* rays_d, in
 int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted,
                      float* add_sorted, float* mul_sorted, int64_t* sort_idx, float* mm_rgb,
                      float* depth_raw, void* stream);
+/* The same operator in two passes (what pnrf_render_rays_fwd runs).  The eight depths of a ray are sorted, so the products must be
+ * fp32-grade wherever two of them are close — and only there.  Pass 1 renders every ray in plain fp16 (one v_mfma_f32_32x32x16_f16 per
+ * product, a third of the split kernel's MFMA work) and carries, per ray, a bound s_k on the standard deviation of its own rounding error
+ * in depth k (variance propagation through the layers from |x_l|^2 and the weights' column norms); a ray is "undecided" when
+ * some adjacent sorted gap is not larger than kappa (s_i + s_i+1) + 2e-6 (far - near), or not finite.  Pass 2 renders the undecided rays
+ * with the split-fp16 kernel of pnrf_sampler_fwd and overwrites their rows.  Result: sort indices as pnrf_sampler_fwd's on every ray;
+ * depths / add / mul of the undecided rays identical to pnrf_sampler_fwd's, of the others within a few s_k (fp16-grade, <= 1e-3 (far - near)).
+ * kappa < 0 selects PNRF_SAMPLER_KAPPA; kappa = 0 leaves only the fp32 round-off allowance (tests); +inf is refused.
+ * workspace: dev, 16-byte aligned, >= pnrf_sampler_workspace_bytes(n) bytes, contents irrelevant (two counters are reset on the stream
+ * by every call); concurrent calls need separate workspaces.  Handles set to a SAMPLER_* variant run that single kernel instead. */
+#define PNRF_SAMPLER_KAPPA 4.0f
+int64_t pnrf_sampler_workspace_bytes(int64_t n);
+int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
+                        float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,
+                        int64_t workspace_bytes, float kappa, void* stream);
 /* Refine: bf16 MLP on refine_in[n,144] -> sigmoid/tanh -> interval refinement -> query points.
  * Outputs dev: z[n,8], pts[n,8,3]  (run_S_eS_eN_alter_trt.py:668-681). */
 int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
                     const float* depth_sorted, float* z, float* pts, int64_t n, void* stream);
-/* Projection + refine in ONE kernel: what pnrf_refine_input_fwd followed by pnrf_refine_fwd compute (bit for bit), without the
- * refine_in [n,144] round trip through HBM: every workgroup projects the samples of its 256 rays into the four neighbour views, fetches
+/* Projection + refine in ONE kernel: what pnrf_refine_input_fwd followed by pnrf_refine_fwd compute, without the refine_in [n,144]
+ * round trip through HBM.  NOT bit for bit: the colours go straight into bf16 operands, so the head uses a linearised projection
+ * p(z) = A + z B per (ray, view) with FMA contraction and v_rcp_f32 for 1 / (1 - d - eps) and 1 / p.z, and skips grid_sample's normalise /
+ * un-normalise round trip: pixel coordinates move by a few fp32 ulps (~1e-4 px), colours by ~1e-4 of the local texel difference, 20x
+ * below the bf16 rounding applied next (tests/test_ops_gpu.py bounds z within 2e-3 of the two-kernel path).  The operator that replays
+ * the reference's fp32 projection sequence exactly is pnrf_refine_input_fwd.  Here every workgroup projects the samples of its 256 rays into the four neighbour views, fetches
  * the colours and encodes the sample Pluecker values in the head of its batch, straight into the MFMA operand registers.
  * rays, or_rays dev [n,11]; depth_sorted dev [n,8]; img4 dev [4,Hf,Wf,4] (pnrf_images_pack); proj dev [4,3,4]; eps as pnrf_refine_input_fwd.
  * This is the refine stage of pnrf_render_rays_fwd.  (run_S_eS_eN_alter_trt.py:637-681; inverse_warp.py:584-619) */
@@ -222,6 +244,8 @@ int pnrf_ctx_free(pnrf_ctx_t* ctx);
 int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_rays,
                          const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
                          float* rgbd, int64_t* sort_idx, int64_t n, void* stream);
+/* Rays the sampler's second pass rendered in the context's most recent pnrf_render_rays_fwd (waits for the device; diagnostics). */
+int pnrf_ctx_sampler_stats(pnrf_ctx_t* ctx, int64_t* rays_second_pass);
 /* Per-stage device time of pnrf_render_rays_fwd (what the reference gets from line_profiler / the cuda events around
  * render(), run_S_eS_eN_alter_trt.py:327-332, at frame granularity): after _begin, the next max_frames calls on this
  * context record an event before and after each of the three kernels on the caller's stream; _end waits for the last

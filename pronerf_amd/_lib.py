@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libpronerf_hip.so')
 
 NET_SAMPLER, NET_REFINE, NET_NERF, NET_NERFCLS = 0, 1, 2, 3
 # kernel variants of a packed handle (pnrf_mlp_set_variant)
-VARIANTS = {'default': 0, 'sampler_f32': 1, 'sampler_f32_full': 2, 'bf16_32x32': 3, 'nerf_4x64': 4}
+VARIANTS = {'default': 0, 'sampler_f32': 1, 'sampler_f32_full': 2, 'bf16_32x32': 3, 'nerf_4x64': 4, 'sampler_split': 5}
 ABI_VERSION = 1
 
 
@@ -52,12 +52,15 @@ SIGNATURES = {
     'pnrf_refine_input_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i64, _p]),
     'pnrf_composite_fwd': (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
     'pnrf_sampler_fwd': (_i, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    'pnrf_sampler_workspace_bytes': (_i64, [_i64]),
+    'pnrf_sampler_fwd_ws': (_i, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _f, _p]),
     'pnrf_refine_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     'pnrf_refine_project_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
     'pnrf_nerf_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     'pnrf_ctx_create': (_i, [_p, _p, _p, _i64, C.POINTER(_p)]),
     'pnrf_ctx_free': (_i, [_p]),
     'pnrf_render_rays_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
+    'pnrf_ctx_sampler_stats': (_i, [_p, C.POINTER(_i64)]),
     'pnrf_ctx_profile_begin': (_i, [_p, _i]),
     'pnrf_ctx_profile_end': (_i, [_p, C.POINTER(C.c_float), C.POINTER(_i)]),
     'pnrf_linspace': (_i, [_f, _f, _i, C.POINTER(_f)]),

@@ -63,6 +63,12 @@ struct pnrf_mlp {
   int* d_inx;            // extra-input map (nerf view k-steps) or NULL
   int* d_out;            // last-layer output map [tiles*64]: (tile, half, reg) -> output index
   int n_in0, n_inx, n_out;
+  void* d_blob_p1;       // sampler only: pass-1 stream of the two-pass scheme (plain fp16, 32x32x16 engine; sampler_p1_kernel)
+  uint32_t nslots_p1;
+  float* d_bias_p1;      // ... its bias table ([tile][half][16], log2(e)-scaled for the ELU layers)
+  int nbias_p1;
+  float* d_p1c;          // ... and the constants of the per-ray error model (pnrf_layout.h: P1_NCONST)
+  int n_p1c;
   float* d_tvals;        // sampler only: t = torch.linspace(0,1,48) of the ray points (trt.py:556-557)
   int device;
   int variant;           // PNRF_VARIANT_* (pnrf_mlp_set_variant); 0 = default kernels

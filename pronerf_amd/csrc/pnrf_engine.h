@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace pnrf {
 
@@ -225,16 +226,20 @@ __device__ __forceinline__ float act_fast(float v, int act) {
 #define PNRF_BF16_ATSTEP 6
 #endif
 constexpr int BF16_PIECES = 2;
-template <int NCB, int KS, int NT, int POS0, int PIECES = BF16_PIECES, class ST, class BFn, class Epi1, class Pre1>
+// F16 = true: the same loop on v_mfma_f32_32x32x16_f16 (fragments and B operands are f16x8): pass 1 of the two-pass sampler.
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <int NCB, int KS, int NT, int POS0, int PIECES = BF16_PIECES, bool F16 = false, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const float* biaslane, BFn Bi, Epi1 epi1, Pre1 pre1,
                                            f32x16 (&last)[NCB]) {
   constexpr int NF = KS * NT;
   constexpr int AHEAD = KS < 8 ? KS : 8;
+  using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   auto frag_ptr = [&](int g) {
-    return (const bf16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+    return (const frag_t*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
   f32x16 pend[NCB];
-  bf16x8 aq[AHEAD];
+  frag_t aq[AHEAD];
   // the bias of tile to+1 is read from LDS at the head of tile `to` (software pipelined): read in place, the first MFMA of
   // every tile would wait a full LDS round trip for its accumulator with both waves of the SIMD phase-locked behind the barrier
   f32x4 nb0, nb1, nb2, nb3;
@@ -260,10 +265,10 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
         for (int u = 0; u < AHEAD; ++u)
           if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
       }
-      const bf16x8 a = aq[f % AHEAD];
+      const frag_t a = aq[f % AHEAD];
       if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);      // keep the queue full
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bi(cb, ks), acc[cb], 0, 0, 0);
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_32x32x16(a, Bi(cb, ks), acc[cb]);
       // deferred epilogue pieces of the previous tile, spread over this tile's k-steps
 #pragma unroll
       for (int pc = 0; pc < PIECES; ++pc) {

@@ -59,6 +59,27 @@ constexpr int SH_SLOTS_PAD = (NSLOTS - SH_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int SH_NSLOTS = SH_SLOTS_USED + SH_SLOTS_PAD;
 static_assert(SH_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
 
+// sampler, pass 1 of the two-pass scheme (sampler_p1_kernel): plain fp16 on v_mfma_f32_32x32x16_f16 — the refine net's engine (32 columns
+// per wave, 32-row tiles, 16-deep k-steps).  Layer 0 is the folded 6 -> 256 layer in split fp16 (fp32-grade: per tile one W_hi and one
+// W_lo fragment, three MFMAs), hidden layers and the output layer are single fp16 products.
+constexpr int P1_SLOTS_L0 = (NT_HID * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;               // 1
+constexpr int P1_SLOTS_H = layer_slots_bf16<W_HID / 16, NT_HID>();                    // 8
+constexpr int P1_SLOTS_LAST = layer_slots_bf16<W_HID / 16, 1>();                      // 1
+constexpr int P1_POS_H = P1_SLOTS_L0 % NSLOTS;
+constexpr int P1_POS_LAST = (P1_POS_H + S_NHID * P1_SLOTS_H) % NSLOTS;
+constexpr int P1_SLOTS_USED = P1_SLOTS_L0 + S_NHID * P1_SLOTS_H + P1_SLOTS_LAST;
+constexpr int P1_SLOTS_PAD = (NSLOTS - P1_SLOTS_USED % NSLOTS) % NSLOTS;
+constexpr int P1_NSLOTS = P1_SLOTS_USED + P1_SLOTS_PAD;
+constexpr int P1_NBIAS = (1 + S_NHID) * W_HID + 32;                                   // [tile][half][16], log2(e)-scaled for the ELU layers
+static_assert(P1_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
+// constants of the per-ray error model (two-pass sampler), computed from the weights at pack time
+constexpr int P1_NCONST = 8;               // [0..4] C_l = max_j sum_i W_l[i,j]^2 of the hidden layers l = 1..5; [5] max_{k<8, j} W_out[k,j]^2 / log2(e)^2; [6], [7] unused
+// output tile of pass 1: half 0 holds the 8 depth logits (registers 0-7) and add (8-15), half 1 mul (0-7) and rgb (8-10)
+__host__ __device__ constexpr int sampler_p1_out(int g, int h) {
+  if (h == 0) return g;                    // depth 0..7, add 8..15
+  return g < 8 ? 16 + g : (g < 11 ? 24 + (g - 8) : -1);
+}
+
 // ---- refine (bf16): k-step = 16 features
 constexpr int R_IN = 144, R_OUT = 35, R_NHID = 5;
 constexpr int R_KS0 = R_IN / 16;                         // 9

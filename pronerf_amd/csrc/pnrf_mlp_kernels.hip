@@ -87,6 +87,9 @@ struct SamplerArgs {
   const float* x; const int* in0;                  // module-level producer
   float* depth_sorted; float* add_sorted; float* mul_sorted; int64_t* sort_idx; float* mm_rgb; float* depth_raw;
   float* y; const int* outmap; int head_act;       // module-level consumer
+  // two-pass scheme: pass 1 (sampler_p1_kernel) appends the rays it cannot decide to list[] (count in counters[0]); pass 2
+  // (sampler_h16_kernel with list != NULL) renders exactly those rays and leaves the count in counters[1]
+  int* list; int* counters; const float* p1c; float kappa;
 };
 
 #define PNRF_CSWAP(i, j)                                                              \
@@ -291,11 +294,20 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * q;
   constexpr float INV = 1.f / H16_LO_SCALE;
+  // pass 2 of the two-pass scheme: the rays to render are list[0 .. counters[0]) (written by pass 1, the previous launch on the stream)
+  int64_t total = a.n;
+  int nbatch = a.nbatch;
+  if (a.list) {
+    const int cnt = __builtin_amdgcn_readfirstlane(a.counters[0]);
+    total = cnt; nbatch = (cnt + NW * 16 - 1) / (NW * 16);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[1] = cnt;            // kept for pnrf_ctx_sampler_stats
+  }
 
-  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
-    const int64_t row = (int64_t)batch * (NW * 16) + wave * 16 + col;
-    const bool valid = row < a.n;
-    const int64_t rr = valid ? row : a.n - 1;
+  for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int64_t pos = (int64_t)batch * (NW * 16) + wave * 16 + col;
+    const bool valid = pos < total;
+    const int64_t row = a.list ? (int64_t)a.list[valid ? pos : total - 1] : pos;
+    const int64_t rr = (valid || a.list) ? row : a.n - 1;
     const float* r = a.rays + rr * 11;
     const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
     const float near = r[6], far = r[7];
@@ -414,6 +426,220 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
         float4* p = (float4*)((q == 1 ? a.add_sorted : a.mul_sorted) + row * 8);
         p[0] = make_float4(perm[0], perm[1], perm[2], perm[3]);
         p[1] = make_float4(perm[4], perm[5], perm[6], perm[7]);
+      }
+    }
+  }
+  st.drain();
+}
+
+// ------------------------------------------------------------------------------------------ sampler, pass 1 of two
+// The sampler's outputs are SORTED, so its products must be fp32-grade wherever two of a ray's eight depths are close — and only there.
+// Pass 1 runs the net for every ray in plain fp16 (one v_mfma_f32_32x32x16_f16 per product instead of the three of layer_h16x2; the folded
+// 6 -> 256 first layer stays split, it is 24 MFMAs) on the refine net's engine, together with a per-ray bound on the standard deviation of
+// its own rounding error, and flags a ray when some adjacent sorted gap is not larger than kappa x that bound; the flagged rays are
+// re-rendered by sampler_h16_kernel (pass 2), which overwrites their rows.  Error model (tools/sampler_twopass_model.py):
+//   rounding an operand to fp16 is a zero-mean error of variance <= c x^2, c = 2^-22 / 3, independent between operands;
+//   with S_l = |x_l|^2 and V_l = sum_i var(dx_l,i):  V_{l+1} <= C_l (2 c S_l + V_l),  C_l = max_j sum_i W_l[i,j]^2  (|ELU'| <= 1);
+//   var(d logit_k) <= M (2 c S_L + V_L),  M = max_{k,j} W_out[k,j]^2;   std(d depth_k) = span d_k (1 - d_k) sqrt(var(d logit_k)).
+// S_l is accumulated from the activations themselves (one v_fma per activation), C_l and M come from the packer (SamplerArgs::p1c).
+__device__ __forceinline__ int cvt_pk_f16(float a, float b) {        // one v_cvt_pk_f16_f32 (round to nearest even; a in the low half)
+  int pk;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+  return pk;
+}
+// deferred hidden-layer epilogue of pass 1, one activation per piece (as HiddenEpi<.., 16>): ELU on the log2(e) scale, |x|^2, fp16 pack
+struct P1Epi {
+  f16x8 (&Bn)[KS_HID];
+  float& ssq;
+  __device__ __forceinline__ void operator()(int to, int pc, f32x16 (&acc)[1]) const {
+    const float v = elu_scaled(acc[0][pc]);
+    acc[0][pc] = v;
+    ssq = fmaf(v, v, ssq);
+    if (pc & 1) {
+      f16x8& frag = Bn[2 * to + pc / 8];
+      i32x4_t w = __builtin_bit_cast(i32x4_t, frag);
+      w[(pc % 8) / 2] = cvt_pk_f16(acc[0][pc - 1], v);
+      frag = __builtin_bit_cast(f16x8, w);
+    }
+  }
+};
+
+__global__ __launch_bounds__(512, 2) void sampler_p1_kernel(SamplerArgs a) {
+  constexpr int TPB = 512, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  young_half_priority<NW>();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + h * 16;
+  constexpr float INV = 1.f / H16_LO_SCALE;
+  constexpr float C2 = 2.f * 7.947285970052083e-08f;                  // 2 c, c = 2^-22 / 3
+  const float m_out = a.p1c[5];
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    const int64_t row = (int64_t)batch * (NW * 32) + wave * 32 + col;
+    const bool valid = row < a.n;
+    const int64_t rr = valid ? row : a.n - 1;
+    const float* r = a.rays + rr * 11;
+    const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
+    const float near = r[6], far = r[7];
+    float hx, hy, hz, m0, m1, m2;
+    unit_dir(dx, dy, dz, hx, hy, hz);
+    moment(ox, oy, oz, dx, dy, dz, 0.f, hx, hy, hz, m0, m1, m2);
+    f16x8 P0h, P0l;                       // layer-0 B operand: half 0 holds the Pluecker 6-vector (split hi / lo 2^11), half 1 padding
+    {
+      const float z = 0.f;
+      const float v[8] = {h == 0 ? hx : z, h == 0 ? hy : z, h == 0 ? hz : z, h == 0 ? m0 : z, h == 0 ? m1 : z, h == 0 ? m2 : z, z, z};
+      split_h16(v, P0h, P0l);
+    }
+    f16x8 Bo[KS_HID], Bn[KS_HID];
+    f32x16 pend[1];
+    float sq_a = 0.f, sq_b = 0.f, V = 0.f;   // |x_l|^2 of the layer being written / the one before it (per-lane partial sums), error variance
+
+    // ---- layer 0: 8 tiles x (W_hi P_hi | W_hi P_lo + W_lo P_hi), one slot; tile t's activation runs behind tile t+1's MFMAs
+    {
+      st.wait_slot();
+      const P1Epi epi{Bn, sq_a};
+#pragma unroll
+      for (int to = 0; to < NT_HID; ++to) {
+        const f16x8 ahi = *(const f16x8*)(ringlane + (2 * to) * FRAG_BYTES), alo = *(const f16x8*)(ringlane + (2 * to + 1) * FRAG_BYTES);
+        f32x16 mn, cr;
+        {
+          const f32x4* bp = (const f32x4*)(biaslane + to * 32);
+          const f32x4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { mn[i] = b0[i]; mn[4 + i] = b1[i]; mn[8 + i] = b2[i]; mn[12 + i] = b3[i]; }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) cr[i] = 0.f;
+        }
+        mn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, P0h, mn, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, P0l, cr, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, P0h, cr, 0, 0, 0);
+        if (to == 0) st.slot_issue(0);
+        if (to > 0) {
+#pragma unroll
+          for (int pc = 0; pc < 16; ++pc) epi(to - 1, pc, pend);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pend[0][i] = fmaf(cr[i], INV, mn[i]);
+      }
+    }
+    // ---- hidden layers (ping-pong Bn -> Bo -> Bn ...); the last tile of a layer is activated in the head of the next one (pre1), so
+    // |x_l|^2 is complete when layer l's call returns: fold it into V there and hand the accumulator to layer l+1's outputs
+    auto hidden = [&](f16x8(&in)[KS_HID], f16x8(&out)[KS_HID], int l, float& sq_in, float& sq_out) {
+      f32x16 np[1];
+      layer_bf16<1, KS_HID, NT_HID, P1_POS_H, 16, true>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int, int ks) { return in[ks]; }, P1Epi{out, sq_out},
+                                                         [&](int pc) { P1Epi{in, sq_in}(NT_HID - 1, pc, pend); }, np);
+      pend[0] = np[0];
+      V = a.p1c[l] * fmaf(C2, sq_in, V);
+      sq_in = 0.f;
+    };
+    static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
+    for (int l = 0; l < 4; l += 2) {
+      hidden(Bn, Bo, l, sq_a, sq_b);
+      hidden(Bo, Bn, l + 1, sq_b, sq_a);
+    }
+    hidden(Bn, Bo, 4, sq_a, sq_b);
+    f32x16 fin[1];
+    layer_bf16<1, KS_HID, 1, P1_POS_LAST, 16, true>(st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int, int ks) { return Bo[ks]; },
+                                                     [&](int, int, f32x16(&)[1]) {}, [&](int pc) { P1Epi{Bo, sq_b}(NT_HID - 1, pc, pend); }, fin);
+#pragma unroll
+    for (int i = 0; i < P1_SLOTS_PAD; ++i) st.begin();
+    // variance bound of a depth logit: both halves of a column hold partial sums over their rows
+    float U = fmaf(C2, sq_b, V);
+    U = __fadd_rn(U, __shfl_xor(U, 32));
+    const float sd = sqrtf(m_out * U);
+
+    // ---- epilogue.  Half 0: registers 0-7 depth logits, 8-15 add; half 1: 0-7 mul, 8-10 rgb (sampler_p1_out)
+    float vals[8], oth[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { vals[i] = fin[0][i]; oth[i] = fin[0][8 + i]; }
+    float dep[8];
+    int idx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dep[i] = sigmoid_f(vals[i]); idx[i] = i; }
+    if (h == 0 && valid && a.depth_raw) {
+      float4* p = (float4*)(a.depth_raw + row * 8);
+      p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
+      p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
+    }
+    const float span = __fsub_rn(far, near);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
+    PNRF_SORT8                                                                             // trt.py:632-635
+    // decidable?  every adjacent gap must exceed kappa x (std bound of the two depths) + an fp32 round-off allowance
+    bool undecided = false;
+    {
+      const float inv_span = 1.f / span;
+      float sdev[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float u = (dep[i] - near) * inv_span;
+        sdev[i] = (dep[i] - near) * (1.f - u) * sd;                     // span d (1 - d) sd
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const float thr = fmaf(a.kappa, sdev[i] + sdev[i + 1], 2e-6f * span);
+        undecided |= !((dep[i + 1] - dep[i]) > thr);                     // also true for NaN / inf (fp16 overflow somewhere in the net)
+      }
+    }
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) word |= (uint32_t)idx[i] << (3 * i);
+    const uint32_t w0 = __shfl(word, col);      // half 0's permutation for this column, in both halves
+    // half 0 permutes add, half 1 mul (trt.py:634-635)
+    float perm[8];
+    {
+      float src[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) src[i] = h == 0 ? oth[i] : vals[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = (w0 >> (3 * i)) & 7;
+        float m = src[0];
+#pragma unroll
+        for (int jj = 1; jj < 8; ++jj) m = (k == jj) ? src[jj] : m;
+        perm[i] = m;
+      }
+    }
+    if (valid) {
+      if (h == 0) {
+        float4* p = (float4*)(a.depth_sorted + row * 8);
+        p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
+        float4* pa = (float4*)(a.add_sorted + row * 8);
+        pa[0] = make_float4(perm[0], perm[1], perm[2], perm[3]);
+        pa[1] = make_float4(perm[4], perm[5], perm[6], perm[7]);
+        if (a.sort_idx) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a.sort_idx[row * 8 + i] = idx[i];
+        }
+      } else {
+        float4* pm = (float4*)(a.mul_sorted + row * 8);
+        pm[0] = make_float4(perm[0], perm[1], perm[2], perm[3]);
+        pm[1] = make_float4(perm[4], perm[5], perm[6], perm[7]);
+        if (a.mm_rgb) {
+          a.mm_rgb[row * 3 + 0] = sigmoid_f(oth[0]);
+          a.mm_rgb[row * 3 + 1] = sigmoid_f(oth[1]);
+          a.mm_rgb[row * 3 + 2] = sigmoid_f(oth[2]);
+        }
+      }
+    }
+    // ---- compact the undecided rays of this wave into list[] (one atomic per wave)
+    {
+      const bool flag = h == 0 && valid && undecided;
+      const uint64_t m = __ballot(flag);
+      if (m) {
+        int base = 0;
+        const int leader = __builtin_ctzll(m);
+        if (lane == leader) base = atomicAdd(a.counters, __builtin_popcountll(m));
+        base = __shfl(base, leader);
+        if (flag) a.list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)row;
       }
     }
   }
@@ -1288,28 +1514,67 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
-extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted,
-                                float* add_sorted, float* mul_sorted, int64_t* sort_idx, float* mm_rgb,
-                                float* depth_raw, void* stream) {
-  PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd: handle is not a sampler net");
-  PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
-  if (n == 0) return 0;
-  const bool h16 = h->variant != PNRF_VARIANT_SAMPLER_F32 && h->variant != PNRF_VARIANT_SAMPLER_F32_FULL;
-  const bool fold = h->variant != PNRF_VARIANT_SAMPLER_F32_FULL;
+static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
+                          int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, float kappa, void* stream) {
   SamplerArgs a = {};
-  a.blob = fold ? h->d_blob_fold : h->d_blob; a.nslots = fold ? h->nslots_fold : h->nslots;
   a.bias = h->d_bias; a.nbias = h->nbias;
   a.n = n; a.nbatch = (int)((n + 127) / 128);
   a.rays = rays; a.tvals = h->d_tvals;
   a.depth_sorted = depth_sorted; a.add_sorted = add_sorted; a.mul_sorted = mul_sorted;
   a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  if (h16) {
+  hipStream_t st = (hipStream_t)stream;
+  if (workspace) {                      // two passes: plain fp16 for every ray, split fp16 for the rays pass 1 cannot decide
+    int* counters = (int*)workspace;
+    PNRF_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+    SamplerArgs p = a;
+    p.blob = h->d_blob_p1; p.nslots = h->nslots_p1; p.bias = h->d_bias_p1; p.nbias = h->nbias_p1;
+    p.nbatch = (int)((n + 255) / 256);
+    p.list = counters + 16; p.counters = counters; p.p1c = h->d_p1c; p.kappa = kappa;
+    int rc = launch_mlp(sampler_p1_kernel, p, 512, RING_BYTES + (size_t)h->nbias_p1 * 4, p.nbatch, st);
+    if (rc) return rc;
     a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
-    return launch_mlp(sampler_h16_kernel, a, 512, lds, a.nbatch, (hipStream_t)stream);
+    a.list = counters + 16; a.counters = counters;
+    return launch_mlp(sampler_h16_kernel, a, 512, lds, a.nbatch, st);        // grid sized for all rays: the count is known on the device only
   }
-  return fold ? launch_mlp(sampler_kernel<2>, a, 512, lds, a.nbatch, (hipStream_t)stream)
-              : launch_mlp(sampler_kernel<1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (h->variant == PNRF_VARIANT_SAMPLER_F32_FULL) {
+    a.blob = h->d_blob; a.nslots = h->nslots;
+    return launch_mlp(sampler_kernel<1>, a, 512, lds, a.nbatch, st);
+  }
+  if (h->variant == PNRF_VARIANT_SAMPLER_F32) {
+    a.blob = h->d_blob_fold; a.nslots = h->nslots_fold;
+    return launch_mlp(sampler_kernel<2>, a, 512, lds, a.nbatch, st);
+  }
+  a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
+  return launch_mlp(sampler_h16_kernel, a, 512, lds, a.nbatch, st);
+}
+
+extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted,
+                                float* add_sorted, float* mul_sorted, int64_t* sort_idx, float* mm_rgb,
+                                float* depth_raw, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd: handle is not a sampler net");
+  PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
+  if (n == 0) return 0;
+  return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, 0.f, stream);
+}
+
+extern "C" int64_t pnrf_sampler_workspace_bytes(int64_t n) { return n < 0 ? 0 : (int64_t)(16 + n) * (int64_t)sizeof(int); }
+
+extern "C" int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
+                                   float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,
+                                   int64_t workspace_bytes, float kappa, void* stream) {
+  PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd_ws: handle is not a sampler net");
+  PNRF_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG,
+               "pnrf_sampler_fwd_ws: null pointer / negative n / more than 2^31 rays");
+  if (n == 0) return 0;
+  PNRF_REQUIRE(workspace && workspace_bytes >= pnrf_sampler_workspace_bytes(n) && ((uintptr_t)workspace & 15) == 0, PNRF_E_ARG,
+               "pnrf_sampler_fwd_ws: workspace of %lld bytes (16-byte aligned) needed for %lld rays, got %lld", (long long)pnrf_sampler_workspace_bytes(n),
+               (long long)n, (long long)workspace_bytes);
+  PNRF_REQUIRE(kappa != kappa || kappa < 1e30f, PNRF_E_ARG, "pnrf_sampler_fwd_ws: bad kappa");
+  if (h->variant != PNRF_VARIANT_DEFAULT)      // the single-kernel variants of a handle (parity tests, A/B timing) ignore the workspace
+    return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, 0.f, stream);
+  return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, workspace,
+                        kappa < 0.f ? PNRF_SAMPLER_KAPPA : kappa, stream);
 }
 
 extern "C" int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays, const float* depth_sorted,

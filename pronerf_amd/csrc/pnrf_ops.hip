@@ -622,7 +622,8 @@ struct pnrf_ctx {
   const pnrf_mlp* refine;
   const pnrf_mlp* nerf;
   int64_t max_rays;
-  float* ws;             // one allocation: depth[8] add[8] mul[8] z[8] pts[24] per ray
+  float* ws;             // one allocation: depth[8] add[8] mul[8] z[8] pts[24] per ray, then the two-pass sampler's workspace
+  void* sampler_ws;      // inside ws: pnrf_sampler_workspace_bytes(max_rays)
   int device;
   // per-stage timing (pnrf_ctx_profile_begin / _end): 4 events per profiled call, recorded on the caller's stream
   hipEvent_t* ev;
@@ -649,7 +650,13 @@ extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refi
   c->sampler = sampler; c->refine = refine; c->nerf = nerf; c->max_rays = max_rays; c->ws = nullptr;
   c->ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_on = false;
   hipError_t e = hipGetDevice(&c->device);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->ws, (size_t)max_rays * WS_FLOATS_PER_RAY * sizeof(float));
+  PNRF_REQUIRE(max_rays < ((int64_t)1 << 31), PNRF_E_ARG, "pnrf_ctx_create: at most 2^31 - 1 rays per context");
+  const size_t ws_rays = (((size_t)max_rays * WS_FLOATS_PER_RAY * sizeof(float)) + 255) & ~(size_t)255;
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ws, ws_rays + (size_t)pnrf_sampler_workspace_bytes(max_rays));
+  if (e == hipSuccess) {
+    c->sampler_ws = (char*)c->ws + ws_rays;
+    e = hipMemset(c->sampler_ws, 0, 64);
+  }
   if (e != hipSuccess) {
     set_error("pnrf_ctx_create: workspace allocation failed: %s", hipGetErrorString(e));
     delete c;
@@ -689,7 +696,8 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
   hipEvent_t* ev = (c->prof_on && c->prof_n < c->prof_cap) ? c->ev + (size_t)c->prof_n * PROF_EVENTS : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (ev) PNRF_HIP(hipEventRecord(ev[0], st));
-  if ((rc = pnrf_sampler_fwd(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, stream))) return rc;   // trt.py:628-635
+  if ((rc = pnrf_sampler_fwd_ws(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, c->sampler_ws,
+                                pnrf_sampler_workspace_bytes(c->max_rays), -1.f, stream))) return rc;                  // trt.py:628-635
   if (ev) PNRF_HIP(hipEventRecord(ev[1], st));
   if ((rc = pnrf_refine_project_fwd(c->refine, rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, z, pts, n, stream))) return rc;   // :637-681
   if (ev) PNRF_HIP(hipEventRecord(ev[2], st));
@@ -698,6 +706,14 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
     PNRF_HIP(hipEventRecord(ev[3], st));
     c->prof_n += 1;
   }
+  return 0;
+}
+
+extern "C" int pnrf_ctx_sampler_stats(pnrf_ctx_t* c, int64_t* rays_second_pass) {
+  PNRF_REQUIRE(c && rays_second_pass, PNRF_E_ARG, "pnrf_ctx_sampler_stats: null argument");
+  int v[2] = {0, 0};
+  PNRF_HIP(hipMemcpy(v, c->sampler_ws, sizeof(v), hipMemcpyDeviceToHost));       // synchronises with the device: diagnostics only
+  *rays_second_pass = v[1];
   return 0;
 }
 

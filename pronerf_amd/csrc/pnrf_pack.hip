@@ -98,6 +98,37 @@ static void pack_layer_h16x2(const Layer& L, char* dst) {
       }
 }
 
+// plain fp16 packing for the 32x32x16 engine (pass 1 of the two-pass sampler): as pack_layer's bf16 branch with fp16 rounding
+static void pack_layer_f16(const Layer& L, char* dst) {
+  for (int to = 0; to < L.nt; ++to)
+    for (int ks = 0; ks < L.nk; ++ks) {
+      uint16_t* frag = (uint16_t*)(dst + ((size_t)to * L.nk + ks) * FRAG_BYTES);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        const int out = L.out_map[to * 32 + r];
+        for (int j = 0; j < 8; ++j) frag[lane * 8 + j] = f2h(wval(L, out, L.in_map[(ks * 2 + h) * 8 + j]));
+      }
+    }
+}
+// ... and its split first layer (one k-step): per tile a W_hi fragment and a W_lo * 2^11 fragment
+static void pack_layer0_f16x2(const Layer& L, char* dst) {
+  for (int to = 0; to < L.nt; ++to) {
+    uint16_t* hi = (uint16_t*)(dst + ((size_t)to * 2 + 0) * FRAG_BYTES);
+    uint16_t* lo = (uint16_t*)(dst + ((size_t)to * 2 + 1) * FRAG_BYTES);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int r = lane & 31, h = lane >> 5;
+      const int out = L.out_map[to * 32 + r];
+      for (int j = 0; j < 8; ++j) {
+        const int in = L.in_map[h * 8 + j];
+        const double w = (out >= 0 && in >= 0) ? (double)L.W[(size_t)out * L.in_dim + in] * L.wscale : 0.0;
+        const uint16_t hh = f2h((float)w);
+        hi[lane * 8 + j] = hh;
+        lo[lane * 8 + j] = f2h((float)((w - (double)h2f(hh)) * H16_LO_SCALE));
+      }
+    }
+  }
+}
+
 // bf16 packing for layer_b16 (16x16x32): in_map [nk][4][8], out_map [nt][16], fragments (tp, ks, tile-in-pair)
 static void pack_layer_b16(const Layer& L, char* dst) {
   const int ntp = L.nt / 2;
@@ -460,6 +491,49 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (auto& L : Lh) { pack_layer_h16x2(L, blob_h16.data() + sh * SLOT_BYTES); sh += hs(L); }
   }
 
+  // sampler: fourth stream = pass 1 of the two-pass scheme (sampler_p1_kernel): plain fp16 on the 32x32x16 engine, folded first layer in
+  // split fp16; its own bias table in that engine's [tile][half][16] order, log2(e)-scaled for the ELU layers; and the constants of the
+  // per-ray error model (pnrf_layout.h: P1_NCONST) taken from the fp32 weights
+  std::vector<char> blob_p1;
+  std::vector<float> bias_p1, p1c;
+  if (net == PNRF_NET_SAMPLER) {
+    std::vector<Layer> Lp = Ls;
+    scale_for_elu(Lp);
+    const std::vector<int> hid = hidden_in(PREC_BF16);
+    for (auto& L : Lp) { L.nt = NT_HID; L.nk = KS_HID; L.in_map = hid; L.out_map = identity_out(W_HID); }
+    Layer& G = Lp[0];
+    G.W = wfold.data(); G.in_dim = 6; G.nk = 1; G.in_map.assign(16, -1);
+    for (int j = 0; j < 6; ++j) G.in_map[j] = j;                   // half 0 supplies the 6 Pluecker features, half 1 padding
+    Layer& Y = Lp[n_layers - 1];
+    Y.nt = 1; Y.out_map.assign(32, -1);
+    for (int hh = 0; hh < 2; ++hh) for (int g = 0; g < 16; ++g) Y.out_map[acc_row(g, hh)] = sampler_p1_out(g, hh);
+    blob_p1.assign((size_t)P1_NSLOTS * SLOT_BYTES, 0);
+    bias_p1.assign(P1_NBIAS, 0.f);
+    size_t sp = 0, bp = 0;
+    for (int l = 0; l < n_layers; ++l) {
+      const Layer& L = Lp[l];
+      if (l == 0) pack_layer0_f16x2(L, blob_p1.data());
+      else pack_layer_f16(L, blob_p1.data() + sp * SLOT_BYTES);
+      pack_bias(L, PREC_BF16, bias_p1.data() + bp);
+      sp += l == 0 ? P1_SLOTS_L0 : layer_slots(L, PREC_BF16);
+      bp += (size_t)L.nt * 32;
+    }
+    PNRF_REQUIRE(sp == (size_t)P1_SLOTS_USED && bp == (size_t)P1_NBIAS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (pass-1 stream %zu slots, %zu bias floats)", sp, bp);
+    p1c.assign(P1_NCONST, 0.f);
+    for (int l = 1; l <= S_NHID; ++l) {                             // C_l = max over input features j of the column norm sum_i W_l[i,j]^2
+      double cmax = 0.0;
+      for (int j = 0; j < W_HID; ++j) {
+        double cn = 0.0;
+        for (int i = 0; i < W_HID; ++i) { const double w = (double)W[l][(size_t)i * W_HID + j]; cn += w * w; }
+        cmax = cn > cmax ? cn : cmax;
+      }
+      p1c[l - 1] = (float)(cmax * (1.0 + 1e-6));
+    }
+    double mmax = 0.0;                                              // depth rows of the output layer
+    for (int k = 0; k < 8; ++k) for (int j = 0; j < W_HID; ++j) { const double w = (double)W[n_layers - 1][(size_t)k * W_HID + j]; mmax = w * w > mmax ? w * w : mmax; }
+    p1c[5] = (float)(mmax / (LOG2E_D * LOG2E_D) * (1.0 + 1e-6));
+  }
+
   // DoNeRFTRT: second stream for the 16x16x32 engine (layer_b16): 16-row tiles in pairs, 32-deep k-steps
   std::vector<char> blob_b16;
   std::vector<float> bias_b16;
@@ -526,6 +600,15 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     e = hipMalloc(&h->d_blob_h16, blob_h16.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_h16, blob_h16.data(), blob_h16.size(), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
+    h->nslots_p1 = P1_NSLOTS; h->nbias_p1 = P1_NBIAS; h->n_p1c = P1_NCONST;
+    e = hipMalloc(&h->d_blob_p1, blob_p1.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_p1, blob_p1.data(), blob_p1.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_p1, bias_p1.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_bias_p1, bias_p1.data(), bias_p1.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_p1c, p1c.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_p1c, p1c.data(), p1c.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && net == PNRF_NET_NERF) {
     h->nslots_b16 = (uint32_t)slots_b16; h->nbias_b16 = (int)bias_b16.size();
     e = hipMalloc(&h->d_blob_b16, blob_b16.size());
@@ -555,6 +638,9 @@ extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
   if (h->d_blob_h16) (void)hipFree(h->d_blob_h16);
   if (h->d_blob_b16) (void)hipFree(h->d_blob_b16);
   if (h->d_bias_b16) (void)hipFree(h->d_bias_b16);
+  if (h->d_blob_p1) (void)hipFree(h->d_blob_p1);
+  if (h->d_bias_p1) (void)hipFree(h->d_bias_p1);
+  if (h->d_p1c) (void)hipFree(h->d_p1c);
   if (h->d_bias) (void)hipFree(h->d_bias);
   if (h->d_in0) (void)hipFree(h->d_in0);
   if (h->d_inx) (void)hipFree(h->d_inx);
@@ -582,8 +668,12 @@ struct EngineHeader {
   uint32_t nslots, nslots_fold, nslots_h16, nslots_b16;
   int32_t nbias_b16, nbias, n_in0, n_inx, n_out, n_tvals;
   uint64_t payload_bytes, checksum;   // FNV-1a 64 of the payload
-  uint8_t reserved[24];
+  uint32_t nslots_p1;                 // format 2: pass-1 stream of the two-pass sampler, its bias table and error-model constants
+  int32_t nbias_p1, n_p1c;
+  uint8_t reserved[12];
 };
+static constexpr uint32_t ENGINE_FORMAT = 2;
+static constexpr int ENGINE_SECTIONS = 13;
 static_assert(sizeof(EngineHeader) == 128, "engine header is 128 bytes");
 static const char ENGINE_MAGIC[8] = {'P', 'N', 'R', 'F', 'E', 'N', 'G', 0};
 
@@ -602,6 +692,9 @@ static int sections(pnrf_mlp* h, int n_tvals, Section* s) {
   s[n++] = {(void**)&h->d_inx, (size_t)h->n_inx * sizeof(int)};
   s[n++] = {(void**)&h->d_out, (size_t)h->n_out * sizeof(int)};
   s[n++] = {(void**)&h->d_tvals, (size_t)n_tvals * sizeof(float)};
+  s[n++] = {&h->d_blob_p1, (size_t)h->nslots_p1 * SLOT_BYTES};
+  s[n++] = {(void**)&h->d_bias_p1, (size_t)h->nbias_p1 * sizeof(float)};
+  s[n++] = {(void**)&h->d_p1c, (size_t)h->n_p1c * sizeof(float)};
   return n;
 }
 
@@ -612,6 +705,7 @@ static void expected_counts(int net, EngineHeader* w) {
     case PNRF_NET_SAMPLER:
       w->prec = PREC_F32; w->in_dim = S_IN; w->out_dim = S_OUT; w->nslots = S_NSLOTS; w->nslots_fold = SF_NSLOTS; w->nslots_h16 = SH_NSLOTS;
       w->nbias = S_NBIAS; w->n_in0 = S_KS0 * 4; w->n_out = 16 * S_NT_LAST; w->n_tvals = S_NPTS;
+      w->nslots_p1 = P1_NSLOTS; w->nbias_p1 = P1_NBIAS; w->n_p1c = P1_NCONST;
       break;
     case PNRF_NET_REFINE:
       w->prec = PREC_BF16; w->in_dim = R_IN; w->out_dim = R_OUT; w->nslots = R_NSLOTS; w->nbias = R_NBIAS; w->n_in0 = R_KS0 * 16; w->n_out = R_NT_LAST * 32;
@@ -640,7 +734,7 @@ extern "C" int pnrf_mlp_serialize(const pnrf_mlp_t* hc, void* buf, int64_t capac
   PNRF_REQUIRE(hc && size, PNRF_E_ARG, "pnrf_mlp_serialize: null argument");
   pnrf_mlp* h = const_cast<pnrf_mlp*>(hc);
   const int n_tvals = h->d_tvals ? S_NPTS : 0;
-  Section sec[10];
+  Section sec[ENGINE_SECTIONS];
   const int ns = sections(h, n_tvals, sec);
   size_t payload = 0;
   for (int i = 0; i < ns; ++i) {
@@ -664,10 +758,11 @@ extern "C" int pnrf_mlp_serialize(const pnrf_mlp_t* hc, void* buf, int64_t capac
   EngineHeader hd;
   memset(&hd, 0, sizeof(hd));
   memcpy(hd.magic, ENGINE_MAGIC, 8);
-  hd.format = 1; hd.abi = PNRF_ABI_VERSION; hd.layout_tag = PNRF_LAYOUT_TAG; hd.slot_bytes = SLOT_BYTES;
+  hd.format = ENGINE_FORMAT; hd.abi = PNRF_ABI_VERSION; hd.layout_tag = PNRF_LAYOUT_TAG; hd.slot_bytes = SLOT_BYTES;
   hd.net = h->net; hd.prec = h->prec; hd.in_dim = h->in_dim; hd.in_dim_x = h->in_dim_x; hd.out_dim = h->out_dim;
   hd.nslots = h->nslots; hd.nslots_fold = h->nslots_fold; hd.nslots_h16 = h->nslots_h16; hd.nslots_b16 = h->nslots_b16;
   hd.nbias_b16 = h->nbias_b16; hd.nbias = h->nbias; hd.n_in0 = h->n_in0; hd.n_inx = h->n_inx; hd.n_out = h->n_out; hd.n_tvals = n_tvals;
+  hd.nslots_p1 = h->nslots_p1; hd.nbias_p1 = h->nbias_p1; hd.n_p1c = h->n_p1c;
   hd.payload_bytes = payload;
   hd.checksum = fnv1a((const uint8_t*)buf + sizeof(EngineHeader), payload);
   memcpy(buf, &hd, sizeof(hd));
@@ -681,14 +776,15 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
   EngineHeader hd;
   memcpy(&hd, buf, sizeof(hd));
   PNRF_REQUIRE(memcmp(hd.magic, ENGINE_MAGIC, 8) == 0, PNRF_E_ARG, "pnrf_mlp_deserialize: not an engine file (bad magic)");
-  PNRF_REQUIRE(hd.format == 1 && hd.abi == PNRF_ABI_VERSION && hd.layout_tag == PNRF_LAYOUT_TAG && hd.slot_bytes == SLOT_BYTES, PNRF_E_STATE,
-               "pnrf_mlp_deserialize: engine written by another build (format %u abi %u layout %08x, this library: 1 %d %08x); export it again",
-               hd.format, hd.abi, hd.layout_tag, PNRF_ABI_VERSION, (unsigned)PNRF_LAYOUT_TAG);
+  PNRF_REQUIRE(hd.format == ENGINE_FORMAT && hd.abi == PNRF_ABI_VERSION && hd.layout_tag == PNRF_LAYOUT_TAG && hd.slot_bytes == SLOT_BYTES, PNRF_E_STATE,
+               "pnrf_mlp_deserialize: engine written by another build (format %u abi %u layout %08x, this library: %u %d %08x); export it again",
+               hd.format, hd.abi, hd.layout_tag, ENGINE_FORMAT, PNRF_ABI_VERSION, (unsigned)PNRF_LAYOUT_TAG);
   PNRF_REQUIRE(hd.net == PNRF_NET_SAMPLER || hd.net == PNRF_NET_REFINE || hd.net == PNRF_NET_NERF || hd.net == PNRF_NET_NERFCLS, PNRF_E_ARG,
                "pnrf_mlp_deserialize: unknown net kind %d", hd.net);
   PNRF_REQUIRE(hd.nbias_b16 >= 0 && hd.nbias >= 0 && hd.n_in0 >= 0 && hd.n_inx >= 0 && hd.n_out >= 0 && (hd.n_tvals == 0 || hd.n_tvals == S_NPTS) &&
                    hd.nslots > 0 && hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
-                   hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20),
+                   hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20) &&
+                   hd.nslots_p1 < (1u << 16) && hd.nbias_p1 >= 0 && hd.nbias_p1 < (1 << 24) && hd.n_p1c >= 0 && hd.n_p1c < (1 << 10),
                PNRF_E_ARG, "pnrf_mlp_deserialize: implausible section counts");
   {
     // section counts the kernels of this net kind index with compile-time constants: an image whose counts differ (a crafted file with a
@@ -698,7 +794,8 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
     PNRF_REQUIRE(hd.prec == want.prec && hd.in_dim == want.in_dim && hd.in_dim_x == want.in_dim_x && hd.out_dim == want.out_dim &&
                      hd.nslots == want.nslots && hd.nslots_fold == want.nslots_fold && hd.nslots_h16 == want.nslots_h16 &&
                      hd.nslots_b16 == want.nslots_b16 && hd.nbias_b16 == want.nbias_b16 && hd.nbias == want.nbias && hd.n_in0 == want.n_in0 &&
-                     hd.n_inx == want.n_inx && hd.n_out == want.n_out && hd.n_tvals == want.n_tvals,
+                     hd.n_inx == want.n_inx && hd.n_out == want.n_out && hd.n_tvals == want.n_tvals && hd.nslots_p1 == want.nslots_p1 &&
+                     hd.nbias_p1 == want.nbias_p1 && hd.n_p1c == want.n_p1c,
                  PNRF_E_ARG, "pnrf_mlp_deserialize: section counts do not match what net kind %d is packed as by this build", hd.net);
   }
   pnrf_mlp* h = new pnrf_mlp();
@@ -706,7 +803,8 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
   h->net = hd.net; h->prec = hd.prec; h->in_dim = hd.in_dim; h->in_dim_x = hd.in_dim_x; h->out_dim = hd.out_dim;
   h->nslots = hd.nslots; h->nslots_fold = hd.nslots_fold; h->nslots_h16 = hd.nslots_h16; h->nslots_b16 = hd.nslots_b16;
   h->nbias_b16 = hd.nbias_b16; h->nbias = hd.nbias; h->n_in0 = hd.n_in0; h->n_inx = hd.n_inx; h->n_out = hd.n_out;
-  Section sec[10];
+  h->nslots_p1 = hd.nslots_p1; h->nbias_p1 = hd.nbias_p1; h->n_p1c = hd.n_p1c;
+  Section sec[ENGINE_SECTIONS];
   const int ns = sections(h, hd.n_tvals, sec);
   size_t payload = 0;
   for (int i = 0; i < ns; ++i) payload += sec[i].bytes;
@@ -742,8 +840,8 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
 extern "C" int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant) {
   PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_set_variant: null handle");
   const bool sampler = h->net == PNRF_NET_SAMPLER;
-  const bool ok = variant == PNRF_VARIANT_DEFAULT || (sampler && (variant == PNRF_VARIANT_SAMPLER_F32 || variant == PNRF_VARIANT_SAMPLER_F32_FULL)) ||
-                  (!sampler && variant == PNRF_VARIANT_BF16_32X32) ||
+  const bool ok = variant == PNRF_VARIANT_DEFAULT || (sampler && (variant == PNRF_VARIANT_SAMPLER_F32 || variant == PNRF_VARIANT_SAMPLER_F32_FULL || variant == PNRF_VARIANT_SAMPLER_SPLIT)) ||
+                  ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_BF16_32X32) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_NERF_4X64);
   PNRF_REQUIRE(ok, PNRF_E_ARG, "pnrf_mlp_set_variant: variant %d does not exist for net kind %d", variant, h->net);
   h->variant = variant;

@@ -287,13 +287,22 @@ def composite(raw, z, rays_d, add=None, mul=None, noise=None, clamp=0.0, white_b
     return rgb, disp, acc, w, depth
 
 
-def sampler_fwd(mlp: PackedMLP, rays, want_idx=True, want_rgb=True, want_raw=False):
+def sampler_fwd(mlp: PackedMLP, rays, want_idx=True, want_rgb=True, want_raw=False, two_pass=False, kappa=None):
+    """pnrf_sampler_fwd; two_pass=True: pnrf_sampler_fwd_ws (plain-fp16 pass for every ray + split-fp16 pass for the undecided ones, what
+    the fused path runs) and the number of rays of the second pass as a seventh return value (a 0-d int32 tensor on the device)."""
     rays = _chk(rays, 'rays', (11,))
     n, dev = rays.shape[0], rays.device
     depth = torch.empty(n, 8, device=dev, dtype=f32); add = torch.empty_like(depth); mul = torch.empty_like(depth)
     idx = torch.empty(n, 8, device=dev, dtype=torch.int64) if want_idx else None
     rgb = torch.empty(n, 3, device=dev, dtype=f32) if want_rgb else None
     draw = torch.empty(n, 8, device=dev, dtype=f32) if want_raw else None
+    if two_pass:
+        lib = _lib.load()
+        nb = int(lib.pnrf_sampler_workspace_bytes(n))
+        ws = torch.empty(max(nb, 64) // 4, device=dev, dtype=torch.int32)
+        check(lib.pnrf_sampler_fwd_ws(mlp.handle, _ptr(rays), n, _ptr(depth), _ptr(add), _ptr(mul), _ptr(idx), _ptr(rgb), _ptr(draw), _ptr(ws), nb,
+                                      -1.0 if kappa is None else float(kappa), _stream()), 'pnrf_sampler_fwd_ws')
+        return depth, idx, add, mul, rgb, draw, ws[1]
     check(_lib.load().pnrf_sampler_fwd(mlp.handle, _ptr(rays), n, _ptr(depth), _ptr(add), _ptr(mul), _ptr(idx), _ptr(rgb), _ptr(draw), _stream()),
           'pnrf_sampler_fwd')
     return depth, idx, add, mul, rgb, draw
@@ -347,6 +356,12 @@ class RenderContext:
             pass
 
     STAGES = ('sampler_kernel', 'refine_kernel', 'nerf_kernel')
+
+    def sampler_stats(self):
+        """Rays the sampler's second (split-fp16) pass rendered in the most recent render_rays call; waits for the device."""
+        v = C.c_int64()
+        check(_lib.load().pnrf_ctx_sampler_stats(self.handle, C.byref(v)), 'pnrf_ctx_sampler_stats')
+        return int(v.value)
 
     def profile_begin(self, max_frames=64):
         """Record per-stage events on the next ``max_frames`` render_rays calls (pnrf_ctx_profile_begin)."""
