@@ -8,8 +8,8 @@
 Workload (BASELINE.json configs[1], BASELINE.md Â§4): one 1008x756 LLFF-Fern-geometry frame =
 762 048 rays, 8 samples/ray, 4 neighbour views, 48 ray-encoding points; synthetic poses/images
 and seeded "trained-like" weights (no dataset/checkpoint ships).  A step = one pass of the hot
-path (three kernels: sampler MLP fp32-grade split fp16 | neighbour projection + refine MLP bf16 | NeRF MLP bf16 + alpha
-compositing) over one frame: ONE pnrf_render_rays_fwd call renders the whole frame, as the reference
+path (sampler MLP in two passes: plain fp16 for every ray + fp32-grade split fp16 for the rays whose depth order the first pass cannot
+decide | neighbour projection + refine MLP bf16 | NeRF MLP bf16 + alpha compositing) over one frame: ONE pnrf_render_rays_fwd call renders the whole frame, as the reference
 renders it in one render() call (run_S_eS_eN_alter_trt.py:329); the "1024-ray chunks" of BASELINE.json
 configs[1] are four of the 256-column workgroup batches each persistent kernel walks through inside its
 single launch.  Rays, images and weights are resident
@@ -24,6 +24,12 @@ eager fp32 torch graph on the same GPU, whole frame in one call, device events â
 "the reference single-GPU PyTorch rays/s" that BASELINE.json's >= 10x target is measured against.  No
 published number exists for the metric (BASELINE.md Â§1), so `vs_baseline` is value / that measured baseline
 and `vs_baseline_kind` says so.  Both baselines run after the timed region; oracle/ is imported only there.
+
+Also after the timed region, at N=1 (each can be switched off): `chunked_1024` â€” the same frame as 745 calls of <= 1024 rays (the literal
+reading of configs[1]) and the same through one hipGraph, next to the one-call figure; `variants` â€” the frame with the round-2 sampler
+(split fp16 for every ray); `train` â€” the training iterations of configs[3] / configs[4] (stage-2 iteration at 4096 rays x 17 views of
+756x1008; stage-1 exploration iterations at 64 and 256 samples per ray) with their algorithmic TFLOP/s, HBM bytes from the committed
+profiles/r03_train_pmc_summary.json and the same iteration as eager torch autograd + torch.optim.Adam on this GPU.
 """
 from __future__ import annotations
 
@@ -60,6 +66,10 @@ def parse():
     ap.add_argument('--no-gpu-eager-baseline', action='store_true', help='skip the eager-PyTorch-on-GPU baseline (rank 0, N=1)')
     ap.add_argument('--no-sustained', action='store_true', help='skip the pure-MFMA ceiling probe (a child process; skipped under rocprofv3)')
     ap.add_argument('--eager-reps', type=int, default=5)
+    ap.add_argument('--no-chunked', action='store_true', help='skip the 745 x 1024-ray rendering of the frame (rank 0, N=1)')
+    ap.add_argument('--no-variants', action='store_true', help='skip the frame with the single-pass split-fp16 sampler (rank 0, N=1)')
+    ap.add_argument('--no-train', action='store_true', help='skip the training-iteration block (rank 0, N=1)')
+    ap.add_argument('--no-train-eager', action='store_true', help='training block without the eager-torch legs')
     ap.add_argument('--launch-timeout', type=float, default=900.0, help='N>1 started without a launcher: seconds before the ranks are stopped')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
                     'the multi-rank path with several ranks sharing one GPU)')
@@ -172,6 +182,139 @@ def pmc_traffic(kernel):
         return json.load(open(files[-1]))['per_kernel'][kernel]['hbm_bytes_per_launch']
     except Exception:
         return None
+
+
+def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2):
+    """configs[1] read literally: the frame as ceil(n / 1024) pnrf_render_rays_fwd calls of <= 1024 rays each (744 x 1024 + 192 for the Fern
+    frame), launched back to back on the stream, and the same call sequence replayed as ONE hipGraph.  Every chunk must equal the
+    corresponding rows of the one-call frame `ref` bit for bit (rays are independent; the kernels walk the same 128 / 256-column batches)."""
+    n = rays.shape[0]
+    out = torch.empty_like(ref)
+    bounds = [(a, min(n, a + chunk)) for a in range(0, n, chunk)]
+
+    def frame():
+        for a, b in bounds:
+            rend.render_rays(rays[a:b], or_rays[a:b], out=out[a:b])
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, (time.perf_counter() - t0) * 1e3 / reps
+    res = {'chunk_rays': chunk, 'calls_per_frame': len(bounds), 'reps': reps}
+    ms, wall = timed(frame)
+    res['calls_ms_per_frame'] = ms
+    res['calls_host_ms_per_frame'] = wall
+    res['calls_bit_identical_to_one_call'] = bool(torch.equal(out, ref))
+    try:
+        out.zero_()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            frame()                                       # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            frame()
+        gms, gwall = timed(g.replay)
+        res['graph_ms_per_frame'] = gms
+        res['graph_host_ms_per_frame'] = gwall
+        res['graph_bit_identical_to_one_call'] = bool(torch.equal(out, ref))
+        del g
+    except Exception as e:                                # capture is best effort: report why instead of failing the bench line
+        res['graph_ms_per_frame'] = None
+        res['graph_error'] = f'{type(e).__name__}: {e}'[:300]
+    return res
+
+
+def train_pmc(workload):
+    """HBM bytes per training iteration from the committed profile of tools/profile_train.sh (profiles/r<NN>_train_pmc_summary.json,
+    newest round): sum over the iteration's kernels of 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)."""
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_pmc_summary.json')),
+                   key=lambda f: int(re.search(r'r(\d+)_train', os.path.basename(f)).group(1)))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))['workloads'][workload]
+    except Exception:
+        return None
+
+
+def train_block(dev, eager=True):
+    """Training iterations at configs[3] / configs[4] size (pronerf_amd.workloads): HIP trainer vs the oracle's eager torch autograd graph +
+    torch.optim.Adam on the same GPU (checker-side, after the timed region).  The iteration is HBM-bound by the builder's own analysis
+    (fp32 activations of the 256-wide layers: DESIGN.md, training), so `frac_of_hbm_roof` = measured HBM bytes per iteration / ms / 8 TB/s."""
+    from pronerf_amd import workloads as wl
+    HBM_PEAK = 8.0e12
+    wk = wl.TrainWorkload(dev, max_samples=256)
+    tr = wk.trainer
+    out = {'what': 'one training iteration = forward (saved activations) + backward + Adam on one fixed synthetic batch; N_rand 4096 rays of one view, '
+                   '17 training views of 756x1008, NeRF-class fine net; layer products in split fp16 (fp32-grade) unless noted',
+           'hbm_peak_TBps': HBM_PEAK / 1e12}
+
+    def entry(name, fn, iters, warm, flop, extra=None):
+        ms, wall = wl.timed_ms(fn, iters, warm)
+        e = {'ms': ms, 'host_ms': wall, 'iters': iters, 'rays_per_s': wk.n / (ms * 1e-3), 'algorithmic_tflop': flop / 1e12, 'tflops': flop / (ms * 1e-3) / 1e12}
+        pm = train_pmc(name)
+        if pm:
+            e['hbm_bytes_per_iter'] = pm['hbm_bytes_per_iter']
+            e['hbm_TBps'] = pm['hbm_bytes_per_iter'] / (ms * 1e-3) / 1e12
+            e['frac_of_hbm_roof'] = e['hbm_TBps'] * 1e12 / HBM_PEAK
+            e['launches_per_iter'] = pm.get('launches_per_iter')
+            e['pmc_source'] = pm.get('source')
+        e.update(extra or {})
+        out[name] = e
+        return e
+
+    s2 = entry('stage2_iteration', wk.stage2_step, 50, 5, wl.train_flop(wk.n, 8),
+               {'workload': 'configs[3]: stage-2 refine iteration (run_S_eS_eN_alter_base_refine2.py:831-878), 8 samples per ray, inverse_warp projection into 4 of 17 views per ray'})
+    tr.set_products('f32')
+    s2['ms_f32_products'] = wl.timed_ms(wk.stage2_step, 30, 3)[0]
+    tr.set_products('f16x2')
+    for n_mult in (8, 32):
+        S = 8 * n_mult
+        entry(f'stage1_explore_{S}', lambda: wk.explore_step(n_mult), 20 if S <= 64 else 10, 3, wl.train_flop(wk.n, S, nerf_only=True),
+              {'workload': f'configs[4]: stage-1 exploration iteration (run_S_eS_eN_alter_base.py:689-729, 929-940), {S} samples per ray'
+                           + (' (the reference\'s cap: n_mult <= 8)' if S == 64 else ' (BASELINE.json configs[4]; n_mult 32)'), 'samples_per_ray': S})
+    if eager:
+        from oracle import pronerf_oracle as orc
+        torch.backends.cuda.matmul.allow_tf32 = False
+        tl = [(torch.tensor(W_, device=dev, requires_grad=True), torch.tensor(b, device=dev, requires_grad=True)) for W_, b in wk.layers]
+        opt = torch.optim.Adam([p for pair in tl for p in pair], lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-8)
+        opt_n = torch.optim.Adam([p for pair in tl[14:] for p in pair], lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-8)
+        prev = torch.get_default_device() if hasattr(torch, 'get_default_device') else 'cpu'
+        torch.set_default_device(dev)
+        try:
+            def eager2():
+                opt.zero_grad()
+                loss, _, _ = orc.stage2_loss(tl, wk.rays, wk.or_rays, wk.target, wk.images_nchw, wk.poses, wk.K, wk.ref_nos, jitter=wk.jitter, jitter_dir=1,
+                                             raw_noise=wk.noise)
+                loss.backward(); opt.step()
+            ms = wl.timed_ms(eager2, 8, 2)[1]
+            out['stage2_iteration'].update(eager_torch_gpu_ms=ms, speedup_vs_eager=ms / out['stage2_iteration']['host_ms'])
+            for n_mult in (8, 32):
+                jd = wk.explore_jitter(n_mult)
+
+                def eagerx():
+                    opt_n.zero_grad()
+                    loss, _, _ = orc.stage1_loss(tl, wk.rays, wk.or_rays, wk.target, wk.images_nchw, wk.poses, wk.K, wk.ref_nos, False, n_mult=n_mult, dir1=1,
+                                                 jitter=jd, dir2=-1)
+                    loss.backward(); opt_n.step()
+                ms = wl.timed_ms(eagerx, 3, 1)[1]
+                e = out[f'stage1_explore_{8 * n_mult}']
+                e.update(eager_torch_gpu_ms=ms, speedup_vs_eager=ms / e['host_ms'])
+        finally:
+            torch.set_default_device(prev)
+        out['eager'] = 'oracle torch graph (fp32, TF32 off) with autograd + torch.optim.Adam on the same GPU, host wall time per iteration'
+        del tl, opt, opt_n
+    del wk, tr
+    torch.cuda.empty_cache()
+    return out
 
 
 def dbg(msg):
@@ -344,7 +487,8 @@ def main():
             'ms_per_step': ms, 'ms_per_frame': ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None,
             'dtype': 'bf16 (refine+NeRF MLP, fp32 accumulate) + ' + ('f32 (sampler MLP, exact f32 MFMA)' if sampler_f32 else
-                                                                  'f16x2 (sampler MLP: split fp16 hi+lo operands, fp32 accumulate, fp32-grade)'),
+                                                                  'f16 | f16x2 (sampler MLP: plain fp16 pass for every ray, split fp16 hi+lo operands = fp32-grade for '
+                                                                  'the rays whose depth order that pass cannot decide; fp32 accumulate)'),
             'data': 'synthetic',
             'backend': (args.backend if world > 1 else None),
             'rccl_ranks': (dist.get_world_size() if world > 1 and args.backend == 'nccl' else None),
@@ -352,8 +496,9 @@ def main():
             'launcher': ('self (bench.py started its own ranks)' if os.environ.get('PNRF_BENCH_CHILD') else
                          'torch.distributed.run' if world > 1 else None),
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, 48 ray-encoding points, '
-                                   'bf16 MLP; one pnrf_render_rays_fwd call renders the whole frame (the 1024-ray chunks of configs[1] = 4 of the '
-                                   '256-column workgroup batches each persistent kernel walks inside its single launch)',
+                                   'bf16 MLP; one pnrf_render_rays_fwd call renders the whole frame, as the reference does (the 1024-ray chunks of '
+                                   'configs[1] = 4 of the 256-column workgroup batches each persistent kernel walks inside its single launch; '
+                                   'the frame as 745 separate 1024-ray calls is timed beside it: chunked_1024)',
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0], 'rays_per_rank': counts,
                        'gather_bytes_per_rank_per_frame': (fg.cmax * 4 * 4 if world > 1 else 0),
                        'gather_bytes_per_frame': (fg.cmax * 4 * 4 * world if world > 1 else 0),
@@ -374,7 +519,7 @@ def main():
                     kern[k].update(achieved_tflops=ach, peak_tflops=peaks[k], frac=ach / peaks[k])
             dom = max(flops, key=lambda k: prof[k])
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
-            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_h16_kernel', 'refine_kernel': 'refine_kernel<1, 8, 1, 1>',
+            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_p1_kernel + sampler_h16_kernel', 'refine_kernel': 'refine_kernel<1, 8, 1, 1>',
                        'nerf_kernel': 'nerf16_kernel<false, 2>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
@@ -386,17 +531,43 @@ def main():
             sus = None if (args.no_sustained or under_profiler()) else sustained_mfma_peak()
             if sus:                            # context for `frac`: the spec peak is not reachable at this chip's power limit with real operand bits
                 res['roofline']['sustained'] = dict(sus, frac_of_sustained=kern[dom]['achieved_tflops'] / sus['random_operands_tflops'])
+            n2 = rend.ctx.sampler_stats()
+            res['sampler_two_pass'] = {'rays_second_pass': n2, 'fraction': n2 / n_total, 'kappa': 4.0,
+                                       'what': 'rays whose depth order the plain-fp16 pass could not decide (adjacent sorted gap <= kappa x its own '
+                                               'error bound): re-rendered by the split-fp16 kernel'}
+            one_call = outs[0][:count].clone()
+            if not args.no_chunked:
+                res['chunked_1024'] = dict(chunked_1024(rend, rays, or_rays, one_call), one_call_ms_per_frame=ms)
+            if not args.no_variants:
+                from pronerf_amd.workloads import timed_ms
+                r2 = Renderer(weights, max_rays=count, device=dev, variants={'sampler': 'sampler_split'})
+                r2.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+                o2 = torch.empty_like(one_call)
+                vms = timed_ms(lambda: r2.render_rays(rays, or_rays, out=o2), 20, 5)[0]
+                dm = float(((o2[:, :3].double() - one_call[:, :3].double()) ** 2).mean())
+                res['variants'] = {'sampler_split': {'ms_per_frame': vms, 'rays_per_s': n_total / vms * 1e3,
+                                                     'what': 'split-fp16 sampler kernel for every ray (PNRF_VARIANT_SAMPLER_SPLIT, the round-2 default)',
+                                                     'rgb_psnr_vs_default_db': (10.0 * float(np.log10(1.0 / dm))) if dm > 0 else float('inf')}}
+                split_rgb = o2[:, :3].clone()
+                del r2, o2
             if not args.no_gpu_eager_baseline:
                 last = outs[0][:count, :3].clone() if not pipeline else None
                 eager, eager_rgb = gpu_eager_baseline(weights, scene, dev, args.eager_reps)
                 if last is not None:             # the two paths rendered the same frame: error of the HIP path against the eager fp32 graph
                     mse = float(((last.double() - eager_rgb.double()) ** 2).mean())
                     eager['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse))) if mse > 0 else float('inf')
+                    if not args.no_variants:
+                        mse2 = float(((split_rgb.double() - eager_rgb.double()) ** 2).mean())
+                        res['variants']['sampler_split']['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse2))) if mse2 > 0 else float('inf')
                 del eager_rgb
                 res['gpu_eager_baseline'] = eager
                 res['vs_baseline'] = value / eager['value']
                 res['vs_baseline_kind'] = ('value / gpu_eager_baseline.value, measured in this run (BASELINE.md Â§4 item 2: the denominator of the >= 10x '
                                            'target); the reference publishes no number for this metric')
+            if not args.no_train:
+                del rend
+                torch.cuda.empty_cache()
+                res['train'] = train_block(dev, eager=not args.no_train_eager)
             if not args.no_cpu_baseline:
                 res['cpu_baseline'] = cpu_baseline(weights, scene, args.cpu_sample_rays)
     if world > 1:

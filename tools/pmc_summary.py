@@ -26,7 +26,7 @@ out_dir = os.path.join(ROOT, 'profiles')
 def short(name):
     if 'nerf16_kernel' in name:
         return 'nerf_kernel'
-    for k in ('nerf_kernel', 'refine_input_kernel', 'refine_kernel', 'sampler_h16_kernel', 'sampler_kernel', 'frame_rays_kernel',
+    for k in ('nerf_kernel', 'refine_input_kernel', 'refine_kernel', 'sampler_p1_kernel', 'sampler_h16_kernel', 'sampler_kernel', 'frame_rays_kernel',
               'images_pack_kernel'):
         if k in name:
             return 'sampler_kernel' if k == 'sampler_h16_kernel' else k
