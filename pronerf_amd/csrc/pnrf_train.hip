@@ -1275,7 +1275,7 @@ int elu_net_forward(pnrf_trainer* t, int first, const float* x0, int in0, float*
     RChainArgs c = {};
     bool ok = fwd_hgemm_args(t, first, x0, in0, h[0], 256, N, T_ACT_ELU, &c.first);
     for (int k = 1; k < 6 && ok; ++k) {
-      HGemmArgs a;
+      HGemmArgs a{};
       ok = fwd_hgemm_args(t, first + k, h[k - 1], 256, h[k], 256, N, T_ACT_ELU, &a) && a.K == 256 && a.N == 256;
       c.l[k - 1] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, h[k], nullptr, nullptr};
     }
@@ -1563,11 +1563,18 @@ extern "C" int pnrf_trainer_flat(pnrf_trainer_t* t, int kind, float** ptr, int64
   return 0;
 }
 
+// captured iterations hold the kernel selection of the moment they were captured: every configuration change drops them
+static void drop_graphs(pnrf_trainer* t) {
+  for (auto& g : t->graphs) (void)hipGraphExecDestroy(g.exec);
+  t->graphs.clear();
+}
+
 // Which weight-gradient kernel the square layers use: tile 0 = by shape and row count (128 x 128 tiles from min_rows_128 rows on, the default:
 // 65 536), 64 / 128 = force that tile where the shape allows it.  A configuration step, like pnrf_mlp_set_variant: the library reads no
 // environment.  (The two kernels differ in fp32 summation order only; tests/test_train_gpu.py runs the same batch through both.)
 extern "C" int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t min_rows_128) {
   PNRF_REQUIRE(t && (tile == 0 || tile == 64 || tile == 128) && min_rows_128 >= 0, PNRF_E_ARG, "pnrf_trainer_set_dw_kernel: tile must be 0, 64 or 128");
+  drop_graphs(t);
   t->dw_tile = tile;
   t->dw128_min_rows = tile == 128 ? (min_rows_128 > 0 ? min_rows_128 : 256) : (min_rows_128 > 0 ? min_rows_128 : 65536);
   return 0;
@@ -1684,7 +1691,7 @@ int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, 
     // (1) the five input-gradient products in one launch, (2) the six weight gradients in one launch
     RChainArgs c = {};
     for (int k = 5; k >= 1; --k) {
-      HGemmArgs a;
+      HGemmArgs a{};
       bwd_hgemm_args(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0, &a);
       c.l[5 - k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, nullptr, t->d_hk[k - 1], h[k - 1], m + (k - 1) * HG_SLOT};
     }
@@ -1873,6 +1880,7 @@ extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_ba
 // accumulation) wherever the shape fits; 1: exact-fp32 MFMA everywhere.
 extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
   PNRF_REQUIRE(t && (kind == 0 || kind == 1), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16) or 1 (fp32)");
+  drop_graphs(t);
   t->use_f16 = kind == 0;
   if (t->use_f16) t->planes_stale = true;
   return 0;
@@ -1881,6 +1889,7 @@ extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
 // 1: replay every iteration as a hipGraph; 0 (default): launch its kernels one by one
 extern "C" int pnrf_trainer_set_graph(pnrf_trainer_t* t, int enable) {
   PNRF_REQUIRE(t, PNRF_E_ARG, "pnrf_trainer_set_graph: null trainer");
+  if (!enable) drop_graphs(t);
   t->use_graph = enable != 0;
   return 0;
 }

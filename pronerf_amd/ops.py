@@ -532,6 +532,9 @@ class Trainer:
 
     def set_products(self, kind):
         """'f16x2' (default): split-fp16 MFMA layer products (fp32-grade); 'f32': exact-fp32 MFMA products (pnrf_trainer_set_products)."""
+        if kind not in ('f16x2', 'f32'):
+            raise PnrfError(f"Trainer.set_products: kind must be 'f16x2' (split-fp16 MFMA products, default) or 'f32' (exact-fp32 MFMA products), got {kind!r} "
+                            '(the training drivers read it from PNRF_TRAIN_PRODUCTS)')
         k = {'f16x2': 0, 'f32': 1}[kind]
         check(_lib.load().pnrf_trainer_set_products(self.handle, k), 'pnrf_trainer_set_products')
 

@@ -1,0 +1,131 @@
+"""GPU: the training iterations at the sizes BASELINE.json names — configs[3] (stage-2 iteration: 4096 rays of one view, 17 training views of
+756 x 1008, NeRF-class fine net) and configs[4] (stage-1 exploration iteration: 4096 rays x 256 samples per ray = 1 048 576 rows through the
+fine net) — one step each through the C ABI trainer (pronerf_amd.workloads.TrainWorkload, the batch bench.py's `train` block times).
+
+Per-ray outputs do not depend on the rest of the batch, so rgb_map1 of a 256-ray subset is compared with the CPU oracle's training-time
+render_rays on exactly those rays (same source views, jitter and noise); the loss is tied to the image it is the mean square of; the two
+product arithmetics (exact fp32 / split fp16), graph replay against kernel-by-kernel launches, finiteness of every gradient and the size of
+the trainer's device allocation are checked on the full batch.  Small-size gradients against torch.autograd: tests/test_train_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pronerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SUB = 256
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from pronerf_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def work(dev):
+    from pronerf_amd import workloads as wl
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    wk = wl.TrainWorkload(dev, max_samples=256)
+    torch.cuda.synchronize()
+    used = free0 - torch.cuda.mem_get_info(dev)[0]
+    print(f'\n[full size] TrainWorkload(4096 rays, 17 views 756x1008, max 256 samples per ray): {used / 2**30:.2f} GiB of device memory '
+          f'(trainer parameters / gradients / Adam state / workspaces for 1 048 576 NeRF rows + 17 packed views + the batch)')
+    assert wk.n == 4096 and wk.nv == 17 and tuple(wk.img4.shape) == (17, 756, 1008, 4)
+    return wk
+
+
+def _subset(wk):
+    sel = torch.linspace(0, wk.n - 1, SUB).long()
+    cpu = lambda t: t[sel.to(t.device)].cpu()
+    layers = [(torch.from_numpy(W), torch.from_numpy(b)) for W, b in wk.layers]
+    return sel, cpu, orc.weights_from_layers(layers)
+
+
+def _grads(tr, layers=range(26)):
+    return [g.clone() for i in layers for g in tr.read('grad', i)]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def test_stage2_iteration_at_config3_size(work, dev):
+    wk, tr = work, work.trainer
+    tr.set_products('f16x2'); tr.set_graph(False)
+    loss, rgb = wk.stage2_step(want_rgb=True, adam=False)
+    g16 = _grads(tr)
+    L = loss.cpu().numpy()
+    assert np.isfinite(L).all() and bool(torch.isfinite(rgb).all()) and all(bool(torch.isfinite(g).all()) for g in g16)
+    # the loss is the mean square of the image that came with it (img2mse, refine2.py:860)
+    mse = float(((rgb.double() - wk.target.double()) ** 2).mean())
+    assert abs(L[1] - mse) < 2e-6 * max(1.0, mse) and abs(L[0] - L[1]) < 1e-12                       # a_mmrgb = 0: total = image loss
+    # 256 rays of the batch against the oracle's stage-2 render_rays on the host
+    sel, cpu, w = _subset(wk)
+    with torch.no_grad():
+        o = orc.render_rays_stage2(w, cpu(wk.rays), cpu(wk.or_rays), wk.images_nchw.cpu(), wk.poses.cpu(), wk.K.cpu(), cpu(wk.ref_nos), jitter=cpu(wk.jitter),
+                                   jitter_dir=1, raw_noise=cpu(wk.noise))
+    tie_free = (o['depth_sorted'][:, 1:] - o['depth_sorted'][:, :-1]).min(1)[0] > 1e-6
+    ps = orc.psnr(cpu(rgb)[tie_free], o['rgb_map1'][tie_free])
+    print(f'\n[full size] stage-2 iteration: loss {L[1]:.6f}; rgb_map1 of {int(tie_free.sum())} subset rays vs the oracle {ps:.1f} dB')
+    assert int(tie_free.sum()) >= SUB - 4 and ps > 80.0                                              # fp32-grade path
+    # exact-fp32 products on the same batch: same loss and image, gradients as close as two fp32 summation orders are (test_train_gpu.py)
+    tr.set_products('f32')
+    loss32, rgb32 = wk.stage2_step(want_rgb=True, adam=False)
+    g32 = _grads(tr)
+    tr.set_products('f16x2')
+    L32 = loss32.cpu().numpy()
+    assert abs(L32[1] - L[1]) < 2e-6 * max(1.0, L[1]) and orc.psnr(rgb.cpu(), rgb32.cpu()) > 90.0
+    worst = max(_rel(a, b) for a, b in zip(g16, g32))
+    print(f'[full size] split-fp16 vs exact-fp32 products: worst relative gradient difference over the 52 tensors {worst:.2e}')
+    assert worst < 2e-2
+    # the iteration replayed as a hipGraph: bit for bit
+    tr.set_graph(True)
+    for _ in range(2):                                     # capture, then replay
+        lossg, rgbg = wk.stage2_step(want_rgb=True, adam=False)
+    gg = _grads(tr)
+    tr.set_graph(False)
+    assert torch.equal(lossg, loss) and torch.equal(rgbg, rgb) and all(torch.equal(a, b) for a, b in zip(gg, g16))
+
+
+def test_exploration_iteration_at_config4_size(work, dev):
+    """4096 rays x 256 samples per ray (n_mult = 32): 1 048 576 rows through the 12 NeRF layers, forward and backward."""
+    wk, tr = work, work.trainer
+    n_mult = 32
+    tr.set_products('f16x2'); tr.set_graph(False)
+    loss, rgb = wk.explore_step(n_mult, want_rgb=True, adam=False)
+    g16 = _grads(tr, range(14, 26))
+    L = loss.cpu().numpy()
+    assert np.isfinite(L).all() and bool(torch.isfinite(rgb).all()) and all(bool(torch.isfinite(g).all()) for g in g16)
+    mse = float(((rgb.double() - wk.target.double()) ** 2).mean())
+    assert abs(L[1] - mse) < 2e-6 * max(1.0, mse)
+    sel, cpu, w = _subset(wk)
+    with torch.no_grad():
+        o = orc.render_rays_stage1(w, cpu(wk.rays), cpu(wk.or_rays), wk.images_nchw.cpu(), wk.poses.cpu(), wk.K.cpu(), cpu(wk.ref_nos), False, n_mult=n_mult,
+                                   dir1=1, jitter=cpu(wk.explore_jitter(n_mult)), dir2=-1)
+    tie_free = (o['depth_sorted'][:, 1:] - o['depth_sorted'][:, :-1]).min(1)[0] > 1e-6
+    ps = orc.psnr(cpu(rgb)[tie_free], o['rgb_map1'][tie_free])
+    print(f'\n[full size] exploration iteration at 256 samples per ray: loss {L[1]:.6f}; rgb_map1 of {int(tie_free.sum())} subset rays vs the oracle {ps:.1f} dB')
+    assert int(tie_free.sum()) >= SUB - 4 and ps > 75.0                                              # 256-term compositing sums in fp32
+    tr.set_products('f32')
+    loss32, rgb32 = wk.explore_step(n_mult, want_rgb=True, adam=False)
+    g32 = _grads(tr, range(14, 26))
+    tr.set_products('f16x2')
+    assert abs(float(loss32[1]) - L[1]) < 2e-6 * max(1.0, L[1]) and orc.psnr(rgb.cpu(), rgb32.cpu()) > 90.0
+    worst = max(_rel(a, b) for a, b in zip(g16, g32))
+    print(f'[full size] split-fp16 vs exact-fp32 products: worst relative gradient difference over the 24 NeRF tensors {worst:.2e}')
+    assert worst < 2e-2
+    tr.set_graph(True)
+    for _ in range(2):
+        lossg, rgbg = wk.explore_step(n_mult, want_rgb=True, adam=False)
+    gg = _grads(tr, range(14, 26))
+    tr.set_graph(False)
+    assert torch.equal(lossg, loss) and torch.equal(rgbg, rgb) and all(torch.equal(a, b) for a, b in zip(gg, g16))
+    # one optimizer step of each kind leaves finite parameters
+    wk.stage2_step(); wk.explore_step(n_mult)
+    assert all(bool(torch.isfinite(p).all()) for i in range(26) for p in tr.read('param', i))

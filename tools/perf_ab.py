@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of library builds and kernel variants in ONE process (cdna guide §5.4 rule 24).
 
-    python tools/perf_ab.py [--rounds 7] [--frames 10] --configs "lib=;lib=head;lib=,sampler=sampler_f32;lib=,bf16=bf16_32x32"
+    python tools/perf_ab.py [--rounds 7] [--frames 10] --configs "lib=;lib=head;lib=,sampler=sampler_split;lib=,nerf=bf16_32x32"
 
 A config selects a library build (lib=<name> -> pronerf_amd/lib/libpronerf_hip_<name>.so, empty = the default build; see
 `python -m pronerf_amd.build --variant <name> [flags]`) and the kernel variants of its handles (pnrf_mlp_set_variant: sampler=
-default | sampler_f32 | sampler_f32_full, bf16= default | bf16_32x32 for the refine and NeRF handles, nerf= default | nerf_4x64 for the NeRF handle
-alone) — explicit configuration, the library reads no environment.
+default (two passes) | sampler_split | sampler_f32 | sampler_f32_full, nerf= default | bf16_32x32 | nerf_4x64 for the NeRF handle; the refine net has
+one engine) — explicit configuration, the library reads no environment.
 Every round renders `--frames` frames per config through pnrf_render_rays_fwd with the context's per-kernel events
 (pnrf_ctx_profile_begin / _end); reports median / min over the rounds per stage kernel on the bench workload (one 1008x756 frame).
 path=ops times the operator-level sequence instead (sampler, refine_input, refine on refine_in, NeRF: four kernels with the [n,144]
@@ -41,7 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--frames', type=int, default=10)
-    ap.add_argument('--configs', default='lib=;lib=,sampler=sampler_f32;lib=,bf16=bf16_32x32')
+    ap.add_argument('--configs', default='lib=;lib=,sampler=sampler_split;lib=,nerf=bf16_32x32')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     weights = synthetic.make_weights(0, 'trained')
@@ -53,8 +53,7 @@ def main():
         if n not in libs:
             libs[n] = load_lib(n)
         _lib._lib = libs[n]
-        bf = c.get('bf16', 'default')
-        var = {k: v for k, v in (('sampler', c.get('sampler', 'default')), ('refine', bf), ('nerf', c.get('nerf', bf))) if v != 'default'}
+        var = {k: v for k, v in (('sampler', c.get('sampler', 'default')), ('nerf', c.get('nerf', 'default'))) if v != 'default'}
         r = Renderer(weights, max_rays=H * W, device=dev, variants=var)
         r.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
         rends.append(r)
