@@ -130,6 +130,19 @@ def _batch(seed, H, W, nv, own=2):
     return dict(w=w, rays=rays, or_rays=or_rays, target=target, images=images, poses=poses, K=K, ref_nos=ref_nos, jitter=jitter, noise=noise, N=N)
 
 
+def low_frequency_nerf(w, keep_octaves):
+    """Zero the fine net's input weights of the positional octaves >= keep_octaves (pts_linears.0 and the skip columns of pts_linears.5).  The
+    kernels are unchanged (they still encode ten octaves), but d(raw)/d(pts) loses its 2^9 factor: the fp32 round-off of the chain then stays at
+    the 1e-5 level instead of 1e-3 .. 5e-2, and the gradient bounds of the HIP trainer can be as tight as a kernel regression needs."""
+    wc = w['nerfcls']
+    for li in (0, 5):
+        W, b = wc['pts_linears'][li]
+        W = W.copy()
+        W[:, 3 + 6 * keep_octaves:63] = 0.0
+        wc['pts_linears'][li] = (W, b)
+    return w
+
+
 def _oracle_step(layers, b, jdir, white, a_mmrgb):
     loss, img_loss, o = orc.stage2_loss(layers, b['rays'], b['or_rays'], b['target'], b['images'], b['poses'], b['K'], b['ref_nos'], jitter=b['jitter'],
                                         jitter_dir=jdir, raw_noise=b['noise'], white_bkgd=white, a_mmrgb=a_mmrgb)
@@ -153,10 +166,14 @@ def _oracle_grads(b, jdir, white, a_mmrgb, dtype):
 @pytest.mark.parametrize('products', ['f16x2', 'f32'])
 @pytest.mark.parametrize('jdir,white,a_mmrgb', [(1, False, 0.0), (-1, True, 1.0)])
 def test_stage2_step_gradients_vs_oracle_autograd(dev, jdir, white, a_mmrgb, products):
-    """Gradients of all 26 Linear layers, with the split-fp16 layer products (the default) and with the exact-fp32 ones.  Arbiter = the oracle run in fp64: its own fp32 run differs from it by 1.3e-3 ..
-    2.5e-3 per tensor on this batch (2^9 positional frequencies and the 1e10 last interval amplify round-off), so two
-    correct fp32 implementations agree to ~1e-3, not 1e-6.  Bounds: relative to the CPU fp32 run's own distance from fp64 (per tensor and
-    in the median); an absolute cap only to catch a wrong formula."""
+    """Gradients of all 26 Linear layers on the ill-conditioned chain the configs really have (2^9 positional frequencies, a 1e10 last
+    interval), with the split-fp16 layer products (the default) and with the exact-fp32 ones.  Arbiter = the oracle run in fp64.  Torch's own
+    fp32 CPU run of this batch is 3e-3 .. 1.8e-2 away from it per tensor (tools/diag_grad.py: 3e-3 .. 5e-2 over six seeds), so what can be
+    asserted HERE is that the HIP trainer's round-off is of that size: per tensor within 6x of the CPU run's distance (a ReLU mask within
+    round-off of zero flips in one implementation and not the other: measured up to 4.2x), within 2.5x of the largest distance any tensor of
+    the CPU run has (the noise amplitude of the batch; measured <= 1.6x), median ratio over the 52 tensors < 2 (measured 0.1 .. 1.4).  A
+    regression of 1e-2 in a product kernel would hide in this noise: the tight bound (1e-4 per tensor) is asserted on a well-conditioned net
+    in test_stage2_step_gradients_tight_on_a_well_conditioned_net below."""
     from pronerf_amd import ops
     b = _batch(0, 12, 16, 7)
     loss64, img64, o64, g64 = _oracle_grads(b, jdir, white, a_mmrgb, torch.float64)
@@ -172,18 +189,48 @@ def test_stage2_step_gradients_vs_oracle_autograd(dev, jdir, white, a_mmrgb, pro
     assert abs(Lh[0] - loss64) < 2e-5 * max(1.0, loss64) and abs(Lh[1] - img64) < 2e-5
     assert bool((o64['edge_margin'] > 1e-5).all())
     assert orc.psnr(rgb.cpu(), o64['rgb_map1'].detach().float()) > 80.0                      # fp32 path
+    cmax = max(max(rel(g32[li][0], g64[li][0]), rel(g32[li][1], g64[li][1])) for li in range(26))     # noise amplitude of this batch
     ratios = []
     for li in range(26):
         gW, gb = tr.read('grad', li)
         eW, eb = rel(gW, g64[li][0]), rel(gb, g64[li][1])
         cW, cb = rel(g32[li][0], g64[li][0]), rel(g32[li][1], g64[li][1])
-        assert eW < 4e-2 and eb < 4e-2, (li, eW, eb)                      # a wrong formula is O(1); the CPU fp32 run itself reaches 1.8e-2 here
+        assert eW < 2.5 * cmax and eb < 2.5 * cmax, (li, eW, eb, cmax)
         ratios += [eW / (cW + 1e-5), eb / (cb + 1e-5)]
-        # one ReLU unit whose pre-activation is within round-off of zero may be on in one fp32 implementation and off in the other: that moves
-        # the gradients of every layer below it by ~3e-3 of their norm (seen at pts_linears 0..3 of the second case) — hence 6x per tensor,
-        # with the median over the 52 tensors held to 2x
         assert eW < 6 * cW + 1e-5 and eb < 6 * cb + 1e-5, (li, eW, cW, eb, cb)
     assert float(np.median(ratios)) < 2.0, sorted(ratios)[-8:]
+
+
+@pytest.mark.parametrize('products', ['f16x2', 'f32'])
+@pytest.mark.parametrize('seed,jdir,white,a_mmrgb', [(0, 1, False, 0.0), (0, -1, True, 1.0), (3, 1, False, 0.0), (3, -1, True, 1.0)])
+def test_stage2_step_gradients_tight_on_a_well_conditioned_net(dev, seed, jdir, white, a_mmrgb, products):
+    """The same iteration with the fine net's input weights of the positional octaves >= 2 set to zero (low_frequency_nerf): every kernel
+    runs as before, but the chain no longer amplifies fp32 round-off by 2^9, so torch's fp32 CPU run is within 7e-6 .. 6e-5 of the fp64 run
+    and the HIP trainer can be held to 1e-4 per gradient tensor with either product arithmetic (measured, tools/diag_grad.py 2: exact fp32
+    <= 9.0e-6, split fp16 <= 2.1e-5 on these four cases) — 100x below the noise of the full-frequency test above, i.e. a relative error of
+    1e-3 in any layer product, epilogue or reduction fails here.  Seeds 0 and 3: batches without a discrete event (a ReLU mask, bilinear tap
+    or sort order decided by round-off) in any of the three fp32 implementations; such events show up as 2e-4 .. 4e-3 on seeds 1, 2, 4, 5."""
+    from pronerf_amd import ops
+    b = _batch(seed, 12, 16, 7)
+    low_frequency_nerf(b['w'], 2)
+    loss64, img64, o64, g64 = _oracle_grads(b, jdir, white, a_mmrgb, torch.float64)
+    layers = orc.trainer_layers(b['w'])
+    tr = ops.Trainer([W for W, _ in layers], [x for _, x in layers], max_rays=b['N'], device=dev)
+    tr.set_products(products)
+    img4 = ops.images_pack(cu(b['images'], dev))
+    L, rgb = tr.fwd_bwd(cu(b['rays'], dev), cu(b['or_rays'], dev), cu(b['target'], dev), img4, cu(b['poses'], dev), cu(b['K'], dev),
+                        b['ref_nos'].to(dev).contiguous(), jitter=cu(b['jitter'], dev), jitter_dir=jdir, raw_noise=cu(b['noise'], dev), white_bkgd=white,
+                        a_mmrgb=a_mmrgb)
+    Lh = L.cpu().numpy()
+    assert abs(Lh[0] - loss64) < 2e-7 * max(1.0, loss64) and abs(Lh[1] - img64) < 2e-7
+    assert orc.psnr(rgb.cpu(), o64['rgb_map1'].detach().float()) > 110.0
+    worst = 0.0
+    for li in range(26):
+        gW, gb = tr.read('grad', li)
+        eW, eb = rel(gW, g64[li][0]), rel(gb, g64[li][1])
+        worst = max(worst, eW, eb)
+        assert eW < 1e-4 and eb < 1e-4, (li, eW, eb)
+    print(f'\n[tight] seed {seed} case {(jdir, white, a_mmrgb)} products {products}: worst relative gradient error over the 52 tensors {worst:.2e}')
 
 
 def test_graph_replay_equals_kernel_by_kernel(dev):
@@ -300,13 +347,21 @@ def test_adam_step_matches_torch_optim(dev):
     np.testing.assert_allclose(vW.cpu().numpy(), st['exp_avg_sq'].numpy(), rtol=1e-4, atol=1e-14)
 
 
-def test_training_loop_reduces_the_loss_like_the_oracle(dev):
-    """Ten iterations on one fixed batch: the loss of the HIP trainer follows the oracle's (torch autograd + torch Adam)."""
+@pytest.mark.parametrize('products', ['f16x2', 'f32'])
+def test_training_loop_reduces_the_loss_like_the_oracle(dev, products):
+    """Ten iterations on one fixed batch: the loss of the HIP trainer follows the oracle's (torch autograd + torch Adam).  On the
+    well-conditioned net (low_frequency_nerf) the gradients of two fp32 implementations agree to ~1e-5, so the trajectories stay together:
+    1e-6 before the first update, 1e-5 after it (measured 1.6e-7).  From then on they separate — the first Adam step moves every weight by
+    +-lr whatever the size of its gradient, including the zeroed high-octave input weights, so the net is full-frequency again and m / sqrt(v)
+    amplifies round-off-sized gradient differences (measured over the ten steps: 1.1e-2 with the split-fp16 products, 3.7e-2 with the
+    exact-fp32 ones): from the third loss on only the common descent is asserted (both curves within 10 % of each other, both down by > 10 %)."""
     from pronerf_amd import ops
-    b = _batch(1, 12, 16, 7)
+    b = _batch(0, 12, 16, 7)
+    low_frequency_nerf(b['w'], 2)
     layers = [(torch.tensor(W, requires_grad=True), torch.tensor(x, requires_grad=True)) for W, x in orc.trainer_layers(b['w'])]
     opt = torch.optim.Adam([p for pair in layers for p in pair], lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-8)
     tr = ops.Trainer([W.detach() for W, _ in layers], [x.detach() for _, x in layers], max_rays=b['N'], device=dev)
+    tr.set_products(products)
     img4 = ops.images_pack(cu(b['images'], dev))
     args = (cu(b['rays'], dev), cu(b['or_rays'], dev), cu(b['target'], dev), img4, cu(b['poses'], dev), cu(b['K'], dev), b['ref_nos'].to(dev).contiguous())
     kw = dict(jitter=cu(b['jitter'], dev), jitter_dir=1, raw_noise=cu(b['noise'], dev))
@@ -319,12 +374,12 @@ def test_training_loop_reduces_the_loss_like_the_oracle(dev):
         L, _ = tr.fwd_bwd(*args, **kw, want_rgb=False)
         tr.adam_step(5e-4, weight_decay=5e-8)
         got.append(float(L[0]))
+    print(f'\n[loop] products {products}: loss {got[0]:.6f} -> {got[-1]:.6f} (oracle {ref[0]:.6f} -> {ref[-1]:.6f}); max relative difference '
+          f'{max(abs(a - c) / c for a, c in zip(got, ref)):.2e}, after the first update {abs(got[1] - ref[1]) / ref[1]:.2e}')
     assert got[-1] < 0.9 * got[0] and ref[-1] < 0.9 * ref[0]
-    # same loss before the first update; after it to 2e-3: Adam's first step moves every weight by +-lr whatever the size of its gradient, so
-    # the handful of entries whose gradient is round-off (or one ReLU mask at zero) step differently in two fp32 implementations
-    np.testing.assert_allclose(got[0], ref[0], rtol=1e-4)
-    np.testing.assert_allclose(got[1], ref[1], rtol=2e-3)
-    np.testing.assert_allclose(got, ref, rtol=5e-2)                  # then Adam's m/sqrt(v) amplifies round-off-level gradient differences
+    np.testing.assert_allclose(got[0], ref[0], rtol=1e-6)
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-5)
+    np.testing.assert_allclose(got, ref, rtol=1e-1)
 
 
 @pytest.mark.parametrize('name', ['stage2_step_12x16', 'stage2_step_white_mmrgb_10x14'])
@@ -361,7 +416,9 @@ def test_stage2_step_vs_reference_golden(dev, golden_dir, name):
             assert float(np.median(ratios)) < 3.0, float(np.median(ratios))    # as a whole: the same noise level as torch's fp32 CPU run
         else:
             tr.adam_step(b['lr'], weight_decay=b['wd'])
-            U.check_against_golden(g, grads, [tr.read('param', i) for i in range(26)], tol_grad=1e-1, tol_norm=5e-2)
+            # the fp32 golden is one more draw of the same round-off noise: per tensor its distance n from the fp64 golden is known, the HIP
+            # trainer was held to 6 n + 1e-3 of the fp64 golden above, so it is within 7 n + 1e-3 of this one
+            U.check_against_golden(g, grads, [tr.read('param', i) for i in range(26)], tol_grad=U.noise_tolerances(g, g64, 7.0, 1e-3), tol_norm=5e-2)
 
 
 @pytest.mark.parametrize('n_mult,dir1,dir2', [(16, 1, -1), (32, -1, 1)])
@@ -431,18 +488,35 @@ def test_stage2_train_driver_end_to_end(dev, tmp_path):
     cfg.write_text(f'expname = s2\nbasedir = {tmp_path}/logs\ndatadir = {root}\npretrain_path = {pre}\nfactor = 4\nllffhold = 8\nN_rand = 512\nN_samples = 8\n'
                    'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\nraw_noise_std = 1e0\nlrate = 5e-4\n'
                    'weight_decay = 5e-8\ni_print = 5\ni_weights = 1000\n')
-    tr, log = s2.train(['--config', str(cfg), '--max_steps', '20'], device=dev)
-    assert [e[0] for e in log] == [5, 10, 15, 20] and all(np.isfinite(e[1]) for e in log)
-    # the logged loss is that of the iteration's own random 512-ray batch with sigma noise: a noisy series (0.053, 0.050, 0.052, 0.109 in
-    # one run) — only that it stays finite and gets below its first value at some point is asserted here; the descent itself is checked
-    # against the oracle's trajectory on a fixed batch in test_training_loop_reduces_the_loss_like_the_oracle
-    assert min(e[1] for e in log[1:]) < log[0][1] and max(e[1] for e in log) < 1.0
-    ck_path = tmp_path / 'logs' / 's2' / '000020.tar'
+    import random
+    random.seed(11); np.random.seed(11); torch.manual_seed(11); torch.cuda.manual_seed_all(11)          # the driver's per-batch draws
+    tr, log = s2.train(['--config', str(cfg), '--max_steps', '40'], device=dev)
+    assert [e[0] for e in log] == [5, 10, 15, 20, 25, 30, 35, 40] and all(np.isfinite(e[1]) for e in log)
+    # the logged loss is that of each iteration's own random 512-ray batch with sigma noise — a noisy series; descent is asserted on ONE fixed
+    # evaluation batch (all 768 rays of training view 0, fixed draws, no sigma noise) with the parameters before and after the 40 iterations
+    from pronerf_amd import ops
+    from pronerf_amd.load_llff import load_llff_data
+    images, poses, _, _, _ = load_llff_data(root, 4, recenter=True, bd_factor=.75, spherify=False)
+    i_train = np.array([i for i in range(images.shape[0]) if i % 8 != 0])
+    Hh, Ww, focal = int(poses[0, 0, -1]), int(poses[0, 1, -1]), float(poses[0, 2, -1])
+    Kk = np.array([[focal, 0, 0.5 * Ww], [0, focal, 0.5 * Hh], [0, 0, 1]], dtype=np.float32)
+    with torch.cuda.device(dev):
+        er, eo = ops.frame_rays(Kk, poses[i_train[0], :3, :4], Hh, Ww, near=0., far=1., device=dev)
+        img4, pz, Kt, rank = s2._train_views(images[i_train], poses[i_train, :3, :4], Kk, dev)
+    et = torch.as_tensor(images[i_train[0]], dtype=torch.float32).reshape(-1, 3).to(dev)
+    eref = rank[0][1:5][None].expand(er.shape[0], -1).contiguous()
+    tr0 = ops.Trainer(*zip(*s2.trainer_layer_list(sds['sampler'], sds['refine'], synth.nerfcls_state_dict(wc))), max_rays=er.shape[0], device=dev)
+    before = float(tr0.fwd_bwd(er, eo, et, img4, pz, Kt, eref, want_rgb=False)[0][1])
+    tr_eval = ops.Trainer(*zip(*[tuple(t.cpu().numpy() for t in tr.read('param', i)) for i in range(26)]), max_rays=er.shape[0], device=dev)
+    after = float(tr_eval.fwd_bwd(er, eo, et, img4, pz, Kt, eref, want_rgb=False)[0][1])
+    print(f'\n[driver] image loss on the fixed evaluation batch: {before:.5f} before, {after:.5f} after 40 iterations; logged batch losses {[round(e[1], 4) for e in log]}')
+    assert after < 0.97 * before and max(e[1] for e in log) < 1.0
+    ck_path = tmp_path / 'logs' / 's2' / '000040.tar'
     ck = torch.load(str(ck_path), map_location='cpu')
     assert sorted(ck['network_fine_state_dict']) == sorted(synth.nerfcls_state_dict(wc))
-    assert sorted(ck['mmr_network_fn_state_dict']) == sorted(sds['sampler']) and ck['global_step'] == 20
+    assert sorted(ck['mmr_network_fn_state_dict']) == sorted(sds['sampler']) and ck['global_step'] == 40
     moved = float((ck['refine_net_state_dict']['fc_output.weight'] - sds['refine']['fc_output.weight']).abs().max())
-    assert 0 < moved <= 20 * 5e-4 * 1.01                              # Adam moves a weight by at most lr per step
+    assert 0 < moved <= 40 * 5e-4 * 1.01                              # Adam moves a weight by at most lr per step
     icfg = tmp_path / 'infer.txt'
     icfg.write_text(f'expname = inf\nbasedir = {tmp_path}/logs\ndatadir = {root}\nft_path = {ck_path}\nfactor = 4\nllffhold = 8\nN_samples = 8\n'
                     'N_point_ray_enc = 48\nmmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\n')
@@ -492,7 +566,7 @@ def test_stage1_iterations_vs_reference_golden(dev, golden_dir, name):
             before = [tr.read('param', i) for i in range(14)]
             tr.adam_step(b['lr'], weight_decay=b['wd'], nerf_only=not joint)
             after = [tr.read('param', i) for i in range(26)]
-            U.check_against_golden(g, grads, after, tol_grad=1e-1, tol_norm=5e-2, layers=active)
+            U.check_against_golden(g, grads, after, tol_grad=U.noise_tolerances(g, g64, 7.0, 1e-3, layers=active), tol_norm=5e-2, layers=active)
             if not joint:                                 # the NeRF-only optimizer leaves the sampler / refine nets alone
                 assert all(torch.equal(before[i][0], after[i][0]) and torch.equal(before[i][1], after[i][1]) for i in range(14))
                 mW, _ = tr.read('m_nerf', 20); jW, _ = tr.read('m', 20)
