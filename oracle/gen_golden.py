@@ -44,6 +44,14 @@ def load_reference():
     return helpers, inverse_warp, trt
 
 
+def driver_K(scene):
+    """The intrinsics as the reference's drivers hold them when they set up rays: a float64 numpy array built from the float32 focal of
+    poses_bounds.npy (run_S_eS_eN_alter_trt.py:737-747; passed as it is to render_path, :798).  K[0][0] is then a numpy float64 scalar, so
+    ndc_rays evaluates -1./(W/(2.*focal)) in double and rounds the factor to fp32 once; with a 0-dim fp32 TENSOR in its place torch would
+    evaluate W / t as t.reciprocal() * W — another rounding, 1 ulp apart for most image sizes (equal at 756 x 1008)."""
+    return np.asarray(scene['K'], dtype=np.float32).astype(np.float64)
+
+
 def build_models(helpers, weights):
     S, NB = synth.N_SAMPLES, synth.NUM_NEIGHBOR
     sd = synth.state_dicts(weights)
@@ -61,16 +69,16 @@ def reference_frame(helpers, trt, scene):
     (render_path, run_S_eS_eN_alter_trt.py:245-302; render_path itself needs a GPU)."""
     S, NB, P = synth.N_SAMPLES, synth.NUM_NEIGHBOR, synth.N_POINT_RAY_ENC
     H, W = scene['H'], scene['W']
-    K = torch.from_numpy(scene['K']); c2w = torch.from_numpy(scene['c2w'])
+    K = torch.from_numpy(scene['K']); c2w = torch.from_numpy(scene['c2w']); Kd = driver_K(scene)
     poses = torch.from_numpy(scene['poses']); images = scene['images']
-    rays_o, rays_d = helpers.get_rays(H, W, K, c2w)
+    rays_o, rays_d = helpers.get_rays(H, W, Kd, c2w)
     viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
     or_o = torch.reshape(rays_o, [-1, 3]).float(); or_d = torch.reshape(rays_d, [-1, 3]).float()
     or_rays = torch.cat([or_o, or_d, 1.0 * torch.ones_like(or_d[..., :1]), 10.0 * torch.ones_like(or_d[..., :1]), viewdirs], -1)
     ro1 = torch.cat([or_o.t()[None], torch.ones(1, 1, or_o.shape[0])], 1).expand(S * NB, -1, -1)
     rd1 = torch.cat([or_d.t()[None], torch.zeros(1, 1, or_d.shape[0])], 1).expand(S * NB, -1, -1)
-    o, d = helpers.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    o, d = helpers.ndc_rays(H, W, Kd[0][0], 1., rays_o, rays_d)
     o = torch.reshape(o, [-1, 3]).float(); d = torch.reshape(d, [-1, 3]).float()
     rays = torch.cat([o, d, 0. * torch.ones_like(d[..., :1]), 1. * torch.ones_like(d[..., :1]), viewdirs], -1)
     embed_rays = helpers.Pluecker()
@@ -153,7 +161,7 @@ def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, r
     out = dict(
         seed=np.int64(seed), kind=np.array(kind), H=np.int64(H), W=np.int64(W),
         Hf=np.int64(scene['images'].shape[1]), Wf=np.int64(scene['images'].shape[2]),
-        rotate=np.bool_(rotate), sigma_t=np.float32(sigma_t), sel=sel, n_full=np.int64(N_full),
+        rotate=np.bool_(rotate), sigma_t=np.float64(sigma_t), sel=sel, n_full=np.int64(N_full),
         rays=g(fr['rays']), or_rays=g(fr['or_rays']), ref_nos=g(fr['ref_nos']), proj=g(fr['proj']),
         mm_input_head=g(fr['mm_input'])[:, :12], mm_input_tail=g(fr['mm_input'])[:, -6:],
         mm_rgb=g(cap['mm_rgb']), depth_raw=g(cap['depth_raw']),
@@ -189,9 +197,9 @@ def run_operator_cases(helpers, iw, trt):
     o = torch.from_numpy(rs.randn(129, 3).astype(np.float32)); d = torch.from_numpy(rs.randn(129, 3).astype(np.float32))
     out['pl_o'] = o.numpy(); out['pl_d'] = d.numpy(); out['pl'] = helpers.Pluecker()(o, d).numpy()
     scene = synth.make_scene(5, H=9, W=13, rotate=True)
-    K = torch.from_numpy(scene['K']); c2w = torch.from_numpy(scene['c2w'])
-    ro, rd = helpers.get_rays(9, 13, K, c2w)
-    no, nd = helpers.ndc_rays(9, 13, K[0][0], 1., ro, rd)
+    Kd = driver_K(scene); c2w = torch.from_numpy(scene['c2w'])
+    ro, rd = helpers.get_rays(9, 13, Kd, c2w)
+    no, nd = helpers.ndc_rays(9, 13, Kd[0][0], 1., ro, rd)
     out['gr_K'] = scene['K']; out['gr_c2w'] = scene['c2w']
     out['gr_o'] = ro.contiguous().numpy(); out['gr_d'] = rd.numpy(); out['ndc_o'] = no.numpy(); out['ndc_d'] = nd.numpy()
     # warp with out-of-range samples: coordinates deliberately span beyond the image
@@ -250,13 +258,13 @@ def run_stage2_case(helpers, s2, name, seed, H, W, nv, randomize, white_bkgd, si
     sampler.load_state_dict(sd['sampler']); refine.load_state_dict(sd['refine']); fine.load_state_dict(synth.nerfcls_state_dict(wc))
     scene = synth.make_scene(seed, H=H, W=W, n_views=nv, sigma_t=sigma_t, rotate=True)
     own = 2                                             # the rays come from training view `own`
-    K = torch.from_numpy(scene['K']); poses = torch.from_numpy(scene['poses']); c2w = poses[own]
-    rays_o, rays_d = helpers.get_rays(H, W, K, c2w)
+    K = torch.from_numpy(scene['K']); poses = torch.from_numpy(scene['poses']); c2w = poses[own]; Kd = driver_K(scene)
+    rays_o, rays_d = helpers.get_rays(H, W, Kd, c2w)
     viewdirs = (rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float()
     or_o, or_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
     N = or_o.shape[0]
     or_rays = torch.cat([or_o, or_d, torch.ones(N, 1), 10 * torch.ones(N, 1), viewdirs], -1)
-    o, d = helpers.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    o, d = helpers.ndc_rays(H, W, Kd[0][0], 1., rays_o, rays_d)
     o, d = o.reshape(-1, 3).float(), d.reshape(-1, 3).float()
     rays = torch.cat([o, d, 1e-6 * torch.ones(N, 1) * 0, torch.ones(N, 1), viewdirs], -1)     # near 0, far 1 (refine2.py:794-795 / fern_refine.txt)
     embed_fn, _ = helpers.get_embedder(synth.MULTIRES, 0)
@@ -290,7 +298,7 @@ def run_stage2_case(helpers, s2, name, seed, H, W, nv, randomize, white_bkgd, si
         pyrandom.sample, pyrandom.random, torch.normal, torch.randn = o_sample, o_rand, o_normal, o_randn
     g = lambda t: t.detach().cpu().numpy()
     out = dict(seed=np.int64(seed), H=np.int64(H), W=np.int64(W), nv=np.int64(nv), own=np.int64(own), randomize=np.bool_(randomize),
-               white_bkgd=np.bool_(white_bkgd), sigma_t=np.float32(sigma_t), rays=g(rays), or_rays=g(or_rays),
+               white_bkgd=np.bool_(white_bkgd), sigma_t=np.float64(sigma_t), rays=g(rays), or_rays=g(or_rays),
                rgb_map0=g(ret['rgb_map0']), rgb_map1=g(ret['rgb_map1']), depth_map=g(ret['depth_map']), mm_rgb=g(ret['mm_rgb']),
                z_vals=g(ret['z_vals']), z_vals0=g(ret['z_vals0']))
     if randomize:
@@ -324,13 +332,13 @@ def run_stage1_case(helpers, s1, name, seed, H, W, nv, train_sampler, pyseed, si
     sampler.load_state_dict(sd['sampler']); refine.load_state_dict(sd['refine']); fine.load_state_dict(synth.nerfcls_state_dict(wc))
     scene = synth.make_scene(seed, H=H, W=W, n_views=nv, sigma_t=sigma_t, rotate=True)
     own = 1
-    K = torch.from_numpy(scene['K']); poses = torch.from_numpy(scene['poses']); c2w = poses[own]
-    rays_o, rays_d = helpers.get_rays(H, W, K, c2w)
+    K = torch.from_numpy(scene['K']); poses = torch.from_numpy(scene['poses']); c2w = poses[own]; Kd = driver_K(scene)
+    rays_o, rays_d = helpers.get_rays(H, W, Kd, c2w)
     viewdirs = (rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float()
     or_o, or_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
     N = or_o.shape[0]
     or_rays = torch.cat([or_o, or_d, torch.ones(N, 1), 10 * torch.ones(N, 1), viewdirs], -1)
-    o, d = helpers.ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    o, d = helpers.ndc_rays(H, W, Kd[0][0], 1., rays_o, rays_d)
     o, d = o.reshape(-1, 3).float(), d.reshape(-1, 3).float()
     rays = torch.cat([o, d, 1e-6 * torch.ones(N, 1), torch.ones(N, 1), viewdirs], -1)          # near = 1e-6 (base.py:798)
     embed_fn, _ = helpers.get_embedder(synth.MULTIRES, 0)
@@ -366,7 +374,7 @@ def run_stage1_case(helpers, s1, name, seed, H, W, nv, train_sampler, pyseed, si
         pyrandom.sample, pyrandom.random, pyrandom.randint, torch.normal, torch.randn = o_sample, o_rand, o_randint, o_normal, o_randn
     g = lambda t: t.detach().cpu().numpy()
     out = dict(seed=np.int64(seed), H=np.int64(H), W=np.int64(W), nv=np.int64(nv), own=np.int64(own), train_sampler=np.bool_(train_sampler),
-               sigma_t=np.float32(sigma_t), rays=g(rays), or_rays=g(or_rays), order_idx=cap['order_idx'],
+               sigma_t=np.float64(sigma_t), rays=g(rays), or_rays=g(or_rays), order_idx=cap['order_idx'],
                rgb_map0=g(ret['rgb_map0']), rgb_map1=g(ret['rgb_map1']), depth_map=g(ret['depth_map']), mm_rgb=g(ret['mm_rgb']),
                depth_map0=g(ret['depth_map0']))
     if train_sampler:

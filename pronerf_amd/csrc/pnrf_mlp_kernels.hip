@@ -46,9 +46,9 @@ __device__ __forceinline__ float dpp_mov(float v) {
 }
 // sum over each aligned group of 8 lanes, result in all 8: xor 1, xor 2 (quad_perm), then the mirrored half row
 __device__ __forceinline__ float sum8_dpp(float v) {
-  v = __fadd_rn(v, dpp_mov<0xB1>(v));
-  v = __fadd_rn(v, dpp_mov<0x4E>(v));
-  return __fadd_rn(v, dpp_mov<0x141>(v));
+  v = ieee_add(v, dpp_mov<0xB1>(v));
+  v = ieee_add(v, dpp_mov<0x4E>(v));
+  return ieee_add(v, dpp_mov<0x141>(v));
 }
 
 // Two waves per SIMD: the second-dispatched half of the workgroup (waves NW/2..NW-1) loses every VALU/MFMA
@@ -73,10 +73,8 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
 // reference's separate torch ops (trt.py:559-560 mul,add; helpers:630-631 cross).
 __device__ __forceinline__ void moment(float ox, float oy, float oz, float dx, float dy, float dz, float t,
                                        float hx, float hy, float hz, float& m0, float& m1, float& m2) {
-  const float px = __fadd_rn(ox, __fmul_rn(dx, t)), py = __fadd_rn(oy, __fmul_rn(dy, t)), pz = __fadd_rn(oz, __fmul_rn(dz, t));
-  m0 = __fsub_rn(__fmul_rn(py, hz), __fmul_rn(pz, hy));
-  m1 = __fsub_rn(__fmul_rn(pz, hx), __fmul_rn(px, hz));
-  m2 = __fsub_rn(__fmul_rn(px, hy), __fmul_rn(py, hx));
+  const float px = ieee_add(ox, ieee_mul(dx, t)), py = ieee_add(oy, ieee_mul(dy, t)), pz = ieee_add(oz, ieee_mul(dz, t));
+  cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
 }
 
 // ------------------------------------------------------------------------------------------ sampler
@@ -224,9 +222,9 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
       p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
       p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
     }
-    const float span = __fsub_rn(far, near);
+    const float span = ieee_sub(far, near);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
+    for (int i = 0; i < 8; ++i) dep[i] = ieee_add(ieee_mul(dep[i], span), near);      // trt.py:631
     // stable ascending sort (19-comparator network on (value, index) keys)          // trt.py:632-635
     PNRF_SORT8
     uint32_t word = 0;
@@ -389,9 +387,9 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
       p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
       p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
     }
-    const float span = __fsub_rn(far, near);
+    const float span = ieee_sub(far, near);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
+    for (int i = 0; i < 8; ++i) dep[i] = ieee_add(ieee_mul(dep[i], span), near);      // trt.py:631
     // stable ascending sort (19-comparator network on (value, index) keys)          // trt.py:632-635
     PNRF_SORT8
     uint32_t word = 0;
@@ -552,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void sampler_p1_kernel(SamplerArgs a) {
     for (int i = 0; i < P1_SLOTS_PAD; ++i) st.begin();
     // variance bound of a depth logit: both halves of a column hold partial sums over their rows
     float U = fmaf(C2, sq_b, V);
-    U = __fadd_rn(U, __shfl_xor(U, 32));
+    U = ieee_add(U, __shfl_xor(U, 32));
     const float sd = sqrtf(m_out * U);
 
     // ---- epilogue.  Half 0: registers 0-7 depth logits, 8-15 add; half 1: 0-7 mul, 8-10 rgb (sampler_p1_out)
@@ -568,9 +566,9 @@ __global__ __launch_bounds__(512, 2) void sampler_p1_kernel(SamplerArgs a) {
       p[0] = make_float4(dep[0], dep[1], dep[2], dep[3]);
       p[1] = make_float4(dep[4], dep[5], dep[6], dep[7]);
     }
-    const float span = __fsub_rn(far, near);
+    const float span = ieee_sub(far, near);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dep[i] = __fadd_rn(__fmul_rn(dep[i], span), near);      // trt.py:631
+    for (int i = 0; i < 8; ++i) dep[i] = ieee_add(ieee_mul(dep[i], span), near);      // trt.py:631
     PNRF_SORT8                                                                             // trt.py:632-635
     // decidable?  every adjacent gap must exceed kappa x (std bound of the two depths) + an fp32 round-off allowance
     bool undecided = false;
@@ -913,10 +911,10 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
       float zz[4], pp[12];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const float lower = __fmul_rn(0.5f, __fadd_rn(w[s4 + 1], w[s4]));       // trt.py:673-675
-        const float upper = __fmul_rn(0.5f, __fadd_rn(w[s4 + 2], w[s4 + 1]));
+        const float lower = ieee_mul(0.5f, ieee_add(w[s4 + 1], w[s4]));       // trt.py:673-675
+        const float upper = ieee_mul(0.5f, ieee_add(w[s4 + 2], w[s4 + 1]));
         const float rf = sigmoid_fast(fin[cb][4 * s4]);                           // bf16-grade logits: hardware exp / rcp are exact enough
-        zz[s4] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), rf));     // :676
+        zz[s4] = ieee_add(lower, ieee_mul(ieee_sub(upper, lower), rf));     // :676
       }
       if (MODE == 2) {           // depth jitter toward the next / previous refined sample (refine2.py:646-662)
         const float o0 = __shfl_xor(zz[0], 32), o3 = __shfl_xor(zz[3], 32);     // the other half's first / last sample
@@ -928,10 +926,10 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
           for (int s4 = 0; s4 < 4; ++s4) {
             if (a.jitter_dir > 0) {
               const float nxt = s4 < 3 ? zz[s4 < 3 ? s4 + 1 : 3] : (h == 0 ? o0 : far);
-              zn[s4] = __fadd_rn(zz[s4], __fmul_rn(jv[s4], fabsf(__fsub_rn(zz[s4], nxt))));
+              zn[s4] = ieee_add(zz[s4], ieee_mul(jv[s4], fabsf(ieee_sub(zz[s4], nxt))));
             } else {
               const float prv = s4 > 0 ? zz[s4 > 0 ? s4 - 1 : 0] : (h == 1 ? o3 : near);
-              zn[s4] = __fadd_rn(zz[s4], __fmul_rn(-jv[s4], fabsf(__fsub_rn(zz[s4], prv))));
+              zn[s4] = ieee_add(zz[s4], ieee_mul(-jv[s4], fabsf(ieee_sub(zz[s4], prv))));
             }
           }
 #pragma unroll
@@ -942,9 +940,9 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
       for (int s4 = 0; s4 < 4; ++s4) {
         const float zv = zz[s4];
         const float fx = tanh_fast(fin[cb][4 * s4 + 1]), fy = tanh_fast(fin[cb][4 * s4 + 2]), fz = tanh_fast(fin[cb][4 * s4 + 3]);
-        pp[3 * s4 + 0] = __fadd_rn(__fadd_rn(ox, __fmul_rn(dx, zv)), __fmul_rn(1e-2f, fx));   // :679-681
-        pp[3 * s4 + 1] = __fadd_rn(__fadd_rn(oy, __fmul_rn(dy, zv)), __fmul_rn(1e-2f, fy));
-        pp[3 * s4 + 2] = __fadd_rn(__fadd_rn(oz, __fmul_rn(dz, zv)), __fmul_rn(1e-2f, fz));
+        pp[3 * s4 + 0] = ieee_add(ieee_add(ox, ieee_mul(dx, zv)), ieee_mul(1e-2f, fx));   // :679-681
+        pp[3 * s4 + 1] = ieee_add(ieee_add(oy, ieee_mul(dy, zv)), ieee_mul(1e-2f, fy));
+        pp[3 * s4 + 2] = ieee_add(ieee_add(oz, ieee_mul(dz, zv)), ieee_mul(1e-2f, fz));
       }
       if (valid[cb]) {
         *(float4*)(a.z + row[cb] * 8 + 4 * h) = make_float4(zz[0], zz[1], zz[2], zz[3]);
@@ -1046,7 +1044,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
       const int64_t rr = valid[cb] ? row[cb] : nrows - 1;
       if (FUSED && composite) {
         const float* r = raw[cb].d;
-        e_dn[cb] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[0], r[0]), __fmul_rn(r[1], r[1])), __fmul_rn(r[2], r[2])));
+        e_dn[cb] = ieee_sqrt(ieee_add(ieee_add(ieee_mul(r[0], r[0]), ieee_mul(r[1], r[1])), ieee_mul(r[2], r[2])));
         e_z[cb] = raw[cb].z; e_add[cb] = raw[cb].add; e_mul[cb] = raw[cb].mul; e_noise[cb] = raw[cb].noise;
       }
       if (FUSED) {
@@ -1216,34 +1214,34 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
         r2 = fminf(fmaxf(r2, -a.clampv), a.clampv); r3 = fminf(fmaxf(r3, -a.clampv), a.clampv);
       }
       const float znext = __shfl_down(zc, 1);
-      float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
-      dist = __fmul_rn(dist, dn);                                                   // :583
+      float dist = (s < 7) ? ieee_sub(znext, zc) : 1e10f;                          // trt.py:579-581
+      dist = ieee_mul(dist, dn);                                                   // :583
       const float cr = sigmoid_f(r0), cg = sigmoid_f(r1), cbv = sigmoid_f(r2);      // :585
-      const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
-      float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));                     // :577,587
-      if (a.mul) alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                          // :588
-      const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
+      const float sg = fmaxf(ieee_add(a.noise ? ieee_add(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
+      float alpha = ieee_sub(1.f, expf(ieee_mul(-sg, dist)));                     // :577,587
+      if (a.mul) alpha = ieee_mul(alpha, fmaxf(mu, 0.f));                          // :588
+      const float xk = ieee_add(ieee_sub(1.f, alpha), 1e-10f);                    // :590
       const int base = lane & 0x38;
       float T = 1.f;
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const float xj = __shfl(xk, base + j);
-        T = (j < s) ? __fmul_rn(T, xj) : T;
+        T = (j < s) ? ieee_mul(T, xj) : T;
       }
-      const float wgt = __fmul_rn(alpha, T);
-      const float c0 = __fmul_rn(wgt, cr), c1 = __fmul_rn(wgt, cg), c2 = __fmul_rn(wgt, cbv), c3 = __fmul_rn(wgt, zc);
+      const float wgt = ieee_mul(alpha, T);
+      const float c0 = ieee_mul(wgt, cr), c1 = ieee_mul(wgt, cg), c2 = ieee_mul(wgt, cbv), c3 = ieee_mul(wgt, zc);
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sa = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        s0 = __fadd_rn(s0, __shfl(c0, base + j));                                   // :591 sum over samples
-        s1 = __fadd_rn(s1, __shfl(c1, base + j));
-        s2 = __fadd_rn(s2, __shfl(c2, base + j));
-        s3 = __fadd_rn(s3, __shfl(c3, base + j));                                   // :593 depth_map
-        sa = __fadd_rn(sa, __shfl(wgt, base + j));                                  // acc_map
+        s0 = ieee_add(s0, __shfl(c0, base + j));                                   // :591 sum over samples
+        s1 = ieee_add(s1, __shfl(c1, base + j));
+        s2 = ieee_add(s2, __shfl(c2, base + j));
+        s3 = ieee_add(s3, __shfl(c3, base + j));                                   // :593 depth_map
+        sa = ieee_add(sa, __shfl(wgt, base + j));                                  // acc_map
       }
       if (a.white_bkgd) {                                                           // refine2.py:519-520
-        const float bg = __fsub_rn(1.f, sa);
-        s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg);
+        const float bg = ieee_sub(1.f, sa);
+        s0 = ieee_add(s0, bg); s1 = ieee_add(s1, bg); s2 = ieee_add(s2, bg);
       }
       if (valid[cb] && h == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(s0, s1, s2, s3);
     });
@@ -1330,7 +1328,7 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
       const float x3[3] = {pp[0], pp[1], pp[2]};
       const float v3[3] = {ry[8], ry[9], ry[10]};
       if (composite) {
-        e_dn[cb] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ry[3], ry[3]), __fmul_rn(ry[4], ry[4])), __fmul_rn(ry[5], ry[5])));
+        e_dn[cb] = ieee_sqrt(ieee_add(ieee_add(ieee_mul(ry[3], ry[3]), ieee_mul(ry[4], ry[4])), ieee_mul(ry[5], ry[5])));
         e_z[cb] = a.z[rr]; e_add[cb] = a.add ? a.add[rr] : 0.f; e_mul[cb] = a.mul ? a.mul[rr] : 1.f;
         e_noise[cb] = a.noise ? a.noise[rr] : 0.f;
       }
@@ -1447,27 +1445,27 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
       // (row_shl / row_shr / quad_perm / row_half_mirror) instead of LDS permutes; tree order instead of torch's left-to-right order,
       // a difference of fp32 round-off under a bf16-grade network output
       const float znext = dpp_mov<0x101>(zc);                                       // row_shl:1
-      float dist = (s < 7) ? __fsub_rn(znext, zc) : 1e10f;                          // trt.py:579-581
-      dist = __fmul_rn(dist, dn);                                                   // :583
+      float dist = (s < 7) ? ieee_sub(znext, zc) : 1e10f;                          // trt.py:579-581
+      dist = ieee_mul(dist, dn);                                                   // :583
       const float cr = sigmoid_fast(r0), cg = sigmoid_fast(r1), cbv = sigmoid_fast(r2);   // :585
-      const float sg = fmaxf(__fadd_rn(a.noise ? __fadd_rn(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
-      float alpha = __fsub_rn(1.f, __expf(__fmul_rn(-sg, dist)));                   // :577,587
-      if (a.mul) alpha = __fmul_rn(alpha, fmaxf(mu, 0.f));                          // :588
-      const float xk = __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f);                    // :590
+      const float sg = fmaxf(ieee_add(a.noise ? ieee_add(r3, e_noise[cb]) : r3, ad), 0.f);     // refine2.py:508
+      float alpha = ieee_sub(1.f, __expf(ieee_mul(-sg, dist)));                   // :577,587
+      if (a.mul) alpha = ieee_mul(alpha, fmaxf(mu, 0.f));                          // :588
+      const float xk = ieee_add(ieee_sub(1.f, alpha), 1e-10f);                    // :590
       // exclusive cumprod: shift by one (row_shr:1), then scan.  Every lane move is executed by all lanes and selected afterwards: under
       // a branch the lanes switched off would read as zero in their neighbours' moves
       const float xprev = dpp_mov<0x111>(xk);
       float T = s >= 1 ? xprev : 1.f;
-      { const float t = dpp_mov<0x111>(T); T = __fmul_rn(T, s >= 1 ? t : 1.f); }
-      { const float t = dpp_mov<0x112>(T); T = __fmul_rn(T, s >= 2 ? t : 1.f); }
-      { const float t = dpp_mov<0x114>(T); T = __fmul_rn(T, s >= 4 ? t : 1.f); }
-      const float wgt = __fmul_rn(alpha, T);
-      float s0 = sum8_dpp(__fmul_rn(wgt, cr)), s1 = sum8_dpp(__fmul_rn(wgt, cg)), s2 = sum8_dpp(__fmul_rn(wgt, cbv));    // :591 sum over samples
-      const float s3 = sum8_dpp(__fmul_rn(wgt, zc));                                // :593 depth_map
+      { const float t = dpp_mov<0x111>(T); T = ieee_mul(T, s >= 1 ? t : 1.f); }
+      { const float t = dpp_mov<0x112>(T); T = ieee_mul(T, s >= 2 ? t : 1.f); }
+      { const float t = dpp_mov<0x114>(T); T = ieee_mul(T, s >= 4 ? t : 1.f); }
+      const float wgt = ieee_mul(alpha, T);
+      float s0 = sum8_dpp(ieee_mul(wgt, cr)), s1 = sum8_dpp(ieee_mul(wgt, cg)), s2 = sum8_dpp(ieee_mul(wgt, cbv));    // :591 sum over samples
+      const float s3 = sum8_dpp(ieee_mul(wgt, zc));                                // :593 depth_map
       const float sa = a.white_bkgd ? sum8_dpp(wgt) : 0.f;                          // acc_map
       if (a.white_bkgd) {                                                           // refine2.py:519-520
-        const float bg = __fsub_rn(1.f, sa);
-        s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg);
+        const float bg = ieee_sub(1.f, sa);
+        s0 = ieee_add(s0, bg); s1 = ieee_add(s1, bg); s2 = ieee_add(s2, bg);
       }
       if (valid[cb] && g == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(s0, s1, s2, s3);
     });

@@ -55,7 +55,7 @@ __global__ void ray_encode_kernel(const float* __restrict__ rays, const float* _
     const float t = tvals[p];
     float hx, hy, hz, m0, m1, m2;
     unit_dir(r[3], r[4], r[5], hx, hy, hz);
-    const float px = __fadd_rn(r[0], __fmul_rn(r[3], t)), py = __fadd_rn(r[1], __fmul_rn(r[4], t)), pz = __fadd_rn(r[2], __fmul_rn(r[5], t));
+    const float px = ieee_add(r[0], ieee_mul(r[3], t)), py = ieee_add(r[1], ieee_mul(r[4], t)), pz = ieee_add(r[2], ieee_mul(r[5], t));
     cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
     float* q = out + i * 6;        // [ray][p][6] == ray*6*n_pts + p*6
     q[0] = hx; q[1] = hy; q[2] = hz; q[3] = m0; q[4] = m1; q[5] = m2;
@@ -63,8 +63,13 @@ __global__ void ray_encode_kernel(const float* __restrict__ rays, const float* _
 }
 
 // ---------------------------------------------------------------- frame rays (trt.py:245-271; helpers:2705-2714, 2776-2793)
+// The NDC scale factors follow the reference drivers' types: K is a float64 numpy array there (run_S_eS_eN_alter_trt.py:742-747, :798), so
+// -1./(W/(2.*focal)) is evaluated in double and rounded to fp32 once, when it meets the fp32 ray tensor (helpers:2781-2786).
+static inline float ndc_scale(int extent, float focal) { return (float)(-1.0 / ((double)extent / (2.0 * (double)focal))); }
+
 struct FrameArgs {
   float K00, K02, K11, K12;
+  float sx, sy;              // ndc_scale(W, K00), ndc_scale(H, K00)
   float R[9], T[3];
   int H, W;
   float near, far, or_near, or_far;
@@ -75,51 +80,50 @@ __global__ void frame_rays_kernel(FrameArgs a, float* __restrict__ rays, float* 
     const int64_t pix = a.first + q;
     const int j = (int)(pix / a.W), i = (int)(pix - (int64_t)j * a.W);
     // dirs = ((i-cx)/fx, -(j-cy)/fy, -1);  rays_d[c] = sum_k dirs[k]*R[c][k]  (products, then a 3-term sum)
-    const float d0 = __fdiv_rn(__fsub_rn((float)i, a.K02), a.K00);
-    const float d1 = -__fdiv_rn(__fsub_rn((float)j, a.K12), a.K11);
+    const float d0 = ieee_div(ieee_sub((float)i, a.K02), a.K00);
+    const float d1 = -ieee_div(ieee_sub((float)j, a.K12), a.K11);
     const float d2 = -1.f;
     float rd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      rd[c] = __fadd_rn(__fadd_rn(__fmul_rn(d0, a.R[c * 3]), __fmul_rn(d1, a.R[c * 3 + 1])), __fmul_rn(d2, a.R[c * 3 + 2]));
+      rd[c] = ieee_add(ieee_add(ieee_mul(d0, a.R[c * 3]), ieee_mul(d1, a.R[c * 3 + 1])), ieee_mul(d2, a.R[c * 3 + 2]));
     const float ro[3] = {a.T[0], a.T[1], a.T[2]};
-    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rd[0], rd[0]), __fmul_rn(rd[1], rd[1])), __fmul_rn(rd[2], rd[2])));
-    const float v0 = __fdiv_rn(rd[0], nrm), v1 = __fdiv_rn(rd[1], nrm), v2 = __fdiv_rn(rd[2], nrm);
+    const float nrm = ieee_sqrt(ieee_fma(rd[2], rd[2], ieee_fma(rd[1], rd[1], ieee_mul(rd[0], rd[0]))));      // torch.norm: an FMA chain (pnrf_geom.h, unit_dir)
+    const float v0 = ieee_div(rd[0], nrm), v1 = ieee_div(rd[1], nrm), v2 = ieee_div(rd[2], nrm);
     float* orr = or_rays + q * 11;
     orr[0] = ro[0]; orr[1] = ro[1]; orr[2] = ro[2]; orr[3] = rd[0]; orr[4] = rd[1]; orr[5] = rd[2];
     orr[6] = a.or_near; orr[7] = a.or_far; orr[8] = v0; orr[9] = v1; orr[10] = v2;
     // ndc_rays(H, W, focal=K00, near=1.)
     const float nearp = 1.f;
-    const float t = __fdiv_rn(-__fadd_rn(nearp, ro[2]), rd[2]);
-    const float ox = __fadd_rn(ro[0], __fmul_rn(t, rd[0])), oy = __fadd_rn(ro[1], __fmul_rn(t, rd[1])), oz = __fadd_rn(ro[2], __fmul_rn(t, rd[2]));
-    const float sx = __fdiv_rn(-1.f, __fdiv_rn((float)a.W, __fmul_rn(2.f, a.K00)));
-    const float sy = __fdiv_rn(-1.f, __fdiv_rn((float)a.H, __fmul_rn(2.f, a.K00)));
-    const float o0 = __fdiv_rn(__fmul_rn(sx, ox), oz);
-    const float o1 = __fdiv_rn(__fmul_rn(sy, oy), oz);
-    const float o2 = __fadd_rn(1.f, __fdiv_rn(__fmul_rn(2.f, nearp), oz));
-    const float e0 = __fmul_rn(sx, __fsub_rn(__fdiv_rn(rd[0], rd[2]), __fdiv_rn(ox, oz)));
-    const float e1 = __fmul_rn(sy, __fsub_rn(__fdiv_rn(rd[1], rd[2]), __fdiv_rn(oy, oz)));
-    const float e2 = __fdiv_rn(__fmul_rn(-2.f, nearp), oz);
+    const float t = ieee_div(-ieee_add(nearp, ro[2]), rd[2]);
+    const float ox = ieee_add(ro[0], ieee_mul(t, rd[0])), oy = ieee_add(ro[1], ieee_mul(t, rd[1])), oz = ieee_add(ro[2], ieee_mul(t, rd[2]));
+    const float sx = a.sx, sy = a.sy;
+    const float o0 = ieee_div(ieee_mul(sx, ox), oz);
+    const float o1 = ieee_div(ieee_mul(sy, oy), oz);
+    const float roz = ieee_div(1.f, oz);                               // python scalar / tensor is tensor.reciprocal() * scalar in torch
+    const float o2 = ieee_add(1.f, ieee_mul(roz, 2.f * nearp));
+    const float e0 = ieee_mul(sx, ieee_sub(ieee_div(rd[0], rd[2]), ieee_div(ox, oz)));
+    const float e1 = ieee_mul(sy, ieee_sub(ieee_div(rd[1], rd[2]), ieee_div(oy, oz)));
+    const float e2 = ieee_mul(roz, -2.f * nearp);
     float* r = rays + q * 11;
     r[0] = o0; r[1] = o1; r[2] = o2; r[3] = e0; r[4] = e1; r[5] = e2; r[6] = a.near; r[7] = a.far; r[8] = v0; r[9] = v1; r[10] = v2;
   }
 }
 
 // ndc_rays on arbitrary ray sets (helpers:2776-2793)
-__global__ void ndc_rays_kernel(const float* __restrict__ o, const float* __restrict__ d, int H, int W, float focal, float nearp,
+__global__ void ndc_rays_kernel(const float* __restrict__ o, const float* __restrict__ d, float sx, float sy, float nearp, float two_near,
                                 float* __restrict__ oo, float* __restrict__ od, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float r0 = o[i * 3], r1 = o[i * 3 + 1], r2 = o[i * 3 + 2], d0 = d[i * 3], d1 = d[i * 3 + 1], d2 = d[i * 3 + 2];
-    const float t = __fdiv_rn(-__fadd_rn(nearp, r2), d2);
-    const float ox = __fadd_rn(r0, __fmul_rn(t, d0)), oy = __fadd_rn(r1, __fmul_rn(t, d1)), oz = __fadd_rn(r2, __fmul_rn(t, d2));
-    const float sx = __fdiv_rn(-1.f, __fdiv_rn((float)W, __fmul_rn(2.f, focal)));
-    const float sy = __fdiv_rn(-1.f, __fdiv_rn((float)H, __fmul_rn(2.f, focal)));
-    oo[i * 3] = __fdiv_rn(__fmul_rn(sx, ox), oz);
-    oo[i * 3 + 1] = __fdiv_rn(__fmul_rn(sy, oy), oz);
-    oo[i * 3 + 2] = __fadd_rn(1.f, __fdiv_rn(__fmul_rn(2.f, nearp), oz));
-    od[i * 3] = __fmul_rn(sx, __fsub_rn(__fdiv_rn(d0, d2), __fdiv_rn(ox, oz)));
-    od[i * 3 + 1] = __fmul_rn(sy, __fsub_rn(__fdiv_rn(d1, d2), __fdiv_rn(oy, oz)));
-    od[i * 3 + 2] = __fdiv_rn(__fmul_rn(-2.f, nearp), oz);
+    const float t = ieee_div(-ieee_add(nearp, r2), d2);
+    const float ox = ieee_add(r0, ieee_mul(t, d0)), oy = ieee_add(r1, ieee_mul(t, d1)), oz = ieee_add(r2, ieee_mul(t, d2));
+    const float roz = ieee_div(1.f, oz);                               // 2.*near / tensor = tensor.reciprocal() * (2.*near)
+    oo[i * 3] = ieee_div(ieee_mul(sx, ox), oz);
+    oo[i * 3 + 1] = ieee_div(ieee_mul(sy, oy), oz);
+    oo[i * 3 + 2] = ieee_add(1.f, ieee_mul(roz, two_near));
+    od[i * 3] = ieee_mul(sx, ieee_sub(ieee_div(d0, d2), ieee_div(ox, oz)));
+    od[i * 3 + 1] = ieee_mul(sy, ieee_sub(ieee_div(d1, d2), ieee_div(oy, oz)));
+    od[i * 3 + 2] = ieee_mul(roz, -two_near);
   }
 }
 
@@ -136,13 +140,13 @@ __global__ void warp_trt_kernel(const float* __restrict__ img, const float* __re
     const float dep = depth[q];
     float w[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) w[c] = __fadd_rn(ro1[b * ray_bstride + c * n + i], __fmul_rn(rd1[b * ray_bstride + c * n + i], dep));   // :600
+    for (int c = 0; c < 4; ++c) w[c] = ieee_add(ro1[b * ray_bstride + c * n + i], ieee_mul(rd1[b * ray_bstride + c * n + i], dep));   // :600
     const float* M = w2c + b * 12;
     float p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)                                                                     // :601 bmm, K=4
-      p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[r * 4], w[0]), __fmul_rn(M[r * 4 + 1], w[1])), __fmul_rn(M[r * 4 + 2], w[2])), __fmul_rn(M[r * 4 + 3], w[3]));
-    const float X = __fdiv_rn(p[0], p[2]), Y = __fdiv_rn(p[1], p[2]);                               // :603-605
+      p[r] = ieee_add(ieee_add(ieee_add(ieee_mul(M[r * 4], w[0]), ieee_mul(M[r * 4 + 1], w[1])), ieee_mul(M[r * 4 + 2], w[2])), ieee_mul(M[r * 4 + 3], w[3]));
+    const float X = ieee_div(p[0], p[2]), Y = ieee_div(p[1], p[2]);                               // :603-605
     int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
     bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
     const bool okx0 = x0 >= 0 && x0 < Wf, okx1 = x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
@@ -151,10 +155,10 @@ __global__ void warp_trt_kernel(const float* __restrict__ img, const float* __re
     for (int c = 0; c < 3; ++c) {
       const float* pc = im + c * plane;
       float acc = 0.f;
-      if (oky0 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0], __fmul_rn(wx0, wy0)));
-      if (oky0 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0 + 1], __fmul_rn(wx1, wy0)));
-      if (oky1 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0], __fmul_rn(wx0, wy1)));
-      if (oky1 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0 + 1], __fmul_rn(wx1, wy1)));
+      if (oky0 && okx0) acc = ieee_add(acc, ieee_mul(pc[(int64_t)y0 * Wf + x0], ieee_mul(wx0, wy0)));
+      if (oky0 && okx1) acc = ieee_add(acc, ieee_mul(pc[(int64_t)y0 * Wf + x0 + 1], ieee_mul(wx1, wy0)));
+      if (oky1 && okx0) acc = ieee_add(acc, ieee_mul(pc[(int64_t)(y0 + 1) * Wf + x0], ieee_mul(wx0, wy1)));
+      if (oky1 && okx1) acc = ieee_add(acc, ieee_mul(pc[(int64_t)(y0 + 1) * Wf + x0 + 1], ieee_mul(wx1, wy1)));
       out[((int64_t)b * 3 + c) * n + i] = acc;
     }
   }
@@ -198,13 +202,13 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restri
     const float4* im = img4 + (int64_t)k * plane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float z3d = __fdiv_rn(1.f, __fsub_rn(__fsub_rn(1.f, dn8[s]), eps));                 // trt.py:637
-      const float w0 = __fadd_rn(o0, __fmul_rn(e0, z3d)), w1 = __fadd_rn(o1, __fmul_rn(e1, z3d)), w2 = __fadd_rn(o2, __fmul_rn(e2, z3d));   // inverse_warp.py:600
+      const float z3d = ieee_div(1.f, ieee_sub(ieee_sub(1.f, dn8[s]), eps));                 // trt.py:637
+      const float w0 = ieee_add(o0, ieee_mul(e0, z3d)), w1 = ieee_add(o1, ieee_mul(e1, z3d)), w2 = ieee_add(o2, ieee_mul(e2, z3d));   // inverse_warp.py:600
       float p[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
-        p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[r * 4], w0), __fmul_rn(M[r * 4 + 1], w1)), __fmul_rn(M[r * 4 + 2], w2)), M[r * 4 + 3]);
-      const float X = __fdiv_rn(p[0], p[2]), Y = __fdiv_rn(p[1], p[2]);
+        p[r] = ieee_add(ieee_add(ieee_add(ieee_mul(M[r * 4], w0), ieee_mul(M[r * 4 + 1], w1)), ieee_mul(M[r * 4 + 2], w2)), M[r * 4 + 3]);
+      const float X = ieee_div(p[0], p[2]), Y = ieee_div(p[1], p[2]);
       int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
       bilinear_setup(X, Y, Hf, Wf, x0, y0, wx0, wx1, wy0, wy1, fin);
       const bool okx0 = x0 >= 0 && x0 < Wf, okx1 = x0 + 1 >= 0 && x0 + 1 < Wf, oky0 = y0 >= 0 && y0 < Hf, oky1 = y0 + 1 >= 0 && y0 + 1 < Hf;
@@ -213,11 +217,11 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restri
       const float4 t01 = (oky0 && okx1) ? im[(int64_t)y0 * Wf + x0 + 1] : zero;
       const float4 t10 = (oky1 && okx0) ? im[(int64_t)(y0 + 1) * Wf + x0] : zero;
       const float4 t11 = (oky1 && okx1) ? im[(int64_t)(y0 + 1) * Wf + x0 + 1] : zero;
-      const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx1, wy0), a10 = __fmul_rn(wx0, wy1), a11 = __fmul_rn(wx1, wy1);
+      const float a00 = ieee_mul(wx0, wy0), a01 = ieee_mul(wx1, wy0), a10 = ieee_mul(wx0, wy1), a11 = ieee_mul(wx1, wy1);
       const int f = 48 + (k * 8 + s) * 3;                                                        // epi index (k*8+s)*3+c
-      sT[(f + 0) * (RI_TILE + 1) + lane] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.x, a00), __fmul_rn(t01.x, a01)), __fmul_rn(t10.x, a10)), __fmul_rn(t11.x, a11));
-      sT[(f + 1) * (RI_TILE + 1) + lane] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.y, a00), __fmul_rn(t01.y, a01)), __fmul_rn(t10.y, a10)), __fmul_rn(t11.y, a11));
-      sT[(f + 2) * (RI_TILE + 1) + lane] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.z, a00), __fmul_rn(t01.z, a01)), __fmul_rn(t10.z, a10)), __fmul_rn(t11.z, a11));
+      sT[(f + 0) * (RI_TILE + 1) + lane] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.x, a00), ieee_mul(t01.x, a01)), ieee_mul(t10.x, a10)), ieee_mul(t11.x, a11));
+      sT[(f + 1) * (RI_TILE + 1) + lane] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.y, a00), ieee_mul(t01.y, a01)), ieee_mul(t10.y, a10)), ieee_mul(t11.y, a11));
+      sT[(f + 2) * (RI_TILE + 1) + lane] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.z, a00), ieee_mul(t01.z, a01)), ieee_mul(t10.z, a10)), ieee_mul(t11.z, a11));
     }
     {                                                                                            // trt.py:656-658: wave k encodes samples 2k, 2k+1
       const float* r = rays + ray * 11;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restri
         const int s = 2 * k + u;
         const float dn = s < 4 ? (s == 0 ? da.x : s == 1 ? da.y : s == 2 ? da.z : da.w) : (s == 4 ? db.x : s == 5 ? db.y : s == 6 ? db.z : db.w);
         float m0, m1, m2;
-        const float px = __fadd_rn(r[0], __fmul_rn(r[3], dn)), py = __fadd_rn(r[1], __fmul_rn(r[4], dn)), pz = __fadd_rn(r[2], __fmul_rn(r[5], dn));
+        const float px = ieee_add(r[0], ieee_mul(r[3], dn)), py = ieee_add(r[1], ieee_mul(r[4], dn)), pz = ieee_add(r[2], ieee_mul(r[5], dn));
         cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
         float* q = sT + (s * 6) * (RI_TILE + 1) + lane;
         q[0] = hx; q[RI_TILE + 1] = hy; q[2 * (RI_TILE + 1)] = hz; q[3 * (RI_TILE + 1)] = m0; q[4 * (RI_TILE + 1)] = m1; q[5 * (RI_TILE + 1)] = m2;
@@ -252,15 +256,15 @@ __device__ __forceinline__ bool project_train(const float* __restrict__ pose /*3
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float r0 = pose[0 * 4 + i], r1 = pose[1 * 4 + i], r2 = pose[2 * 4 + i];       // row i of R^T = column i of R
-    tt[i] = -__fadd_rn(__fadd_rn(__fmul_rn(r0, pose[3]), __fmul_rn(r1, pose[7])), __fmul_rn(r2, pose[11]));
-    c2[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r0, w0), __fmul_rn(r1, w1)), __fmul_rn(r2, w2)), tt[i]);
+    tt[i] = -ieee_add(ieee_add(ieee_mul(r0, pose[3]), ieee_mul(r1, pose[7])), ieee_mul(r2, pose[11]));
+    c2[i] = ieee_add(ieee_add(ieee_add(ieee_mul(r0, w0), ieee_mul(r1, w1)), ieee_mul(r2, w2)), tt[i]);
   }
-  const float z = __fadd_rn(fabsf(c2[2]), 1e-8f);
-  const float cx = __fdiv_rn(c2[0], z), cy = -__fdiv_rn(c2[1], z);
-  X = __fadd_rn(__fadd_rn(__fmul_rn(K[0], cx), __fmul_rn(K[1], cy)), K[2]);
-  Y = __fadd_rn(__fadd_rn(__fmul_rn(K[3], cx), __fmul_rn(K[4], cy)), K[5]);
-  const float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, X), (float)(Wf - 1)), 1.f);
-  const float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, Y), (float)(Hf - 1)), 1.f);
+  const float z = ieee_add(fabsf(c2[2]), 1e-8f);
+  const float cx = ieee_div(c2[0], z), cy = -ieee_div(c2[1], z);
+  X = ieee_add(ieee_add(ieee_mul(K[0], cx), ieee_mul(K[1], cy)), K[2]);
+  Y = ieee_add(ieee_add(ieee_mul(K[3], cx), ieee_mul(K[4], cy)), K[5]);
+  const float xn = ieee_sub(ieee_div(ieee_mul(2.f, X), (float)(Wf - 1)), 1.f);
+  const float yn = ieee_sub(ieee_div(ieee_mul(2.f, Y), (float)(Hf - 1)), 1.f);
   return xn <= 1.f && xn >= -1.f && yn <= 1.f && yn >= -1.f;
 }
 
@@ -276,8 +280,8 @@ __global__ void warp_train_kernel(const float* __restrict__ img, const float* __
     const float dep = depth[q];
     const float* ro = ro1 + b * ray_bstride;
     const float* rd = rd1 + b * ray_bstride;
-    const float w0 = __fadd_rn(ro[i], __fmul_rn(rd[i], dep)), w1 = __fadd_rn(ro[n + i], __fmul_rn(rd[n + i], dep)),
-                w2 = __fadd_rn(ro[2 * n + i], __fmul_rn(rd[2 * n + i], dep));
+    const float w0 = ieee_add(ro[i], ieee_mul(rd[i], dep)), w1 = ieee_add(ro[n + i], ieee_mul(rd[n + i], dep)),
+                w2 = ieee_add(ro[2 * n + i], ieee_mul(rd[2 * n + i], dep));
     float X, Y;
     const bool inside = project_train(c2w2 + b * 12, Kmat + b * 9, w0, w1, w2, Hf, Wf, X, Y);
     int x0, y0; float wx0, wx1, wy0, wy1; bool fin;
@@ -289,10 +293,10 @@ __global__ void warp_train_kernel(const float* __restrict__ img, const float* __
     for (int c = 0; c < 3; ++c) {
       const float* pc = im + c * plane;
       float acc = 0.f;
-      if (oky0 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0], __fmul_rn(wx0, wy0)));
-      if (oky0 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)y0 * Wf + x0 + 1], __fmul_rn(wx1, wy0)));
-      if (oky1 && okx0) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0], __fmul_rn(wx0, wy1)));
-      if (oky1 && okx1) acc = __fadd_rn(acc, __fmul_rn(pc[(int64_t)(y0 + 1) * Wf + x0 + 1], __fmul_rn(wx1, wy1)));
+      if (oky0 && okx0) acc = ieee_add(acc, ieee_mul(pc[(int64_t)y0 * Wf + x0], ieee_mul(wx0, wy0)));
+      if (oky0 && okx1) acc = ieee_add(acc, ieee_mul(pc[(int64_t)y0 * Wf + x0 + 1], ieee_mul(wx1, wy0)));
+      if (oky1 && okx0) acc = ieee_add(acc, ieee_mul(pc[(int64_t)(y0 + 1) * Wf + x0], ieee_mul(wx0, wy1)));
+      if (oky1 && okx1) acc = ieee_add(acc, ieee_mul(pc[(int64_t)(y0 + 1) * Wf + x0 + 1], ieee_mul(wx1, wy1)));
       out[((int64_t)b * 3 + c) * n + i] = acc;
     }
   }
@@ -318,9 +322,9 @@ __global__ void refine_input_train_kernel(const float* __restrict__ rays, const 
     const int k = t >> 3, s = t & 7;
     const float dn = depth_sorted[ray * 8 + s];
     const float* orr = or_rays + ray * 11;
-    const float z3d = __fdiv_rn(1.f, __fsub_rn(__fsub_rn(1.f, dn), eps));
-    const float w0 = __fadd_rn(orr[0], __fmul_rn(orr[3], z3d)), w1 = __fadd_rn(orr[1], __fmul_rn(orr[4], z3d)),
-                w2 = __fadd_rn(orr[2], __fmul_rn(orr[5], z3d));
+    const float z3d = ieee_div(1.f, ieee_sub(ieee_sub(1.f, dn), eps));
+    const float w0 = ieee_add(orr[0], ieee_mul(orr[3], z3d)), w1 = ieee_add(orr[1], ieee_mul(orr[4], z3d)),
+                w2 = ieee_add(orr[2], ieee_mul(orr[5], z3d));
     int64_t view = ref_nos[ray * 4 + k];
     view = view < 0 ? 0 : (view >= nv ? nv - 1 : view);
     float X, Y;
@@ -335,32 +339,32 @@ __global__ void refine_input_train_kernel(const float* __restrict__ rays, const 
     const float4 t01 = (oky0 && okx1) ? im[(int64_t)y0 * Wf + x0 + 1] : zero;
     const float4 t10 = (oky1 && okx0) ? im[(int64_t)(y0 + 1) * Wf + x0] : zero;
     const float4 t11 = (oky1 && okx1) ? im[(int64_t)(y0 + 1) * Wf + x0 + 1] : zero;
-    const float a00 = __fmul_rn(wx0, wy0), a01 = __fmul_rn(wx1, wy0), a10 = __fmul_rn(wx0, wy1), a11 = __fmul_rn(wx1, wy1);
+    const float a00 = ieee_mul(wx0, wy0), a01 = ieee_mul(wx1, wy0), a10 = ieee_mul(wx0, wy1), a11 = ieee_mul(wx1, wy1);
     float v[3];
-    v[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.x, a00), __fmul_rn(t01.x, a01)), __fmul_rn(t10.x, a10)), __fmul_rn(t11.x, a11));
-    v[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.y, a00), __fmul_rn(t01.y, a01)), __fmul_rn(t10.y, a10)), __fmul_rn(t11.y, a11));
-    v[2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t00.z, a00), __fmul_rn(t01.z, a01)), __fmul_rn(t10.z, a10)), __fmul_rn(t11.z, a11));
+    v[0] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.x, a00), ieee_mul(t01.x, a01)), ieee_mul(t10.x, a10)), ieee_mul(t11.x, a11));
+    v[1] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.y, a00), ieee_mul(t01.y, a01)), ieee_mul(t10.y, a10)), ieee_mul(t11.y, a11));
+    v[2] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.z, a00), ieee_mul(t01.z, a01)), ieee_mul(t10.z, a10)), ieee_mul(t11.z, a11));
     // valid = (sum_c rgb > 0); mean over the valid neighbours of this sample, in k order (refine2.py:622-624)
-    const float valid = (__fadd_rn(__fadd_rn(v[0], v[1]), v[2]) > 0.f) ? 1.f : 0.f;
+    const float valid = (ieee_add(ieee_add(v[0], v[1]), v[2]) > 0.f) ? 1.f : 0.f;
     const int base = (threadIdx.x & 63 & 32) + s;
     float cnt = 0.f, m[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const float vk = __shfl(valid, base + kk * 8);
-      cnt = __fadd_rn(cnt, vk);
+      cnt = ieee_add(cnt, vk);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) m[c] = __fadd_rn(m[c], __fmul_rn(vk, __shfl(v[c], base + kk * 8)));
+      for (int c = 0; c < 3; ++c) m[c] = ieee_add(m[c], ieee_mul(vk, __shfl(v[c], base + kk * 8)));
     }
-    const float den = __fadd_rn(cnt, 1e-6f);
+    const float den = ieee_add(cnt, 1e-6f);
     if (live) {
       float* o = out + ray * 144 + 48 + (layout == 0 ? t * 3 : s * 12 + k * 3);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] = __fadd_rn(__fmul_rn(v[c], valid), __fmul_rn(__fdiv_rn(m[c], den), __fsub_rn(1.f, valid)));
+      for (int c = 0; c < 3; ++c) o[c] = ieee_add(ieee_mul(v[c], valid), ieee_mul(ieee_div(m[c], den), ieee_sub(1.f, valid)));
       if (k == 0) {
         const float* r = rays + ray * 11;
         float hx, hy, hz, m0, m1, m2;
         unit_dir(r[3], r[4], r[5], hx, hy, hz);
-        const float px = __fadd_rn(r[0], __fmul_rn(r[3], dn)), py = __fadd_rn(r[1], __fmul_rn(r[4], dn)), pz = __fadd_rn(r[2], __fmul_rn(r[5], dn));
+        const float px = ieee_add(r[0], ieee_mul(r[3], dn)), py = ieee_add(r[1], ieee_mul(r[4], dn)), pz = ieee_add(r[2], ieee_mul(r[5], dn));
         cross_rn(px, py, pz, hx, hy, hz, m0, m1, m2);
         float* pl = out + ray * 144 + s * 6;
         pl[0] = hx; pl[1] = hy; pl[2] = hz; pl[3] = m0; pl[4] = m1; pl[5] = m2;
@@ -389,10 +393,10 @@ __global__ void explore_kernel(ExploreArgs a, const float* __restrict__ z8, cons
     if (a.n_mult > 1) {
       for (int s = 0; s < 8; ++s) {
         const float nb = a.dir1 > 0 ? (s < 7 ? z[s + 1] : far) : (s > 0 ? z[s - 1] : near);
-        const float diff = fabsf(__fsub_rn(z[s], nb));
+        const float diff = fabsf(ieee_sub(z[s], nb));
         for (int j = 0; j < a.n_mult; ++j) {
           const float m = a.dir1 > 0 ? a.mults[j] : -a.mults[j];
-          zz[s * a.n_mult + j] = __fadd_rn(z[s], __fmul_rn(m, diff));
+          zz[s * a.n_mult + j] = ieee_add(z[s], ieee_mul(m, diff));
         }
       }
       for (int u = 1; u < S; ++u) {               // insertion sort (ascending), S <= 256
@@ -409,11 +413,11 @@ __global__ void explore_kernel(ExploreArgs a, const float* __restrict__ z8, cons
       const float cur = zz[u];
       const float nb = a.dir2 > 0 ? (u + 1 < S ? zz[u + 1] : far) : prev;
       const float jv = jitter[i * S + u];
-      const float zo = __fadd_rn(cur, __fmul_rn(a.dir2 > 0 ? jv : -jv, fabsf(__fsub_rn(cur, nb))));
+      const float zo = ieee_add(cur, ieee_mul(a.dir2 > 0 ? jv : -jv, fabsf(ieee_sub(cur, nb))));
       prev = cur;
       z_out[i * S + u] = zo;
       float* p = pts_out + (i * S + u) * 3;
-      p[0] = __fadd_rn(r[0], __fmul_rn(r[3], zo)); p[1] = __fadd_rn(r[1], __fmul_rn(r[4], zo)); p[2] = __fadd_rn(r[2], __fmul_rn(r[5], zo));
+      p[0] = ieee_add(r[0], ieee_mul(r[3], zo)); p[1] = ieee_add(r[1], ieee_mul(r[4], zo)); p[2] = ieee_add(r[2], ieee_mul(r[5], zo));
     }
   }
 }
@@ -425,7 +429,7 @@ __global__ void composite_kernel(const float* __restrict__ raw, const float* __r
                                  float* __restrict__ weights, float* __restrict__ depth, int64_t n, int S) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float* d = rays_d + i * d_stride;
-    const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float dn = ieee_sqrt(ieee_add(ieee_add(ieee_mul(d[0], d[0]), ieee_mul(d[1], d[1])), ieee_mul(d[2], d[2])));
     float T = 1.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, sd = 0.f, sa = 0.f;
     for (int s = 0; s < S; ++s) {
       const int64_t e = i * S + s;
@@ -435,28 +439,28 @@ __global__ void composite_kernel(const float* __restrict__ raw, const float* __r
         r2 = fminf(fmaxf(r2, -clampv), clampv); r3 = fminf(fmaxf(r3, -clampv), clampv);
       }
       const float zc = z[e];
-      float dist = (s + 1 < S) ? __fsub_rn(z[e + 1], zc) : 1e10f;
-      dist = __fmul_rn(dist, dn);
+      float dist = (s + 1 < S) ? ieee_sub(z[e + 1], zc) : 1e10f;
+      dist = ieee_mul(dist, dn);
       float sg = r3;
-      if (noise) sg = __fadd_rn(sg, noise[e]);
-      if (add) sg = __fadd_rn(sg, add[e]);
+      if (noise) sg = ieee_add(sg, noise[e]);
+      if (add) sg = ieee_add(sg, add[e]);
       sg = fmaxf(sg, 0.f);
-      float alpha = __fsub_rn(1.f, expf(__fmul_rn(-sg, dist)));
-      if (mul) alpha = __fmul_rn(alpha, fmaxf(mul[e], 0.f));
-      const float w = __fmul_rn(alpha, T);
-      T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
-      s0 = __fadd_rn(s0, __fmul_rn(w, sigmoid_f(r0)));
-      s1 = __fadd_rn(s1, __fmul_rn(w, sigmoid_f(r1)));
-      s2 = __fadd_rn(s2, __fmul_rn(w, sigmoid_f(r2)));
-      sd = __fadd_rn(sd, __fmul_rn(w, zc));
-      sa = __fadd_rn(sa, w);
+      float alpha = ieee_sub(1.f, expf(ieee_mul(-sg, dist)));
+      if (mul) alpha = ieee_mul(alpha, fmaxf(mul[e], 0.f));
+      const float w = ieee_mul(alpha, T);
+      T = ieee_mul(T, ieee_add(ieee_sub(1.f, alpha), 1e-10f));
+      s0 = ieee_add(s0, ieee_mul(w, sigmoid_f(r0)));
+      s1 = ieee_add(s1, ieee_mul(w, sigmoid_f(r1)));
+      s2 = ieee_add(s2, ieee_mul(w, sigmoid_f(r2)));
+      sd = ieee_add(sd, ieee_mul(w, zc));
+      sa = ieee_add(sa, w);
       if (weights) weights[e] = w;
     }
-    if (white_bkgd) { const float bg = __fsub_rn(1.f, sa); s0 = __fadd_rn(s0, bg); s1 = __fadd_rn(s1, bg); s2 = __fadd_rn(s2, bg); }
+    if (white_bkgd) { const float bg = ieee_sub(1.f, sa); s0 = ieee_add(s0, bg); s1 = ieee_add(s1, bg); s2 = ieee_add(s2, bg); }
     if (rgb) { rgb[i * 3] = s0; rgb[i * 3 + 1] = s1; rgb[i * 3 + 2] = s2; }
     if (depth) depth[i] = sd;
     if (acc_out) acc_out[i] = sa;
-    if (disp) disp[i] = __fdiv_rn(1.f, fmaxf(1e-10f, __fdiv_rn(sd, sa)));
+    if (disp) disp[i] = ieee_div(1.f, fmaxf(1e-10f, ieee_div(sd, sa)));
   }
 }
 
@@ -518,6 +522,7 @@ extern "C" int pnrf_frame_rays_fwd(const float* K, const float* c2w, int H, int 
   PNRF_REQUIRE(rays && or_rays, PNRF_E_ARG, "pnrf_frame_rays_fwd: null output");
   FrameArgs a;
   a.K00 = K[0]; a.K02 = K[2]; a.K11 = K[4]; a.K12 = K[5];
+  a.sx = ndc_scale(W, K[0]); a.sy = ndc_scale(H, K[0]);
   for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) a.R[r * 3 + c] = c2w[r * 4 + c]; a.T[r] = c2w[r * 4 + 3]; }
   a.H = H; a.W = W; a.near = near; a.far = far; a.or_near = or_near; a.or_far = or_far; a.first = first; a.count = count;
   hipLaunchKernelGGL(frame_rays_kernel, dim3(grid_for(count)), dim3(TPB), 0, (hipStream_t)stream, a, rays, or_rays);
@@ -530,7 +535,8 @@ extern "C" int pnrf_ndc_rays_fwd(const float* rays_o, const float* rays_d, int H
   PNRF_REQUIRE(n >= 0 && H > 0 && W > 0, PNRF_E_ARG, "pnrf_ndc_rays_fwd: bad sizes");
   if (n == 0) return 0;
   PNRF_REQUIRE(rays_o && rays_d && out_o && out_d, PNRF_E_ARG, "pnrf_ndc_rays_fwd: null pointer");
-  hipLaunchKernelGGL(ndc_rays_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, rays_o, rays_d, H, W, focal, near, out_o, out_d, n);
+  hipLaunchKernelGGL(ndc_rays_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, rays_o, rays_d, ndc_scale(W, focal), ndc_scale(H, focal), near,
+                     (float)(2.0 * (double)near), out_o, out_d, n);
   PNRF_LAUNCH_CHECK();
   return 0;
 }

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "pnrf_common.h"
+#include "pnrf_ieee.h"
 
 using namespace pnrf;
 
@@ -667,11 +668,11 @@ __global__ void sampler_head_fwd_kernel(const float* __restrict__ y, const float
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float* yr = y + i * 27;
     const float near = rays[i * 11 + 6], far = rays[i * 11 + 7];
-    const float span = __fsub_rn(far, near);
+    const float span = ieee_sub(far, near);
     float dep[8];
     int idx[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { dep[s] = __fadd_rn(__fmul_rn(sigmoid_f(yr[s]), span), near); idx[s] = s; }
+    for (int s = 0; s < 8; ++s) { dep[s] = ieee_add(ieee_mul(sigmoid_f(yr[s]), span), near); idx[s] = s; }
     // insertion sort on (value, index): stable, 8 elements
 #pragma unroll
     for (int a = 1; a < 8; ++a) {
@@ -747,9 +748,9 @@ __global__ void refine_head_fwd_kernel(const float* __restrict__ y, const float*
     for (int s = 0; s < 8; ++s) D[s] = depth_sorted[i * 8 + s];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float lower = s == 0 ? __fmul_rn(0.5f, __fadd_rn(near, D[0])) : __fmul_rn(0.5f, __fadd_rn(D[s], D[s - 1]));
-      const float upper = s == 7 ? __fmul_rn(0.5f, __fadd_rn(far, D[7])) : __fmul_rn(0.5f, __fadd_rn(D[s + 1], D[s]));
-      zz[s] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), sigmoid_f(yr[s])));
+      const float lower = s == 0 ? ieee_mul(0.5f, ieee_add(near, D[0])) : ieee_mul(0.5f, ieee_add(D[s], D[s - 1]));
+      const float upper = s == 7 ? ieee_mul(0.5f, ieee_add(far, D[7])) : ieee_mul(0.5f, ieee_add(D[s + 1], D[s]));
+      zz[s] = ieee_add(lower, ieee_mul(ieee_sub(upper, lower), sigmoid_f(yr[s])));
       z_pre[i * 8 + s] = zz[s];
     }
     if (jitter) {
@@ -757,8 +758,8 @@ __global__ void refine_head_fwd_kernel(const float* __restrict__ y, const float*
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const float j = jitter[i * 8 + s];
-        if (jitter_dir > 0) zn[s] = __fadd_rn(zz[s], __fmul_rn(j, fabsf(__fsub_rn(zz[s], s < 7 ? zz[s < 7 ? s + 1 : 7] : far))));
-        else zn[s] = __fsub_rn(zz[s], __fmul_rn(j, fabsf(__fsub_rn(zz[s], s > 0 ? zz[s > 0 ? s - 1 : 0] : near))));
+        if (jitter_dir > 0) zn[s] = ieee_add(zz[s], ieee_mul(j, fabsf(ieee_sub(zz[s], s < 7 ? zz[s < 7 ? s + 1 : 7] : far))));
+        else zn[s] = ieee_sub(zz[s], ieee_mul(j, fabsf(ieee_sub(zz[s], s > 0 ? zz[s > 0 ? s - 1 : 0] : near))));
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s) zz[s] = zn[s];
@@ -768,7 +769,7 @@ __global__ void refine_head_fwd_kernel(const float* __restrict__ y, const float*
       z[i * 8 + s] = zz[s];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        pts[(i * 8 + s) * 3 + c] = __fadd_rn(__fadd_rn(r[c], __fmul_rn(r[3 + c], zz[s])), __fmul_rn(1e-2f, tanhf(yr[8 + 3 * s + c])));
+        pts[(i * 8 + s) * 3 + c] = ieee_add(ieee_add(r[c], ieee_mul(r[3 + c], zz[s])), ieee_mul(1e-2f, tanhf(yr[8 + 3 * s + c])));
     }
     if (rgb0) {
 #pragma unroll

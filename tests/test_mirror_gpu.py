@@ -72,9 +72,9 @@ def test_module_forwards_and_operators(dev, golden_dir):
     np.testing.assert_allclose(emb(torch.from_numpy(g['pe_x']).to(dev)).cpu().numpy(), g['pe10'], rtol=0, atol=2e-6)
     np.testing.assert_allclose(h.Pluecker()(torch.from_numpy(g['pl_o']).to(dev), torch.from_numpy(g['pl_d']).to(dev)).cpu().numpy(), g['pl'], rtol=0, atol=1e-6)
     ro, rd_ = h.get_rays(9, 13, torch.from_numpy(g['gr_K']), torch.from_numpy(g['gr_c2w']).to(dev))
-    np.testing.assert_allclose(rd_.cpu().numpy(), g['gr_d'], atol=1e-6)
+    np.testing.assert_array_equal(rd_.cpu().numpy(), g['gr_d'])
     no, nd = h.ndc_rays(9, 13, float(g['gr_K'][0, 0]), 1., ro, rd_)
-    np.testing.assert_allclose(no.cpu().numpy(), g['ndc_o'], atol=2e-6); np.testing.assert_allclose(nd.cpu().numpy(), g['ndc_d'], atol=2e-6)
+    np.testing.assert_array_equal(no.cpu().numpy(), g['ndc_o']); np.testing.assert_array_equal(nd.cpu().numpy(), g['ndc_d'])
     B, n = g['wp_depth'].shape[0], g['wp_depth'].shape[2]
     ro1 = torch.from_numpy(g['wp_ro1']).to(dev)[None].expand(B, -1, -1); rd1 = torch.from_numpy(g['wp_rd1']).to(dev)[None].expand(B, -1, -1)
     warped, none = iw.inverse_warp_rod1_rt2_coords_trt(torch.from_numpy(g['wp_img']).to(dev), torch.from_numpy(g['wp_depth']).to(dev),

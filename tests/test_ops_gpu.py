@@ -51,11 +51,12 @@ def test_operator_goldens(dev, golden_dir):
     from pronerf_amd import ops
     g = dict(np.load(os.path.join(golden_dir, 'operators.npz')))
     np.testing.assert_allclose(ops.posenc(cu(g['pe_x'], dev), 10).cpu().numpy(), g['pe10'], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(ops.plucker(cu(g['pl_o'], dev), cu(g['pl_d'], dev)).cpu().numpy(), g['pl'], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(ops.plucker(cu(g['pl_o'], dev), cu(g['pl_d'], dev)).cpu().numpy(), g['pl'])
+    # ray set-up: bit for bit what torch computes on the CPU (same operation order, IEEE divisions and square root, torch.norm's FMA chain)
     rays, orr = ops.frame_rays(g['gr_K'], g['gr_c2w'], 9, 13, device=dev)
-    np.testing.assert_allclose(orr[:, 3:6].cpu().numpy().reshape(9, 13, 3), g['gr_d'], atol=1e-6)
-    np.testing.assert_allclose(rays[:, 0:3].cpu().numpy().reshape(9, 13, 3), g['ndc_o'], atol=2e-6)
-    np.testing.assert_allclose(rays[:, 3:6].cpu().numpy().reshape(9, 13, 3), g['ndc_d'], atol=2e-6)
+    np.testing.assert_array_equal(orr[:, 3:6].cpu().numpy().reshape(9, 13, 3), g['gr_d'])
+    np.testing.assert_array_equal(rays[:, 0:3].cpu().numpy().reshape(9, 13, 3), g['ndc_o'])
+    np.testing.assert_array_equal(rays[:, 3:6].cpu().numpy().reshape(9, 13, 3), g['ndc_d'])
     out = ops.warp_trt(cu(g['wp_img'], dev), cu(g['wp_depth'][:, 0, :], dev), cu(g['wp_ro1'], dev), cu(g['wp_rd1'], dev), cu(g['wp_w2c'], dev))
     np.testing.assert_allclose(out.cpu().numpy(), g['wp_out'][:, :, 0, :], rtol=0, atol=1e-5)
     r = ops.composite(cu(g['c_raw'], dev), cu(g['c_z'], dev), cu(g['c_d'], dev), cu(g['c_add'], dev), cu(g['c_mul'], dev))
@@ -69,12 +70,12 @@ def test_frame_rays_and_ray_encode(dev, H, W, rot):
     scene = synth.make_scene(3, H=H, W=W, rotate=rot)
     fr = orc.frame_setup(scene)
     rays, orr = ops.frame_rays(scene['K'], scene['c2w'], H, W, device=dev)
-    np.testing.assert_allclose(rays.cpu().numpy(), fr['rays'].numpy(), rtol=0, atol=2e-6)
-    np.testing.assert_allclose(orr.cpu().numpy(), fr['or_rays'].numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(rays.cpu().numpy(), fr['rays'].numpy())                     # 0 ulp: origins, directions, NDC, view directions
+    np.testing.assert_array_equal(orr.cpu().numpy(), fr['or_rays'].numpy())
     sub, _ = ops.frame_rays(scene['K'], scene['c2w'], H, W, first=37, count=101, device=dev)    # ray-range sharding
     np.testing.assert_array_equal(sub.cpu().numpy(), rays[37:138].cpu().numpy())
     mm = ops.ray_encode(cu(fr['rays'], dev), 48).cpu()
-    np.testing.assert_allclose(mm.numpy(), fr['mm_input'].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(mm.numpy(), fr['mm_input'].numpy())
 
 
 def test_composite_variants(dev):

@@ -44,7 +44,7 @@ def test_render_rays_vs_golden(dev, golden_dir, name):
     np.testing.assert_array_equal(ref_nos, g['ref_nos'])
     np.testing.assert_allclose(rend.proj.cpu().numpy(), g['proj'], rtol=1e-6, atol=1e-5)
     rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
-    np.testing.assert_allclose(rays.cpu().numpy(), g['rays'], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(rays.cpu().numpy(), g['rays'])                               # the reference's own rays, bit for bit
     rgbd, idx = rend.render_rays(rays, or_rays, want_idx=True)
     rgbd = rgbd.cpu(); idx = idx.cpu().numpy()
     tie_free = np.diff(g['depth_sorted'], axis=1).min(axis=1) > 1e-6
@@ -69,7 +69,7 @@ def test_render_rays_fern_geometry_subset(dev, golden_dir):
     rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], 756, 1008)
     sel = torch.from_numpy(g['sel']).to(dev)
-    np.testing.assert_allclose(rays[sel].cpu().numpy(), g['rays'], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(rays[sel].cpu().numpy(), g['rays'])
     rgbd, idx = rend.render_rays(rays[sel].contiguous(), or_rays[sel].contiguous(), want_idx=True)
     np.testing.assert_array_equal(idx.cpu().numpy(), g['sort_idx'])
     assert orc.psnr(rgbd[:, :3].cpu(), torch.from_numpy(g['rgb'])) > 46.4
