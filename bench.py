@@ -486,7 +486,7 @@ def main():
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'ms_per_frame': ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'bf16 (refine+NeRF MLP, fp32 accumulate) + ' + ('f32 (sampler MLP, exact f32 MFMA)' if sampler_f32 else
+            'dtype': 'f16 (refine+NeRF MLP operands, 11 significand bits >= the bf16 of configs[1]; fp32 accumulate) + ' + ('f32 (sampler MLP, exact f32 MFMA)' if sampler_f32 else
                                                                   'f16 | f16x2 (sampler MLP: plain fp16 pass for every ray, split fp16 hi+lo operands = fp32-grade for '
                                                                   'the rays whose depth order that pass cannot decide; fp32 accumulate)'),
             'data': 'synthetic',
@@ -496,7 +496,7 @@ def main():
             'launcher': ('self (bench.py started its own ranks)' if os.environ.get('PNRF_BENCH_CHILD') else
                          'torch.distributed.run' if world > 1 else None),
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, 48 ray-encoding points, '
-                                   'bf16 MLP; one pnrf_render_rays_fwd call renders the whole frame, as the reference does (the 1024-ray chunks of '
+                                   'fp16 MLPs (bf16 timed beside it: variants.bf16); one pnrf_render_rays_fwd call renders the whole frame, as the reference does (the 1024-ray chunks of '
                                    'configs[1] = 4 of the 256-column workgroup batches each persistent kernel walks inside its single launch; '
                                    'the frame as 745 separate 1024-ray calls is timed beside it: chunked_1024)',
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0], 'rays_per_rank': counts,
@@ -520,7 +520,7 @@ def main():
             dom = max(flops, key=lambda k: prof[k])
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
             symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_p1_kernel + sampler_h16_kernel', 'refine_kernel': 'refine_kernel<1, 8, 1, 1>',
-                       'nerf_kernel': 'nerf16_kernel<false, 2>'}
+                       'nerf_kernel': 'nerf16_kernel<false, 2, PrecF16>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
             res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
@@ -538,28 +538,33 @@ def main():
             one_call = outs[0][:count].clone()
             if not args.no_chunked:
                 res['chunked_1024'] = dict(chunked_1024(rend, rays, or_rays, one_call), one_call_ms_per_frame=ms)
+            var_rgb = {}
             if not args.no_variants:
                 from pronerf_amd.workloads import timed_ms
-                r2 = Renderer(weights, max_rays=count, device=dev, variants={'sampler': 'sampler_split'})
-                r2.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
-                o2 = torch.empty_like(one_call)
-                vms = timed_ms(lambda: r2.render_rays(rays, or_rays, out=o2), 20, 5)[0]
-                dm = float(((o2[:, :3].double() - one_call[:, :3].double()) ** 2).mean())
-                res['variants'] = {'sampler_split': {'ms_per_frame': vms, 'rays_per_s': n_total / vms * 1e3,
-                                                     'what': 'split-fp16 sampler kernel for every ray (PNRF_VARIANT_SAMPLER_SPLIT, the round-2 default)',
-                                                     'rgb_psnr_vs_default_db': (10.0 * float(np.log10(1.0 / dm))) if dm > 0 else float('inf')}}
-                split_rgb = o2[:, :3].clone()
-                del r2, o2
+                res['variants'] = {}
+                for vname, vset, what in (
+                        ('sampler_split', {'sampler': 'sampler_split'}, 'split-fp16 sampler kernel for every ray (PNRF_VARIANT_SAMPLER_SPLIT, the round-2 sampler)'),
+                        ('bf16', {'refine': 'bf16', 'nerf': 'bf16'}, 'refine + NeRF MLPs on bf16 operands (PNRF_VARIANT_BF16: the literal "bf16 MLP" of configs[1])'),
+                        ('round2', {'sampler': 'sampler_split', 'refine': 'bf16', 'nerf': 'bf16'}, 'both: the kernels of the round-2 default')):
+                    r2 = Renderer(weights, max_rays=count, device=dev, variants=vset)
+                    r2.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+                    o2 = torch.empty_like(one_call)
+                    vms = timed_ms(lambda: r2.render_rays(rays, or_rays, out=o2), 20, 5)[0]
+                    dm = float(((o2[:, :3].double() - one_call[:, :3].double()) ** 2).mean())
+                    res['variants'][vname] = {'ms_per_frame': vms, 'rays_per_s': n_total / vms * 1e3, 'what': what,
+                                              'rgb_psnr_vs_default_db': (10.0 * float(np.log10(1.0 / dm))) if dm > 0 else float('inf')}
+                    var_rgb[vname] = o2[:, :3].clone()
+                    del r2, o2
             if not args.no_gpu_eager_baseline:
                 last = outs[0][:count, :3].clone() if not pipeline else None
                 eager, eager_rgb = gpu_eager_baseline(weights, scene, dev, args.eager_reps)
                 if last is not None:             # the two paths rendered the same frame: error of the HIP path against the eager fp32 graph
                     mse = float(((last.double() - eager_rgb.double()) ** 2).mean())
                     eager['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse))) if mse > 0 else float('inf')
-                    if not args.no_variants:
-                        mse2 = float(((split_rgb.double() - eager_rgb.double()) ** 2).mean())
-                        res['variants']['sampler_split']['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse2))) if mse2 > 0 else float('inf')
-                del eager_rgb
+                    for vname, vr in var_rgb.items():
+                        mse2 = float(((vr.double() - eager_rgb.double()) ** 2).mean())
+                        res['variants'][vname]['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse2))) if mse2 > 0 else float('inf')
+                del eager_rgb, var_rgb
                 res['gpu_eager_baseline'] = eager
                 res['vs_baseline'] = value / eager['value']
                 res['vs_baseline_kind'] = ('value / gpu_eager_baseline.value, measured in this run (BASELINE.md §4 item 2: the denominator of the >= 10x '

@@ -71,13 +71,17 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 
 /* Kernel variant of a packed network.  PNRF_VARIANT_DEFAULT is what pack / deserialize produce and what every product path runs:
  * sampler with the folded first layer in split fp16 (fp32-grade, three v_mfma_f32_16x16x32_f16 per product) — through pnrf_sampler_fwd_ws /
- * pnrf_render_rays_fwd as the second of two passes, see there —, refine stage on v_mfma_f32_32x32x16_bf16, NeRF stage on
- * v_mfma_f32_16x16x32_bf16.  The others exist for parity tests and A/B timing (tools/perf_ab.py):
+ * pnrf_render_rays_fwd as the second of two passes, see there —, refine stage on v_mfma_f32_32x32x16_f16, NeRF stage on
+ * v_mfma_f32_16x16x32_f16: fp16 operands (11 significand bits, like the FP16 TensorRT engines of the reference's own fast path,
+ * trt_infer_v2.py), fp32 accumulation; packed activations saturate at 65 504 instead of overflowing.  The others exist for parity
+ * tests and A/B timing (tools/perf_ab.py):
  *   SAMPLER_F32       sampler on the exact fp32 FMA chain (v_mfma_f32_16x16x4_f32), folded first layer;
  *   SAMPLER_F32_FULL  ... with the full K = 288 first layer on the 48 Pluecker points (no fold);
  *   SAMPLER_SPLIT     the split-fp16 kernel for every ray, also where a workspace is given (single pass: the default of round 2);
+ *   BF16              refine / NeRF handles: the default engines on bf16 operands (8 significand bits; the round-2 default, what
+ *                     BASELINE.json configs[1] words as "bf16 MLP") — same MFMA cycles, same streams in the other type;
  *   BF16_32X32        NeRF handles: the v_mfma_f32_32x32x16_bf16 engine (the refine net has one engine);
- *   NERF_4X64         NeRF handles: 4 waves of 64 columns per workgroup (one wave per SIMD) instead of 8 waves of 32 — same arithmetic,
+ *   NERF_4X64         NeRF handles: bf16, 4 waves of 64 columns per workgroup (one wave per SIMD) instead of 8 waves of 32 — same arithmetic,
  *                     same packed stream, every weight fragment read from LDS feeds four MFMAs instead of two.
  * A variant is part of a handle's configuration, like its weights: set it right after pack / deserialize, before the handle is given to
  * a context or a stream (the call is not synchronised against launches that use the handle).  Nothing in the library reads the process
@@ -88,6 +92,7 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 #define PNRF_VARIANT_BF16_32X32 3
 #define PNRF_VARIANT_NERF_4X64 4
 #define PNRF_VARIANT_SAMPLER_SPLIT 5
+#define PNRF_VARIANT_BF16 6
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear

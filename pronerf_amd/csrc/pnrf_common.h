@@ -69,6 +69,8 @@ struct pnrf_mlp {
   int nbias_p1;
   float* d_p1c;          // ... and the constants of the per-ray error model (pnrf_layout.h: P1_NCONST)
   int n_p1c;
+  void* d_blob_f16;      // refine / NeRF handles: the stream of the default engine with fp16 operands (refine: as d_blob; NeRF: as d_blob_b16)
+  uint32_t nslots_f16;
   float* d_tvals;        // sampler only: t = torch.linspace(0,1,48) of the ray points (trt.py:556-557)
   int device;
   int variant;           // PNRF_VARIANT_* (pnrf_mlp_set_variant); 0 = default kernels

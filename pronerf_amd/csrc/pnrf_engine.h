@@ -475,15 +475,18 @@ __host__ __device__ constexpr int hidden_feat_h16(int ks, int g, int j) { return
 #define PNRF_B16_ATSTEP 2
 #endif
 // NCB: 16-column blocks per wave fed by every weight fragment (2 with 8 waves per workgroup, 4 with 4 waves: half the LDS fragment reads per MFMA)
-template <int KS, int NTP, int POS0, int NCB = 2, class ST, class BFn, class Epi1, class Pre1>
+// VT = bf16x8 (v_mfma_f32_16x16x32_bf16) or f16x8 (v_mfma_f32_16x16x32_f16: same cycles, 11 significand bits instead of 8)
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <int KS, int NTP, int POS0, int NCB = 2, class VT = bf16x8, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][NCB]) {
   constexpr int NF = NTP * KS * 2;
   constexpr int AHEAD = NF < PNRF_B16_AHEAD ? NF : PNRF_B16_AHEAD;
   auto frag_ptr = [&](int g) {
-    return (const bf16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+    return (const VT*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
   f32x4 pend[2][NCB];
-  bf16x8 aq[AHEAD];
+  VT aq[AHEAD];
   f32x4 nbias[2] = {*(const f32x4*)biaslane, *(const f32x4*)(biaslane + 16)};
 #pragma unroll
   for (int tp = 0; tp < NTP; ++tp) {
@@ -507,10 +510,10 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
           for (int u = 0; u < AHEAD; ++u)
             if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
         }
-        const bf16x8 a = aq[f % AHEAD];
+        const VT a = aq[f % AHEAD];
         if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bf(cb, ks), acc[t][cb], 0, 0, 0);
+        for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = mfma_16x16x32(a, Bf(cb, ks), acc[t][cb]);
         st.slot_issue(f % SLOT_FRAGS);
       }
       // deferred epilogue of the previous pair in NCB pieces (tile pc, column blocks [cb0, cb0 + 2)): with one wave per SIMD (NCB = 4) nothing

@@ -69,6 +69,43 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
   return r;
 }
 
+__device__ __forceinline__ f16x8 pack_f16(const float (&v)[8]) {
+  f16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (_Float16)v[j];
+  return r;
+}
+// Operand type of the refine / NeRF stages.  The MFMA cycles are the same; fp16 keeps 11 significand bits where bf16 keeps 8 (the reference's
+// own fast path runs FP16 TensorRT engines, trt_infer_v2.py).  fp16 has a finite range: a packed activation above 65 504 would be +inf and
+// NaN one layer on.  The fp16 kernels therefore run with MODE.FP16_OVFL = 1 (set once per wave at kernel entry): an fp32 -> fp16 conversion
+// that overflows then returns +-65 504 instead of +-inf, at no cost per activation (tools/fp16_ovfl_probe.hip: 1e6 -> 0x7bff, -1e6 -> 0xfbff
+// on gfx950; tests/test_ops_gpu.py::test_fp16_operands_precision_and_saturation).
+struct PrecBf16 {
+  using v8 = bf16x8;
+  static __device__ __forceinline__ void enter() {}
+  static __device__ __forceinline__ v8 pack(const float (&v)[8]) { return pack_bf16(v); }
+  static __device__ __forceinline__ int cvt_pk(float a, float b) {
+    int pk;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+    return pk;
+  }
+};
+struct PrecF16 {
+  using v8 = f16x8;
+  static __device__ __forceinline__ void enter() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }      // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
+  static __device__ __forceinline__ v8 pack(const float (&v)[8]) {
+    i32x4_t w;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w[d] = cvt_pk(v[2 * d], v[2 * d + 1]);
+    return __builtin_bit_cast(v8, w);
+  }
+  static __device__ __forceinline__ int cvt_pk(float a, float b) {      // volatile: must not move in front of enter()
+    int pk;
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+    return pk;
+  }
+};
+
 // Pluecker moment of point p=o+t*d with unit direction hd, arithmetic un-fused like the
 // reference's separate torch ops (trt.py:559-560 mul,add; helpers:630-631 cross).
 __device__ __forceinline__ void moment(float ox, float oy, float oz, float dx, float dy, float dz, float t,
@@ -653,9 +690,9 @@ __device__ __forceinline__ int cvt_pk_bf16(float a, float b) {      // one v_cvt
   return pk;
 }
 // PIECES = 2: piece pc = registers 8pc..8pc+7 = one whole B fragment; PIECES = 8: registers 2pc, 2pc+1 = one dword of a fragment; PIECES = 16: register pc.
-template <int NCB, int ACT, int PIECES = 2>
+template <int NCB, int ACT, int PIECES = 2, class P = PrecBf16>
 struct HiddenEpi {
-  bf16x8 (&Bn)[NCB][KS_HID];
+  typename P::v8 (&Bn)[NCB][KS_HID];
   __device__ __forceinline__ void operator()(int to, int pc, f32x16 (&acc)[NCB]) const {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -663,23 +700,23 @@ struct HiddenEpi {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act_fast(acc[cb][8 * pc + j], ACT);
-        Bn[cb][2 * to + pc] = pack_bf16(v);
+        Bn[cb][2 * to + pc] = P::pack(v);
       } else if constexpr (PIECES == 16) {      // one activation per piece: the even one waits, activated, in its accumulator register
         acc[cb][pc] = act_fast(acc[cb][pc], ACT);
         if (pc & 1) {
-          bf16x8& frag = Bn[cb][2 * to + pc / 8];
+          typename P::v8& frag = Bn[cb][2 * to + pc / 8];
           i32x4_t w = __builtin_bit_cast(i32x4_t, frag);
-          w[(pc % 8) / 2] = cvt_pk_bf16(acc[cb][pc - 1], acc[cb][pc]);
-          frag = __builtin_bit_cast(bf16x8, w);
+          w[(pc % 8) / 2] = P::cvt_pk(acc[cb][pc - 1], acc[cb][pc]);
+          frag = __builtin_bit_cast(typename P::v8, w);
         }
       } else {
         constexpr int E = 16 / PIECES;
-        bf16x8& frag = Bn[cb][2 * to + (E * pc) / 8];
+        typename P::v8& frag = Bn[cb][2 * to + (E * pc) / 8];
         i32x4_t w = __builtin_bit_cast(i32x4_t, frag);
 #pragma unroll
         for (int d = 0; d < E / 2; ++d)
-          w[((E * pc) % 8) / 2 + d] = cvt_pk_bf16(act_fast(acc[cb][E * pc + 2 * d], ACT), act_fast(acc[cb][E * pc + 2 * d + 1], ACT));
-        frag = __builtin_bit_cast(bf16x8, w);
+          w[((E * pc) % 8) / 2 + d] = P::cvt_pk(act_fast(acc[cb][E * pc + 2 * d], ACT), act_fast(acc[cb][E * pc + 2 * d + 1], ACT));
+        frag = __builtin_bit_cast(typename P::v8, w);
       }
     }
   }
@@ -700,11 +737,14 @@ struct RefineArgs {
 // HEAD 0: the 144 inputs of a ray come from refine_in [n,144] in memory; 1: they are produced in the batch head — neighbour projection +
 // bilinear colour fetch + sample Pluecker (run_S_eS_eN_alter_trt.py:637-661), each lane for its own two views and four samples
 // (refine_in0): no [n,144] round trip through HBM, one kernel launch less per frame.
-template <int NCB, int NW, int MODE, int HEAD = 0>
+template <int NCB, int NW, int MODE, int HEAD = 0, class P = PrecBf16>
 __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(RefineArgs a) {
   constexpr bool FUSED = MODE != 0;
   static_assert(HEAD == 0 || (NCB == 1 && MODE == 1), "the projecting head exists for the fused inference stage");
   constexpr int TPB = 64 * NW;
+  constexpr bool F16 = std::is_same<P, PrecF16>::value;
+  using v8 = typename P::v8;
+  P::enter();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
@@ -721,7 +761,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
     int64_t row[NCB];
     bool valid[NCB];
-    bf16x8 Bo[NCB][KS_HID], Bn[NCB][KS_HID];
+    v8 Bo[NCB][KS_HID], Bn[NCB][KS_HID];
     float e_ray[NCB][8];         // inputs of the fused epilogue, fetched with the batch's features (see nerf_kernel's RawIn)
     float4 e_d0[NCB], e_d1[NCB];
     static_for<NCB>([&](auto cbc) {
@@ -746,7 +786,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         for (int ks = 0; ks < R_KS0; ++ks) {
           const float4 lo = ks < 6 ? xc[2 * ks] : xp[2 * (ks - 6)], hi = ks < 6 ? xc[2 * ks + 1] : xp[2 * (ks - 6) + 1];
           const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          Bo[cb][ks] = pack_bf16(v);
+          Bo[cb][ks] = P::pack(v);
         }
       } else {
         // lane (ray, h): views 2h, 2h+1 x 8 samples (48 colours) + Pluecker of samples 4h..4h+3 (24 values), in the order of refine_in0
@@ -820,7 +860,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = feat[8 * ks + j];
-          Bo[cb][ks] = pack_bf16(v);
+          Bo[cb][ks] = P::pack(v);
         }
       }
     });
@@ -831,14 +871,14 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
 #define PNRF_REFINE_PIECES 16
 #endif
     constexpr int RP = PNRF_REFINE_PIECES;      // pieces of the deferred hidden-layer epilogue (2, 8 or 16)
-    auto hidden = [&](bf16x8(&in)[NCB][KS_HID], bf16x8(&out)[NCB][KS_HID], int l) {
+    auto hidden = [&](v8(&in)[NCB][KS_HID], v8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
-      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H, RP>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
-                                                   HiddenEpi<NCB, ACT_ELU, RP>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU, RP>{in}(NT_HID - 1, pc, pend); }, np);
+      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H, RP, F16>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+                                                   HiddenEpi<NCB, ACT_ELU, RP, P>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU, RP, P>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
     };
-    layer_bf16<NCB, R_KS0, NT_HID, 0, RP>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU, RP>{Bn}, [](int) {}, pend);
+    layer_bf16<NCB, R_KS0, NT_HID, 0, RP, F16>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU, RP, P>{Bn}, [](int) {}, pend);
     static_assert(R_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
     for (int l = 0; l < 4; l += 2) {
       hidden(Bn, Bo, l);
@@ -846,7 +886,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
     }
     hidden(Bn, Bo, 4);
     const float* blast = biaslane + (1 + R_NHID) * W_HID;
-    auto pre_last = [&](int pc) { HiddenEpi<NCB, ACT_ELU>{Bo}(NT_HID - 1, pc, pend); };
+    auto pre_last = [&](int pc) { HiddenEpi<NCB, ACT_ELU, 2, P>{Bo}(NT_HID - 1, pc, pend); };
     f32x16 fin[NCB];
     if (!FUSED) {
       auto store_tile = [&](int to, int pc, f32x16(&acc)[NCB]) {
@@ -862,7 +902,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
             }
           }
       };
-      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, store_tile, pre_last, fin);
+      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, store_tile, pre_last, fin);
       store_tile(R_NT_LAST - 1, 0, fin);
       store_tile(R_NT_LAST - 1, 1, fin);
 #pragma unroll
@@ -870,12 +910,12 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
       continue;
     }
     if constexpr (MODE == 1) {
-      layer_bf16<NCB, KS_HID, 1, R_POS_LAST>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
+      layer_bf16<NCB, KS_HID, 1, R_POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
 #pragma unroll
       for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
     } else {                   // training: tile 0 = refine + offsets, tile 1 = rgb head (rgb_map0, refine2.py:637)
       f32x16 t1[NCB];
-      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST>(
+      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST, BF16_PIECES, F16>(
           st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
           [&](int, int pc, f32x16(&acc)[NCB]) {
 #pragma unroll
@@ -1268,17 +1308,23 @@ __device__ __forceinline__ int relu_pack_bf16(float a, float b) {
   return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, pk), i16x2_t{0, 0}));
 #endif
 }
-template <int NCB>
+template <class P>
+__device__ __forceinline__ int relu_pack(float a, float b) {
+  if constexpr (std::is_same<P, PrecBf16>::value) return relu_pack_bf16(a, b);
+  // the same ReLU on the packed pair (the conversion saturates: MODE.FP16_OVFL)
+  return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, P::cvt_pk(a, b)), i16x2_t{0, 0}));
+}
+template <int NCB, class P = PrecBf16>
 struct HiddenEpi16 {
-  bf16x8 (&Bn)[NCB][NB_KS_H];
+  typename P::v8 (&Bn)[NCB][NB_KS_H];
   // column blocks cb0, cb0 + 1 of tile pc
   __device__ __forceinline__ void operator()(int tp, int pc, f32x4 (&acc)[2][NCB], int cb0) const {
 #pragma unroll
     for (int cb = cb0; cb < cb0 + 2; ++cb) {
       i32x4_t w = __builtin_bit_cast(i32x4_t, Bn[cb][tp]);
-      w[2 * pc] = relu_pack_bf16(acc[pc][cb][0], acc[pc][cb][1]);
-      w[2 * pc + 1] = relu_pack_bf16(acc[pc][cb][2], acc[pc][cb][3]);
-      Bn[cb][tp] = __builtin_bit_cast(bf16x8, w);
+      w[2 * pc] = relu_pack<P>(acc[pc][cb][0], acc[pc][cb][1]);
+      w[2 * pc + 1] = relu_pack<P>(acc[pc][cb][2], acc[pc][cb][3]);
+      Bn[cb][tp] = __builtin_bit_cast(typename P::v8, w);
     }
   }
 };
@@ -1286,10 +1332,12 @@ struct HiddenEpi16 {
 // CLS = false: DoNeRFTRT; CLS = true: the NeRF class (layer sequence as nerf_kernel<.., CLS>, feature_linear folded, alpha as a 9th tile)
 // NCB = 2: 8 waves of 32 columns, two waves per SIMD (the default).  NCB = 4: 4 waves of 64 columns, one wave per SIMD: every weight fragment read
 // from LDS feeds four MFMAs instead of two (tools/lds_mfma_probe.hip: 1.57 -> 1.81 PFLOP/s for the bare hidden-layer loop).
-template <bool CLS, int NCB = 2>
+template <bool CLS, int NCB = 2, class P = PrecBf16>
 __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfArgs a) {
   constexpr int NW = 16 / NCB, TPB = 64 * NW;
-  using Epi = HiddenEpi16<NCB>;
+  using Epi = HiddenEpi16<NCB, P>;
+  using v8 = typename P::v8;
+  P::enter();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
@@ -1316,7 +1364,7 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
     int64_t row[NCB];
     bool valid[NCB];
-    bf16x8 Bo[NCB][NB_KS_H], Bn[NCB][NB_KS_H], Bx[NCB];
+    v8 Bo[NCB][NB_KS_H], Bn[NCB][NB_KS_H], Bx[NCB];
     float e_dn[NCB], e_z[NCB], e_add[NCB], e_mul[NCB], e_noise[NCB];
     static_for<NCB>([&](auto cbc) {
       constexpr int cb = decltype(cbc)::value;
@@ -1354,59 +1402,59 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = f0[ks * 8 + j];
-        Bo[cb][ks] = pack_bf16(v);
+        Bo[cb][ks] = P::pack(v);
       }
-      Bx[cb] = pack_bf16(fx);
+      Bx[cb] = P::pack(fx);
     });
     f32x4 fin[2][NCB], pend[2][NCB];
     if constexpr (!CLS) {
-      auto hidden = [&](bf16x8(&in)[NCB][NB_KS_H], bf16x8(&out)[NCB][NB_KS_H], int l) {
+      auto hidden = [&](v8(&in)[NCB][NB_KS_H], v8(&out)[NCB][NB_KS_H], int l) {
         f32x4 np[2][NCB];
-        layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H, NCB>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
+        layer_b16<NB_KS_H, NB_NTP_H, NB_POS_H, NCB, v8>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
                                                [&](int pc, int cb0) { Epi{in}(NB_NTP_H - 1, pc, pend, cb0); }, np);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
-      layer_b16<NB_KS0, NB_NTP_H, 0, NCB>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
+      layer_b16<NB_KS0, NB_NTP_H, 0, NCB, v8>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
       static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
       for (int l = 0; l < N_NHID; l += 2) {
         hidden(Bn, Bo, l);
         hidden(Bo, Bn, l + 1);
       }
-      layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB>(
+      layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB, v8>(
           st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
           [&](int, int, f32x4(&)[2][NCB], int) {}, [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, fin);
 #pragma unroll
       for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
     } else {
       // E0 Bo->Bn | E1..E4 ping-pong (ends in Bn) | E5 [Bn, P]->Bo | E6 Bo->Bn | E7 Bn->Bo | E89 [Bo, Bx]->Bn (128 wide) + alpha | E10 Bn -> rgb
-      bf16x8 P[NCB][NB_KS0];                  // positional fragments, needed again by the skip connection at layer 5
+      v8 Pz[NCB][NB_KS0];                  // positional fragments, needed again by the skip connection at layer 5
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int k = 0; k < NB_KS0; ++k) P[cb][k] = Bo[cb][k];
-      auto hidden = [&](bf16x8(&in)[NCB][NB_KS_H], bf16x8(&out)[NCB][NB_KS_H], int l, auto posc) {
+        for (int k = 0; k < NB_KS0; ++k) Pz[cb][k] = Bo[cb][k];
+      auto hidden = [&](v8(&in)[NCB][NB_KS_H], v8(&out)[NCB][NB_KS_H], int l, auto posc) {
         constexpr int POS = decltype(posc)::value;
         f32x4 np[2][NCB];
-        layer_b16<NB_KS_H, NB_NTP_H, POS, NCB>(st, ringlane, biaslane + l * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
+        layer_b16<NB_KS_H, NB_NTP_H, POS, NCB, v8>(st, ringlane, biaslane + l * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
                                           [&](int pc, int cb0) { Epi{in}(NB_NTP_H - 1, pc, pend, cb0); }, np);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
-      layer_b16<NB_KS0, NB_NTP_H, 0, NCB>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
+      layer_b16<NB_KS0, NB_NTP_H, 0, NCB, v8>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
       for (int l = 1; l < 5; l += 2) {        // E1..E4
         hidden(Bn, Bo, l, std::integral_constant<int, CB_POS_E1>{});
         hidden(Bo, Bn, l + 1, std::integral_constant<int, CB_POS_E1>{});
       }
       {                                       // E5: cat[pts, h] -> 256 (skip connection after layer 4)
         f32x4 np[2][NCB];
-        layer_b16<CB_KS5, NB_NTP_H, CB_POS_E5, NCB>(
+        layer_b16<CB_KS5, NB_NTP_H, CB_POS_E5, NCB, v8>(
             st, ringlane, biaslane + 5 * W_HID,
-            [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : P[cb][ks >= NB_KS_H ? ks - NB_KS_H : 0]; }, Epi{Bo},
+            [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Pz[cb][ks >= NB_KS_H ? ks - NB_KS_H : 0]; }, Epi{Bo},
             [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, np);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -1416,10 +1464,10 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
       hidden(Bo, Bn, 6, std::integral_constant<int, CB_POS_E6>{});
       hidden(Bn, Bo, 7, std::integral_constant<int, CB_POS_E6>{});
       f32x4 al[2][NCB];                         // E89: view tiles (pairs 0..3, ReLU -> Bn k-steps 0..3) + alpha (pair 4, tile 0, row 0)
-      layer_b16<NB_KS_LAST, CB_NTP89, CB_POS_E89, NCB>(
+      layer_b16<NB_KS_LAST, CB_NTP89, CB_POS_E89, NCB, v8>(
           st, ringlane, biaslane + CB_BIAS_E89, [&](int cb, int ks) { return ks < NB_KS_H ? Bo[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; }, Epi{Bn},
           [&](int pc, int cb0) { Epi{Bo}(NB_NTP_H - 1, pc, pend, cb0); }, al);
-      layer_b16<CB_KS10, 1, CB_POS_E10, NCB>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
+      layer_b16<CB_KS10, 1, CB_POS_E10, NCB, v8>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
                                         [&](int, int, f32x4(&)[2][NCB], int) {}, [](int, int) {}, fin);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) fin[0][cb][3] = al[0][cb][0];          // raw = [rgb, alpha] (helpers:851)
@@ -1588,7 +1636,9 @@ extern "C" int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in
   a.jitter = jitter; a.jitter_dir = jitter_dir; a.rgb0 = rgb0;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   a.nbatch = (int)((n + 255) / 256);
-  return launch_mlp(refine_kernel<1, 8, 2>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 8, 2>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
+  return launch_mlp(refine_kernel<1, 8, 2, 0, PrecF16>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
@@ -1602,7 +1652,9 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   a.nbatch = (int)((n + 255) / 256);      // 256 columns per workgroup batch
-  return launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
+  return launch_mlp(refine_kernel<1, 8, 1, 0, PrecF16>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
@@ -1612,14 +1664,16 @@ extern "C" int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, c
                "pnrf_refine_project_fwd: bad sizes (nb must be 4, got %d; nb * Hf * Wf must stay below 2^27 texels)", nb);
   if (n == 0) return 0;
   PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && proj && z && pts, PNRF_E_ARG, "pnrf_refine_project_fwd: null pointer");
-  PNRF_REQUIRE(h->variant == PNRF_VARIANT_DEFAULT, PNRF_E_STATE, "pnrf_refine_project_fwd: the refine net has one kernel variant");
+
   RefineArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = n;
   a.or_rays = or_rays; a.img4 = (const float4*)img4; a.proj = proj; a.Hf = Hf; a.Wf = Wf; a.eps = eps;
   a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
   a.nbatch = (int)((n + 255) / 256);
-  return launch_mlp(refine_kernel<1, 8, 1, 1>, a, 512, RING_BYTES + (size_t)h->nbias * 4, a.nbatch, (hipStream_t)stream);
+  if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 8, 1, 1>, a, 512, RING_BYTES + (size_t)h->nbias * 4, a.nbatch, (hipStream_t)stream);
+  a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
+  return launch_mlp(refine_kernel<1, 8, 1, 1, PrecF16>, a, 512, RING_BYTES + (size_t)h->nbias * 4, a.nbatch, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
@@ -1646,22 +1700,22 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);
+  // default: the 16x16x32 engine with fp16 operands; PNRF_VARIANT_BF16: the same engine on bf16; NERF_4X64 / BF16_32X32: bf16 variants
   const bool b16 = h->variant != PNRF_VARIANT_BF16_32X32;
+  const bool f16 = h->variant == PNRF_VARIANT_DEFAULT;
+  if (b16) {
+    a.blob = f16 ? h->d_blob_f16 : h->d_blob_b16; a.nslots = f16 ? h->nslots_f16 : h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
+  }
+  const size_t lds16 = RING_BYTES + (size_t)h->nbias_b16 * 4;
   if (h->net == PNRF_NET_NERFCLS) {
-    if (b16) {
-      a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
-      if (h->variant == PNRF_VARIANT_NERF_4X64)
-        return launch_mlp(nerf16_kernel<true, 4>, a, 256, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
-      return launch_mlp(nerf16_kernel<true, 2>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
-    }
+    if (f16) return launch_mlp(nerf16_kernel<true, 2, PrecF16>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
+    if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<true, 4>, a, 256, lds16, a.nbatch, (hipStream_t)stream);
+    if (b16) return launch_mlp(nerf16_kernel<true, 2>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
     return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
   }
-  if (b16) {
-    a.blob = h->d_blob_b16; a.nslots = h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
-    if (h->variant == PNRF_VARIANT_NERF_4X64)
-      return launch_mlp(nerf16_kernel<false, 4>, a, 256, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
-    return launch_mlp(nerf16_kernel<false, 2>, a, 512, RING_BYTES + (size_t)h->nbias_b16 * 4, a.nbatch, (hipStream_t)stream);
-  }
+  if (f16) return launch_mlp(nerf16_kernel<false, 2, PrecF16>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
+  if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<false, 4>, a, 256, lds16, a.nbatch, (hipStream_t)stream);
+  if (b16) return launch_mlp(nerf16_kernel<false, 2>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
   return launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream);
 }
 

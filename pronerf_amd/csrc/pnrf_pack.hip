@@ -130,7 +130,7 @@ static void pack_layer0_f16x2(const Layer& L, char* dst) {
 }
 
 // bf16 packing for layer_b16 (16x16x32): in_map [nk][4][8], out_map [nt][16], fragments (tp, ks, tile-in-pair)
-static void pack_layer_b16(const Layer& L, char* dst) {
+static void pack_layer_b16(const Layer& L, char* dst, bool f16 = false) {
   const int ntp = L.nt / 2;
   for (int tp = 0; tp < ntp; ++tp)
     for (int ks = 0; ks < L.nk; ++ks)
@@ -139,7 +139,10 @@ static void pack_layer_b16(const Layer& L, char* dst) {
         for (int lane = 0; lane < 64; ++lane) {
           const int r = lane & 15, g = lane >> 4;
           const int out = L.out_map[(2 * tp + t) * 16 + r];
-          for (int j = 0; j < 8; ++j) frag[lane * 8 + j] = f2bf(wval(L, out, L.in_map[(ks * 4 + g) * 8 + j]));
+          for (int j = 0; j < 8; ++j) {
+            const float w = wval(L, out, L.in_map[(ks * 4 + g) * 8 + j]);
+            frag[lane * 8 + j] = f16 ? f2h(w) : f2bf(w);
+          }
         }
       }
 }
@@ -306,12 +309,13 @@ static int pack_nerfcls(const float* const* W, const float* const* b, const int*
   slots_b16 += (NSLOTS - slots_b16 % NSLOTS) % NSLOTS;
   PNRF_REQUIRE(slots_b16 == (size_t)CB_NSLOTS && nb16 == (size_t)CB_NBIAS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal NeRF-class b16 layout mismatch (%zu slots, %zu bias floats)",
                slots_b16, nb16);
-  std::vector<char> blob_b16(slots_b16 * SLOT_BYTES, 0);
+  std::vector<char> blob_b16(slots_b16 * SLOT_BYTES, 0), blob_f16(slots_b16 * SLOT_BYTES, 0);      // the same stream with bf16 / fp16 operands
   std::vector<float> bias_b16(nb16, 0.f);
   {
     size_t sb = 0, bb = 0;
     for (auto& L : Lb) {
       pack_layer_b16(L, blob_b16.data() + sb * SLOT_BYTES);
+      pack_layer_b16(L, blob_f16.data() + sb * SLOT_BYTES, true);
       pack_bias(L, PREC_F32, bias_b16.data() + bb);
       sb += bs(L); bb += (size_t)L.nt * 16;
     }
@@ -329,6 +333,9 @@ static int pack_nerfcls(const float* const* W, const float* const* b, const int*
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_b16, blob_b16.data(), blob_b16.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_b16, nb16 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_b16.data(), nb16 * sizeof(float), hipMemcpyHostToDevice);
+    h->nslots_f16 = (uint32_t)slots_b16;
+    if (e == hipSuccess) e = hipMalloc(&h->d_blob_f16, blob_f16.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_f16, blob_f16.data(), blob_f16.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { set_error("pnrf_mlp_pack: device allocation/copy failed: %s", hipGetErrorString(e)); rc = (int)e; }
   }
   if (rc) { pnrf_mlp_free(h); return rc; }
@@ -443,6 +450,16 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     pack_bias(L, prec, bias.data() + bo);
     so += layer_slots(L, prec);
     bo += (size_t)L.nt * tile_rows;
+  }
+
+  // refine: the same stream with fp16 operands (default of the refine stage; the bf16 stream above stays as PNRF_VARIANT_BF16)
+  std::vector<char> blob_f16;
+  size_t slots_f16 = 0;
+  if (net == PNRF_NET_REFINE) {
+    slots_f16 = slots;
+    blob_f16.assign(slots_f16 * SLOT_BYTES, 0);
+    size_t sf = 0;
+    for (auto& L : Ls) { pack_layer_f16(L, blob_f16.data() + sf * SLOT_BYTES); sf += layer_slots(L, prec); }
   }
 
   // sampler: second stream with the folded first layer Wf[256x6] = sum_p W0[:, 6p:6p+6] (fp64 sum)
@@ -563,10 +580,13 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     slots_b16 += (NSLOTS - slots_b16 % NSLOTS) % NSLOTS;
     PNRF_REQUIRE(slots_b16 == (size_t)NB_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (b16 stream %zu slots, expected %d)", slots_b16, NB_NSLOTS);
     blob_b16.assign(slots_b16 * SLOT_BYTES, 0);
+    slots_f16 = slots_b16;
+    blob_f16.assign(slots_f16 * SLOT_BYTES, 0);                             // ... and with fp16 operands (the default of the NeRF stage)
     bias_b16.assign(nb, 0.f);
     size_t sb = 0, bb = 0;
     for (auto& L : Lb) {
       pack_layer_b16(L, blob_b16.data() + sb * SLOT_BYTES);
+      pack_layer_b16(L, blob_f16.data() + sb * SLOT_BYTES, true);
       pack_bias(L, PREC_F32, bias_b16.data() + bb);                        // [tile][16 rows]
       sb += bs(L); bb += (size_t)L.nt * 16;
     }
@@ -599,6 +619,11 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     h->nslots_h16 = (uint32_t)slots_h16;
     e = hipMalloc(&h->d_blob_h16, blob_h16.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_h16, blob_h16.data(), blob_h16.size(), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && slots_f16) {
+    h->nslots_f16 = (uint32_t)slots_f16;
+    e = hipMalloc(&h->d_blob_f16, blob_f16.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_f16, blob_f16.data(), blob_f16.size(), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
     h->nslots_p1 = P1_NSLOTS; h->nbias_p1 = P1_NBIAS; h->n_p1c = P1_NCONST;
@@ -641,6 +666,7 @@ extern "C" int pnrf_mlp_free(pnrf_mlp_t* h) {
   if (h->d_blob_p1) (void)hipFree(h->d_blob_p1);
   if (h->d_bias_p1) (void)hipFree(h->d_bias_p1);
   if (h->d_p1c) (void)hipFree(h->d_p1c);
+  if (h->d_blob_f16) (void)hipFree(h->d_blob_f16);
   if (h->d_bias) (void)hipFree(h->d_bias);
   if (h->d_in0) (void)hipFree(h->d_in0);
   if (h->d_inx) (void)hipFree(h->d_inx);
@@ -670,10 +696,11 @@ struct EngineHeader {
   uint64_t payload_bytes, checksum;   // FNV-1a 64 of the payload
   uint32_t nslots_p1;                 // format 2: pass-1 stream of the two-pass sampler, its bias table and error-model constants
   int32_t nbias_p1, n_p1c;
-  uint8_t reserved[12];
+  uint32_t nslots_f16;                // format 3: fp16-operand stream of the refine / NeRF stages
+  uint8_t reserved[8];
 };
-static constexpr uint32_t ENGINE_FORMAT = 2;
-static constexpr int ENGINE_SECTIONS = 13;
+static constexpr uint32_t ENGINE_FORMAT = 3;
+static constexpr int ENGINE_SECTIONS = 14;
 static_assert(sizeof(EngineHeader) == 128, "engine header is 128 bytes");
 static const char ENGINE_MAGIC[8] = {'P', 'N', 'R', 'F', 'E', 'N', 'G', 0};
 
@@ -695,6 +722,7 @@ static int sections(pnrf_mlp* h, int n_tvals, Section* s) {
   s[n++] = {&h->d_blob_p1, (size_t)h->nslots_p1 * SLOT_BYTES};
   s[n++] = {(void**)&h->d_bias_p1, (size_t)h->nbias_p1 * sizeof(float)};
   s[n++] = {(void**)&h->d_p1c, (size_t)h->n_p1c * sizeof(float)};
+  s[n++] = {&h->d_blob_f16, (size_t)h->nslots_f16 * SLOT_BYTES};
   return n;
 }
 
@@ -709,14 +737,17 @@ static void expected_counts(int net, EngineHeader* w) {
       break;
     case PNRF_NET_REFINE:
       w->prec = PREC_BF16; w->in_dim = R_IN; w->out_dim = R_OUT; w->nslots = R_NSLOTS; w->nbias = R_NBIAS; w->n_in0 = R_KS0 * 16; w->n_out = R_NT_LAST * 32;
+      w->nslots_f16 = R_NSLOTS;
       break;
     case PNRF_NET_NERF:
       w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = N_OUT; w->nslots = N_NSLOTS; w->nslots_b16 = NB_NSLOTS;
       w->nbias = N_NBIAS; w->nbias_b16 = ((1 + N_NHID) * (W_HID / 16) + 2) * 16; w->n_in0 = N_KS0 * 16; w->n_inx = N_KSX * 16; w->n_out = 32;
+      w->nslots_f16 = NB_NSLOTS;
       break;
     default:      // PNRF_NET_NERFCLS
       w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = 4; w->nslots = C_NSLOTS; w->nslots_b16 = CB_NSLOTS;
       w->nbias = C_NBIAS; w->nbias_b16 = CB_NBIAS; w->n_in0 = N_KS0 * 16; w->n_inx = N_KSX * 16; w->n_out = 64;
+      w->nslots_f16 = CB_NSLOTS;
       break;
   }
 }
@@ -762,7 +793,7 @@ extern "C" int pnrf_mlp_serialize(const pnrf_mlp_t* hc, void* buf, int64_t capac
   hd.net = h->net; hd.prec = h->prec; hd.in_dim = h->in_dim; hd.in_dim_x = h->in_dim_x; hd.out_dim = h->out_dim;
   hd.nslots = h->nslots; hd.nslots_fold = h->nslots_fold; hd.nslots_h16 = h->nslots_h16; hd.nslots_b16 = h->nslots_b16;
   hd.nbias_b16 = h->nbias_b16; hd.nbias = h->nbias; hd.n_in0 = h->n_in0; hd.n_inx = h->n_inx; hd.n_out = h->n_out; hd.n_tvals = n_tvals;
-  hd.nslots_p1 = h->nslots_p1; hd.nbias_p1 = h->nbias_p1; hd.n_p1c = h->n_p1c;
+  hd.nslots_p1 = h->nslots_p1; hd.nbias_p1 = h->nbias_p1; hd.n_p1c = h->n_p1c; hd.nslots_f16 = h->nslots_f16;
   hd.payload_bytes = payload;
   hd.checksum = fnv1a((const uint8_t*)buf + sizeof(EngineHeader), payload);
   memcpy(buf, &hd, sizeof(hd));
@@ -784,7 +815,7 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
   PNRF_REQUIRE(hd.nbias_b16 >= 0 && hd.nbias >= 0 && hd.n_in0 >= 0 && hd.n_inx >= 0 && hd.n_out >= 0 && (hd.n_tvals == 0 || hd.n_tvals == S_NPTS) &&
                    hd.nslots > 0 && hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
                    hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20) &&
-                   hd.nslots_p1 < (1u << 16) && hd.nbias_p1 >= 0 && hd.nbias_p1 < (1 << 24) && hd.n_p1c >= 0 && hd.n_p1c < (1 << 10),
+                   hd.nslots_p1 < (1u << 16) && hd.nslots_f16 < (1u << 16) && hd.nbias_p1 >= 0 && hd.nbias_p1 < (1 << 24) && hd.n_p1c >= 0 && hd.n_p1c < (1 << 10),
                PNRF_E_ARG, "pnrf_mlp_deserialize: implausible section counts");
   {
     // section counts the kernels of this net kind index with compile-time constants: an image whose counts differ (a crafted file with a
@@ -795,7 +826,7 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
                      hd.nslots == want.nslots && hd.nslots_fold == want.nslots_fold && hd.nslots_h16 == want.nslots_h16 &&
                      hd.nslots_b16 == want.nslots_b16 && hd.nbias_b16 == want.nbias_b16 && hd.nbias == want.nbias && hd.n_in0 == want.n_in0 &&
                      hd.n_inx == want.n_inx && hd.n_out == want.n_out && hd.n_tvals == want.n_tvals && hd.nslots_p1 == want.nslots_p1 &&
-                     hd.nbias_p1 == want.nbias_p1 && hd.n_p1c == want.n_p1c,
+                     hd.nbias_p1 == want.nbias_p1 && hd.n_p1c == want.n_p1c && hd.nslots_f16 == want.nslots_f16,
                  PNRF_E_ARG, "pnrf_mlp_deserialize: section counts do not match what net kind %d is packed as by this build", hd.net);
   }
   pnrf_mlp* h = new pnrf_mlp();
@@ -803,7 +834,7 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
   h->net = hd.net; h->prec = hd.prec; h->in_dim = hd.in_dim; h->in_dim_x = hd.in_dim_x; h->out_dim = hd.out_dim;
   h->nslots = hd.nslots; h->nslots_fold = hd.nslots_fold; h->nslots_h16 = hd.nslots_h16; h->nslots_b16 = hd.nslots_b16;
   h->nbias_b16 = hd.nbias_b16; h->nbias = hd.nbias; h->n_in0 = hd.n_in0; h->n_inx = hd.n_inx; h->n_out = hd.n_out;
-  h->nslots_p1 = hd.nslots_p1; h->nbias_p1 = hd.nbias_p1; h->n_p1c = hd.n_p1c;
+  h->nslots_p1 = hd.nslots_p1; h->nbias_p1 = hd.nbias_p1; h->n_p1c = hd.n_p1c; h->nslots_f16 = hd.nslots_f16;
   Section sec[ENGINE_SECTIONS];
   const int ns = sections(h, hd.n_tvals, sec);
   size_t payload = 0;
@@ -842,6 +873,7 @@ extern "C" int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant) {
   const bool sampler = h->net == PNRF_NET_SAMPLER;
   const bool ok = variant == PNRF_VARIANT_DEFAULT || (sampler && (variant == PNRF_VARIANT_SAMPLER_F32 || variant == PNRF_VARIANT_SAMPLER_F32_FULL || variant == PNRF_VARIANT_SAMPLER_SPLIT)) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_BF16_32X32) ||
+                  (!sampler && variant == PNRF_VARIANT_BF16) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_NERF_4X64);
   PNRF_REQUIRE(ok, PNRF_E_ARG, "pnrf_mlp_set_variant: variant %d does not exist for net kind %d", variant, h->net);
   h->variant = variant;

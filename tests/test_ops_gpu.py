@@ -258,9 +258,9 @@ def test_refine_and_nerf_stages(dev):
 
 @pytest.mark.parametrize('net', ['nerf', 'nerfcls'])
 def test_nerf_stage_variants_agree(dev, net):
-    """PNRF_VARIANT_NERF_4X64 (4 waves of 64 columns) runs the same MFMAs on the same packed stream in the same accumulation order as the
-    default (8 waves of 32 columns): bit-identical raw outputs and composited pixels, ragged row counts included.  PNRF_VARIANT_BF16_32X32
-    (the 32x32x16 engine) contracts in another order: bf16-grade agreement."""
+    """PNRF_VARIANT_NERF_4X64 (4 waves of 64 columns) runs the same MFMAs on the same packed bf16 stream in the same accumulation order as
+    PNRF_VARIANT_BF16 (8 waves of 32 columns): bit-identical raw outputs and composited pixels, ragged row counts included.
+    PNRF_VARIANT_BF16_32X32 (the 32x32x16 engine) contracts in another order, and the default runs fp16 operands: bf16-grade agreement."""
     from pronerf_amd import ops
     w = synth.make_weights(0, 'trained')
     if net == 'nerf':
@@ -277,12 +277,13 @@ def test_nerf_stage_variants_agree(dev, net):
         pts = torch.from_numpy(rs.uniform(-1, 1, (n, 8, 3)).astype(np.float32))
         add = torch.from_numpy(rs.randn(n, 8).astype(np.float32)); mul = torch.from_numpy(rs.rand(n, 8).astype(np.float32))
         outs = {}
-        for var in ('default', 'nerf_4x64', 'bf16_32x32'):
+        for var in ('default', 'bf16', 'nerf_4x64', 'bf16_32x32'):
             mlp = ops.PackedMLP(kind, Ws, bs, variant=var)
             outs[var] = ops.nerf_fwd(mlp, cu(pts, dev), cu(rays, dev), cu(z, dev), cu(add, dev), cu(mul, dev), want_raw=True)
-        for a_, b_ in zip(outs['default'], outs['nerf_4x64']):
+        for a_, b_ in zip(outs['bf16'], outs['nerf_4x64']):
             assert torch.equal(a_, b_), (net, n)
-        assert relrms(outs['bf16_32x32'][1].cpu(), outs['default'][1].cpu()) < 2e-2
+        assert relrms(outs['bf16_32x32'][1].cpu(), outs['bf16'][1].cpu()) < 2e-2
+        assert relrms(outs['default'][1].cpu(), outs['bf16'][1].cpu()) < 2e-2
 
 
 def test_nerf_class_network(dev, golden_dir):
@@ -319,3 +320,36 @@ def test_nerf_class_network(dev, golden_dir):
     np.testing.assert_array_equal(idx.cpu().numpy(), o['sort_idx'].numpy())
     assert orc.psnr(rgbd[:, :3].cpu(), o['rgb']) > 46.4
     np.testing.assert_allclose(rgbd[:, 3].cpu().numpy(), o['depth'].numpy(), rtol=0, atol=2e-2)
+
+
+def test_fp16_operands_precision_and_saturation(dev):
+    """Refine and NeRF stages with fp16 operands (the default) against the oracle, next to the bf16 variant: the raw NeRF output is held to the
+    tolerance the reference's authors used for their FP16 TensorRT engines (rtol 1e-3 / atol 1e-5 as a norm-wise bound, trt_infer_v2.py:444),
+    which bf16 misses by an order of magnitude.  Then the range: with the first NeRF layer scaled so that hidden activations pass 65 504 the packed
+    fp16 activations saturate (v_pk_min_i16 on the packed pair) — every output stays finite, where an unguarded conversion gives inf and NaN."""
+    from pronerf_amd import ops
+    w, mlps = _packed(dev, 0, 'trained')
+    scene = synth.make_scene(0, H=30, W=41, rotate=True)
+    fr = orc.frame_setup(scene)
+    o = orc.render_rays_infer(w, fr['rays'], fr['or_rays'], fr['images'], fr['proj'])
+    rays = cu(fr['rays'], dev)
+    args = (cu(o['pts'], dev), rays, cu(o['z'], dev), cu(o['add_sorted'], dev), cu(o['mul_sorted'], dev))
+    err = {}
+    for variant in ('default', 'bf16'):
+        nerf = ops.PackedMLP(ops.NET_NERF, w['nerf']['W'], w['nerf']['b'], variant=variant)
+        refine = ops.PackedMLP(ops.NET_REFINE, w['refine']['W'], w['refine']['b'], variant=variant)
+        _, raw = ops.nerf_fwd(nerf, *args, want_raw=True)
+        z, _ = ops.refine_fwd(refine, cu(o['refine_in'], dev), rays, cu(o['depth_sorted'], dev))
+        err[variant] = (relrms(raw.cpu(), o['raw']), relrms(z.cpu(), o['z']))
+    print(f'\n[fp16] raw NeRF output rel. RMS vs the oracle: fp16 {err["default"][0]:.2e}, bf16 {err["bf16"][0]:.2e}; refined depths: fp16 {err["default"][1]:.2e}, '
+          f'bf16 {err["bf16"][1]:.2e}')
+    assert err['default'][0] < 1.5e-3 and err['default'][1] < 3e-4
+    assert err['bf16'][0] < 2e-2 and err['default'][0] < 0.25 * err['bf16'][0]
+    # saturation: hidden activations of ~1e6
+    big = [x.copy() for x in w['nerf']['W']]
+    big[0] = big[0] * 3e5
+    nerf = ops.PackedMLP(ops.NET_NERF, big, w['nerf']['b'])
+    rgbd, raw = ops.nerf_fwd(nerf, *args, want_raw=True)
+    h = torch.relu(orc.posenc(o['pts'].reshape(-1, 3), 10) @ torch.from_numpy(big[0]).T + torch.from_numpy(w['nerf']['b'][0]))
+    assert float(h.max()) > 65504 * 4                                        # the case does leave the fp16 range
+    assert bool(torch.isfinite(raw).all()) and bool(torch.isfinite(rgbd).all())
