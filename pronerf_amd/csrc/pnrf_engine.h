@@ -478,7 +478,9 @@ __host__ __device__ constexpr int hidden_feat_h16(int ks, int g, int j) { return
 // VT = bf16x8 (v_mfma_f32_16x16x32_bf16) or f16x8 (v_mfma_f32_16x16x32_f16: same cycles, 11 significand bits instead of 8)
 __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-template <int KS, int NTP, int POS0, int NCB = 2, class VT = bf16x8, class ST, class BFn, class Epi1, class Pre1>
+// TMAX = 1: only the first tile of every pair carries output rows (the 4-wide output layers): the second tile's fragments still pass through
+// the ring (the stream layout is unchanged) but no MFMA is issued for them and last[1][*] stays the bias.
+template <int KS, int NTP, int POS0, int NCB = 2, class VT = bf16x8, int TMAX = 2, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][NCB]) {
   constexpr int NF = NTP * KS * 2;
   constexpr int AHEAD = NF < PNRF_B16_AHEAD ? NF : PNRF_B16_AHEAD;
@@ -512,8 +514,10 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
         }
         const VT a = aq[f % AHEAD];
         if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);
+        if (t < TMAX) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = mfma_16x16x32(a, Bf(cb, ks), acc[t][cb]);
+          for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = mfma_16x16x32(a, Bf(cb, ks), acc[t][cb]);
+        }
         st.slot_issue(f % SLOT_FRAGS);
       }
       // deferred epilogue of the previous pair in NCB pieces (tile pc, column blocks [cb0, cb0 + 2)): with one wave per SIMD (NCB = 4) nothing

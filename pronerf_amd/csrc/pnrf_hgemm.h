@@ -606,23 +606,30 @@ __global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
 // next product from the maximum over the workgroup's own 16 rows.
 constexpr int RC_LDX = 256 + 8;                                // halfs per row of a resident operand plane
 constexpr int HG_CHAIN_MAX = 6;
-struct RChainLayer { const _Float16 *Bh, *Bl; int ldb, n_pad; const float* bias; float* C; const float* H; float* c_amax; };
+// per resident layer: act = T_ACT_ELU / T_ACT_RELU / T_ACT_NONE (forward: the layer's activation; backward: the activation whose derivative
+// is taken at H); ldc / ldh = row strides of C and H (floats, multiples of 4; 0 = 256)
+struct RChainLayer { const _Float16 *Bh, *Bl; int ldb, n_pad; const float* bias; float* C; const float* H; float* c_amax; int act, ldc, ldh; };
 struct RChainArgs {
-  HGemmArgs first; int has_first;                              // optional leading layer through hgemm_body (forward: 288 / 144 -> 256)
-  const float* X0; const float* x0_amax;                       // [M, 256] input rows of the first resident layer; its max-|.| slot or NULL
+  HGemmArgs first; int has_first;                              // optional leading layer through hgemm_body (forward: 288 / 144 / 63 / 320 -> 256)
+  const float* X0; const float* x0_amax; int ldx0;             // [M, 256] input rows of the first resident layer (row stride ldx0, 0 = 256); its max-|.| slot or NULL
   RChainLayer l[HG_CHAIN_MAX]; int n;
-  int64_t M; int bwd;                                          // forward: C = ELU(X W^T + bias); backward: C = (X W^T) * ELU'(H)
+  int64_t M; int bwd;                                          // forward: C = act(X W^T + bias); backward: C = (X W^T) * act'(H)
 };
 // MI: 16-row MFMA tiles per workgroup.  Every workgroup reads all 256 KB of a layer's weight planes from L2: with 16-row tiles (256 workgroups
 // for 4096 rows) that is 64 MB per layer — 6 us of L2 bandwidth; 32-row tiles halve it and still give half of the CUs a workgroup.
+// MI = 4 (64-row tiles, the NeRF layers' 32 768 .. 1 M rows: a quarter of the weight traffic of 16-row tiles) keeps ONE operand region and
+// rewrites it in place — the next layer's planes are written behind the barrier that follows the last MFMA of the current one, so nobody
+// reads the old planes any more — which brings the workgroup to 134 KB of LDS; MI <= 2 alternate between two regions as before.
 template <int MI>
 __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
   constexpr int ROWS = 16 * MI, QN = 2 * MI;
   constexpr int XPLANE = ROWS * RC_LDX;                        // halfs per plane
-  __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<MI>::BYTES > 4 * XPLANE * 2 + ROWS * HG_LDC * 4 ? HgShape<MI>::BYTES : 4 * XPLANE * 2 + ROWS * HG_LDC * 4];
+  constexpr int REGIONS = MI >= 4 ? 1 : 2;
+  constexpr int XBYTES = REGIONS * 2 * XPLANE * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<MI>::BYTES > XBYTES + ROWS * HG_LDC * 4 ? HgShape<MI>::BYTES : XBYTES + ROWS * HG_LDC * 4];
   __shared__ float s_red[16];
   _Float16* const sX = (_Float16*)smem;                        // [region][plane hi / lo][ROWS][RC_LDX]
-  float* const sC = (float*)(smem + 4 * XPLANE * 2);
+  float* const sC = (float*)(smem + XBYTES);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m16 = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   if (c.has_first) {
@@ -638,9 +645,10 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
   float in_scale = 1.f;
   {
     if (c.x0_amax) in_scale = hg_scale_for(hg_slot_read(c.x0_amax, s_red));
+    const int ldx0 = c.ldx0 ? c.ldx0 : 256;
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-      const f32x4_t x = *(const f32x4_t*)(c.X0 + rr[q] * 256 + cl);
+      const f32x4_t x = *(const f32x4_t*)(c.X0 + rr[q] * ldx0 + cl);
       f16x4_t h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float v = x[e] * in_scale; const _Float16 vh = (_Float16)v; h[e] = vh; l[e] = (_Float16)((v - (float)vh) * HG_LO_SCALE); }
@@ -672,12 +680,14 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
   __syncthreads();                                             // the first resident operand planes are complete
   for (int i = 0; i < c.n; ++i) {
     const RChainLayer& L = c.l[i];
-    const _Float16* xh = sX + (i & 1) * 2 * XPLANE;
+    const _Float16* xh = sX + (i & (REGIONS - 1)) * 2 * XPLANE;
     const _Float16* xl = xh + XPLANE;
+    const int ldc = L.ldc ? L.ldc : 256, ldh = L.ldh ? L.ldh : 256;
+    const bool use_h = c.bwd && L.act != T_ACT_NONE;
     f32x4_t hv[QN];
-    if (c.bwd) {
+    if (use_h) {
 #pragma unroll
-      for (int q = 0; q < QN; ++q) hv[q] = *(const f32x4_t*)(L.H + rr[q] * 256 + cl);
+      for (int q = 0; q < QN; ++q) hv[q] = *(const f32x4_t*)(L.H + rr[q] * ldh + cl);
     }
     f32x4_t accm[MI][2], accx[MI][2];
 #pragma unroll
@@ -724,19 +734,24 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
       v[q] = *(const f32x4_t*)(sC + (rl0 + 8 * q) * HG_LDC + cl) + b4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (!c.bwd) v[q][e] = v[q][e] > 0.f ? v[q][e] : expm1f(v[q][e]);
-        else v[q][e] = hv[q][e] > 0.f ? v[q][e] : v[q][e] * (hv[q][e] + 1.f);
+        if (!c.bwd) {
+          if (L.act == T_ACT_ELU) v[q][e] = v[q][e] > 0.f ? v[q][e] : expm1f(v[q][e]);
+          else if (L.act == T_ACT_RELU) v[q][e] = fmaxf(v[q][e], 0.f);
+        } else if (use_h) {
+          if (L.act == T_ACT_ELU) v[q][e] = hv[q][e] > 0.f ? v[q][e] : v[q][e] * (hv[q][e] + 1.f);
+          else v[q][e] = hv[q][e] > 0.f ? v[q][e] : 0.f;
+        }
       }
       if (row0 + rl0 + 8 * q < c.M) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[q][0]), fabsf(v[q][1]))), fmaxf(fabsf(v[q][2]), fabsf(v[q][3])));
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // (the bias fetch)
 #pragma unroll
     for (int q = 0; q < QN; ++q)
-      if (row0 + rl0 + 8 * q < c.M) *(f32x4_t*)(L.C + rr[q] * 256 + cl) = v[q];
+      if (row0 + rl0 + 8 * q < c.M) *(f32x4_t*)(L.C + rr[q] * ldc + cl) = v[q];
     in_scale = 1.f;
     if (c.bwd) in_scale = hg_scale_for(hg_slot_write(L.c_amax, amax, s_red, blockIdx.x));   // the workgroup's own maximum
     if (i + 1 < c.n) {
-      _Float16* nh = sX + ((i + 1) & 1) * 2 * XPLANE;
+      _Float16* nh = sX + ((i + 1) & (REGIONS - 1)) * 2 * XPLANE;
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
         f16x4_t h, l;

@@ -16,6 +16,9 @@
 #include "pnrf_common.h"
 #include "pnrf_geom.h"
 
+#ifndef PNRF_LAST_TMAX
+#define PNRF_LAST_TMAX 1          // output layers of the NeRF nets: 4 (3) rows, all in the first 16-row tile of the pair
+#endif
 #ifndef PNRF_YOUNG_PRIO
 #define PNRF_YOUNG_PRIO 1
 #endif
@@ -99,9 +102,15 @@ struct PrecF16 {
     for (int d = 0; d < 4; ++d) w[d] = cvt_pk(v[2 * d], v[2 * d + 1]);
     return __builtin_bit_cast(v8, w);
   }
-  static __device__ __forceinline__ int cvt_pk(float a, float b) {      // volatile: must not move in front of enter()
+  // (not volatile: the operands of every conversion come from loads / MFMAs issued after enter(), so it cannot move in front of the mode
+  // switch, and a volatile statement could not be interleaved with the engine's other asm statements)
+  static __device__ __forceinline__ int cvt_pk(float a, float b) {
     int pk;
+#ifdef PNRF_F16_CVT_VOLATILE
     asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+#else
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+#endif
     return pk;
   }
 };
@@ -1423,7 +1432,7 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
         hidden(Bn, Bo, l);
         hidden(Bo, Bn, l + 1);
       }
-      layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB, v8>(
+      layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB, v8, PNRF_LAST_TMAX>(
           st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
           [&](int, int, f32x4(&)[2][NCB], int) {}, [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, fin);
 #pragma unroll
@@ -1467,7 +1476,7 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
       layer_b16<NB_KS_LAST, CB_NTP89, CB_POS_E89, NCB, v8>(
           st, ringlane, biaslane + CB_BIAS_E89, [&](int cb, int ks) { return ks < NB_KS_H ? Bo[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; }, Epi{Bn},
           [&](int pc, int cb0) { Epi{Bo}(NB_NTP_H - 1, pc, pend, cb0); }, al);
-      layer_b16<CB_KS10, 1, CB_POS_E10, NCB, v8>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
+      layer_b16<CB_KS10, 1, CB_POS_E10, NCB, v8, PNRF_LAST_TMAX>(st, ringlane, biaslane + CB_BIAS_E10, [&](int cb, int ks) { return Bn[cb][ks < CB_KS10 ? ks : 0]; },
                                         [&](int, int, f32x4(&)[2][NCB], int) {}, [](int, int) {}, fin);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) fin[0][cb][3] = al[0][cb][0];          // raw = [rgb, alpha] (helpers:851)

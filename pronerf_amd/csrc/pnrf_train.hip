@@ -1052,6 +1052,8 @@ struct pnrf_trainer {
   SplitArgs split;
   bool planes_stale = true;                      // parameters changed since the planes were last written
   bool use_f16 = true;                           // split-fp16 layer products (default) or the exact-fp32 MFMA kernels throughout
+  bool nerf_chains = false;                      // the fine net's 256 -> 256 forward layers as two layer chains (hgemm_rchain_kernel<4>) instead of one product per
+                                                 // layer: bit-identical, measured 2 % SLOWER (below) — kept selectable (pnrf_trainer_set_products kind 2)
   float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
   size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
   DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
@@ -1264,7 +1266,8 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
 // 16-row tiles while they fit one wave of workgroups (4096 rows: 1.227 ms per iteration; with 32-row tiles 1.254 — the chain is bound by its
 // latencies, not by the weight planes every workgroup streams from L2), 32-row tiles beyond
 void launch_rchain(const RChainArgs& c, int64_t N, hipStream_t s) {
-  if (N > 4096) hipLaunchKernelGGL((hgemm_rchain_kernel<2>), dim3((unsigned)((N + 31) / 32)), dim3(512), 0, s, c);
+  if (N > 16384) hipLaunchKernelGGL((hgemm_rchain_kernel<4>), dim3((unsigned)((N + 63) / 64)), dim3(512), 0, s, c);      // the NeRF layers' rows
+  else if (N > 4096) hipLaunchKernelGGL((hgemm_rchain_kernel<2>), dim3((unsigned)((N + 31) / 32)), dim3(512), 0, s, c);
   else hipLaunchKernelGGL((hgemm_rchain_kernel<1>), dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
 }
 // rows few enough that a layer product is bound by launch and pipeline-fill latency: walk the layers in one launch (hgemm_rchain_kernel)
@@ -1278,7 +1281,7 @@ int elu_net_forward(pnrf_trainer* t, int first, const float* x0, int in0, float*
     for (int k = 1; k < 6 && ok; ++k) {
       HGemmArgs a{};
       ok = fwd_hgemm_args(t, first + k, h[k - 1], 256, h[k], 256, N, T_ACT_ELU, &a) && a.K == 256 && a.N == 256;
-      c.l[k - 1] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, h[k], nullptr, nullptr};
+      c.l[k - 1] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, h[k], nullptr, nullptr, T_ACT_ELU, 256, 256};
     }
     if (ok) {
       c.has_first = 1; c.X0 = h[0]; c.x0_amax = nullptr; c.n = 5; c.M = N; c.bwd = 0;
@@ -1632,14 +1635,58 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   const int64_t R = bt->n * S;
   hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->emb, 90, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
   PNRF_LAUNCH_CHECK();
-  T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
-  for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
-  T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + C5_H, LD_C5, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
-  T_RC(layer_fwd(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, s));
-  T_RC(layer_fwd(t, L_N + 6, t->n_a5, 256, t->n_a6, 256, R, T_ACT_RELU, s));
-  T_RC(layer_fwd(t, L_N + 7, t->n_a6, 256, t->n_a7, 256, R, T_ACT_RELU, s));
+  // Rows are independent through the layers, so the 256 -> 256 layers CAN run as two layer chains (pnrf_hgemm.h), each workgroup keeping its 64
+  // rows on chip from layer to layer — a layer then writes its activation (the backward pass and the weight gradient need it) and reads
+  // nothing but weights: 435 MB of activation traffic per forward pass at 32 768 rows instead of 670 MB.  Chain A: pts0 (general body,
+  // 63 -> 256) | pts1 | pts2 | pts3 | pts4 (into the skip layer's input rows); chain B: pts5 (general body, [gamma(x) | h] -> 256) | pts6 |
+  // pts7 | feature (no activation, into the view layer's input rows).  Same products in the same order as one launch per layer:
+  // bit-identical results (tests/test_train_fullsize_gpu.py).  Measured (round 3, tools/train_iter.py, one MI355X): stage-2 iteration 1.301 ms
+  // chained vs 1.278 ms unchained, exploration at 64 / 256 samples 5.89 / 23.16 vs 5.76 / 22.50 ms — the chain is 2 % SLOWER: at 64-row tiles
+  // its operand planes + staging tile take 134 KB of LDS, one workgroup per CU, and inside that workgroup MFMA steps, the LDS round trip of the
+  // epilogue, the 64 KB store and the hand-over run one after the other (~13 us per layer and tile against 3 us of MFMAs), whereas the
+  // persistent product kernel overlaps its loads and stores with the MFMAs of the next chunks.  Hence off by default.
+  bool chained = false;
+  if (t->use_f16 && t->nerf_chains && R > 16384) {
+    RChainArgs ca = {}, cb = {};
+    bool ok = fwd_hgemm_args(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, &ca.first);
+    float* outa[4] = {t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H};
+    const float* ina[4] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3]};
+    for (int k = 0; k < 4 && ok; ++k) {
+      HGemmArgs a{};
+      const int ldc = k == 3 ? LD_C5 : 256;
+      ok = fwd_hgemm_args(t, L_N + 1 + k, ina[k], 256, outa[k], ldc, R, T_ACT_RELU, &a) && a.K == 256 && a.N == 256;
+      ca.l[k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, outa[k], nullptr, nullptr, T_ACT_RELU, ldc, 0};
+    }
+    ok = ok && fwd_hgemm_args(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, &cb.first);
+    float* outb[3] = {t->n_a6, t->n_a7, t->n_cv};
+    const float* inb[3] = {t->n_a5, t->n_a6, t->n_a7};
+    const int lib[3] = {L_N + 6, L_N + 7, L_FEAT};
+    for (int k = 0; k < 3 && ok; ++k) {
+      HGemmArgs a{};
+      const int ldc = k == 2 ? LD_CV : 256, act = k == 2 ? T_ACT_NONE : T_ACT_RELU;
+      ok = fwd_hgemm_args(t, lib[k], inb[k], 256, outb[k], ldc, R, act, &a) && a.K == 256 && a.N == 256;
+      cb.l[k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, outb[k], nullptr, nullptr, act, ldc, 0};
+    }
+    if (ok) {
+      ca.has_first = 1; ca.X0 = t->n_a[0]; ca.n = 4; ca.M = R; ca.bwd = 0;
+      cb.has_first = 1; cb.X0 = t->n_a5; cb.n = 3; cb.M = R; cb.bwd = 0;
+      launch_rchain(ca, R, s);
+      PNRF_LAUNCH_CHECK();
+      launch_rchain(cb, R, s);
+      PNRF_LAUNCH_CHECK();
+      chained = true;
+    }
+  }
+  if (!chained) {
+    T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
+    for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
+    T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + C5_H, LD_C5, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
+    T_RC(layer_fwd(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, s));
+    T_RC(layer_fwd(t, L_N + 6, t->n_a5, 256, t->n_a6, 256, R, T_ACT_RELU, s));
+    T_RC(layer_fwd(t, L_N + 7, t->n_a6, 256, t->n_a7, 256, R, T_ACT_RELU, s));
+    T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, LD_CV, R, T_ACT_NONE, s));
+  }
   T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
-  T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, LD_CV, R, T_ACT_NONE, s));
   T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));
   T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
   return 0;
@@ -1694,7 +1741,7 @@ int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, 
     for (int k = 5; k >= 1; --k) {
       HGemmArgs a{};
       bwd_hgemm_args(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0, &a);
-      c.l[5 - k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, nullptr, t->d_hk[k - 1], h[k - 1], m + (k - 1) * HG_SLOT};
+      c.l[5 - k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, nullptr, t->d_hk[k - 1], h[k - 1], m + (k - 1) * HG_SLOT, T_ACT_ELU, 256, 256};
     }
     c.has_first = 0; c.X0 = t->d_hk[5]; c.x0_amax = m + 5 * HG_SLOT; c.n = 5; c.M = N; c.bwd = 1;
     launch_rchain(c, N, s);
@@ -1880,9 +1927,10 @@ extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_ba
 // How the layer products are computed.  0 (default): split-fp16 MFMA (pnrf_hgemm.h: fp32-grade, 22 significand bits per operand, fp32
 // accumulation) wherever the shape fits; 1: exact-fp32 MFMA everywhere.
 extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
-  PNRF_REQUIRE(t && (kind == 0 || kind == 1), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16) or 1 (fp32)");
+  PNRF_REQUIRE(t && (kind == 0 || kind == 1 || kind == 2), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16), 1 (fp32) or 2 (split fp16, fine net's forward as layer chains)");
   drop_graphs(t);
-  t->use_f16 = kind == 0;
+  t->use_f16 = kind != 1;
+  t->nerf_chains = kind == 2;
   if (t->use_f16) t->planes_stale = true;
   return 0;
 }
