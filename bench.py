@@ -519,8 +519,9 @@ def main():
                     kern[k].update(achieved_tflops=ach, peak_tflops=peaks[k], frac=ach / peaks[k])
             dom = max(flops, key=lambda k: prof[k])
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
-            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_p1_kernel + sampler_h16_kernel', 'refine_kernel': 'refine_kernel<1, 8, 1, 1>',
-                       'nerf_kernel': 'nerf16_kernel<false, 2, PrecF16>'}
+            symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_p1_kernel + sampler_h16_kernel',
+                       'refine_kernel': 'refine_kernel<1, 8, 1, 1, (anonymous namespace)::PrecF16>',
+                       'nerf_kernel': 'nerf16_kernel<false, 2, (anonymous namespace)::PrecF16>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
             res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],

@@ -68,7 +68,7 @@ for k, c in acc.items():
 summary = {
     'round': tag,
     'command': 'rocprofv3 --pmc <C> --kernel-trace --output-format csv -d <pass dir> -- python3 bench.py --steps 3 --warmup 1 '
-               '--no-cpu-baseline --no-gpu-eager-baseline   (tools/profile_round.sh: one pass per counter set)',
+               '--no-cpu-baseline --no-gpu-eager-baseline --no-sustained --no-chunked --no-variants --no-train   (tools/profile_round.sh: one pass per counter set)',
     'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over launches); see tools/pmc_summary.py for the derived fields',
     'per_kernel': per,
 }
