@@ -357,10 +357,10 @@ int pnrf_trainer_set_graph(pnrf_trainer_t* t, int enable);
 /* Arithmetic of the layer products X W^T and dZ W.  kind 0 (default): split-fp16 MFMA — both operands as hi + 2^-11 lo fp16 pairs (22
    significand bits), three fp16 MFMAs per product block, fp32 accumulation; gradients are scaled by a power of two taken from their
    recorded maximum before the split.  kind 1: exact-fp32 MFMA products everywhere (the reference trains in fp32; torch's fp32 GEMMs are
-   this).  kind 2: the split-fp16 products with the 256 -> 256 layers of the fine net's forward pass as two layer chains (a workgroup keeps its
-   64 rows on chip from layer to layer: same arithmetic in the same order, bit-identical results, 35 % less activation traffic — and measured
-   2 % slower than one persistent product launch per layer; kept for A/B timing).  The narrow heads (fewer than 64 output columns)
-   always use the fp32 kernel. */
+   this).  kind 2: the split-fp16 products with one launch per layer of the fine net's forward pass instead of its two layer chains (from 8192
+   rows on kind 0 keeps a workgroup's 64 rows on chip through pts1-4 and through pts6, pts7, feature: same arithmetic in the same order,
+   bit-identical results, ~1 % faster; kind 2 is there for A/B timing and tests).  The narrow heads (fewer than 64 output columns) always
+   use the fp32 kernel. */
 int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind);
 /* optimizer.step() of torch.optim.Adam (L2 weight decay added to the gradient).  which 0: the joint optimizer over all
  * parameters (run_S_eS_eN_alter_base_refine2.py:394, 869; stage 1 s_optimizer); which 1: the NeRF-only optimizer of stage 1

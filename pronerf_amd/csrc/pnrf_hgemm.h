@@ -765,3 +765,179 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
     __syncthreads();
   }
 }
+
+// ------------------------------------------------------------------------------------------ layer chains of the wide (NeRF) layers, register epilogue
+// hgemm_rchain_kernel at 64-row tiles holds ONE workgroup per CU (134 KB of LDS) and runs MFMA steps, the epilogue's LDS round trip, the store
+// and the hand-over one after the other: measured 2 % slower than one persistent product per layer.  This kernel is shaped for TWO workgroups
+// per CU, so that one's epilogue overlaps the other's MFMAs:
+//   * workgroup = 4 waves on 32 rows x 256 columns; wave w owns columns 64 w .. 64 w + 63 (four 16-column MFMA tiles) of both 16-row tiles:
+//     2 x 4 x 2 accumulators = 64 registers, four rotating sets of weight fragments (4 tiles x 2 planes) = 128, <= 256 in all: 2 waves per SIMD;
+//   * LDS = the two fp16 operand planes of its 32 rows only (33 KB, rewritten in place behind the barrier that follows the layer's last
+//     MFMA): the epilogue runs from the accumulator registers — D register e of lane (m, g) is C[row m][column 4 g + e], i.e. four consecutive
+//     columns: one float4 of bias, one 16-byte store per tile (a wave instruction covers 16 rows x 64 bytes) and two 8-byte LDS writes
+//     (hi, lo planes) for the hand-over;
+//   * persistent over the row tiles (grid = 2 x CUs); the weight stream runs three steps ahead across layer and tile boundaries.
+// Forward (bwd = 0): C = act(X W^T + bias).  Backward (bwd = 1): C = (X W^T) * act'(H), X scaled by a power of two from its recorded maximum
+// (first layer) / from the workgroup's own maximum (later layers), max |C| left in the layer's slot.  Same products in the same order as
+// hgemm_body: bit-identical results.
+template <int MI = 4>
+__global__ __launch_bounds__(256, 2) void hgemm_wchain_kernel(RChainArgs c) {
+  constexpr int NI = 4, ROWS = 16 * MI, QL = ROWS / 4;
+  constexpr int XPLANE = ROWS * RC_LDX;                        // halfs per plane
+  __shared__ __attribute__((aligned(16))) _Float16 sX[2 * XPLANE];   // [plane hi / lo][ROWS][RC_LDX]
+  __shared__ float s_red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m16 = lane & 15, g = lane >> 4;
+  const int64_t ntiles = (c.M + ROWS - 1) / ROWS;
+  const int ldx0 = c.ldx0 ? c.ldx0 : 256;
+  // weight stream: step s of layer i of tile t = global step (t n + i) 8 + s; two register sets, one step (48 MFMAs per wave, two waves
+  // per SIMD: ~1500 cycles) ahead of the MFMAs that consume them
+  struct WFrag { f16x8_t h[NI], l[NI]; };
+  int w_layer = 0, w_ks = 0;
+  auto load_w = [&](WFrag& w) {
+    const RChainLayer& L = c.l[w_layer];
+    const int plane_bytes = L.n_pad * L.ldb * 2;
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc((void*)L.Bh, 0, plane_bytes, HG_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc((void*)L.Bl, 0, plane_bytes, HG_BUF_FLAGS);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const unsigned off = (unsigned)(((wave * NI + j) * (L.ldb >> 5)) * 1024 + lane * 16);
+      w.h[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(hr, off, w_ks * 1024, 0));
+      w.l[j] = __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(lr, off, w_ks * 1024, 0));
+    }
+    if (++w_ks == 8) { w_ks = 0; if (++w_layer == c.n) w_layer = 0; }
+  };
+  WFrag w0, w1;
+  load_w(w0);
+  const float x0_scale = c.x0_amax ? hg_scale_for(hg_slot_read(c.x0_amax, s_red)) : 1.f;
+  // loader of a tile's first operand planes: thread t -> rows (t >> 6) + 4 q (q < QL), columns 4 (t & 63) .. + 3
+  const int cl = 4 * (threadIdx.x & 63), rl0 = threadIdx.x >> 6;
+  float amax_l[HG_CHAIN_MAX];
+#pragma unroll
+  for (int i = 0; i < HG_CHAIN_MAX; ++i) amax_l[i] = 0.f;
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * ROWS;
+    float in_scale = x0_scale;
+    {
+      f32x4_t xin[QL];
+#pragma unroll
+      for (int q = 0; q < QL; ++q) {
+        int64_t r = row0 + rl0 + 4 * q;
+        r = r < c.M ? r : c.M - 1;
+        xin[q] = *(const f32x4_t*)(c.X0 + r * ldx0 + cl);
+      }
+      __syncthreads();                                         // the previous tile's last layer has read the planes
+#pragma unroll
+      for (int q = 0; q < QL; ++q) {
+        f16x4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float v = xin[q][e] * in_scale; const _Float16 vh = (_Float16)v; h[e] = vh; l[e] = (_Float16)((v - (float)vh) * HG_LO_SCALE); }
+        const int off = (rl0 + 4 * q) * RC_LDX + cl;
+        *(f16x4_t*)(sX + off) = h;
+        *(f16x4_t*)(sX + XPLANE + off) = l;
+      }
+      __syncthreads();
+    }
+    for (int i = 0; i < c.n; ++i) {
+      const RChainLayer& L = c.l[i];
+      const int ldc = L.ldc ? L.ldc : 256, ldh = L.ldh ? L.ldh : 256;
+      const bool use_h = c.bwd && L.act != T_ACT_NONE;
+      f32x4_t accm[MI][NI], accx[MI][NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { accm[mi][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accx[mi][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      auto step = [&](const WFrag& w, int s) {
+        // the activation fragments of 16-row tile mi + 1 are read while the MFMAs of tile mi run (two register pairs, not MI)
+        auto rd = [&](int mi, f16x8_t& h, f16x8_t& l) {
+          const int off = (16 * mi + m16) * RC_LDX + 32 * s + 8 * g;
+          h = *(const f16x8_t*)(sX + off); l = *(const f16x8_t*)(sX + XPLANE + off);
+        };
+        f16x8_t ah[2], al[2];
+        rd(0, ah[0], al[0]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if (mi + 1 < MI) rd(mi + 1, ah[(mi + 1) & 1], al[(mi + 1) & 1]);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            accx[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[j], al[mi & 1], accx[mi][j], 0, 0, 0);
+            accm[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[j], ah[mi & 1], accm[mi][j], 0, 0, 0);
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[j], ah[mi & 1], accx[mi][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // (same accumulation order per output element as hgemm_body / hgemm_rchain_kernel: steps 0 .. 7, cross before main inside a step)
+      load_w(w1); step(w0, 0); load_w(w0); step(w1, 1); load_w(w1); step(w0, 2); load_w(w0); step(w1, 3);
+      load_w(w1); step(w0, 4); load_w(w0); step(w1, 5); load_w(w1); step(w0, 6); load_w(w0); step(w1, 7);
+      // now w0 holds step 0 of the next layer (of the next tile's first layer behind the last one)
+      // ---- epilogue from the accumulators
+      const float inv = 1.f / in_scale;
+      f32x4_t v[MI][NI];
+      float amax = 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = wave * 64 + 16 * j + 4 * g;
+        const f32x4_t b4 = (!c.bwd && L.bias) ? *(const f32x4_t*)(L.bias + col) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          int64_t r = row0 + 16 * mi + m16;
+          const bool on = r < c.M;
+          r = on ? r : c.M - 1;
+          f32x4_t x = (accm[mi][j] + accx[mi][j] * HG_LO_INV) * inv + b4;
+          if (!c.bwd) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (L.act == T_ACT_ELU) x[e] = x[e] > 0.f ? x[e] : expm1f(x[e]);
+              else if (L.act == T_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+            }
+          } else if (use_h) {
+            const f32x4_t hv = *(const f32x4_t*)(L.H + r * ldh + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (L.act == T_ACT_ELU) x[e] = hv[e] > 0.f ? x[e] : x[e] * (hv[e] + 1.f);
+              else x[e] = hv[e] > 0.f ? x[e] : 0.f;
+            }
+          }
+          if (on) {
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+#if !(defined(PNRF_WCHAIN_PROBE) && (PNRF_WCHAIN_PROBE & 1))
+            *(f32x4_t*)(L.C + r * ldc + col) = x;
+#endif
+          }
+          v[mi][j] = x;
+        }
+      }
+      amax_l[i] = fmaxf(amax_l[i], amax);
+      in_scale = 1.f;
+      if (i + 1 < c.n) {
+        if (c.bwd) {                                           // the next product's scale from the workgroup's own rows (undone in its epilogue)
+          float m = amax;
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          if (lane == 0) s_red[wave] = m;
+        }
+        __syncthreads();                                       // every wave is past its MFMAs: the planes may be rewritten
+        if (c.bwd) in_scale = hg_scale_for(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            f16x4_t h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float x = v[mi][j][e] * in_scale; const _Float16 xh = (_Float16)x; h[e] = xh; l[e] = (_Float16)((x - (float)xh) * HG_LO_SCALE); }
+            const int off = (16 * mi + m16) * RC_LDX + wave * 64 + 16 * j + 4 * g;
+            *(f16x4_t*)(sX + off) = h;
+            *(f16x4_t*)(sX + XPLANE + off) = l;
+          }
+        __syncthreads();
+      }
+    }
+  }
+  // max |C| of every layer into its slot (backward): one atomic per workgroup and layer
+  if (c.bwd) {
+    for (int i = 0; i < c.n; ++i)
+      if (c.l[i].c_amax) (void)hg_slot_write(c.l[i].c_amax, amax_l[i], s_red, blockIdx.x);
+  }
+}

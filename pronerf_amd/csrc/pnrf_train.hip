@@ -1052,8 +1052,8 @@ struct pnrf_trainer {
   SplitArgs split;
   bool planes_stale = true;                      // parameters changed since the planes were last written
   bool use_f16 = true;                           // split-fp16 layer products (default) or the exact-fp32 MFMA kernels throughout
-  bool nerf_chains = false;                      // the fine net's 256 -> 256 forward layers as two layer chains (hgemm_rchain_kernel<4>) instead of one product per
-                                                 // layer: bit-identical, measured 2 % SLOWER (below) — kept selectable (pnrf_trainer_set_products kind 2)
+  bool nerf_chains = true;                       // the fine net's 256 -> 256 forward layers as two layer chains (hgemm_wchain_kernel) from 8192 rows on; false
+                                                 // (pnrf_trainer_set_products kind 2): one product launch per layer — bit-identical either way
   float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
   size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
   DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
@@ -1266,9 +1266,24 @@ int layer_fwd(pnrf_trainer* t, int li, const float* X, int ldx, float* Y, int ld
 // 16-row tiles while they fit one wave of workgroups (4096 rows: 1.227 ms per iteration; with 32-row tiles 1.254 — the chain is bound by its
 // latencies, not by the weight planes every workgroup streams from L2), 32-row tiles beyond
 void launch_rchain(const RChainArgs& c, int64_t N, hipStream_t s) {
-  if (N > 16384) hipLaunchKernelGGL((hgemm_rchain_kernel<4>), dim3((unsigned)((N + 63) / 64)), dim3(512), 0, s, c);      // the NeRF layers' rows
-  else if (N > 4096) hipLaunchKernelGGL((hgemm_rchain_kernel<2>), dim3((unsigned)((N + 31) / 32)), dim3(512), 0, s, c);
+  if (N > 4096) hipLaunchKernelGGL((hgemm_rchain_kernel<2>), dim3((unsigned)((N + 31) / 32)), dim3(512), 0, s, c);
   else hipLaunchKernelGGL((hgemm_rchain_kernel<1>), dim3((unsigned)((N + 15) / 16)), dim3(512), 0, s, c);
+}
+inline int trainer_num_cu() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+// wide layers: two 4-wave workgroups per CU, persistent over 64-row tiles (hgemm_wchain_kernel)
+void launch_wchain(const RChainArgs& c, int64_t N, hipStream_t s) {
+  const int64_t ntiles = (N + 63) / 64;
+  const int64_t cap = 2 * (int64_t)trainer_num_cu();
+  hipLaunchKernelGGL((hgemm_wchain_kernel<4>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, c);
 }
 // rows few enough that a layer product is bound by launch and pipeline-fill latency: walk the layers in one launch (hgemm_rchain_kernel)
 inline bool chain_rows(int64_t R) { return (R + 15) / 16 <= 512; }
@@ -1635,20 +1650,23 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   const int64_t R = bt->n * S;
   hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->emb, 90, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
   PNRF_LAUNCH_CHECK();
-  // Rows are independent through the layers, so the 256 -> 256 layers CAN run as two layer chains (pnrf_hgemm.h), each workgroup keeping its 64
-  // rows on chip from layer to layer — a layer then writes its activation (the backward pass and the weight gradient need it) and reads
-  // nothing but weights: 435 MB of activation traffic per forward pass at 32 768 rows instead of 670 MB.  Chain A: pts0 (general body,
-  // 63 -> 256) | pts1 | pts2 | pts3 | pts4 (into the skip layer's input rows); chain B: pts5 (general body, [gamma(x) | h] -> 256) | pts6 |
-  // pts7 | feature (no activation, into the view layer's input rows).  Same products in the same order as one launch per layer:
-  // bit-identical results (tests/test_train_fullsize_gpu.py).  Measured (round 3, tools/train_iter.py, one MI355X): stage-2 iteration 1.301 ms
-  // chained vs 1.278 ms unchained, exploration at 64 / 256 samples 5.89 / 23.16 vs 5.76 / 22.50 ms — the chain is 2 % SLOWER: at 64-row tiles
-  // its operand planes + staging tile take 134 KB of LDS, one workgroup per CU, and inside that workgroup MFMA steps, the LDS round trip of the
-  // epilogue, the 64 KB store and the hand-over run one after the other (~13 us per layer and tile against 3 us of MFMAs), whereas the
-  // persistent product kernel overlaps its loads and stores with the MFMAs of the next chunks.  Hence off by default.
+  // Rows are independent through the layers, so the 256 -> 256 layers run as two layer chains (hgemm_wchain_kernel, pnrf_hgemm.h): a workgroup
+  // keeps its 64 rows on chip from layer to layer — a chained layer writes its activation (the backward pass and the weight gradient need it)
+  // and reads nothing but weights: 418 MB of activation traffic per forward pass at 32 768 rows instead of 670 MB.  pts0 and pts5 (63 / 320
+  // inputs) stay products of their own; chain A = pts1 | pts2 | pts3 | pts4 (into the skip layer's input rows), chain B = pts6 | pts7 |
+  // feature (no activation, into the view layer's input rows).  Same products in the same order as one launch per layer: bit-identical
+  // results (tests/test_train_fullsize_gpu.py).  Measured (round 3, tools/train_iter.py): stage-2 iteration 1.254 vs 1.271 ms, exploration at
+  // 64 samples 5.63 vs 5.68 ms — 1 % faster, not the 35 % the traffic suggests: the chain kernel keeps the MFMA pipes 31 % busy (the
+  // product kernel 20 %), half of its wave time is spent in s_waitcnt / barriers (SQ_WAIT_ANY 49 %) — weight fragments one step ahead are
+  // not far enough ahead of an L2 under this load, and the 16 x 64-byte stores of the register epilogue cost 23 % (no-store probe build:
+  // 411 vs 535 us per launch).  A first version on hgemm_rchain_kernel<4> (LDS round trip in the epilogue, one workgroup per CU) was 2 % slower.
   bool chained = false;
-  if (t->use_f16 && t->nerf_chains && R > 16384) {
+  if (t->use_f16 && t->nerf_chains && R >= 8192) {
+    // pts0 and pts5 (63 / 320 inputs) as products of their own; the 256 -> 256 layers behind each as a chain
     RChainArgs ca = {}, cb = {};
-    bool ok = fwd_hgemm_args(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, &ca.first);
+    HGemmArgs h0{}, h5{};
+    bool ok = fwd_hgemm_args(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, &h0) &&
+              fwd_hgemm_args(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, &h5);
     float* outa[4] = {t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H};
     const float* ina[4] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3]};
     for (int k = 0; k < 4 && ok; ++k) {
@@ -1657,7 +1675,6 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
       ok = fwd_hgemm_args(t, L_N + 1 + k, ina[k], 256, outa[k], ldc, R, T_ACT_RELU, &a) && a.K == 256 && a.N == 256;
       ca.l[k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, outa[k], nullptr, nullptr, T_ACT_RELU, ldc, 0};
     }
-    ok = ok && fwd_hgemm_args(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, &cb.first);
     float* outb[3] = {t->n_a6, t->n_a7, t->n_cv};
     const float* inb[3] = {t->n_a5, t->n_a6, t->n_a7};
     const int lib[3] = {L_N + 6, L_N + 7, L_FEAT};
@@ -1668,11 +1685,13 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
       cb.l[k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, a.bias, outb[k], nullptr, nullptr, act, ldc, 0};
     }
     if (ok) {
-      ca.has_first = 1; ca.X0 = t->n_a[0]; ca.n = 4; ca.M = R; ca.bwd = 0;
-      cb.has_first = 1; cb.X0 = t->n_a5; cb.n = 3; cb.M = R; cb.bwd = 0;
-      launch_rchain(ca, R, s);
+      ca.has_first = 0; ca.X0 = t->n_a[0]; ca.n = 4; ca.M = R; ca.bwd = 0;
+      cb.has_first = 0; cb.X0 = t->n_a5; cb.n = 3; cb.M = R; cb.bwd = 0;
+      T_RC(launch_hgemm(h0, s));
+      launch_wchain(ca, R, s);
       PNRF_LAUNCH_CHECK();
-      launch_rchain(cb, R, s);
+      T_RC(launch_hgemm(h5, s));
+      launch_wchain(cb, R, s);
       PNRF_LAUNCH_CHECK();
       chained = true;
     }
@@ -1927,10 +1946,10 @@ extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_ba
 // How the layer products are computed.  0 (default): split-fp16 MFMA (pnrf_hgemm.h: fp32-grade, 22 significand bits per operand, fp32
 // accumulation) wherever the shape fits; 1: exact-fp32 MFMA everywhere.
 extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
-  PNRF_REQUIRE(t && (kind == 0 || kind == 1 || kind == 2), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16), 1 (fp32) or 2 (split fp16, fine net's forward as layer chains)");
+  PNRF_REQUIRE(t && (kind == 0 || kind == 1 || kind == 2), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16), 1 (fp32) or 2 (split fp16, one launch per layer)");
   drop_graphs(t);
   t->use_f16 = kind != 1;
-  t->nerf_chains = kind == 2;
+  t->nerf_chains = kind == 0;
   if (t->use_f16) t->planes_stale = true;
   return 0;
 }

@@ -531,12 +531,12 @@ class Trainer:
         check(_lib.load().pnrf_trainer_set_graph(self.handle, int(bool(enable))), 'pnrf_trainer_set_graph')
 
     def set_products(self, kind):
-        """'f16x2' (default): split-fp16 MFMA layer products (fp32-grade); 'f32': exact-fp32 MFMA products; 'f16x2_chained': split fp16 with the
-        fine net's forward layers as layer chains (bit-identical to 'f16x2', measured 2 % slower; pnrf_trainer_set_products)."""
-        if kind not in ('f16x2', 'f32', 'f16x2_chained'):
+        """'f16x2' (default): split-fp16 MFMA layer products (fp32-grade); 'f32': exact-fp32 MFMA products; 'f16x2_unchained': split fp16 with
+        one launch per layer of the fine net's forward instead of its layer chains (bit-identical to 'f16x2'; pnrf_trainer_set_products)."""
+        if kind not in ('f16x2', 'f32', 'f16x2_unchained'):
             raise PnrfError(f"Trainer.set_products: kind must be 'f16x2' (split-fp16 MFMA products, default) or 'f32' (exact-fp32 MFMA products), got {kind!r} "
                             '(the training drivers read it from PNRF_TRAIN_PRODUCTS)')
-        k = {'f16x2': 0, 'f32': 1, 'f16x2_chained': 2}[kind]
+        k = {'f16x2': 0, 'f32': 1, 'f16x2_unchained': 2}[kind]
         check(_lib.load().pnrf_trainer_set_products(self.handle, k), 'pnrf_trainer_set_products')
 
     def set_step(self, step, step_nerf=0):

@@ -92,8 +92,8 @@ def test_stage2_iteration_at_config3_size(work, dev):
     gg = _grads(tr)
     tr.set_graph(False)
     assert torch.equal(lossg, loss) and torch.equal(rgbg, rgb) and all(torch.equal(a, b) for a, b in zip(gg, g16))
-    # the fine net's forward as layer chains (hgemm_rchain_kernel<4>) against one launch per layer: the same products in the same order, bit for bit
-    tr.set_products('f16x2_chained')
+    # the fine net's forward as layer chains (hgemm_wchain_kernel, the default) against one launch per layer: the same products in the same order, bit for bit
+    tr.set_products('f16x2_unchained')
     lossu, rgbu = wk.stage2_step(want_rgb=True, adam=False)
     gu = _grads(tr)
     tr.set_products('f16x2')
@@ -133,7 +133,7 @@ def test_exploration_iteration_at_config4_size(work, dev):
     gg = _grads(tr, range(14, 26))
     tr.set_graph(False)
     assert torch.equal(lossg, loss) and torch.equal(rgbg, rgb) and all(torch.equal(a, b) for a, b in zip(gg, g16))
-    tr.set_products('f16x2_chained')
+    tr.set_products('f16x2_unchained')
     lossu, rgbu = wk.explore_step(n_mult, want_rgb=True, adam=False)
     gu = _grads(tr, range(14, 26))
     tr.set_products('f16x2')

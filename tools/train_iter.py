@@ -13,6 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from pronerf_amd import _lib                     # noqa: E402
 from pronerf_amd import workloads as wl          # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -20,7 +21,10 @@ ap.add_argument('--workload', default='stage2_iteration')
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--products', default='f16x2')
+ap.add_argument('--lib', default='', help='time another build: pronerf_amd/lib/libpronerf_hip_<name>.so (python -m pronerf_amd.build --variant <name> ...)')
 args = ap.parse_args()
+if args.lib:
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f'libpronerf_hip_{args.lib}.so')
 S = 8 if args.workload == 'stage2_iteration' else int(args.workload.rsplit('_', 1)[1])
 wk = wl.TrainWorkload('cuda:0', max_samples=S)
 wk.trainer.set_products(args.products)
