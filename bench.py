@@ -486,7 +486,7 @@ def main():
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'ms_per_frame': ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'f16 (refine+NeRF MLP operands, 11 significand bits >= the bf16 of configs[1]; fp32 accumulate) + ' + ('f32 (sampler MLP, exact f32 MFMA)' if sampler_f32 else
+            'dtype': 'bf16 (NeRF MLP operands) + f16 (refine MLP operands); fp32 accumulate + ' + ('f32 (sampler MLP, exact f32 MFMA)' if sampler_f32 else
                                                                   'f16 | f16x2 (sampler MLP: plain fp16 pass for every ray, split fp16 hi+lo operands = fp32-grade for '
                                                                   'the rays whose depth order that pass cannot decide; fp32 accumulate)'),
             'data': 'synthetic',
@@ -496,7 +496,7 @@ def main():
             'launcher': ('self (bench.py started its own ranks)' if os.environ.get('PNRF_BENCH_CHILD') else
                          'torch.distributed.run' if world > 1 else None),
             'config': {'workload': 'LLFF fern geometry 1008x756 frame (762048 rays), 8 samples/ray, 4 neighbour views, 48 ray-encoding points, '
-                                   'fp16 MLPs (bf16 timed beside it: variants.bf16); one pnrf_render_rays_fwd call renders the whole frame, as the reference does (the 1024-ray chunks of '
+                                   'bf16 NeRF MLP, fp16 refine MLP (all-fp16 and all-bf16 timed beside it: variants); one pnrf_render_rays_fwd call renders the whole frame, as the reference does (the 1024-ray chunks of '
                                    'configs[1] = 4 of the 256-column workgroup batches each persistent kernel walks inside its single launch; '
                                    'the frame as 745 separate 1024-ray calls is timed beside it: chunked_1024)',
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0], 'rays_per_rank': counts,
@@ -521,7 +521,7 @@ def main():
             # symbols as rocprofv3 prints them in profiles/*_kernel_stats.csv (default build: split-fp16 sampler, 16x16x32 NeRF stage)
             symbols = {'sampler_kernel': 'sampler_kernel' if sampler_f32 else 'sampler_p1_kernel + sampler_h16_kernel',
                        'refine_kernel': 'refine_kernel<1, 8, 1, 1, (anonymous namespace)::PrecF16>',
-                       'nerf_kernel': 'nerf16_kernel<false, 2, (anonymous namespace)::PrecF16>'}
+                       'nerf_kernel': 'nerf16_kernel<false, 2, (anonymous namespace)::PrecBf16>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
             res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
@@ -545,8 +545,9 @@ def main():
                 res['variants'] = {}
                 for vname, vset, what in (
                         ('sampler_split', {'sampler': 'sampler_split'}, 'split-fp16 sampler kernel for every ray (PNRF_VARIANT_SAMPLER_SPLIT, the round-2 sampler)'),
-                        ('bf16', {'refine': 'bf16', 'nerf': 'bf16'}, 'refine + NeRF MLPs on bf16 operands (PNRF_VARIANT_BF16: the literal "bf16 MLP" of configs[1])'),
-                        ('round2', {'sampler': 'sampler_split', 'refine': 'bf16', 'nerf': 'bf16'}, 'both: the kernels of the round-2 default')):
+                        ('nerf_f16', {'nerf': 'f16'}, 'NeRF MLP on fp16 operands too (PNRF_VARIANT_F16; raw output within the authors\' FP16-engine tolerance)'),
+                        ('refine_bf16', {'refine': 'bf16'}, 'refine MLP on bf16 operands too (PNRF_VARIANT_BF16: every MLP behind the sampler in bf16)'),
+                        ('round2', {'sampler': 'sampler_split', 'refine': 'bf16'}, 'split sampler + bf16 refine: the kernels of the round-2 default')):
                     r2 = Renderer(weights, max_rays=count, device=dev, variants=vset)
                     r2.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
                     o2 = torch.empty_like(one_call)

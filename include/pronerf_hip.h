@@ -71,15 +71,16 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 
 /* Kernel variant of a packed network.  PNRF_VARIANT_DEFAULT is what pack / deserialize produce and what every product path runs:
  * sampler with the folded first layer in split fp16 (fp32-grade, three v_mfma_f32_16x16x32_f16 per product) — through pnrf_sampler_fwd_ws /
- * pnrf_render_rays_fwd as the second of two passes, see there —, refine stage on v_mfma_f32_32x32x16_f16, NeRF stage on
- * v_mfma_f32_16x16x32_f16: fp16 operands (11 significand bits, like the FP16 TensorRT engines of the reference's own fast path,
- * trt_infer_v2.py), fp32 accumulation; packed activations saturate at 65 504 instead of overflowing.  The others exist for parity
- * tests and A/B timing (tools/perf_ab.py):
+ * pnrf_render_rays_fwd as the second of two passes, see there —, refine stage on v_mfma_f32_32x32x16_f16 (fp16 operands: its refined depths
+ * feed 2^9 positional octaves, and with bf16 operands they are the largest error of the frame), NeRF stage on v_mfma_f32_16x16x32_bf16
+ * (the "bf16 MLP" of BASELINE.json configs[1]); fp32 accumulation everywhere.  fp16 kernels run with MODE.FP16_OVFL: packed activations
+ * saturate at 65 504 instead of overflowing.  The others exist for parity tests and A/B timing (tools/perf_ab.py, tools/variant_psnr.py):
  *   SAMPLER_F32       sampler on the exact fp32 FMA chain (v_mfma_f32_16x16x4_f32), folded first layer;
  *   SAMPLER_F32_FULL  ... with the full K = 288 first layer on the 48 Pluecker points (no fold);
  *   SAMPLER_SPLIT     the split-fp16 kernel for every ray, also where a workspace is given (single pass: the default of round 2);
- *   BF16              refine / NeRF handles: the default engines on bf16 operands (8 significand bits; the round-2 default, what
- *                     BASELINE.json configs[1] words as "bf16 MLP") — same MFMA cycles, same streams in the other type;
+ *   BF16              refine handles: bf16 operands (8 significand bits; the round-2 default); NeRF handles: same as DEFAULT;
+ *   F16               NeRF handles: fp16 operands (11 significand bits, like the FP16 TensorRT engines of the reference's own fast path,
+ *                     trt_infer_v2.py: raw output within the authors' 1e-3 tolerance) — same MFMA count, 5 % slower under the power limit;
  *   BF16_32X32        NeRF handles: the v_mfma_f32_32x32x16_bf16 engine (the refine net has one engine);
  *   NERF_4X64         NeRF handles: bf16, 4 waves of 64 columns per workgroup (one wave per SIMD) instead of 8 waves of 32 — same arithmetic,
  *                     same packed stream, every weight fragment read from LDS feeds four MFMAs instead of two.
@@ -93,6 +94,7 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 #define PNRF_VARIANT_NERF_4X64 4
 #define PNRF_VARIANT_SAMPLER_SPLIT 5
 #define PNRF_VARIANT_BF16 6
+#define PNRF_VARIANT_F16 7
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear

@@ -1709,9 +1709,9 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);
-  // default: the 16x16x32 engine with fp16 operands; PNRF_VARIANT_BF16: the same engine on bf16; NERF_4X64 / BF16_32X32: bf16 variants
+  // default: the 16x16x32 engine on bf16 operands; PNRF_VARIANT_F16: the same engine on fp16 operands; NERF_4X64 / BF16_32X32: bf16 variants
   const bool b16 = h->variant != PNRF_VARIANT_BF16_32X32;
-  const bool f16 = h->variant == PNRF_VARIANT_DEFAULT;
+  const bool f16 = h->variant == PNRF_VARIANT_F16;
   if (b16) {
     a.blob = f16 ? h->d_blob_f16 : h->d_blob_b16; a.nslots = f16 ? h->nslots_f16 : h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
   }

@@ -873,7 +873,7 @@ extern "C" int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant) {
   const bool sampler = h->net == PNRF_NET_SAMPLER;
   const bool ok = variant == PNRF_VARIANT_DEFAULT || (sampler && (variant == PNRF_VARIANT_SAMPLER_F32 || variant == PNRF_VARIANT_SAMPLER_F32_FULL || variant == PNRF_VARIANT_SAMPLER_SPLIT)) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_BF16_32X32) ||
-                  (!sampler && variant == PNRF_VARIANT_BF16) ||
+                  (!sampler && variant == PNRF_VARIANT_BF16) || ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_F16) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_NERF_4X64);
   PNRF_REQUIRE(ok, PNRF_E_ARG, "pnrf_mlp_set_variant: variant %d does not exist for net kind %d", variant, h->net);
   h->variant = variant;
