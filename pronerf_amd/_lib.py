@@ -100,6 +100,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own libamdhip64.so.  Loaded after this library (which would then have pulled in /opt/rocm's copy),
+    # the process ends up with two HIP runtimes and every hipMalloc of this library fails with "no ROCm-capable device is detected"
+    # (seen with __graft_entry__.build() followed by smoke() in one process).  With torch's runtime already mapped, the library binds to it.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PnrfError(f'{LIB_PATH} is missing: run `python -m pronerf_amd.build` (or __graft_entry__.build()). '
                         'pronerf_amd has no CPU fallback.')
