@@ -354,3 +354,37 @@ def test_fp16_operands_precision_and_saturation(dev):
     h = torch.relu(orc.posenc(o['pts'].reshape(-1, 3), 10) @ torch.from_numpy(big[0]).T + torch.from_numpy(w['nerf']['b'][0]))
     assert float(h.max()) > 65504 * 4                                        # the case does leave the fp16 range
     assert bool(torch.isfinite(raw).all()) and bool(torch.isfinite(rgbd).all())
+
+
+def test_two_pass_sampler_arguments(dev):
+    """pnrf_sampler_fwd_ws: workspace size / alignment and kappa are checked; the single-kernel variants ignore the workspace; ragged ray counts
+    (1, 255, 257) agree with the split kernel on every row pass 2 re-rendered and to fp16 grade elsewhere."""
+    import ctypes as C
+    from pronerf_amd import _lib, ops
+    w, mlps = _packed(dev, 0, 'trained')
+    lib = _lib.load()
+    scene = synth.make_scene(0, H=17, W=23, rotate=True)
+    rays = cu(orc.frame_setup(scene)['rays'], dev)
+    n = rays.shape[0]
+    need = int(lib.pnrf_sampler_workspace_bytes(n))
+    assert need == (16 + n) * 4 and int(lib.pnrf_sampler_workspace_bytes(-5)) == 0
+    d = torch.empty(n, 8, device=dev); a = torch.empty_like(d); m = torch.empty_like(d)
+    ws = torch.empty(need // 4 + 8, device=dev, dtype=torch.int32)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    call = lambda wsp, nbytes, kappa: lib.pnrf_sampler_fwd_ws(mlps['sampler'].handle, p(rays), n, p(d), p(a), p(m), None, None, None, wsp, nbytes, kappa, None)
+    assert call(p(ws), need - 4, -1.0) == -1 and b'workspace' in lib.pnrf_last_error()
+    assert call(C.c_void_p(ws.data_ptr() + 4), need, -1.0) == -1                                   # not 16-byte aligned
+    assert call(None, need, -1.0) == -1
+    assert call(p(ws), need, float('inf')) == -1 and b'kappa' in lib.pnrf_last_error()
+    assert call(p(ws), need, -1.0) == 0
+    for k in (1, 255, 257):
+        r = rays[:k].contiguous()
+        two = ops.sampler_fwd(mlps['sampler'], r, two_pass=True, want_raw=True)
+        one = ops.sampler_fwd(mlps['sampler'], r, want_raw=True)
+        assert torch.equal(two[1], one[1])                                                         # indices (no ties on these weights)
+        np.testing.assert_allclose(two[0].cpu().numpy(), one[0].cpu().numpy(), rtol=0, atol=2e-3)
+        assert 0 <= int(two[6]) <= k
+    split = ops.PackedMLP(ops.NET_SAMPLER, w['sampler']['W'], w['sampler']['b'], variant='sampler_split')
+    s2 = ops.sampler_fwd(split, rays, two_pass=True, want_raw=True)                                # variant handles run their one kernel
+    s1 = ops.sampler_fwd(split, rays, want_raw=True)
+    assert all(torch.equal(x, y) for x, y in zip(s2[:6], s1[:6]) if x is not None)
