@@ -273,7 +273,13 @@ __device__ __forceinline__ void hgemm_body(const HGemmArgs& a, const int bx, con
     }
     if (use_h) {
 #pragma unroll
-      for (int q = 0; q < QN; ++q) hv[q] = *(const f32x4_t*)hp[q];
+      for (int q = 0; q < QN; ++q) {
+#ifdef PNRF_HG_PROBE_NOH
+        hv[q] = f32x4_t{1.f, 1.f, 1.f, 1.f};                   // timing probe only: what the act'(H) rows cost (results are wrong)
+#else
+        hv[q] = *(const f32x4_t*)hp[q];
+#endif
+      }
     }
     if (use_c) {
 #pragma unroll

@@ -196,3 +196,32 @@ def test_full_frame_rgb_vs_eager_oracle_on_device(dev, seed):
     assert mism == 0
     assert ps > 46.4 and rel < 1e-2 and derr < 2e-2
     assert bool(torch.isfinite(rgbd).all())
+
+
+def test_full_frame_rgb_vs_the_cpu_oracle(dev):
+    """65 536 rays strided over the whole 756 x 1008 frame, rendered by the fused path inside the full-frame call, against the CPU oracle itself (fp32
+    torch on the host — the graph the goldens pin to the reference — not its copy on the device): indices, rgb, depth map."""
+    from pronerf_amd.render import Renderer
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    seed = 0
+    scene = synth.make_scene(seed, H=H, W=W, focal=FOCAL, rotate=True)
+    w = synth.make_weights(seed, 'trained')
+    rend = Renderer(w, max_rays=N, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W)
+    rgbd, idx = rend.render_rays(rays, or_rays, want_idx=True)
+    fr = orc.frame_setup(scene)
+    sel = torch.linspace(0, N - 1, 65536).long()
+    assert torch.equal(rays.cpu()[sel], fr['rays'][sel])                           # same rays on both sides, bit for bit
+    with torch.no_grad():
+        ref = orc.render_rays_infer(w, fr['rays'][sel].contiguous(), fr['or_rays'][sel].contiguous(), fr['images'], fr['proj'])
+    free = (ref['depth_sorted'][:, 1:] - ref['depth_sorted'][:, :-1]).min(1)[0] > TIE
+    got = rgbd.cpu()[sel]
+    mism = int((idx.cpu()[sel][free] != ref['sort_idx'][free]).any(1).sum())
+    ps = orc.psnr(got[free, :3], ref['rgb'][free])
+    rel = float(((got[free, :3].double() - ref['rgb'][free].double()) ** 2).mean().sqrt() / (ref['rgb'][free].double() ** 2).mean().sqrt())
+    derr = float((got[free, 3] - ref['depth'][free]).abs().max())
+    print(f'\n[full frame vs CPU oracle] {int(free.sum())} of 65536 rays outside the tie set: index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
+          f'max depth error {derr:.2e}')
+    assert int((~free).sum()) <= 16 and mism == 0
+    assert ps > 46.4 and rel < 1e-2 and derr < 2e-2
