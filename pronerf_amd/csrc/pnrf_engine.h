@@ -66,8 +66,12 @@ __host__ __device__ constexpr bool queue_fill(int f, int u, int nf) {        // 
 __host__ __device__ constexpr bool queue_refill(int f, int ahead, int nf) {  // after consuming f: load fragment f+ahead?
   return f + ahead < nf && (XSLOT ? true : ((f + ahead) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + ahead < SLOT_FRAGS));
 }
-template <int NW>
+// PD_ slots in flight in a ring of NS_ = PD_ + 1 (the inference kernels: 3 of 4; the trainer's forward chain, whose per-layer stores share
+// vmcnt with the LDS-DMA and have to have completed PD_ - 1 slots after their issue, runs 7 of 8)
+template <int NW, int PD_ = PD, int NS_ = NSLOTS>
 struct WStream {
+  static_assert(NS_ == PD_ + 1 && (NS_ & (NS_ - 1)) == 0, "ring protocol assumes one free slot and a power-of-two ring");
+  static constexpr int RING_SLOTS = NS_;
   static constexpr int LOADS_PER_WAVE = SLOT_FRAGS / NW;
   const char* g;       // packed blob
   char* ring;          // LDS ring base
@@ -109,7 +113,7 @@ struct WStream {
   }
   __device__ __forceinline__ void advance() {
     src_slot = (src_slot + 1 == nslots) ? 0u : src_slot + 1;
-    dst_pos = (dst_pos + 1) & (NSLOTS - 1);
+    dst_pos = (dst_pos + 1) & (NS_ - 1);
   }
   __device__ __forceinline__ void issue() { issue_loads(); advance(); }
   // Refill of the ring position freed by wait_slot(); the layers call it after the first MFMA of every slot, so that the
@@ -121,7 +125,7 @@ struct WStream {
   // Fill the pipeline: PD slots in flight.
   __device__ __forceinline__ void prologue() {
 #pragma unroll
-    for (int i = 0; i < PD; ++i) issue();
+    for (int i = 0; i < PD_; ++i) issue();
   }
   // Called at the boundary between slot q-1 and slot q, by every wave, in the same order.
   //  vmcnt(N): my share of slot q has landed (N = LOADS_PER_WAVE * (PD-1) younger loads may still be in
@@ -132,7 +136,7 @@ struct WStream {
   //  the barrier with an 8-slot ring bought nothing, so reads stay inside their slot.)
   __device__ __forceinline__ void begin() { wait_slot(); issue(); }
   __device__ __forceinline__ void wait_slot() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD - 1 - XSLOT)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_WAVE * (PD_ - 1 - XSLOT)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
@@ -390,13 +394,13 @@ template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + 
 // which packs the pair)
 constexpr int H16_PIECES = PNRF_H16_PIECES;
 constexpr float H16_LO_SCALE = 2048.f;
-template <int KS, int NTP, int POS0, class ST, class BFn, class Epi1, class Pre1>
+template <int KS, int NTP, int POS0, int QUEUE = PNRF_H16_AHEAD, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1,
                                             f32x4 (&last_main)[2], f32x4 (&last_cross)[2]) {
   constexpr int NF = NTP * KS * 4;
-  constexpr int AHEAD = NF < PNRF_H16_AHEAD ? NF : PNRF_H16_AHEAD;
+  constexpr int AHEAD = NF < QUEUE ? NF : QUEUE;
   auto frag_ptr = [&](int g) {
-    return (const f16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+    return (const f16x8*)(ringlane + ((POS0 + g / SLOT_FRAGS) % ST::RING_SLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
   f32x4 pm[2], pc_[2];
   f16x8 aq[AHEAD];

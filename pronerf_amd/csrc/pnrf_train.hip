@@ -36,6 +36,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 }  // namespace
 namespace {
 #include "pnrf_hgemm.h"
+#include "pnrf_tchain.h"
 
 // ------------------------------------------------------------------------------------------ layer products with fused epilogues
 // The forward product Y = act(X W^T + b) and the input gradient dX = (dZ W [+ dX]) * act'(H_prev) of a Linear layer as ONE kernel each, on
@@ -1052,8 +1053,10 @@ struct pnrf_trainer {
   SplitArgs split;
   bool planes_stale = true;                      // parameters changed since the planes were last written
   bool use_f16 = true;                           // split-fp16 layer products (default) or the exact-fp32 MFMA kernels throughout
-  bool nerf_chains = true;                       // the fine net's 256 -> 256 forward layers as two layer chains (hgemm_wchain_kernel) from 8192 rows on; false
-                                                 // (pnrf_trainer_set_products kind 2): one product launch per layer — bit-identical either way
+  _Float16* tc_stream = nullptr;                 // the fine net's pts0 .. feature weights as the fused-MLP engine's fragment stream (pnrf_tchain.h)
+  TChainPackArgs tc_pack;
+  int nerf_fwd = 0;                              // fine net's forward from 8192 rows on: 0 one engine launch (tchain_fwd_kernel), 3 two 64-row layer chains
+                                                 // (hgemm_wchain_kernel), 2 one product launch per layer (pnrf_trainer_set_products)
   float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
   size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
   DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
@@ -1493,6 +1496,14 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     PNRF_HIP(hipMemset(t->w_gapped, 0, (size_t)g.out * g.in_x() * 4));
     t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam; t->split.gapped = t->w_gapped;
     t->planes_stale = true;
+    T_ALLOC(t->tc_stream, (size_t)TC_NFRAGS * FRAG_BYTES / sizeof(_Float16));
+    memset(&t->tc_pack, 0, sizeof(t->tc_pack));
+    t->tc_pack.P = t->P; t->tc_pack.stream = t->tc_stream;
+    for (int l = 0; l < TC_NL; ++l) {
+      const TLin& tl = t->L[l < 8 ? L_N + l : L_FEAT];
+      PNRF_REQUIRE(tl.out == 256 && tl.in == (l == 0 ? 63 : l == 5 ? 319 : 256), PNRF_E_SHAPE, "pnrf_trainer: fine-net layer %d is %d -> %d", l, tl.in, tl.out);
+      t->tc_pack.w[l] = tl.w; t->tc_pack.in_dim[l] = tl.in;
+    }
     T_ALLOC(t->amax, N_AMAX * HG_SLOT);
     PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * HG_SLOT * 4));
   }
@@ -1661,7 +1672,24 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   // not far enough ahead of an L2 under this load, and the 16 x 64-byte stores of the register epilogue cost 23 % (no-store probe build:
   // 411 vs 535 us per launch).  A first version on hgemm_rchain_kernel<4> (LDS round trip in the epilogue, one workgroup per CU) was 2 % slower.
   bool chained = false;
-  if (t->use_f16 && t->nerf_chains && R >= 8192) {
+  if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192) {
+    // pts0 .. pts7 and feature_linear in one launch on the fused-MLP engine: 128 rows per workgroup stay in registers through the nine layers
+    TChainArgs c = {};
+    c.blob = t->tc_stream;
+    float* outs[TC_NL] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H, t->n_a5, t->n_a6, t->n_a7, t->n_cv};
+    for (int l = 0; l < TC_NL; ++l) {
+      c.bias[l] = t->P + t->L[l < 8 ? L_N + l : L_FEAT].b;
+      c.out[l] = outs[l]; c.ldo[l] = l == 4 ? LD_C5 : (l == 8 ? LD_CV : 256);
+    }
+    c.X0 = t->n_c5; c.ldx0 = LD_C5; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
+    const size_t lds = TC_LDS_BYTES;
+    PNRF_HIP(hipFuncSetAttribute((const void*)tchain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ncu = trainer_num_cu();
+    hipLaunchKernelGGL(tchain_fwd_kernel, dim3((unsigned)(c.nbatch < ncu ? c.nbatch : ncu)), dim3(512), lds, s, c);
+    PNRF_LAUNCH_CHECK();
+    chained = true;
+  }
+  if (!chained && t->use_f16 && t->nerf_fwd == 3 && R >= 8192) {
     // pts0 and pts5 (63 / 320 inputs) as products of their own; the 256 -> 256 layers behind each as a chain
     RChainArgs ca = {}, cb = {};
     HGemmArgs h0{}, h5{};
@@ -1877,6 +1905,8 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
   if (t->planes_stale) {
     hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, s, t->split);
     PNRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NFRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
+    PNRF_LAUNCH_CHECK();
     t->planes_stale = false;
   }
   StageArgs sa = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
@@ -1946,10 +1976,11 @@ extern "C" int pnrf_train_explore_fwd_bwd(pnrf_trainer_t* t, const pnrf_train_ba
 // How the layer products are computed.  0 (default): split-fp16 MFMA (pnrf_hgemm.h: fp32-grade, 22 significand bits per operand, fp32
 // accumulation) wherever the shape fits; 1: exact-fp32 MFMA everywhere.
 extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
-  PNRF_REQUIRE(t && (kind == 0 || kind == 1 || kind == 2), PNRF_E_ARG, "pnrf_trainer_set_products: kind 0 (split fp16), 1 (fp32) or 2 (split fp16, one launch per layer)");
+  PNRF_REQUIRE(t && kind >= 0 && kind <= 3, PNRF_E_ARG,
+               "pnrf_trainer_set_products: kind 0 (split fp16), 1 (fp32), 2 (split fp16, one launch per layer) or 3 (split fp16, 64-row layer chains)");
   drop_graphs(t);
   t->use_f16 = kind != 1;
-  t->nerf_chains = kind == 0;
+  t->nerf_fwd = kind == 1 ? 0 : kind;
   if (t->use_f16) t->planes_stale = true;
   return 0;
 }

@@ -531,12 +531,14 @@ class Trainer:
         check(_lib.load().pnrf_trainer_set_graph(self.handle, int(bool(enable))), 'pnrf_trainer_set_graph')
 
     def set_products(self, kind):
-        """'f16x2' (default): split-fp16 MFMA layer products (fp32-grade); 'f32': exact-fp32 MFMA products; 'f16x2_unchained': split fp16 with
-        one launch per layer of the fine net's forward instead of its layer chains (bit-identical to 'f16x2'; pnrf_trainer_set_products)."""
-        if kind not in ('f16x2', 'f32', 'f16x2_unchained'):
+        """'f16x2' (default): split-fp16 MFMA layer products (fp32-grade), the fine net's forward as one launch on the fused-MLP engine; 'f32':
+        exact-fp32 MFMA products; 'f16x2_unchained': split fp16 with one launch per layer of the fine net's forward; 'f16x2_wchain': with its
+        256 -> 256 layers as two 64-row layer chains (bit-identical to 'f16x2_unchained'; pnrf_trainer_set_products)."""
+        kinds = {'f16x2': 0, 'f32': 1, 'f16x2_unchained': 2, 'f16x2_wchain': 3}
+        if kind not in kinds:
             raise PnrfError(f"Trainer.set_products: kind must be 'f16x2' (split-fp16 MFMA products, default) or 'f32' (exact-fp32 MFMA products), got {kind!r} "
                             '(the training drivers read it from PNRF_TRAIN_PRODUCTS)')
-        k = {'f16x2': 0, 'f32': 1, 'f16x2_unchained': 2}[kind]
+        k = kinds[kind]
         check(_lib.load().pnrf_trainer_set_products(self.handle, k), 'pnrf_trainer_set_products')
 
     def set_step(self, step, step_nerf=0):
