@@ -394,7 +394,7 @@ template <int KS4, int NT> constexpr int layer_slots_f32() { return (KS4 * NT + 
 // which packs the pair)
 constexpr int H16_PIECES = PNRF_H16_PIECES;
 constexpr float H16_LO_SCALE = 2048.f;
-template <int KS, int NTP, int POS0, int QUEUE = PNRF_H16_AHEAD, class ST, class BFn, class Epi1, class Pre1>
+template <int KS, int NTP, int POS0, int QUEUE = PNRF_H16_AHEAD, bool BIAS = true, class ST, class BFn, class Epi1, class Pre1>
 __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1,
                                             f32x4 (&last_main)[2], f32x4 (&last_cross)[2]) {
   constexpr int NF = NTP * KS * 4;
@@ -404,13 +404,14 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
   };
   f32x4 pm[2], pc_[2];
   f16x8 aq[AHEAD];
-  f32x4 nbias[2] = {*(const f32x4*)biaslane, *(const f32x4*)(biaslane + 16)};     // bias of the next tile pair, one pair ahead
+  f32x4 nbias[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // bias of the next tile pair, one pair ahead (BIAS = false: none —
+  if constexpr (BIAS) { nbias[0] = *(const f32x4*)biaslane; nbias[1] = *(const f32x4*)(biaslane + 16); }   // the trainer's input-gradient products)
 #pragma unroll
   for (int tp = 0; tp < NTP; ++tp) {
     f32x4 mn[2], cr[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) { mn[t] = nbias[t]; cr[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if (tp + 1 < NTP) {
+    if (BIAS && tp + 1 < NTP) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) nbias[t] = *(const f32x4*)(biaslane + (2 * (tp + 1) + t) * 16);
     }

@@ -94,7 +94,11 @@ struct TChainArgs {
   const void* blob;                  // TC_NSLOTS slots
   const float* bias[TC_NL];
   const float* X0; int ldx0;         // [n][ldx0] fp32, 16-byte aligned rows: columns 0 .. 63 = position embedding (63) + one zero
-  float* out[TC_NL]; int ldo[TC_NL]; // saved activations [n][ldo], 16-byte aligned rows
+  float* out[TC_NL]; int ldo[TC_NL]; // saved activations [n rounded up to TC_ROWS][ldo], 16-byte aligned rows: whole batches are written, no row predicate —
+                                     // a predicated store is a branch, and eight of them in a row serialise the flush of a staged group
+  uint2* mask;                       // [batch][wave][layer][lane]: two words (tile pairs 0-3 | 4-7), bit 31 - (8 (tp & 3) + 4 t + r) = (activation of the lane's row, feature 32 tp + 16 t
+                                     // + 4 g + r) > 0 — what
+                                     // tchain_bwd_kernel needs of the saved activations (32 bytes per row and layer instead of 1 KiB)
   int64_t n; int nbatch;
 };
 
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     const int64_t row = (int64_t)batch * TC_ROWS + wave * 16 + col;
     const bool valid = row < a.n;
     const int64_t rr = valid ? row : a.n - 1;
-    f16x8 Gh[2], Gl[2];                    // the 64 input columns: k-step ks, group g = columns 32 ks + 8 g .. + 7
-    {
+    f16x8 Gh[2], Gl[2];                    // the 64 input columns: k-step ks, group g = columns 32 ks + 8 g .. + 7.  Fetched for pts0 and again
+    auto load_inputs = [&]() {             // for the skip layer: 16 registers that pts1 .. pts4 do not have to carry
       const float4* x = (const float4*)(a.X0 + rr * a.ldx0 + 8 * g);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
           Gl[ks][j] = (_Float16)((v[j] - (float)h) * H16_LO_SCALE);
         }
       }
-    }
+    };
+    load_inputs();
     f16x8 Xh[NTP], Xl[NTP], Yh[NTP], Yl[NTP];      // activations ping-pong between X and Y: per 32-feature k-step one hi and one lo plane
     f32x4 pm[2], pc[2];                            // pending (deferred) tile pair of the previous layer
     // Saved activations leave through a per-wave staging tile in LDS: four tile pairs (128 features) of the wave's 16 rows are collected, then
@@ -142,17 +147,27 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     float* const stage_w = stage + col * TC_STG_ROW + 4 * g;                       // this lane's accumulator tiles go here (+ 32 (tp & 3) + 16 t)
     const float* const stage_r = stage + (lane >> 5) * TC_STG_ROW + 4 * (lane & 31);   // ... and it reads rows 2 i + (lane >> 5), 16 bytes at 4 (lane & 31)
     const int64_t row_f = (int64_t)batch * TC_ROWS + wave * 16 + (lane >> 5);      // first of the rows this lane writes out
-    const int rows_left = (int)(a.n - row_f < 16 ? a.n - row_f : 16);              // rows 2 i with 2 i < rows_left exist
-    float* o_prev = nullptr;                       // where the pending tile pair's rows go (flush base of its layer) ...
+    float* o_prev = a.out[0];                      // where the pending tile pair's rows go (its layer's buffer; + this lane's 32-bit byte offset) ...
     int ld_prev = 0;
+    uint32_t off_prev = 0;
+    uint2* const m_lane = a.mask + ((int64_t)batch * 8 + wave) * TC_NL * 64 + lane;      // ReLU masks of this lane: + 64 l
+    int l_prev = 0;                                // ... and its layer (for the mask)
+    uint32_t mb0 = 0, mb1 = 0;                     // mask bits of the layer whose pieces are running (tile pairs 0-3 | 4-7)
 
     // piece pcx = accumulator register pcx & 3 of tile pcx >> 2 of a tile pair: bias is in the accumulator; combine, activate (floor = 0: ReLU,
     // -inf: none), park the value in the accumulator register; the odd piece packs the pair into the next layer's planes (as sampler_h16_kernel),
     // the last piece of a tile stages its four features — registers 0 .. 3 of lane (column, g) are features 16 T + 4 g .. + 3 of the row
-    auto piece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float floor_, float* optr, int ld) {
+    auto piece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float floor_, float* optr, uint32_t ooff, int ld, int lm) {
       const int t = pcx >> 2, r = pcx & 3, p = r >> 1;
       const float v = fmaxf(fmaf(cr[t][r], INV, mn[t][r]), floor_);
       mn[t][r] = v;
+      // mask word <- 2 word + (v > 0): the compare's carry goes in through v_addc.  32 pieces fill a word: piece (tp, pcx) is bit 31 - (8 (tp & 3) + pcx)
+      if (tp < 4) asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mb0) : "v"(v) : "vcc");
+      else asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mb1) : "v"(v) : "vcc");
+      if (tp == NTP - 1 && pcx == 7) {               // the layer's last activation of this lane
+        *(uint2*)(m_lane + 64 * lm) = make_uint2(mb0, mb1);
+        mb0 = 0; mb1 = 0;
+      }
       if (!(r & 1)) return;
       const float v0 = mn[t][r - 1], v1 = v;
       int hi, lo;
@@ -170,11 +185,9 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
         for (int i = 0; i < 8; ++i) {
           const f32x4 w = *(const f32x4*)(stage_r + 2 * i * TC_STG_ROW);
 #ifdef PNRF_TC_PROBE_NOSTORE
-          if (2 * i < rows_left && w[0] == 123.456f)
-#else
-          if (2 * i < rows_left)
+          if (w[0] == 123.456f)
 #endif
-            tc_store(optr + (int64_t)(2 * i) * ld + 32 * (tp & ~3), w);
+            tc_store((float*)((char*)(optr + ((2 * i) * ld + 32 * (tp & ~3))) + ooff), w);       // uniform pointer + this lane's 32-bit offset
         }
       }
     };
@@ -182,9 +195,10 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     auto layer = [&](auto ksc, auto posc, f16x8(&ih)[NTP], f16x8(&il)[NTP], f16x8(&oh)[NTP], f16x8(&ol)[NTP], int l, float floor_prev, float floor_) {
       constexpr int KS = decltype(ksc)::value;
       f32x4 nm[2], nc[2];
-      const int ld_cur = a.ldo[l], ld_pre = ld_prev;
-      float* const o_cur = a.out[l] + row_f * ld_cur + 4 * (lane & 31);
+      const int ld_cur = a.ldo[l], ld_pre = ld_prev, l_pre = l_prev;
+      float* const o_cur = a.out[l];
       float* const o_pre = o_prev;
+      const uint32_t off_cur = ((uint32_t)row_f * (uint32_t)ld_cur + 4u * (lane & 31)) * 4u, off_pre = off_prev;   // < 4 GiB: checked by the launcher
       layer_h16x2<KS, NTP, decltype(posc)::value, TC_QUEUE>(
           st, ringlane, biaslane + l * W_HID,
           [&](int ks, int pl) {
@@ -192,11 +206,11 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
             else if constexpr (KS == 10) return ks < 2 ? (pl == 0 ? Gh[ks & 1] : Gl[ks & 1]) : (pl == 0 ? ih[(ks - 2) & 7] : il[(ks - 2) & 7]);
             else return pl == 0 ? ih[ks] : il[ks];
           },
-          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { piece(oh, ol, tp, pcx, mn, cr, floor_, o_cur, ld_cur); },
-          [&](int pcx) { if constexpr (KS != 2) piece(ih, il, NTP - 1, pcx, pm, pc, floor_prev, o_pre, ld_pre); }, nm, nc);
+          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { piece(oh, ol, tp, pcx, mn, cr, floor_, o_cur, off_cur, ld_cur, l); },
+          [&](int pcx) { if constexpr (KS != 2) piece(ih, il, NTP - 1, pcx, pm, pc, floor_prev, o_pre, off_pre, ld_pre, l_pre); }, nm, nc);
 #pragma unroll
       for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
-      o_prev = o_cur; ld_prev = ld_cur;
+      o_prev = o_cur; ld_prev = ld_cur; off_prev = off_cur; l_prev = l;
     };
     const float NEG = -__builtin_inff();
 #define POS(l) std::integral_constant<int, tc_pos(l)>{}
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
       layer(K8{}, POS(1), Xh, Xl, Yh, Yl, 2 * p + 1, 0.f, 0.f);
       layer(K8{}, POS(2), Yh, Yl, Xh, Xl, 2 * p + 2, 0.f, 0.f);
     }
+    load_inputs();
     layer(std::integral_constant<int, 10>{}, POS(5), Xh, Xl, Yh, Yl, 5, 0.f, 0.f);                      // the skip layer: [input columns | pts4's planes]
     layer(K8{}, POS(6), Yh, Yl, Xh, Xl, 6, 0.f, 0.f);
     layer(K8{}, POS(7), Xh, Xl, Yh, Yl, 7, 0.f, 0.f);
@@ -225,8 +240,319 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
 #endif
     // the last layer's last tile pair (its planes go to Y, which nobody reads)
 #pragma unroll
-    for (int pcx = 0; pcx < 8; ++pcx) piece(Yh, Yl, NTP - 1, pcx, pm, pc, NEG, o_prev, ld_prev);
+    for (int pcx = 0; pcx < 8; ++pcx) piece(Yh, Yl, NTP - 1, pcx, pm, pc, NEG, o_prev, off_prev, ld_prev, l_prev);
   }
 #undef POS
+  st.drain();
+}
+
+// ------------------------------------------------------------------------------------------ backward: the input-gradient chain
+// dZ_k = (dZ_{k+1} W_{k+1}) * relu'(a_k) from the feature / alpha gradients down to pts0, one launch on the same engine: a workgroup's 128 rows of
+// gradient stay in registers (MFMA B operand, split fp16), the TRANSPOSED weights stream through LDS, every dZ_k is written once (fp32, for the
+// weight-gradient products that follow as launches of their own) and nothing of the saved activations is read but their sign bits
+// (tchain_fwd_kernel's masks).  Stream layers (fragments as in the forward stream):
+//   s0  [feature_linear^T ; alpha_linear^T]  9 k-steps (256 feature gradients + the alpha gradient) -> dZ7      s4  pts4^T -> dZ3
+//   s1  pts7^T -> dZ6                                                                                          s5  pts3^T -> dZ2
+//   s2  pts6^T -> dZ5                                                                                          s6  pts2^T -> dZ1
+//   s3  pts5^T: 8 tile pairs of hidden columns -> dZ4, then 2 pairs of embedding columns -> d embedding         s7  pts1^T -> dZ0
+//                                                                                                               s8  pts0^T: 2 pairs -> d embedding
+// Gradient range.  Gradients are 1e-9 .. 1e-3; the planes carry them times a power of two PER ROW.  The first comes from the row's own maximum
+// (max |x| s in [2^13, 2^14)); from layer to layer the accumulators hold c' = (a s) W and |c'_j| <= |a s|_2 |W_:j|_2 <= |a s|_2 C with C^2 the
+// layer's largest column sum of squares (tchain_norms_kernel), so t = the power of two with |a s|_2 C t < 2^14 is known — before the first
+// output is split — from the sum of squares of the row's planes, which the previous layer's epilogue accumulated; the next planes are c' t,
+// never above 2^14.  All factors are powers of two: undone exactly in the epilogue that stores dZ.
+constexpr int TB_NS = 9;
+__host__ __device__ constexpr int tb_ks(int s) { return s == 0 ? 9 : 8; }
+__host__ __device__ constexpr int tb_ntp(int s) { return s == 3 ? 10 : (s == 8 ? 2 : 8); }
+__host__ __device__ constexpr int tb_frags(int s) { return tb_ntp(s) * tb_ks(s) * 4; }
+__host__ __device__ constexpr int tb_frag0(int s) { int f = 0; for (int i = 0; i < s; ++i) f += tb_frags(i); return f; }
+constexpr int TB_NFRAGS = tb_frag0(TB_NS);                                         // 2208
+constexpr int TB_PAD_SLOTS = (NSLOTS - (TB_NFRAGS / SLOT_FRAGS) % NSLOTS) % NSLOTS;  // 2: a batch is a whole number of ring revolutions
+constexpr int TB_NSLOTS = TB_NFRAGS / SLOT_FRAGS + TB_PAD_SLOTS;                   // 140
+__host__ __device__ constexpr int tb_pos(int s) { return (tb_frag0(s) / SLOT_FRAGS) % NSLOTS; }
+static_assert(TB_NFRAGS % SLOT_FRAGS == 0 && tb_frags(0) % SLOT_FRAGS != 1, "whole slots");
+static_assert(tb_frags(0) % SLOT_FRAGS == 0 && tb_frags(3) % SLOT_FRAGS == 0 && tb_frags(8) % SLOT_FRAGS == 0, "whole slots per layer");
+constexpr int TB_LDS_BYTES = TC_RING_BYTES + TC_STG_BYTES + 8 * 16 * 4;
+
+struct TChainBwdPackArgs {
+  const float* P;
+  size_t w[TC_NL];                   // weights of pts0 .. pts7, feature (as TChainPackArgs)
+  size_t w_alpha;                    // alpha_linear [1][256]
+  _Float16* stream;                  // TB_NSLOTS slots
+  float* cmax;                       // [TB_NS] largest column sum of squares per stream layer (of the columns whose outputs are split again)
+};
+// which Linear a stream layer transposes: index into TChainPackArgs::w order (pts0 .. pts7 = 0 .. 7, feature = 8)
+__host__ __device__ constexpr int tb_linear(int s) { return s == 0 ? 8 : 8 - s; }
+// element (k, j) of stream layer s: weight that output gradient k contributes to input gradient j (0 where the layout pads)
+__device__ __forceinline__ float tb_weight(const TChainBwdPackArgs& a, int s, int k, int j) {
+  if (s == 0) return k < 256 ? a.P[a.w[8] + (size_t)k * 256 + j] : (k == 256 ? a.P[a.w_alpha + j] : 0.f);
+  const int L = tb_linear(s);
+  if (L == 5) {                                              // [256][319]: embedding columns 0 .. 62, hidden columns 63 ..
+    if (j < 256) return a.P[a.w[5] + (size_t)k * 319 + 63 + j];
+    return j - 256 < 63 ? a.P[a.w[5] + (size_t)k * 319 + (j - 256)] : 0.f;
+  }
+  if (L == 0) return j < 63 ? a.P[a.w[0] + (size_t)k * 63 + j] : 0.f;
+  return a.P[a.w[L] + (size_t)k * 256 + j];
+}
+__global__ void tchain_pack_bwd_kernel(TChainBwdPackArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < TB_NS) a.cmax[p] = 0.f;
+  if (p >= TB_NSLOTS * SLOT_FRAGS * 64) return;
+  const int F = p >> 6, lane = p & 63;
+  f16x8 v;
+  if (F >= TB_NFRAGS) {                                      // the padding slots
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+    *(f16x8*)(a.stream + (size_t)p * 8) = v;
+    return;
+  }
+  int s = 0;
+  while (s + 1 < TB_NS && F >= tb_frag0(s + 1)) ++s;
+  const int f = F - tb_frag0(s), pl = f & 1, t = (f >> 1) & 1, KS = tb_ks(s), ks = (f >> 2) % KS, tp = (f >> 2) / KS;
+  const int out = 32 * tp + 16 * t + (lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = s == 0 ? 32 * ks + 8 * g + j : hidden_feat_h16(ks, g, j);      // s0 reads its gradients from HBM in their natural order
+    const float x = tb_weight(a, s, k, out);
+    const _Float16 h = (_Float16)x;
+    v[j] = pl ? (_Float16)((x - (float)h) * H16_LO_SCALE) : h;
+  }
+  *(f16x8*)(a.stream + (size_t)p * 8) = v;
+}
+// cmax[s] = max over the re-split output columns j of sum_k w(k, j)^2.  Block (s, b): columns 16 b .. 16 b + 15, 16 partial sums each; cmax is
+// zeroed by tchain_pack_bwd_kernel (the launch before this one)
+__global__ void tchain_norms_kernel(TChainBwdPackArgs a) {
+  __shared__ float red[256];
+  const int s = blockIdx.x, j = 16 * blockIdx.y + (threadIdx.x & 15), part = threadIdx.x >> 4;
+  float acc = 0.f;
+  const int nk = s == 0 ? 257 : 256;
+  if (s != 8)
+    for (int k = part; k < nk; k += 16) { const float w = tb_weight(a, s, k, j); acc = fmaf(w, w, acc); }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 16; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  for (int o = 8; o >= 1; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) atomicMax((unsigned int*)a.cmax + s, __float_as_uint(red[0]));
+}
+
+struct TChainBwdArgs {
+  const void* blob;                  // TB_NSLOTS slots
+  const float* dF; int lddf;         // d feature: columns 0 .. 255 of [n][lddf], 16-byte aligned rows
+  const float* dA; int ldda;         // d alpha: dA[row * ldda]
+  const uint2* mask;                 // tchain_fwd_kernel's ReLU masks (same batch / wave / lane geometry)
+  const float* cmax;                 // [TB_NS]
+  float* dz[8];                      // dZ_k [n][256], k = 0 .. 7
+  float* slot[9];                    // max |dZ_k| slots (HG_SLOT floats each; pnrf_hgemm.h), [8] = scratch
+  float* dg; int lddg;               // d embedding from the skip layer: columns 0 .. 63 of [n][lddg]
+  float* de0;                        // d embedding from pts0: [n][64]       (every output buffer: n rounded up to TC_ROWS rows, as in the forward pass)
+  int64_t n; int nbatch;
+};
+
+__global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
+  constexpr int NW = 8, NTP = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, g = lane >> 4;
+  WStream<NW> st;
+  st.init(a.blob, TB_NSLOTS, smem);
+  st.prologue();
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+  const char* ringlane = smem + lane * 16;
+  constexpr float INV = 1.f / H16_LO_SCALE;
+  float* const stage = (float*)(smem + TC_RING_BYTES) + wave * (16 * TC_STG_ROW);
+  float* const stage_w = stage + col * TC_STG_ROW + 4 * g;
+  const float* const stage_r = stage + (lane >> 5) * TC_STG_ROW + 4 * (lane & 31);        // 128-feature groups: rows 2 i + (lane >> 5)
+  float* const wave_max = (float*)(smem + TC_RING_BYTES + TC_STG_BYTES) + wave * 16;     // [wave][9]: max |dZ_k| of the wave's rows (k = 8: scratch)
+  if (lane < 9) wave_max[lane] = 0.f;
+  auto pow2 = [](int k) { return __int_as_float((127 + (k < -120 ? -120 : (k > 120 ? 120 : k))) << 23); };
+
+  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    const int64_t row = (int64_t)batch * TC_ROWS + wave * 16 + col;
+    const int64_t rr = row < a.n ? row : a.n - 1;
+    const int64_t row_f = (int64_t)batch * TC_ROWS + wave * 16 + (lane >> 5);
+    const uint2* const m_lane = a.mask + ((int64_t)batch * 8 + wave) * TC_NL * 64 + lane;
+    const uint32_t off_z = ((uint32_t)row_f * 256u + 4u * (lane & 31)) * 4u;               // this lane's byte offset in a [n][256] buffer
+
+    f16x8 Xh[NTP], Xl[NTP], Yh[NTP], Yl[NTP], Ah, Al;        // gradient planes; Ah / Al: s0's ninth k-step (the alpha gradient)
+    f32x4 pm[2], pc[2];
+    // per-row scale bookkeeping (all lanes of a column agree): planes = true value / inv
+    float inv_in = 1.f, inv_cur, tscale = 1.f, sumsq, amax = 0.f;
+    uint2 mk = make_uint2(0, 0), mk_next;
+    int slot_prev = 8;                             // which buffer's maximum is being accumulated (8: s0's inputs, nobody's business)
+    {   // s0's inputs: 256 feature gradients + the alpha gradient of the row, scaled by the row's own maximum
+      const float4* x = (const float4*)(a.dF + rr * a.lddf + 8 * g);
+      float v[NTP][8];
+      float m = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NTP; ++ks) {
+        const float4 lo = x[8 * ks], hi = x[8 * ks + 1];
+        v[ks][0] = lo.x; v[ks][1] = lo.y; v[ks][2] = lo.z; v[ks][3] = lo.w; v[ks][4] = hi.x; v[ks][5] = hi.y; v[ks][6] = hi.z; v[ks][7] = hi.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[ks][j]));
+      }
+      const float da = a.dA[rr * a.ldda];
+      m = fmaxf(m, fabsf(da));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), 0x401F)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(m))));
+      const int e = (__float_as_int(m) >> 23) - 127;             // floor(log2 m) for normal m
+      const int k = m > 1e-37f && m < 1e37f ? 13 - e : 0;
+      const float s0 = pow2(k);
+      inv_cur = pow2(-k);
+      sumsq = 0.f;
+      auto split = [&](const float (&u)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xs = u[j] * s0;
+          const _Float16 h = (_Float16)xs;
+          hi[j] = h; lo[j] = (_Float16)((xs - (float)h) * H16_LO_SCALE);
+          sumsq = fmaf(xs, xs, sumsq);
+        }
+      };
+#pragma unroll
+      for (int ks = 0; ks < NTP; ++ks) split(v[ks], Yh[ks], Yl[ks]);
+      const float z = 0.f;
+      const float u[8] = {g == 0 ? da : z, z, z, z, z, z, z, z};
+      split(u, Ah, Al);
+    }
+
+    // a piece of a layer whose outputs are split again: scale, ReLU mask, statistics, planes, staged store of the true value
+    auto bpiece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float ts, float inv_o, uint2 mw, float* optr) {
+      const int t = pcx >> 2, r = pcx & 3, p = r >> 1;
+      float xv = fmaf(cr[t][r], INV, mn[t][r]) * ts;
+      const int sel = __builtin_amdgcn_sbfe((int)(tp < 4 ? mw.x : mw.y), 31 - (8 * (tp & 3) + pcx), 1);       // 0 or -1
+      xv = __int_as_float(__float_as_int(xv) & sel);
+      sumsq = fmaf(xv, xv, sumsq);
+      amax = fmaxf(amax, fabsf(xv));
+      mn[t][r] = xv;
+      if (!(r & 1)) return;
+      const float v0 = mn[t][r - 1], v1 = xv;
+      int hi, lo;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+      const float s0 = v0 * H16_LO_SCALE, s1 = v1 * H16_LO_SCALE, sc = H16_LO_SCALE;
+      asm("v_fma_mixlo_f16 %0, -%1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(sc), "v"(s0));
+      asm("v_fma_mixhi_f16 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(sc), "v"(s1));
+      tc_i32x4 wh = __builtin_bit_cast(tc_i32x4, dh[tp]), wl = __builtin_bit_cast(tc_i32x4, dl[tp]);
+      wh[2 * t + p] = hi; wl[2 * t + p] = lo;
+      dh[tp] = __builtin_bit_cast(f16x8, wh); dl[tp] = __builtin_bit_cast(f16x8, wl);
+      if (r != 3) return;
+      *(f32x4*)(stage_w + 32 * (tp & 3) + 16 * t) = mn[t] * inv_o;
+      if (t == 1 && (tp & 3) == 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 w = *(const f32x4*)(stage_r + 2 * i * TC_STG_ROW);
+          tc_store((float*)((char*)(optr + ((2 * i) * 256 + 32 * (tp & ~3))) + off_z), w);
+        }
+      }
+    };
+    // a piece of a store-only tile pair (the embedding gradients): pair index q = 0, 1 of a 64-column group
+    auto spiece = [&](int q, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float inv_src, float* optr, int ld) {
+      const int t = pcx >> 2, r = pcx & 3;
+      mn[t][r] = fmaf(cr[t][r], INV, mn[t][r]) * inv_src;
+      if (r != 3) return;
+      *(f32x4*)(stage_w + 32 * q + 16 * t) = mn[t];
+      if (t == 1 && q == 1) {                      // 64 columns of 16 rows: a store instruction = 4 rows x 256 B (rows 4 i + (lane >> 4))
+        const int64_t row_f4 = (int64_t)batch * TC_ROWS + wave * 16 + (lane >> 4);
+        const float* const stage_r4 = stage + (lane >> 4) * TC_STG_ROW + 4 * (lane & 15);
+        const uint32_t off4 = ((uint32_t)row_f4 * (uint32_t)ld + 4u * (lane & 15)) * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 w = *(const f32x4*)(stage_r4 + 4 * i * TC_STG_ROW);
+          tc_store((float*)((char*)(optr + (int64_t)(4 * i) * ld) + off4), w);
+        }
+      }
+    };
+    // at a layer's first own piece: the previous outputs (this layer's inputs) are complete.  Their maximum goes to its slot, their sum of
+    // squares fixes this layer's scale, the next mask takes over.
+    auto switch_ctx = [&](int s, int slot_now) {
+      float n2 = sumsq;
+      n2 += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(n2), 0x401F));                       // lane ^ 16 (bit-mask mode: and 0x1f, xor 0x10)
+      n2 += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(n2)));           // lane ^ 32
+      atomicMax((unsigned int*)wave_max + slot_prev, __float_as_uint(amax * inv_cur));                      // ds_max_u32: non-negative floats order like their bits
+      slot_prev = slot_now;
+      inv_in = inv_cur;
+      const float b2 = n2 * a.cmax[s];
+      const int e = (__float_as_int(b2) >> 23) - 127;
+      const int k = b2 > 1e-37f && b2 < 1e37f ? 14 - ((e + 2) >> 1) : 0;
+      tscale = pow2(k);
+      inv_cur = inv_in * pow2(-k);
+      sumsq = 0.f; amax = 0.f;
+      mk = mk_next;
+    };
+    // one layer whose outputs are split again.  SP: its pending predecessor pair is a store-only pair (after s3)
+    auto layer = [&](auto ksc, auto posc, auto spc, f16x8(&ih)[NTP], f16x8(&il)[NTP], f16x8(&oh)[NTP], f16x8(&ol)[NTP], int s, int k) {
+      constexpr int KS = decltype(ksc)::value;
+      constexpr bool SP = decltype(spc)::value;
+      f32x4 nm[2], nc[2];
+      mk_next = m_lane[64 * k];
+      float* const o_cur = a.dz[k];
+      float* const o_pre = a.dz[k + 1 < 8 ? k + 1 : 7];
+      const float ts_pre = tscale, inv_pre = inv_cur;
+      const uint2 mk_pre = mk;
+      layer_h16x2<KS, NTP, decltype(posc)::value, TC_QUEUE, false>(
+          st, ringlane, (const float*)nullptr,
+          [&](int ks, int pl) {
+            if constexpr (KS == 9) return ks < 8 ? (pl == 0 ? ih[ks & 7] : il[ks & 7]) : (pl == 0 ? Ah : Al);
+            else return pl == 0 ? ih[ks] : il[ks];
+          },
+          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
+            if (tp == 0 && pcx == 0) switch_ctx(s, k);
+            bpiece(oh, ol, tp, pcx, mn, cr, tscale, inv_cur, mk, o_cur);
+          },
+          [&](int pcx) {
+            if constexpr (KS == 9) return;
+            else if constexpr (SP) spiece(1, pcx, pm, pc, inv_in, a.dg, a.lddg);
+            else bpiece(ih, il, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, o_pre);
+          }, nm, nc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
+    };
+    using K8 = std::integral_constant<int, 8>;
+    using NoSp = std::false_type;
+#define TBPOS(s) std::integral_constant<int, tb_pos(s)>{}
+    layer(std::integral_constant<int, 9>{}, TBPOS(0), NoSp{}, Yh, Yl, Xh, Xl, 0, 7);          // [feature ; alpha]^T : Y (+ A) -> X = dZ7
+    layer(K8{}, TBPOS(1), NoSp{}, Xh, Xl, Yh, Yl, 1, 6);                                      // pts7^T -> dZ6
+    layer(K8{}, TBPOS(2), NoSp{}, Yh, Yl, Xh, Xl, 2, 5);                                      // pts6^T -> dZ5
+    {   // s3 = pts5^T: tile pairs 0 .. 7 the hidden columns -> Y = dZ4, pairs 8, 9 the embedding columns -> stored only
+      f32x4 nm[2], nc[2];
+      mk_next = m_lane[64 * 4];
+      const float ts_pre = tscale, inv_pre = inv_cur;
+      const uint2 mk_pre = mk;
+      layer_h16x2<8, 10, tb_pos(3), TC_QUEUE, false>(
+          st, ringlane, (const float*)nullptr, [&](int ks, int pl) { return pl == 0 ? Xh[ks] : Xl[ks]; },
+          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
+            if (tp == 0 && pcx == 0) switch_ctx(3, 4);
+            if (tp < 8) bpiece(Yh, Yl, tp & 7, pcx, mn, cr, tscale, inv_cur, mk, a.dz[4]);
+            else spiece(0, pcx, mn, cr, inv_in, a.dg, a.lddg);                                // (tp = 8: the first embedding pair)
+          },
+          [&](int pcx) { bpiece(Xh, Xl, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, a.dz[5]); }, nm, nc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
+    }
+    layer(K8{}, TBPOS(4), std::true_type{}, Yh, Yl, Xh, Xl, 4, 3);                            // pts4^T -> dZ3 (its first pieces finish the embedding pair)
+    layer(K8{}, TBPOS(5), NoSp{}, Xh, Xl, Yh, Yl, 5, 2);                                      // pts3^T -> dZ2
+    layer(K8{}, TBPOS(6), NoSp{}, Yh, Yl, Xh, Xl, 6, 1);                                      // pts2^T -> dZ1
+    layer(K8{}, TBPOS(7), NoSp{}, Xh, Xl, Yh, Yl, 7, 0);                                      // pts1^T -> Y = dZ0
+    {   // s8 = pts0^T: two tile pairs -> d embedding [n][64], stored only
+      f32x4 nm[2], nc[2];
+      const float ts_pre = tscale, inv_pre = inv_cur;
+      const uint2 mk_pre = mk;
+      layer_h16x2<8, 2, tb_pos(8), TC_QUEUE, false>(
+          st, ringlane, (const float*)nullptr, [&](int ks, int pl) { return pl == 0 ? Yh[ks] : Yl[ks]; },
+          [&](int, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { spiece(0, pcx, mn, cr, inv_pre, a.de0, 64); },
+          [&](int pcx) { bpiece(Yh, Yl, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, a.dz[0]); }, nm, nc);
+#pragma unroll
+      for (int pcx = 0; pcx < 8; ++pcx) spiece(1, pcx, nm, nc, inv_pre, a.de0, 64);
+    }
+#undef TBPOS
+#pragma unroll
+    for (int i = 0; i < TB_PAD_SLOTS; ++i) st.begin();
+    {   // dZ0's maximum; then the wave's maxima go to the slots (lane k: buffer k)
+      atomicMax((unsigned int*)wave_max + slot_prev, __float_as_uint(amax * inv_cur));
+      if (lane < 8) {
+        const float m = wave_max[lane];
+        if (m > 0.f) atomicMax((unsigned int*)a.slot[lane] + ((unsigned)blockIdx.x & (HG_SLOT - 1)), __float_as_uint(m));
+      }
+      if (lane < 9) wave_max[lane] = 0.f;
+    }
+  }
   st.drain();
 }

@@ -1055,6 +1055,10 @@ struct pnrf_trainer {
   bool use_f16 = true;                           // split-fp16 layer products (default) or the exact-fp32 MFMA kernels throughout
   _Float16* tc_stream = nullptr;                 // the fine net's pts0 .. feature weights as the fused-MLP engine's fragment stream (pnrf_tchain.h)
   TChainPackArgs tc_pack;
+  _Float16* tb_stream = nullptr;                 // ... and the transposed layers' stream of the input-gradient chain (tchain_bwd_kernel)
+  TChainBwdPackArgs tb_pack;
+  uint2* tc_mask = nullptr;                      // ReLU masks of pts0 .. pts7 (written by the forward chain, read by the backward chain)
+  float* dz_x[6] = {};                           // dZ5 .. dZ0 of the backward chain (dZ7 = d_a, dZ6 = d_b)
   int nerf_fwd = 0;                              // fine net's forward from 8192 rows on: 0 one engine launch (tchain_fwd_kernel), 3 two 64-row layer chains
                                                  // (hgemm_wchain_kernel), 2 one product launch per layer (pnrf_trainer_set_products)
   float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
@@ -1504,6 +1508,12 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
       PNRF_REQUIRE(tl.out == 256 && tl.in == (l == 0 ? 63 : l == 5 ? 319 : 256), PNRF_E_SHAPE, "pnrf_trainer: fine-net layer %d is %d -> %d", l, tl.in, tl.out);
       t->tc_pack.w[l] = tl.w; t->tc_pack.in_dim[l] = tl.in;
     }
+    T_ALLOC(t->tb_stream, (size_t)TB_NSLOTS * SLOT_BYTES / sizeof(_Float16));
+    memset(&t->tb_pack, 0, sizeof(t->tb_pack));
+    t->tb_pack.P = t->P; t->tb_pack.stream = t->tb_stream;
+    for (int l = 0; l < TC_NL; ++l) t->tb_pack.w[l] = t->tc_pack.w[l];
+    t->tb_pack.w_alpha = t->L[L_ALPHA].w;
+    T_ALLOC(t->tb_pack.cmax, 16);
     T_ALLOC(t->amax, N_AMAX * HG_SLOT);
     PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * HG_SLOT * 4));
   }
@@ -1514,17 +1524,22 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->sort_idx, N * 8);
   T_ALLOC(t->refine_in, N * 144); T_ALLOC(t->r_y, N * 35); T_ALLOC(t->z_pre, N * 8); T_ALLOC(t->z, R); T_ALLOC(t->pts, R * 3); T_ALLOC(t->rgb0, N * 3);
   T_ALLOC(t->emb, R * 90);
-  for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], R * 256);
-  T_ALLOC(t->n_c5, R * LD_C5); T_ALLOC(t->n_a5, R * 256); T_ALLOC(t->n_a6, R * 256); T_ALLOC(t->n_a7, R * 256);
-  T_ALLOC(t->n_cv, R * LD_CV); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
-  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, R * 256);
-  T_ALLOC(t->d_b, R * 256); T_ALLOC(t->d_c5, R * LD_C5); T_ALLOC(t->d_e0, N * 8 * 64); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
+  // the chain kernels (pnrf_tchain.h) write whole batches of TC_ROWS rows: their buffers hold the row count rounded up
+  const int64_t Rp = (R + TC_ROWS - 1) / TC_ROWS * TC_ROWS;
+  PNRF_REQUIRE(Rp * LD_C5 * 4 < ((int64_t)1 << 32), PNRF_E_ARG, "pnrf_trainer_create: %lld sample rows exceed the 32-bit row offsets of the layer chains", (long long)Rp);
+  for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], Rp * 256);
+  T_ALLOC(t->n_c5, Rp * LD_C5); T_ALLOC(t->n_a5, Rp * 256); T_ALLOC(t->n_a6, Rp * 256); T_ALLOC(t->n_a7, Rp * 256);
+  T_ALLOC(t->n_cv, Rp * LD_CV); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
+  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, Rp * 256);
+  T_ALLOC(t->d_b, Rp * 256); T_ALLOC(t->d_c5, Rp * LD_C5); T_ALLOC(t->d_e0, Rp * 64); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
+  for (int k = 0; k < 6; ++k) T_ALLOC(t->dz_x[k], Rp * 256);
+  T_ALLOC(t->tc_mask, Rp / TC_ROWS * 8 * TC_NL * 64);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
   T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); for (int k = 0; k < 6; ++k) T_ALLOC(t->d_hk[k], N * 256);
   t->d_h0 = t->d_hk[0]; t->d_h1 = t->d_hk[1];
   // padding columns of the concatenated rows are zero and stay zero (the kernels write the payload columns only, or zeros)
-  PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)R * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)R * LD_C5 * 4));
-  PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)R * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)R * LD_CV * 4));
+  PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)Rp * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)Rp * LD_C5 * 4));
+  PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)Rp * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)R * LD_CV * 4));
   T_ALLOC(t->st_rays, N * 11); T_ALLOC(t->st_or_rays, N * 11); T_ALLOC(t->st_target, N * 3); T_ALLOC(t->st_ref_nos, N * 4); T_ALLOC(t->st_jitter, R); T_ALLOC(t->st_noise, R);
   T_ALLOC(t->loss, 8);                              // [total, mse x 3, completion counter of losses_kernel]
   PNRF_HIP(hipMemset(t->loss, 0, 32));
@@ -1681,7 +1696,7 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
       c.bias[l] = t->P + t->L[l < 8 ? L_N + l : L_FEAT].b;
       c.out[l] = outs[l]; c.ldo[l] = l == 4 ? LD_C5 : (l == 8 ? LD_CV : 256);
     }
-    c.X0 = t->n_c5; c.ldx0 = LD_C5; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
+    c.X0 = t->n_c5; c.ldx0 = LD_C5; c.mask = t->tc_mask; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
     const size_t lds = TC_LDS_BYTES;
     PNRF_HIP(hipFuncSetAttribute((const void*)tchain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ncu = trainer_num_cu();
@@ -1750,6 +1765,35 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   float* m = t->amax + slot0 * HG_SLOT;
   T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
   T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0 * HG_SLOT, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->dw_tile == 0) {
+    // The nine input-gradient products below the view layer as ONE launch (tchain_bwd_kernel): the rows' gradients stay in registers from the
+    // feature / alpha gradients down to pts0, each dZ_k is written once, the ReLU derivatives come from the forward chain's masks.  The weight
+    // gradients follow as launches of their own, each reading its dZ_k and the saved activation below it once.
+    float* dz[8] = {t->dz_x[5], t->dz_x[4], t->dz_x[3], t->dz_x[2], t->dz_x[1], t->dz_x[0], t->d_b, t->d_a};      // dz[k] = dZ_k
+    const TLin& lf = t->L[L_FEAT];
+    T_RC(gemm_dw(t, t->n_a7, 256, t->d_cv, LD_CV, m + 1 * HG_SLOT, t->G + lf.w, t->G + lf.b, lf.in_x(), lf.gap, lf.out, R, s));
+    T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, nullptr, 0, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));          // weight gradient only
+    TChainBwdArgs c = {};
+    c.blob = t->tb_stream; c.dF = t->d_cv; c.lddf = LD_CV; c.dA = t->d_raw + 3; c.ldda = 4; c.mask = t->tc_mask; c.cmax = t->tb_pack.cmax;
+    for (int k = 0; k < 8; ++k) { c.dz[k] = dz[k]; c.slot[k] = m + (9 - k) * HG_SLOT; }
+    c.slot[8] = m + 10 * HG_SLOT;
+    c.dg = t->d_c5; c.lddg = LD_C5; c.de0 = t->d_e0; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
+    PNRF_HIP(hipFuncSetAttribute((const void*)tchain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_BYTES));
+    const int ncu = trainer_num_cu();
+    hipLaunchKernelGGL(tchain_bwd_kernel, dim3((unsigned)(c.nbatch < ncu ? c.nbatch : ncu)), dim3(512), TB_LDS_BYTES, s, c);
+    PNRF_LAUNCH_CHECK();
+    const float* xin[8] = {t->emb, t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5, t->n_a5, t->n_a6};
+    const int ldx[8] = {90, 256, 256, 256, 256, LD_C5, 256, 256};
+    for (int k = 7; k >= 0; --k) {
+      const TLin& l = t->L[L_N + k];
+      T_RC(gemm_dw(t, xin[k], ldx[k], dz[k], 256, c.slot[k], t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s));
+    }
+    if (want_dpts) {
+      hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 64, t->d_c5, LD_C5, t->d_pts, R, 10);
+      PNRF_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   T_RC(layer_bwd(t, L_FEAT, t->d_cv, LD_CV, m + 1 * HG_SLOT, t->n_a7, 256, t->d_a, 256, m + 2 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, t->d_a, 256, m + 2 * HG_SLOT, 1.f, R, T_ACT_RELU, t->n_a7, 256, 0, s));
   T_RC(layer_bwd(t, L_N + 7, t->d_a, 256, m + 2 * HG_SLOT, t->n_a6, 256, t->d_b, 256, m + 3 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a6, 256, 0, s));
@@ -1906,6 +1950,10 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, s, t->split);
     PNRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NFRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
+    PNRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tchain_pack_bwd_kernel, dim3(TB_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tb_pack);
+    PNRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tchain_norms_kernel, dim3(TB_NS, 16), dim3(256), 0, s, t->tb_pack);
     PNRF_LAUNCH_CHECK();
     t->planes_stale = false;
   }
