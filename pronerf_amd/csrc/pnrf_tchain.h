@@ -16,12 +16,14 @@
 // whole number of ring revolutions so that all of them start at ring position 0.
 #pragma once
 
-constexpr int TC_NL = 9;                                   // pts0 .. pts7, feature
-__host__ __device__ constexpr int tc_ks(int l) { return l == 0 ? 2 : (l == 5 ? 10 : 8); }      // k-steps of 32: 63 (+1) | 256 | 64 + 256 inputs
-__host__ __device__ constexpr int tc_frags(int l) { return 8 * tc_ks(l) * 4; }
+constexpr int TC_NL = 10;                                  // pts0 .. pts7, feature, views
+__host__ __device__ constexpr int tc_ks(int l) { return l == 0 ? 2 : (l == 5 ? 10 : (l == 9 ? 9 : 8)); }   // k-steps of 32: 63 (+1) | 256 | 64 + 256 | 256 + 27 (+5) inputs
+__host__ __device__ constexpr int tc_ntp(int l) { return l == 9 ? 4 : 8; }                       // tile pairs of 32 outputs: 256, views_linear 128
+__host__ __device__ constexpr int tc_frags(int l) { return tc_ntp(l) * tc_ks(l) * 4; }
 __host__ __device__ constexpr int tc_frag0(int l) { int s = 0; for (int i = 0; i < l; ++i) s += tc_frags(i); return s; }
-constexpr int TC_NFRAGS = tc_frag0(TC_NL);                 // 2176
-constexpr int TC_NSLOTS = TC_NFRAGS / SLOT_FRAGS;          // 136 slots of 16 KiB
+constexpr int TC_NFRAGS = tc_frag0(TC_NL);                 // 2320
+constexpr int TC_PAD_SLOTS = (NSLOTS - (TC_NFRAGS / SLOT_FRAGS) % NSLOTS) % NSLOTS;            // 3: a batch is a whole number of ring revolutions
+constexpr int TC_NSLOTS = TC_NFRAGS / SLOT_FRAGS + TC_PAD_SLOTS;                               // 148 slots of 16 KiB
 constexpr int TC_ROWS = 128;                               // rows per workgroup and batch
 #ifndef PNRF_TC_QUEUE
 #define PNRF_TC_QUEUE 8
@@ -33,7 +35,7 @@ constexpr int TC_STG_ROW = 128 + 4;                        // floats per staged 
 constexpr int TC_STG_BYTES = 8 * 16 * TC_STG_ROW * 4;      // eight waves x 16 rows
 constexpr int TC_LDS_BYTES = TC_RING_BYTES + TC_NL * W_HID * 4 + TC_STG_BYTES;
 __host__ __device__ constexpr int tc_pos(int l) { return (tc_frag0(l) / SLOT_FRAGS) % TC_RING; }   // ring position of layer l's first slot
-static_assert(tc_frags(0) % SLOT_FRAGS == 0 && tc_frags(1) % SLOT_FRAGS == 0 && tc_frags(5) % SLOT_FRAGS == 0 && TC_NSLOTS % TC_RING == 0,
+static_assert(tc_frags(0) % SLOT_FRAGS == 0 && tc_frags(1) % SLOT_FRAGS == 0 && tc_frags(5) % SLOT_FRAGS == 0 && tc_frags(9) % SLOT_FRAGS == 0 && TC_NSLOTS % TC_RING == 0,
               "whole slots per layer, whole ring revolutions per batch");
 static_assert(H16_PIECES == 8, "tchain_fwd_kernel's epilogue pieces are written for one accumulator register per piece");
 
@@ -42,14 +44,21 @@ typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
 struct TChainPackArgs {
   const float* P;                    // the trainer's flat parameters
   size_t w[TC_NL];                   // offset of layer l's weights [256][in_dim]
-  int in_dim[TC_NL];                 // 63 | 256 | 319 (skip layer: [embedding 63 | h 256], run_nerf_helpers.py:829-831)
+  int in_dim[TC_NL];                 // 63 | 256 | 319 (skip layer: [embedding 63 | h 256], run_nerf_helpers.py:829-831) | 283 (views: [feature 256 | view embedding 27], :842-843)
   _Float16* stream;                  // TC_NFRAGS KiB
 };
 // one thread per 16-byte piece of the stream (lane `lane` of fragment F)
 __global__ void tchain_pack_kernel(TChainPackArgs a) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= TC_NFRAGS * 64) return;
+  if (p >= TC_NSLOTS * SLOT_FRAGS * 64) return;
   const int F = p >> 6, lane = p & 63;
+  if (F >= TC_NFRAGS) {                                      // the padding slots
+    f16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+    *(f16x8*)(a.stream + (size_t)p * 8) = z;
+    return;
+  }
   int l = 0;
   while (l + 1 < TC_NL && F >= tc_frag0(l + 1)) ++l;
   const int f = F - tc_frag0(l), pl = f & 1, t = (f >> 1) & 1, KS = tc_ks(l), ks = (f >> 2) % KS, tp = (f >> 2) / KS;
@@ -62,6 +71,8 @@ __global__ void tchain_pack_kernel(TChainPackArgs a) {
     if (l == 0 || (l == 5 && ks < 2)) {                    // the 64 input columns in their natural order; column 63 is padding
       in = 32 * ks + 8 * g + j;
       if (in >= 63) in = -1;
+    } else if (l == 9 && ks == 8) {                        // the view embedding: 27 columns + padding, natural order, behind the 256 feature columns
+      in = 8 * g + j < 27 ? 256 + 8 * g + j : -1;
     } else {
       in = hidden_feat_h16(l == 5 ? ks - 2 : ks, g, j) + (l == 5 ? 63 : 0);
     }
@@ -94,6 +105,7 @@ struct TChainArgs {
   const void* blob;                  // TC_NSLOTS slots
   const float* bias[TC_NL];
   const float* X0; int ldx0;         // [n][ldx0] fp32, 16-byte aligned rows: columns 0 .. 63 = position embedding (63) + one zero
+  const float* XV; int ldxv;         // [n][ldxv]: columns 0 .. 31 = view embedding (27) + zeros
   float* out[TC_NL]; int ldo[TC_NL]; // saved activations [n rounded up to TC_ROWS][ldo], 16-byte aligned rows: whole batches are written, no row predicate —
                                      // a predicated store is a branch, and eight of them in a row serialise the flush of a staged group
   uint2* mask;                       // [batch][wave][layer][lane]: two words (tile pairs 0-3 | 4-7), bit 31 - (8 (tp & 3) + 4 t + r) = (activation of the lane's row, feature 32 tp + 16 t
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
   constexpr int NW = 8, NTP = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + TC_RING_BYTES);        // [layer][256]
-  for (int i = threadIdx.x; i < TC_NL * W_HID; i += 512) bias_lds[i] = a.bias[i >> 8][i & 255];
+  for (int i = threadIdx.x; i < TC_NL * W_HID; i += 512) bias_lds[i] = (i >> 8) == 9 && (i & 255) >= 128 ? 0.f : a.bias[i >> 8][i & 255];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, g = lane >> 4;
   WStream<NW> st;
@@ -157,14 +169,14 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     // piece pcx = accumulator register pcx & 3 of tile pcx >> 2 of a tile pair: bias is in the accumulator; combine, activate (floor = 0: ReLU,
     // -inf: none), park the value in the accumulator register; the odd piece packs the pair into the next layer's planes (as sampler_h16_kernel),
     // the last piece of a tile stages its four features — registers 0 .. 3 of lane (column, g) are features 16 T + 4 g .. + 3 of the row
-    auto piece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float floor_, float* optr, uint32_t ooff, int ld, int lm) {
+    auto piece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float floor_, float* optr, uint32_t ooff, int ld, int lm, int ltp = NTP - 1) {
       const int t = pcx >> 2, r = pcx & 3, p = r >> 1;
       const float v = fmaxf(fmaf(cr[t][r], INV, mn[t][r]), floor_);
       mn[t][r] = v;
       // mask word <- 2 word + (v > 0): the compare's carry goes in through v_addc.  32 pieces fill a word: piece (tp, pcx) is bit 31 - (8 (tp & 3) + pcx)
       if (tp < 4) asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mb0) : "v"(v) : "vcc");
       else asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mb1) : "v"(v) : "vcc");
-      if (tp == NTP - 1 && pcx == 7) {               // the layer's last activation of this lane
+      if (tp == ltp && pcx == 7) {                   // the layer's last activation of this lane
         *(uint2*)(m_lane + 64 * lm) = make_uint2(mb0, mb1);
         mb0 = 0; mb1 = 0;
       }
@@ -194,19 +206,21 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     // one layer: KSc = its k-steps (2: from the input columns; 10: input columns, then the hidden planes; 8: hidden planes)
     auto layer = [&](auto ksc, auto posc, f16x8(&ih)[NTP], f16x8(&il)[NTP], f16x8(&oh)[NTP], f16x8(&ol)[NTP], int l, float floor_prev, float floor_) {
       constexpr int KS = decltype(ksc)::value;
+      constexpr int LNTP = KS == 9 ? 4 : NTP;        // views_linear: 128 outputs
       f32x4 nm[2], nc[2];
       const int ld_cur = a.ldo[l], ld_pre = ld_prev, l_pre = l_prev;
       float* const o_cur = a.out[l];
       float* const o_pre = o_prev;
       const uint32_t off_cur = ((uint32_t)row_f * (uint32_t)ld_cur + 4u * (lane & 31)) * 4u, off_pre = off_prev;   // < 4 GiB: checked by the launcher
-      layer_h16x2<KS, NTP, decltype(posc)::value, TC_QUEUE>(
+      layer_h16x2<KS, LNTP, decltype(posc)::value, TC_QUEUE>(
           st, ringlane, biaslane + l * W_HID,
           [&](int ks, int pl) {
             if constexpr (KS == 2) return pl == 0 ? Gh[ks & 1] : Gl[ks & 1];
             else if constexpr (KS == 10) return ks < 2 ? (pl == 0 ? Gh[ks & 1] : Gl[ks & 1]) : (pl == 0 ? ih[(ks - 2) & 7] : il[(ks - 2) & 7]);
+            else if constexpr (KS == 9) return ks < 8 ? (pl == 0 ? ih[ks & 7] : il[ks & 7]) : (pl == 0 ? Gh[0] : Gl[0]);      // views: G holds the view embedding
             else return pl == 0 ? ih[ks] : il[ks];
           },
-          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { piece(oh, ol, tp, pcx, mn, cr, floor_, o_cur, off_cur, ld_cur, l); },
+          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { piece(oh, ol, tp, pcx, mn, cr, floor_, o_cur, off_cur, ld_cur, l, LNTP - 1); },
           [&](int pcx) { if constexpr (KS != 2) piece(ih, il, NTP - 1, pcx, pm, pc, floor_prev, o_pre, off_pre, ld_pre, l_pre); }, nm, nc);
 #pragma unroll
       for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
@@ -217,16 +231,6 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     layer(std::integral_constant<int, 2>{}, POS(0), Yh, Yl, Xh, Xl, 0, 0.f, 0.f);                       // pts0: input columns -> X
     using K8 = std::integral_constant<int, 8>;
     static_assert(tc_pos(1) == tc_pos(3) && tc_pos(2) == tc_pos(4), "pts1 .. pts4 as a loop of two layers");
-#ifdef PNRF_TC_STRAIGHT
-    layer(K8{}, POS(1), Xh, Xl, Yh, Yl, 1, 0.f, 0.f);
-    layer(K8{}, POS(2), Yh, Yl, Xh, Xl, 2, 0.f, 0.f);
-    layer(K8{}, POS(3), Xh, Xl, Yh, Yl, 3, 0.f, 0.f);
-    layer(K8{}, POS(4), Yh, Yl, Xh, Xl, 4, 0.f, 0.f);
-    layer(std::integral_constant<int, 10>{}, POS(5), Xh, Xl, Yh, Yl, 5, 0.f, 0.f);
-    layer(K8{}, POS(6), Yh, Yl, Xh, Xl, 6, 0.f, 0.f);
-    layer(K8{}, POS(7), Xh, Xl, Yh, Yl, 7, 0.f, 0.f);
-    layer(K8{}, POS(8), Yh, Yl, Xh, Xl, 8, 0.f, NEG);
-#else
 #pragma nounroll
     for (int p = 0; p < 2; ++p) {                                                               // pts1 .. pts4
       layer(K8{}, POS(1), Xh, Xl, Yh, Yl, 2 * p + 1, 0.f, 0.f);
@@ -237,10 +241,23 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     layer(K8{}, POS(6), Yh, Yl, Xh, Xl, 6, 0.f, 0.f);
     layer(K8{}, POS(7), Xh, Xl, Yh, Yl, 7, 0.f, 0.f);
     layer(K8{}, POS(8), Yh, Yl, Xh, Xl, 8, 0.f, NEG);                                                   // feature_linear has no activation
-#endif
+    {   // views_linear reads [feature | view embedding]: the embedding's k-step comes from the rows the rgb branch's weight gradient reads
+      const float4* x = (const float4*)(a.XV + rr * a.ldxv + 8 * g);
+      const float4 lo = x[0], hi = x[1];
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        Gh[0][j] = h;
+        Gl[0][j] = (_Float16)((v[j] - (float)h) * H16_LO_SCALE);
+      }
+    }
+    layer(std::integral_constant<int, 9>{}, POS(9), Xh, Xl, Yh, Yl, 9, NEG, 0.f);                       // views_linear (ReLU)
     // the last layer's last tile pair (its planes go to Y, which nobody reads)
 #pragma unroll
-    for (int pcx = 0; pcx < 8; ++pcx) piece(Yh, Yl, NTP - 1, pcx, pm, pc, NEG, o_prev, off_prev, ld_prev, l_prev);
+    for (int pcx = 0; pcx < 8; ++pcx) piece(Yh, Yl, 3, pcx, pm, pc, 0.f, o_prev, off_prev, ld_prev, l_prev, 3);
+#pragma unroll
+    for (int i = 0; i < TC_PAD_SLOTS; ++i) st.begin();
   }
 #undef POS
   st.drain();

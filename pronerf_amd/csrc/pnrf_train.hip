@@ -1500,12 +1500,13 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     PNRF_HIP(hipMemset(t->w_gapped, 0, (size_t)g.out * g.in_x() * 4));
     t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam; t->split.gapped = t->w_gapped;
     t->planes_stale = true;
-    T_ALLOC(t->tc_stream, (size_t)TC_NFRAGS * FRAG_BYTES / sizeof(_Float16));
+    T_ALLOC(t->tc_stream, (size_t)TC_NSLOTS * SLOT_BYTES / sizeof(_Float16));
     memset(&t->tc_pack, 0, sizeof(t->tc_pack));
     t->tc_pack.P = t->P; t->tc_pack.stream = t->tc_stream;
     for (int l = 0; l < TC_NL; ++l) {
-      const TLin& tl = t->L[l < 8 ? L_N + l : L_FEAT];
-      PNRF_REQUIRE(tl.out == 256 && tl.in == (l == 0 ? 63 : l == 5 ? 319 : 256), PNRF_E_SHAPE, "pnrf_trainer: fine-net layer %d is %d -> %d", l, tl.in, tl.out);
+      const TLin& tl = t->L[l < 8 ? L_N + l : (l == 8 ? L_FEAT : L_VIEWS)];
+      PNRF_REQUIRE(tl.out == (l == 9 ? 128 : 256) && tl.in == (l == 0 ? 63 : l == 5 ? 319 : l == 9 ? 283 : 256), PNRF_E_SHAPE,
+                   "pnrf_trainer: fine-net layer %d is %d -> %d", l, tl.in, tl.out);
       t->tc_pack.w[l] = tl.w; t->tc_pack.in_dim[l] = tl.in;
     }
     T_ALLOC(t->tb_stream, (size_t)TB_NSLOTS * SLOT_BYTES / sizeof(_Float16));
@@ -1529,7 +1530,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   PNRF_REQUIRE(Rp * LD_C5 * 4 < ((int64_t)1 << 32), PNRF_E_ARG, "pnrf_trainer_create: %lld sample rows exceed the 32-bit row offsets of the layer chains", (long long)Rp);
   for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], Rp * 256);
   T_ALLOC(t->n_c5, Rp * LD_C5); T_ALLOC(t->n_a5, Rp * 256); T_ALLOC(t->n_a6, Rp * 256); T_ALLOC(t->n_a7, Rp * 256);
-  T_ALLOC(t->n_cv, Rp * LD_CV); T_ALLOC(t->n_hv, R * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
+  T_ALLOC(t->n_cv, Rp * LD_CV); T_ALLOC(t->n_hv, Rp * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
   T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, Rp * 256);
   T_ALLOC(t->d_b, Rp * 256); T_ALLOC(t->d_c5, Rp * LD_C5); T_ALLOC(t->d_e0, Rp * 64); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   for (int k = 0; k < 6; ++k) T_ALLOC(t->dz_x[k], Rp * 256);
@@ -1686,23 +1687,24 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   // product kernel 20 %), half of its wave time is spent in s_waitcnt / barriers (SQ_WAIT_ANY 49 %) — weight fragments one step ahead are
   // not far enough ahead of an L2 under this load, and the 16 x 64-byte stores of the register epilogue cost 23 % (no-store probe build:
   // 411 vs 535 us per launch).  A first version on hgemm_rchain_kernel<4> (LDS round trip in the epilogue, one workgroup per CU) was 2 % slower.
-  bool chained = false;
+  bool chained = false, engine = false;
   if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192) {
     // pts0 .. pts7 and feature_linear in one launch on the fused-MLP engine: 128 rows per workgroup stay in registers through the nine layers
     TChainArgs c = {};
     c.blob = t->tc_stream;
-    float* outs[TC_NL] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H, t->n_a5, t->n_a6, t->n_a7, t->n_cv};
+    float* outs[TC_NL] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H, t->n_a5, t->n_a6, t->n_a7, t->n_cv, t->n_hv};
     for (int l = 0; l < TC_NL; ++l) {
-      c.bias[l] = t->P + t->L[l < 8 ? L_N + l : L_FEAT].b;
-      c.out[l] = outs[l]; c.ldo[l] = l == 4 ? LD_C5 : (l == 8 ? LD_CV : 256);
+      c.bias[l] = t->P + t->L[l < 8 ? L_N + l : (l == 8 ? L_FEAT : L_VIEWS)].b;
+      c.out[l] = outs[l]; c.ldo[l] = l == 4 ? LD_C5 : (l == 8 ? LD_CV : (l == 9 ? 128 : 256));
     }
+    c.XV = t->n_cv + 256; c.ldxv = LD_CV;
     c.X0 = t->n_c5; c.ldx0 = LD_C5; c.mask = t->tc_mask; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
     const size_t lds = TC_LDS_BYTES;
     PNRF_HIP(hipFuncSetAttribute((const void*)tchain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ncu = trainer_num_cu();
     hipLaunchKernelGGL(tchain_fwd_kernel, dim3((unsigned)(c.nbatch < ncu ? c.nbatch : ncu)), dim3(512), lds, s, c);
     PNRF_LAUNCH_CHECK();
-    chained = true;
+    chained = true; engine = true;
   }
   if (!chained && t->use_f16 && t->nerf_fwd == 3 && R >= 8192) {
     // pts0 and pts5 (63 / 320 inputs) as products of their own; the 256 -> 256 layers behind each as a chain
@@ -1749,7 +1751,7 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
     T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, LD_CV, R, T_ACT_NONE, s));
   }
   T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
-  T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));
+  if (!engine) T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));            // (the engine launch ran views_linear as its tenth layer)
   T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
   return 0;
 }
@@ -1771,7 +1773,19 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     // gradients follow as launches of their own, each reading its dZ_k and the saved activation below it once.
     float* dz[8] = {t->dz_x[5], t->dz_x[4], t->dz_x[3], t->dz_x[2], t->dz_x[1], t->dz_x[0], t->d_b, t->d_a};      // dz[k] = dZ_k
     const TLin& lf = t->L[L_FEAT];
-    T_RC(gemm_dw(t, t->n_a7, 256, t->d_cv, LD_CV, m + 1 * HG_SLOT, t->G + lf.w, t->G + lf.b, lf.in_x(), lf.gap, lf.out, R, s));
+    DwhGroupArgs grp = {};
+    int grp_blocks = 0;
+    auto dw_job = [&](const float* X, int ldx, const float* dZ, int ldz, const float* amax_slot, const TLin& l) -> int {
+      DwDefer d;
+      int rc = gemm_dw(t, X, ldx, dZ, ldz, amax_slot, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s, &d);
+      if (rc) return rc;
+      if (!d.set) return 0;                                  // gemm_dw launched another kernel itself
+      grp.j[grp.n] = d.args; grp.first[grp.n] = grp_blocks; grp.tiles[grp.n] = d.tiles;
+      grp_blocks += d.tiles * d.splits;
+      ++grp.n;
+      return 0;
+    };
+    T_RC(dw_job(t->n_a7, 256, t->d_cv, LD_CV, m + 1 * HG_SLOT, lf));
     T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, nullptr, 0, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));          // weight gradient only
     TChainBwdArgs c = {};
     c.blob = t->tb_stream; c.dF = t->d_cv; c.lddf = LD_CV; c.dA = t->d_raw + 3; c.ldda = 4; c.mask = t->tc_mask; c.cmax = t->tb_pack.cmax;
@@ -1784,9 +1798,12 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     PNRF_LAUNCH_CHECK();
     const float* xin[8] = {t->emb, t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5, t->n_a5, t->n_a6};
     const int ldx[8] = {90, 256, 256, 256, 256, LD_C5, 256, 256};
-    for (int k = 7; k >= 0; --k) {
-      const TLin& l = t->L[L_N + k];
-      T_RC(gemm_dw(t, xin[k], ldx[k], dz[k], 256, c.slot[k], t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s));
+    // the nine 256-wide weight gradients as one grouped launch: at 32 768 rows each of them alone is a 30 us launch of 256 workgroups
+    for (int k = 7; k >= 0; --k) T_RC(dw_job(xin[k], ldx[k], dz[k], 256, c.slot[k], t->L[L_N + k]));
+    if (grp.n) {
+      grp.first[grp.n] = grp_blocks;
+      hipLaunchKernelGGL(dwh_group_kernel, dim3((unsigned)grp_blocks), dim3(512), 0, s, grp);
+      PNRF_LAUNCH_CHECK();
     }
     if (want_dpts) {
       hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 64, t->d_c5, LD_C5, t->d_pts, R, 10);
@@ -1949,7 +1966,7 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
   if (t->planes_stale) {
     hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, s, t->split);
     PNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NFRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
+    hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
     PNRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(tchain_pack_bwd_kernel, dim3(TB_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tb_pack);
     PNRF_LAUNCH_CHECK();
