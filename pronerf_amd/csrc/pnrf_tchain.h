@@ -264,46 +264,46 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: the input-gradient chain
-// dZ_k = (dZ_{k+1} W_{k+1}) * relu'(a_k) from the feature / alpha gradients down to pts0, one launch on the same engine: a workgroup's 128 rows of
-// gradient stay in registers (MFMA B operand, split fp16), the TRANSPOSED weights stream through LDS, every dZ_k is written once (fp32, for the
-// weight-gradient products that follow as launches of their own) and nothing of the saved activations is read but their sign bits
-// (tchain_fwd_kernel's masks).  Stream layers (fragments as in the forward stream):
-//   s0  [feature_linear^T ; alpha_linear^T]  9 k-steps (256 feature gradients + the alpha gradient) -> dZ7      s4  pts4^T -> dZ3
-//   s1  pts7^T -> dZ6                                                                                          s5  pts3^T -> dZ2
-//   s2  pts6^T -> dZ5                                                                                          s6  pts2^T -> dZ1
-//   s3  pts5^T: 8 tile pairs of hidden columns -> dZ4, then 2 pairs of embedding columns -> d embedding         s7  pts1^T -> dZ0
-//                                                                                                               s8  pts0^T: 2 pairs -> d embedding
+// dZ_k = (dZ_{k+1} W_{k+1}) * relu'(a_k) from the rgb branch's hidden gradient down to pts0, one launch on the same engine: a workgroup's 128 rows
+// of gradient stay in registers (MFMA B operand, split fp16), the TRANSPOSED weights stream through LDS, every gradient the weight-gradient
+// products need is written once (fp32; those products follow as one grouped launch) and nothing of the saved activations is read but their
+// sign bits (tchain_fwd_kernel's masks).  Stream layers (fragments as in the forward stream):
+//   s0  views_linear^T, feature columns: 4 k-steps (128 hidden gradients of the rgb branch) -> d feature          s5  pts4^T -> dZ3
+//   s1  [feature_linear^T ; alpha_linear^T]: 9 k-steps (d feature + the alpha gradient) -> dZ7                   s6  pts3^T -> dZ2
+//   s2  pts7^T -> dZ6                                                                                           s7  pts2^T -> dZ1
+//   s3  pts6^T -> dZ5                                                                                           s8  pts1^T -> dZ0
+//   s4  pts5^T: 8 tile pairs of hidden columns -> dZ4, then 2 pairs of embedding columns -> d embedding          s9  pts0^T: 2 pairs -> d embedding
 // Gradient range.  Gradients are 1e-9 .. 1e-3; the planes carry them times a power of two PER ROW.  The first comes from the row's own maximum
 // (max |x| s in [2^13, 2^14)); from layer to layer the accumulators hold c' = (a s) W and |c'_j| <= |a s|_2 |W_:j|_2 <= |a s|_2 C with C^2 the
 // layer's largest column sum of squares (tchain_norms_kernel), so t = the power of two with |a s|_2 C t < 2^14 is known — before the first
 // output is split — from the sum of squares of the row's planes, which the previous layer's epilogue accumulated; the next planes are c' t,
-// never above 2^14.  All factors are powers of two: undone exactly in the epilogue that stores dZ.
-constexpr int TB_NS = 9;
-__host__ __device__ constexpr int tb_ks(int s) { return s == 0 ? 9 : 8; }
-__host__ __device__ constexpr int tb_ntp(int s) { return s == 3 ? 10 : (s == 8 ? 2 : 8); }
+// never above 2^14.  All factors are powers of two: undone exactly in the epilogue that stores the gradient.
+constexpr int TB_NS = 10;
+__host__ __device__ constexpr int tb_ks(int s) { return s == 0 ? 4 : (s == 1 ? 9 : 8); }
+__host__ __device__ constexpr int tb_ntp(int s) { return s == 4 ? 10 : (s == 9 ? 2 : 8); }
 __host__ __device__ constexpr int tb_frags(int s) { return tb_ntp(s) * tb_ks(s) * 4; }
 __host__ __device__ constexpr int tb_frag0(int s) { int f = 0; for (int i = 0; i < s; ++i) f += tb_frags(i); return f; }
-constexpr int TB_NFRAGS = tb_frag0(TB_NS);                                         // 2208
+constexpr int TB_NFRAGS = tb_frag0(TB_NS);                                         // 2336
 constexpr int TB_PAD_SLOTS = (NSLOTS - (TB_NFRAGS / SLOT_FRAGS) % NSLOTS) % NSLOTS;  // 2: a batch is a whole number of ring revolutions
-constexpr int TB_NSLOTS = TB_NFRAGS / SLOT_FRAGS + TB_PAD_SLOTS;                   // 140
+constexpr int TB_NSLOTS = TB_NFRAGS / SLOT_FRAGS + TB_PAD_SLOTS;                   // 148
 __host__ __device__ constexpr int tb_pos(int s) { return (tb_frag0(s) / SLOT_FRAGS) % NSLOTS; }
-static_assert(TB_NFRAGS % SLOT_FRAGS == 0 && tb_frags(0) % SLOT_FRAGS != 1, "whole slots");
-static_assert(tb_frags(0) % SLOT_FRAGS == 0 && tb_frags(3) % SLOT_FRAGS == 0 && tb_frags(8) % SLOT_FRAGS == 0, "whole slots per layer");
+static_assert(TB_NFRAGS % SLOT_FRAGS == 0 && tb_frags(0) % SLOT_FRAGS == 0 && tb_frags(1) % SLOT_FRAGS == 0 && tb_frags(4) % SLOT_FRAGS == 0 &&
+              tb_frags(9) % SLOT_FRAGS == 0, "whole slots per layer");
+constexpr int TB_NSLOT_MAX = 10;                                                   // gradient buffers with a max-|.| slot: dZ0 .. dZ7, d feature, scratch
 constexpr int TB_LDS_BYTES = TC_RING_BYTES + TC_STG_BYTES + 8 * 16 * 4;
 
 struct TChainBwdPackArgs {
   const float* P;
-  size_t w[TC_NL];                   // weights of pts0 .. pts7, feature (as TChainPackArgs)
+  size_t w[TC_NL];                   // weights of pts0 .. pts7, feature, views (as TChainPackArgs)
   size_t w_alpha;                    // alpha_linear [1][256]
   _Float16* stream;                  // TB_NSLOTS slots
   float* cmax;                       // [TB_NS] largest column sum of squares per stream layer (of the columns whose outputs are split again)
 };
-// which Linear a stream layer transposes: index into TChainPackArgs::w order (pts0 .. pts7 = 0 .. 7, feature = 8)
-__host__ __device__ constexpr int tb_linear(int s) { return s == 0 ? 8 : 8 - s; }
 // element (k, j) of stream layer s: weight that output gradient k contributes to input gradient j (0 where the layout pads)
 __device__ __forceinline__ float tb_weight(const TChainBwdPackArgs& a, int s, int k, int j) {
-  if (s == 0) return k < 256 ? a.P[a.w[8] + (size_t)k * 256 + j] : (k == 256 ? a.P[a.w_alpha + j] : 0.f);
-  const int L = tb_linear(s);
+  if (s == 0) return k < 128 ? a.P[a.w[9] + (size_t)k * 283 + j] : 0.f;           // views_linear [128][283]: feature columns 0 .. 255
+  if (s == 1) return k < 256 ? a.P[a.w[8] + (size_t)k * 256 + j] : (k == 256 ? a.P[a.w_alpha + j] : 0.f);
+  const int L = 9 - s;                                       // pts7 .. pts0
   if (L == 5) {                                              // [256][319]: embedding columns 0 .. 62, hidden columns 63 ..
     if (j < 256) return a.P[a.w[5] + (size_t)k * 319 + 63 + j];
     return j - 256 < 63 ? a.P[a.w[5] + (size_t)k * 319 + (j - 256)] : 0.f;
@@ -329,7 +329,8 @@ __global__ void tchain_pack_bwd_kernel(TChainBwdPackArgs a) {
   const int out = 32 * tp + 16 * t + (lane & 15), g = lane >> 4;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int k = s == 0 ? 32 * ks + 8 * g + j : hidden_feat_h16(ks, g, j);      // s0 reads its gradients from HBM in their natural order
+    // s0 reads its gradients from HBM in their natural order; s1's ninth k-step is the alpha gradient (element 0 of group 0)
+    const int k = s == 0 ? 32 * ks + 8 * g + j : (s == 1 && ks == 8 ? 256 + 8 * g + j : hidden_feat_h16(ks, g, j));
     const float x = tb_weight(a, s, k, out);
     const _Float16 h = (_Float16)x;
     v[j] = pl ? (_Float16)((x - (float)h) * H16_LO_SCALE) : h;
@@ -342,8 +343,8 @@ __global__ void tchain_norms_kernel(TChainBwdPackArgs a) {
   __shared__ float red[256];
   const int s = blockIdx.x, j = 16 * blockIdx.y + (threadIdx.x & 15), part = threadIdx.x >> 4;
   float acc = 0.f;
-  const int nk = s == 0 ? 257 : 256;
-  if (s != 8)
+  const int nk = s == 0 ? 128 : (s == 1 ? 257 : 256);
+  if (s != 9)
     for (int k = part; k < nk; k += 16) { const float w = tb_weight(a, s, k, j); acc = fmaf(w, w, acc); }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -354,12 +355,13 @@ __global__ void tchain_norms_kernel(TChainBwdPackArgs a) {
 
 struct TChainBwdArgs {
   const void* blob;                  // TB_NSLOTS slots
-  const float* dF; int lddf;         // d feature: columns 0 .. 255 of [n][lddf], 16-byte aligned rows
+  const float* dH; int lddh;         // gradient of the rgb branch's hidden layer (after relu'): [n][lddh], 128 columns, 16-byte aligned rows
   const float* dA; int ldda;         // d alpha: dA[row * ldda]
   const uint2* mask;                 // tchain_fwd_kernel's ReLU masks (same batch / wave / lane geometry)
   const float* cmax;                 // [TB_NS]
   float* dz[8];                      // dZ_k [n][256], k = 0 .. 7
-  float* slot[9];                    // max |dZ_k| slots (HG_SLOT floats each; pnrf_hgemm.h), [8] = scratch
+  float* dF; int lddf;               // d feature: columns 0 .. 255 of [n][lddf] (the views layer's input gradient; the rest of the row is not written)
+  float* slot[TB_NSLOT_MAX];         // max-|.| slots (HG_SLOT floats each; pnrf_hgemm.h): [k] of dZ_k, [8] of d feature, [9] scratch
   float* dg; int lddg;               // d embedding from the skip layer: columns 0 .. 63 of [n][lddg]
   float* de0;                        // d embedding from pts0: [n][64]       (every output buffer: n rounded up to TC_ROWS rows, as in the forward pass)
   int64_t n; int nbatch;
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
   float* const stage = (float*)(smem + TC_RING_BYTES) + wave * (16 * TC_STG_ROW);
   float* const stage_w = stage + col * TC_STG_ROW + 4 * g;
   const float* const stage_r = stage + (lane >> 5) * TC_STG_ROW + 4 * (lane & 31);        // 128-feature groups: rows 2 i + (lane >> 5)
-  float* const wave_max = (float*)(smem + TC_RING_BYTES + TC_STG_BYTES) + wave * 16;     // [wave][9]: max |dZ_k| of the wave's rows (k = 8: scratch)
-  if (lane < 9) wave_max[lane] = 0.f;
+  float* const wave_max = (float*)(smem + TC_RING_BYTES + TC_STG_BYTES) + wave * 16;     // [wave][slot]: max |gradient| of the wave's rows
+  if (lane < TB_NSLOT_MAX) wave_max[lane] = 0.f;
   auto pow2 = [](int k) { return __int_as_float((127 + (k < -120 ? -120 : (k > 120 ? 120 : k))) << 23); };
 
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
@@ -389,50 +391,48 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
     const uint2* const m_lane = a.mask + ((int64_t)batch * 8 + wave) * TC_NL * 64 + lane;
     const uint32_t off_z = ((uint32_t)row_f * 256u + 4u * (lane & 31)) * 4u;               // this lane's byte offset in a [n][256] buffer
 
-    f16x8 Xh[NTP], Xl[NTP], Yh[NTP], Yl[NTP], Ah, Al;        // gradient planes; Ah / Al: s0's ninth k-step (the alpha gradient)
+    f16x8 Xh[NTP], Xl[NTP], Yh[NTP], Yl[NTP], Ah, Al;        // gradient planes; Ah / Al: s1's ninth k-step (the alpha gradient)
     f32x4 pm[2], pc[2];
     // per-row scale bookkeeping (all lanes of a column agree): planes = true value / inv
     float inv_in = 1.f, inv_cur, tscale = 1.f, sumsq, amax = 0.f;
     uint2 mk = make_uint2(0, 0), mk_next;
-    int slot_prev = 8;                             // which buffer's maximum is being accumulated (8: s0's inputs, nobody's business)
-    {   // s0's inputs: 256 feature gradients + the alpha gradient of the row, scaled by the row's own maximum
-      const float4* x = (const float4*)(a.dF + rr * a.lddf + 8 * g);
-      float v[NTP][8];
+    int slot_prev = TB_NSLOT_MAX - 1;              // which buffer's maximum is being accumulated (the last: s0's inputs, nobody's business)
+    const float da = a.dA[rr * a.ldda];            // the row's alpha gradient: joins s1's inputs, so s0's output scale has to hold it too
+    float da_in;                                   // |da| on the scale of s0's input planes
+    {   // s0's inputs: the 128 hidden gradients of the row, scaled by the row's own maximum -> Y[0 .. 3]
+      const float4* x = (const float4*)(a.dH + rr * a.lddh + 8 * g);
+      float v[4][8];
       float m = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < NTP; ++ks) {
+      for (int ks = 0; ks < 4; ++ks) {
         const float4 lo = x[8 * ks], hi = x[8 * ks + 1];
         v[ks][0] = lo.x; v[ks][1] = lo.y; v[ks][2] = lo.z; v[ks][3] = lo.w; v[ks][4] = hi.x; v[ks][5] = hi.y; v[ks][6] = hi.z; v[ks][7] = hi.w;
 #pragma unroll
         for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[ks][j]));
       }
-      const float da = a.dA[rr * a.ldda];
-      m = fmaxf(m, fabsf(da));
       m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), 0x401F)));
       m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(m))));
       const int e = (__float_as_int(m) >> 23) - 127;             // floor(log2 m) for normal m
       const int k = m > 1e-37f && m < 1e37f ? 13 - e : 0;
       const float s0 = pow2(k);
       inv_cur = pow2(-k);
+      da_in = fabsf(da) * s0;
       sumsq = 0.f;
-      auto split = [&](const float (&u)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xs = u[j] * s0;
+          const float xs = v[ks][j] * s0;
           const _Float16 h = (_Float16)xs;
-          hi[j] = h; lo[j] = (_Float16)((xs - (float)h) * H16_LO_SCALE);
+          Yh[ks][j] = h; Yl[ks][j] = (_Float16)((xs - (float)h) * H16_LO_SCALE);
           sumsq = fmaf(xs, xs, sumsq);
         }
-      };
-#pragma unroll
-      for (int ks = 0; ks < NTP; ++ks) split(v[ks], Yh[ks], Yl[ks]);
-      const float z = 0.f;
-      const float u[8] = {g == 0 ? da : z, z, z, z, z, z, z, z};
-      split(u, Ah, Al);
+      }
     }
 
-    // a piece of a layer whose outputs are split again: scale, ReLU mask, statistics, planes, staged store of the true value
-    auto bpiece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float ts, float inv_o, uint2 mw, float* optr) {
+    // a piece of a layer whose outputs are split again: scale, ReLU mask, statistics, planes, staged store of the true value ([n][ld] buffer)
+    auto bpiece = [&](f16x8(&dh)[NTP], f16x8(&dl)[NTP], int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2], float ts, float inv_o, uint2 mw, float* optr,
+                      uint32_t ooff, int ld) {
       const int t = pcx >> 2, r = pcx & 3, p = r >> 1;
       float xv = fmaf(cr[t][r], INV, mn[t][r]) * ts;
       const int sel = __builtin_amdgcn_sbfe((int)(tp < 4 ? mw.x : mw.y), 31 - (8 * (tp & 3) + pcx), 1);       // 0 or -1
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const f32x4 w = *(const f32x4*)(stage_r + 2 * i * TC_STG_ROW);
-          tc_store((float*)((char*)(optr + ((2 * i) * 256 + 32 * (tp & ~3))) + off_z), w);
+          tc_store((float*)((char*)(optr + ((2 * i) * ld + 32 * (tp & ~3))) + ooff), w);
         }
       }
     };
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
     };
     // at a layer's first own piece: the previous outputs (this layer's inputs) are complete.  Their maximum goes to its slot, their sum of
     // squares fixes this layer's scale, the next mask takes over.
-    auto switch_ctx = [&](int s, int slot_now) {
+    auto switch_ctx = [&](int s, int slot_now, float other = 0.f) {     // other: |.| of a value (on the input planes' scale) that will join the outputs' planes
       float n2 = sumsq;
       n2 += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(n2), 0x401F));                       // lane ^ 16 (bit-mask mode: and 0x1f, xor 0x10)
       n2 += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(n2)));           // lane ^ 32
@@ -488,36 +488,47 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
       inv_in = inv_cur;
       const float b2 = n2 * a.cmax[s];
       const int e = (__float_as_int(b2) >> 23) - 127;
-      const int k = b2 > 1e-37f && b2 < 1e37f ? 14 - ((e + 2) >> 1) : 0;
+      int k = b2 > 1e-37f && b2 < 1e37f ? 14 - ((e + 2) >> 1) : 0;
+      if (other > 1e-37f && other < 1e37f) {                 // other t < 2^14 as well
+        const int k2 = 13 - ((__float_as_int(other) >> 23) - 127);
+        k = k < k2 ? k : k2;
+      }
       tscale = pow2(k);
       inv_cur = inv_in * pow2(-k);
       sumsq = 0.f; amax = 0.f;
       mk = mk_next;
     };
-    // one layer whose outputs are split again.  SP: its pending predecessor pair is a store-only pair (after s3)
+    // one layer whose outputs are split again: stream layer s -> gradient buffer k (8: d feature).  SP: its pending predecessor pair is a
+    // store-only pair (after s4)
     auto layer = [&](auto ksc, auto posc, auto spc, f16x8(&ih)[NTP], f16x8(&il)[NTP], f16x8(&oh)[NTP], f16x8(&ol)[NTP], int s, int k) {
       constexpr int KS = decltype(ksc)::value;
       constexpr bool SP = decltype(spc)::value;
       f32x4 nm[2], nc[2];
-      mk_next = m_lane[64 * k];
-      float* const o_cur = a.dz[k];
-      float* const o_pre = a.dz[k + 1 < 8 ? k + 1 : 7];
+      if (k < 8) mk_next = m_lane[64 * k]; else mk_next = make_uint2(0xffffffffu, 0xffffffffu);          // feature_linear has no activation
+      float* const o_cur = k < 8 ? a.dz[k] : a.dF;
+      const int ld_cur = k < 8 ? 256 : a.lddf;
+      const uint32_t off_cur = k < 8 ? off_z : ((uint32_t)row_f * (uint32_t)ld_cur + 4u * (lane & 31)) * 4u;
+      // the predecessor's pending pair: dZ_{k+1} (k = 7: d feature, stream layer s0's outputs)
+      float* const o_pre = k == 7 ? a.dF : a.dz[k + 1 < 8 ? k + 1 : 7];
+      const int ld_pre = k == 7 ? a.lddf : 256;
+      const uint32_t off_pre = k == 7 ? ((uint32_t)row_f * (uint32_t)ld_pre + 4u * (lane & 31)) * 4u : off_z;
       const float ts_pre = tscale, inv_pre = inv_cur;
       const uint2 mk_pre = mk;
       layer_h16x2<KS, NTP, decltype(posc)::value, TC_QUEUE, false>(
           st, ringlane, (const float*)nullptr,
           [&](int ks, int pl) {
             if constexpr (KS == 9) return ks < 8 ? (pl == 0 ? ih[ks & 7] : il[ks & 7]) : (pl == 0 ? Ah : Al);
+            else if constexpr (KS == 4) return pl == 0 ? ih[ks & 3] : il[ks & 3];
             else return pl == 0 ? ih[ks] : il[ks];
           },
           [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
-            if (tp == 0 && pcx == 0) switch_ctx(s, k);
-            bpiece(oh, ol, tp, pcx, mn, cr, tscale, inv_cur, mk, o_cur);
+            if (tp == 0 && pcx == 0) switch_ctx(s, k, KS == 4 ? da_in : 0.f);
+            bpiece(oh, ol, tp, pcx, mn, cr, tscale, inv_cur, mk, o_cur, off_cur, ld_cur);
           },
           [&](int pcx) {
-            if constexpr (KS == 9) return;
+            if constexpr (KS == 4) return;
             else if constexpr (SP) spiece(1, pcx, pm, pc, inv_in, a.dg, a.lddg);
-            else bpiece(ih, il, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, o_pre);
+            else bpiece(ih, il, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, o_pre, off_pre, ld_pre);
           }, nm, nc);
 #pragma unroll
       for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
@@ -525,37 +536,47 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
     using K8 = std::integral_constant<int, 8>;
     using NoSp = std::false_type;
 #define TBPOS(s) std::integral_constant<int, tb_pos(s)>{}
-    layer(std::integral_constant<int, 9>{}, TBPOS(0), NoSp{}, Yh, Yl, Xh, Xl, 0, 7);          // [feature ; alpha]^T : Y (+ A) -> X = dZ7
-    layer(K8{}, TBPOS(1), NoSp{}, Xh, Xl, Yh, Yl, 1, 6);                                      // pts7^T -> dZ6
-    layer(K8{}, TBPOS(2), NoSp{}, Yh, Yl, Xh, Xl, 2, 5);                                      // pts6^T -> dZ5
-    {   // s3 = pts5^T: tile pairs 0 .. 7 the hidden columns -> Y = dZ4, pairs 8, 9 the embedding columns -> stored only
+    layer(std::integral_constant<int, 4>{}, TBPOS(0), NoSp{}, Yh, Yl, Xh, Xl, 0, 8);          // views^T : Y[0 .. 3] -> X = d feature
+    {   // the alpha gradient joins as a ninth k-step, on the scale the feature gradient's planes got
+      const float sc = __int_as_float(0x7f000000 - __float_as_int(inv_cur));                 // 1 / inv_cur (a power of two)
+      const float xs = g == 0 ? da * sc : 0.f;
+      const _Float16 h = (_Float16)xs;
+      const _Float16 z = (_Float16)0.f;
+      Ah = f16x8{h, z, z, z, z, z, z, z};
+      Al = f16x8{(_Float16)((xs - (float)h) * H16_LO_SCALE), z, z, z, z, z, z, z};
+      sumsq = fmaf(xs, xs, sumsq);
+    }
+    layer(std::integral_constant<int, 9>{}, TBPOS(1), NoSp{}, Xh, Xl, Yh, Yl, 1, 7);          // [feature ; alpha]^T : X (+ A) -> Y = dZ7
+    layer(K8{}, TBPOS(2), NoSp{}, Yh, Yl, Xh, Xl, 2, 6);                                      // pts7^T -> X = dZ6
+    layer(K8{}, TBPOS(3), NoSp{}, Xh, Xl, Yh, Yl, 3, 5);                                      // pts6^T -> Y = dZ5
+    {   // s4 = pts5^T: tile pairs 0 .. 7 the hidden columns -> X = dZ4, pairs 8, 9 the embedding columns -> stored only
       f32x4 nm[2], nc[2];
       mk_next = m_lane[64 * 4];
       const float ts_pre = tscale, inv_pre = inv_cur;
       const uint2 mk_pre = mk;
-      layer_h16x2<8, 10, tb_pos(3), TC_QUEUE, false>(
-          st, ringlane, (const float*)nullptr, [&](int ks, int pl) { return pl == 0 ? Xh[ks] : Xl[ks]; },
+      layer_h16x2<8, 10, tb_pos(4), TC_QUEUE, false>(
+          st, ringlane, (const float*)nullptr, [&](int ks, int pl) { return pl == 0 ? Yh[ks] : Yl[ks]; },
           [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) {
-            if (tp == 0 && pcx == 0) switch_ctx(3, 4);
-            if (tp < 8) bpiece(Yh, Yl, tp & 7, pcx, mn, cr, tscale, inv_cur, mk, a.dz[4]);
+            if (tp == 0 && pcx == 0) switch_ctx(4, 4);
+            if (tp < 8) bpiece(Xh, Xl, tp & 7, pcx, mn, cr, tscale, inv_cur, mk, a.dz[4], off_z, 256);
             else spiece(0, pcx, mn, cr, inv_in, a.dg, a.lddg);                                // (tp = 8: the first embedding pair)
           },
-          [&](int pcx) { bpiece(Xh, Xl, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, a.dz[5]); }, nm, nc);
+          [&](int pcx) { bpiece(Yh, Yl, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, a.dz[5], off_z, 256); }, nm, nc);
 #pragma unroll
       for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
     }
-    layer(K8{}, TBPOS(4), std::true_type{}, Yh, Yl, Xh, Xl, 4, 3);                            // pts4^T -> dZ3 (its first pieces finish the embedding pair)
-    layer(K8{}, TBPOS(5), NoSp{}, Xh, Xl, Yh, Yl, 5, 2);                                      // pts3^T -> dZ2
-    layer(K8{}, TBPOS(6), NoSp{}, Yh, Yl, Xh, Xl, 6, 1);                                      // pts2^T -> dZ1
-    layer(K8{}, TBPOS(7), NoSp{}, Xh, Xl, Yh, Yl, 7, 0);                                      // pts1^T -> Y = dZ0
-    {   // s8 = pts0^T: two tile pairs -> d embedding [n][64], stored only
+    layer(K8{}, TBPOS(5), std::true_type{}, Xh, Xl, Yh, Yl, 5, 3);                            // pts4^T -> Y = dZ3 (its first pieces finish the embedding pair)
+    layer(K8{}, TBPOS(6), NoSp{}, Yh, Yl, Xh, Xl, 6, 2);                                      // pts3^T -> X = dZ2
+    layer(K8{}, TBPOS(7), NoSp{}, Xh, Xl, Yh, Yl, 7, 1);                                      // pts2^T -> Y = dZ1
+    layer(K8{}, TBPOS(8), NoSp{}, Yh, Yl, Xh, Xl, 8, 0);                                      // pts1^T -> X = dZ0
+    {   // s9 = pts0^T: two tile pairs -> d embedding [n][64], stored only
       f32x4 nm[2], nc[2];
       const float ts_pre = tscale, inv_pre = inv_cur;
       const uint2 mk_pre = mk;
-      layer_h16x2<8, 2, tb_pos(8), TC_QUEUE, false>(
-          st, ringlane, (const float*)nullptr, [&](int ks, int pl) { return pl == 0 ? Yh[ks] : Yl[ks]; },
+      layer_h16x2<8, 2, tb_pos(9), TC_QUEUE, false>(
+          st, ringlane, (const float*)nullptr, [&](int ks, int pl) { return pl == 0 ? Xh[ks] : Xl[ks]; },
           [&](int, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { spiece(0, pcx, mn, cr, inv_pre, a.de0, 64); },
-          [&](int pcx) { bpiece(Yh, Yl, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, a.dz[0]); }, nm, nc);
+          [&](int pcx) { bpiece(Xh, Xl, NTP - 1, pcx, pm, pc, ts_pre, inv_pre, mk_pre, a.dz[0], off_z, 256); }, nm, nc);
 #pragma unroll
       for (int pcx = 0; pcx < 8; ++pcx) spiece(1, pcx, nm, nc, inv_pre, a.de0, 64);
     }
@@ -564,11 +585,11 @@ __global__ __launch_bounds__(512, 2) void tchain_bwd_kernel(TChainBwdArgs a) {
     for (int i = 0; i < TB_PAD_SLOTS; ++i) st.begin();
     {   // dZ0's maximum; then the wave's maxima go to the slots (lane k: buffer k)
       atomicMax((unsigned int*)wave_max + slot_prev, __float_as_uint(amax * inv_cur));
-      if (lane < 8) {
+      if (lane < TB_NSLOT_MAX - 1) {
         const float m = wave_max[lane];
         if (m > 0.f) atomicMax((unsigned int*)a.slot[lane] + ((unsigned)blockIdx.x & (HG_SLOT - 1)), __float_as_uint(m));
       }
-      if (lane < 9) wave_max[lane] = 0.f;
+      if (lane < TB_NSLOT_MAX) wave_max[lane] = 0.f;
     }
   }
   st.drain();

@@ -1531,7 +1531,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], Rp * 256);
   T_ALLOC(t->n_c5, Rp * LD_C5); T_ALLOC(t->n_a5, Rp * 256); T_ALLOC(t->n_a6, Rp * 256); T_ALLOC(t->n_a7, Rp * 256);
   T_ALLOC(t->n_cv, Rp * LD_CV); T_ALLOC(t->n_hv, Rp * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
-  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, R * LD_CV); T_ALLOC(t->d_a, Rp * 256);
+  T_ALLOC(t->d_rgb_map, N * 3); T_ALLOC(t->d_raw, R * 4); T_ALLOC(t->d_hv, R * 128); T_ALLOC(t->d_cv, Rp * LD_CV); T_ALLOC(t->d_a, Rp * 256);
   T_ALLOC(t->d_b, Rp * 256); T_ALLOC(t->d_c5, Rp * LD_C5); T_ALLOC(t->d_e0, Rp * 64); T_ALLOC(t->d_pts, N * 24); T_ALLOC(t->d_z, N * 8);
   for (int k = 0; k < 6; ++k) T_ALLOC(t->dz_x[k], Rp * 256);
   T_ALLOC(t->tc_mask, Rp / TC_ROWS * 8 * TC_NL * 64);
@@ -1540,7 +1540,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   t->d_h0 = t->d_hk[0]; t->d_h1 = t->d_hk[1];
   // padding columns of the concatenated rows are zero and stay zero (the kernels write the payload columns only, or zeros)
   PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)Rp * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)Rp * LD_C5 * 4));
-  PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)Rp * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)R * LD_CV * 4));
+  PNRF_HIP(hipMemset(t->n_cv, 0, (size_t)Rp * LD_CV * 4)); PNRF_HIP(hipMemset(t->d_cv, 0, (size_t)Rp * LD_CV * 4));
   T_ALLOC(t->st_rays, N * 11); T_ALLOC(t->st_or_rays, N * 11); T_ALLOC(t->st_target, N * 3); T_ALLOC(t->st_ref_nos, N * 4); T_ALLOC(t->st_jitter, R); T_ALLOC(t->st_noise, R);
   T_ALLOC(t->loss, 8);                              // [total, mse x 3, completion counter of losses_kernel]
   PNRF_HIP(hipMemset(t->loss, 0, 32));
@@ -1766,11 +1766,13 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   // one max-|gradient| slot per gradient buffer write (the two products that add up d_a share one)
   float* m = t->amax + slot0 * HG_SLOT;
   T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
-  T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0 * HG_SLOT, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
-  if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->dw_tile == 0) {
-    // The nine input-gradient products below the view layer as ONE launch (tchain_bwd_kernel): the rows' gradients stay in registers from the
-    // feature / alpha gradients down to pts0, each dZ_k is written once, the ReLU derivatives come from the forward chain's masks.  The weight
-    // gradients follow as launches of their own, each reading its dZ_k and the saved activation below it once.
+  const bool engine = t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->dw_tile == 0;
+  if (!engine) T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0 * HG_SLOT, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
+  if (engine) {
+    // The ten input-gradient products from the view layer down as ONE launch (tchain_bwd_kernel): the rows' gradients stay in registers from
+    // the rgb branch's hidden gradient to pts0, every gradient a weight-gradient product needs is written once, the ReLU derivatives come from
+    // the forward chain's masks.  The weight gradients follow as one grouped launch, each reading its gradient and the saved activation below
+    // it once.
     float* dz[8] = {t->dz_x[5], t->dz_x[4], t->dz_x[3], t->dz_x[2], t->dz_x[1], t->dz_x[0], t->d_b, t->d_a};      // dz[k] = dZ_k
     const TLin& lf = t->L[L_FEAT];
     DwhGroupArgs grp = {};
@@ -1785,12 +1787,15 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
       ++grp.n;
       return 0;
     };
+    T_RC(dw_job(t->n_cv, LD_CV, t->d_hv, 128, m + 0 * HG_SLOT, t->L[L_VIEWS]));
     T_RC(dw_job(t->n_a7, 256, t->d_cv, LD_CV, m + 1 * HG_SLOT, lf));
     T_RC(layer_bwd(t, L_ALPHA, t->d_raw + 3, 4, none, t->n_a7, 256, nullptr, 0, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));          // weight gradient only
     TChainBwdArgs c = {};
-    c.blob = t->tb_stream; c.dF = t->d_cv; c.lddf = LD_CV; c.dA = t->d_raw + 3; c.ldda = 4; c.mask = t->tc_mask; c.cmax = t->tb_pack.cmax;
+    c.blob = t->tb_stream; c.dH = t->d_hv; c.lddh = 128; c.dF = t->d_cv; c.lddf = LD_CV; c.dA = t->d_raw + 3; c.ldda = 4; c.mask = t->tc_mask;
+    c.cmax = t->tb_pack.cmax;
     for (int k = 0; k < 8; ++k) { c.dz[k] = dz[k]; c.slot[k] = m + (9 - k) * HG_SLOT; }
-    c.slot[8] = m + 10 * HG_SLOT;
+    c.slot[8] = m + 1 * HG_SLOT;                         // d feature (the rows of d_cv)
+    c.slot[9] = m + 10 * HG_SLOT;                        // scratch
     c.dg = t->d_c5; c.lddg = LD_C5; c.de0 = t->d_e0; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
     PNRF_HIP(hipFuncSetAttribute((const void*)tchain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_BYTES));
     const int ncu = trainer_num_cu();
