@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512) void layer_bwd_kernel(HGemmArgs g, DwhArgs d, 
 // ------------------------------------------------------------------------------------------ grouped weight gradients
 // The weight gradients of several layers in one launch (their dZ / X buffers must all still exist): blocks [first[j], first[j + 1]) belong to
 // job j as (tile, split) = (b % tiles, b / tiles).
-constexpr int DH_GROUP_MAX = 10;
+constexpr int DH_GROUP_MAX = 24;
 struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int tiles[DH_GROUP_MAX]; int n; };
 __global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DH_BYTES];

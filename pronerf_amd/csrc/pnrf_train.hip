@@ -1064,6 +1064,9 @@ struct pnrf_trainer {
   float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
   size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
   DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
+  DwhGroupArgs grp;                              // split-fp16 weight gradients waiting for the iteration's one grouped launch (flush_dw_group): the 256-wide
+  int grp_blocks = 0;                            // layers of all three nets; their gradient / activation buffers stay untouched until then
+  float* d_hs[6] = {};                           // the sampler net's hidden gradients (d_hk holds the refine net's until the grouped launch)
 };
 
 namespace {
@@ -1180,8 +1183,26 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   ++t->jobs.n;
   return 0;
 }
-void begin_dw(pnrf_trainer* t) { t->jobs.n = 0; t->pool_used = 0; }
+void begin_dw(pnrf_trainer* t) { t->jobs.n = 0; t->pool_used = 0; t->grp.n = 0; t->grp_blocks = 0; }
+// a deferred split-fp16 weight gradient joins the iteration's grouped launch (dwh_group_kernel)
+int group_dw(pnrf_trainer* t, const DwDefer& d) {
+  PNRF_REQUIRE(t->grp.n < DH_GROUP_MAX, PNRF_E_STATE, "pnrf_trainer: more than %d grouped weight gradients", DH_GROUP_MAX);
+  DwhGroupArgs& g = t->grp;
+  g.j[g.n] = d.args; g.first[g.n] = t->grp_blocks; g.tiles[g.n] = d.tiles;
+  t->grp_blocks += d.tiles * d.splits;
+  ++g.n;
+  return 0;
+}
+int flush_dw_group(pnrf_trainer* t, hipStream_t s) {
+  if (!t->grp.n) return 0;
+  t->grp.first[t->grp.n] = t->grp_blocks;
+  hipLaunchKernelGGL(dwh_group_kernel, dim3((unsigned)t->grp_blocks), dim3(512), 0, s, t->grp);
+  PNRF_LAUNCH_CHECK();
+  t->grp.n = 0; t->grp_blocks = 0;
+  return 0;
+}
 int flush_dw_reduce(pnrf_trainer* t, hipStream_t s) {
+  { int rc = flush_dw_group(t, s); if (rc) return rc; }
   if (!t->jobs.n) return 0;
   const DwJob& last = t->jobs.j[t->jobs.n - 1];
   hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)(last.block0 + last.blocks)), dim3(TPB), 0, s, t->jobs);
@@ -1536,7 +1557,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   for (int k = 0; k < 6; ++k) T_ALLOC(t->dz_x[k], Rp * 256);
   T_ALLOC(t->tc_mask, Rp / TC_ROWS * 8 * TC_NL * 64);
   T_ALLOC(t->d_add, N * 8); T_ALLOC(t->d_mul, N * 8); T_ALLOC(t->d_depth, N * 8); T_ALLOC(t->d_ry, N * 35); T_ALLOC(t->d_sy, N * 27);
-  T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); for (int k = 0; k < 6; ++k) T_ALLOC(t->d_hk[k], N * 256);
+  T_ALLOC(t->d_rgb0, N * 3); T_ALLOC(t->d_mmrgb, N * 3); for (int k = 0; k < 6; ++k) { T_ALLOC(t->d_hk[k], N * 256); T_ALLOC(t->d_hs[k], N * 256); }
   t->d_h0 = t->d_hk[0]; t->d_h1 = t->d_hk[1];
   // padding columns of the concatenated rows are zero and stay zero (the kernels write the payload columns only, or zeros)
   PNRF_HIP(hipMemset(t->n_c5, 0, (size_t)Rp * LD_C5 * 4)); PNRF_HIP(hipMemset(t->d_c5, 0, (size_t)Rp * LD_C5 * 4));
@@ -1775,17 +1796,11 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     // it once.
     float* dz[8] = {t->dz_x[5], t->dz_x[4], t->dz_x[3], t->dz_x[2], t->dz_x[1], t->dz_x[0], t->d_b, t->d_a};      // dz[k] = dZ_k
     const TLin& lf = t->L[L_FEAT];
-    DwhGroupArgs grp = {};
-    int grp_blocks = 0;
     auto dw_job = [&](const float* X, int ldx, const float* dZ, int ldz, const float* amax_slot, const TLin& l) -> int {
       DwDefer d;
       int rc = gemm_dw(t, X, ldx, dZ, ldz, amax_slot, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s, &d);
-      if (rc) return rc;
-      if (!d.set) return 0;                                  // gemm_dw launched another kernel itself
-      grp.j[grp.n] = d.args; grp.first[grp.n] = grp_blocks; grp.tiles[grp.n] = d.tiles;
-      grp_blocks += d.tiles * d.splits;
-      ++grp.n;
-      return 0;
+      if (rc || !d.set) return rc;                           // (not set: gemm_dw launched another kernel itself)
+      return group_dw(t, d);
     };
     T_RC(dw_job(t->n_cv, LD_CV, t->d_hv, 128, m + 0 * HG_SLOT, t->L[L_VIEWS]));
     T_RC(dw_job(t->n_a7, 256, t->d_cv, LD_CV, m + 1 * HG_SLOT, lf));
@@ -1803,13 +1818,8 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     PNRF_LAUNCH_CHECK();
     const float* xin[8] = {t->emb, t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5, t->n_a5, t->n_a6};
     const int ldx[8] = {90, 256, 256, 256, 256, LD_C5, 256, 256};
-    // the nine 256-wide weight gradients as one grouped launch: at 32 768 rows each of them alone is a 30 us launch of 256 workgroups
+    // the ten wide weight gradients join the iteration's grouped launch (flush_dw_group): at 32 768 rows each of them alone is a 30 us launch
     for (int k = 7; k >= 0; --k) T_RC(dw_job(xin[k], ldx[k], dz[k], 256, c.slot[k], t->L[L_N + k]));
-    if (grp.n) {
-      grp.first[grp.n] = grp_blocks;
-      hipLaunchKernelGGL(dwh_group_kernel, dim3((unsigned)grp_blocks), dim3(512), 0, s, grp);
-      PNRF_LAUNCH_CHECK();
-    }
     if (want_dpts) {
       hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 64, t->d_c5, LD_C5, t->d_pts, R, 10);
       PNRF_LAUNCH_CHECK();
@@ -1842,42 +1852,36 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
 // output-layer gradient dy [N, out_last] -> gradients of a 7-layer ELU net (sampler: first = L_S, refine: first = L_R); no gradient reaches the
 // net's input (the Pluecker moment is depth-independent; the projection is under no_grad in the reference)
 int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, float* const* h, const float* x0, int in0, int64_t N, hipStream_t s) {
-  float* m = t->amax + (first == L_S ? 16 : 24) * HG_SLOT;                // max-|gradient| slots of this net's six hidden gradients
+  float* m = t->amax + (first == L_S ? 16 : 24) * HG_SLOT;
+  float* const* dh = first == L_S ? t->d_hs : t->d_hk;     // one set per net: the weight gradients read them in the iteration's grouped launch                // max-|gradient| slots of this net's six hidden gradients
   // dZ of hidden layer k lives in d_hk[k]; the output layer's product writes d_hk[5]
-  T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, t->d_hk[5], 256, m + 5 * HG_SLOT, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
+  T_RC(layer_bwd(t, first + 6, dy, out_last, nullptr, h[5], 256, dh[5], 256, m + 5 * HG_SLOT, 0.f, N, T_ACT_ELU, h[5], 256, 0, s));
   bool chain = chain_rows(N) && t->dw_tile == 0;
   for (int k = 5; k >= 1 && chain; --k)
-    chain = hgemm_fits(t, 256, t->L[first + k].out, N, 256, t->d_hk[k - 1], 256, h[k - 1], 256, 0) && t->L[first + k].in == 256 && t->L[first + k].out == 256;
+    chain = hgemm_fits(t, 256, t->L[first + k].out, N, 256, dh[k - 1], 256, h[k - 1], 256, 0) && t->L[first + k].in == 256 && t->L[first + k].out == 256;
   if (chain) {
-    // (1) the five input-gradient products in one launch, (2) the six weight gradients in one launch
+    // (1) the five input-gradient products in one launch, (2) the six weight gradients join the iteration's grouped launch
     RChainArgs c = {};
     for (int k = 5; k >= 1; --k) {
       HGemmArgs a{};
-      bwd_hgemm_args(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0, &a);
-      c.l[5 - k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, nullptr, t->d_hk[k - 1], h[k - 1], m + (k - 1) * HG_SLOT, T_ACT_ELU, 256, 256};
+      bwd_hgemm_args(t, first + k, dh[k], 256, m + k * HG_SLOT, dh[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, 0, &a);
+      c.l[5 - k] = RChainLayer{a.Bh, a.Bl, a.ldb, a.n_pad, nullptr, dh[k - 1], h[k - 1], m + (k - 1) * HG_SLOT, T_ACT_ELU, 256, 256};
     }
-    c.has_first = 0; c.X0 = t->d_hk[5]; c.x0_amax = m + 5 * HG_SLOT; c.n = 5; c.M = N; c.bwd = 1;
+    c.has_first = 0; c.X0 = dh[5]; c.x0_amax = m + 5 * HG_SLOT; c.n = 5; c.M = N; c.bwd = 1;
     launch_rchain(c, N, s);
     PNRF_LAUNCH_CHECK();
-    DwhGroupArgs g = {};
-    int blocks = 0;
     for (int k = 5; k >= 0; --k) {
       const TLin& l = t->L[first + k];
       DwDefer d;
-      T_RC(gemm_dw(t, k ? h[k - 1] : x0, k ? 256 : in0, t->d_hk[k], 256, m + k * HG_SLOT, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, N, s, &d));
+      T_RC(gemm_dw(t, k ? h[k - 1] : x0, k ? 256 : in0, dh[k], 256, m + k * HG_SLOT, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, N, s, &d));
       PNRF_REQUIRE(d.set, PNRF_E_STATE, "pnrf_trainer: a hidden layer of an ELU net did not take the split-fp16 weight-gradient kernel");
-      g.j[g.n] = d.args; g.first[g.n] = blocks; g.tiles[g.n] = d.tiles;
-      blocks += d.tiles * d.splits;
-      ++g.n;
+      T_RC(group_dw(t, d));
     }
-    g.first[g.n] = blocks;
-    hipLaunchKernelGGL(dwh_group_kernel, dim3((unsigned)blocks), dim3(512), 0, s, g);
-    PNRF_LAUNCH_CHECK();
     return 0;
   }
   for (int k = 5; k >= 1; --k)
-    T_RC(layer_bwd(t, first + k, t->d_hk[k], 256, m + k * HG_SLOT, h[k - 1], 256, t->d_hk[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
-  return layer_bwd(t, first + 0, t->d_hk[0], 256, m, x0, in0, nullptr, 0, nullptr, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
+    T_RC(layer_bwd(t, first + k, dh[k], 256, m + k * HG_SLOT, h[k - 1], 256, dh[k - 1], 256, m + (k - 1) * HG_SLOT, 0.f, N, T_ACT_ELU, h[k - 1], 256, 0, s));
+  return layer_bwd(t, first + 0, dh[0], 256, m, x0, in0, nullptr, 0, nullptr, 0.f, N, T_ACT_NONE, nullptr, 0, 0, s);
 }
 
 int check_batch(const pnrf_trainer* t, const pnrf_train_batch_t* bt, const float* loss, int S, const char* who) {
