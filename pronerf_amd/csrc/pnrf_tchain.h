@@ -31,6 +31,10 @@ constexpr int TC_ROWS = 128;                               // rows per workgroup
 constexpr int TC_QUEUE = PNRF_TC_QUEUE;                    // A fragments held in registers ahead of their MFMAs
 constexpr int TC_RING = NSLOTS;                           // (a 7-of-8 ring, WStream<8, 7, 8>, measured no faster: the stores' cost is not their vmcnt)
 constexpr int TC_RING_BYTES = TC_RING * SLOT_BYTES;
+#ifndef PNRF_TC_GROUP_PAIRS
+#define PNRF_TC_GROUP_PAIRS 4
+#endif
+constexpr int TC_GROUP_PAIRS = PNRF_TC_GROUP_PAIRS;        // forward chain: tile pairs per staged group (4: 512-byte row segments, 2: 256-byte)
 constexpr int TC_STG_ROW = 128 + 4;                        // floats per staged row: 128 features + padding (bank spread of the 16-byte accesses)
 constexpr int TC_STG_BYTES = 8 * 16 * TC_STG_ROW * 4;      // eight waves x 16 rows
 constexpr int TC_LDS_BYTES = TC_RING_BYTES + TC_NL * W_HID * 4 + TC_STG_BYTES;
@@ -157,8 +161,9 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     // stride and the launch ran at 2.3 TB/s of writes (1.06 ms at 262 144 rows; 0.65 ms without the stores; a plain fill writes 6.8 TB/s).
     float* const stage = (float*)(smem + TC_RING_BYTES + TC_NL * W_HID * 4) + wave * (16 * TC_STG_ROW);
     float* const stage_w = stage + col * TC_STG_ROW + 4 * g;                       // this lane's accumulator tiles go here (+ 32 (tp & 3) + 16 t)
-    const float* const stage_r = stage + (lane >> 5) * TC_STG_ROW + 4 * (lane & 31);   // ... and it reads rows 2 i + (lane >> 5), 16 bytes at 4 (lane & 31)
-    const int64_t row_f = (int64_t)batch * TC_ROWS + wave * 16 + (lane >> 5);      // first of the rows this lane writes out
+    constexpr int GP = TC_GROUP_PAIRS, LPR = 8 * GP, RPI = 64 / LPR;                 // tile pairs per staged group; lanes per row, rows per store instruction
+    const float* const stage_r = stage + (lane / LPR) * TC_STG_ROW + 4 * (lane % LPR);   // ... and it reads rows RPI i + lane / LPR, 16 bytes at 4 (lane % LPR)
+    const int64_t row_f = (int64_t)batch * TC_ROWS + wave * 16 + lane / LPR;      // first of the rows this lane writes out
     float* o_prev = a.out[0];                      // where the pending tile pair's rows go (its layer's buffer; + this lane's 32-bit byte offset) ...
     int ld_prev = 0;
     uint32_t off_prev = 0;
@@ -191,15 +196,15 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
       wh[2 * t + p] = hi; wl[2 * t + p] = lo;
       dh[tp] = __builtin_bit_cast(f16x8, wh); dl[tp] = __builtin_bit_cast(f16x8, wl);
       if (r != 3) return;
-      *(f32x4*)(stage_w + 32 * (tp & 3) + 16 * t) = mn[t];
-      if (t == 1 && (tp & 3) == 3) {               // 128 features of 16 rows complete: out they go
+      *(f32x4*)(stage_w + 32 * (tp % GP) + 16 * t) = mn[t];
+      if (t == 1 && tp % GP == GP - 1) {           // 32 GP features of 16 rows complete: out they go
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x4 w = *(const f32x4*)(stage_r + 2 * i * TC_STG_ROW);
+        for (int i = 0; i < 16 / RPI; ++i) {
+          const f32x4 w = *(const f32x4*)(stage_r + RPI * i * TC_STG_ROW);
 #ifdef PNRF_TC_PROBE_NOSTORE
           if (w[0] == 123.456f)
 #endif
-            tc_store((float*)((char*)(optr + ((2 * i) * ld + 32 * (tp & ~3))) + ooff), w);       // uniform pointer + this lane's 32-bit offset
+            tc_store((float*)((char*)(optr + ((RPI * i) * ld + 32 * (tp - tp % GP))) + ooff), w);       // uniform pointer + this lane's 32-bit offset
         }
       }
     };
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
       const int ld_cur = a.ldo[l], ld_pre = ld_prev, l_pre = l_prev;
       float* const o_cur = a.out[l];
       float* const o_pre = o_prev;
-      const uint32_t off_cur = ((uint32_t)row_f * (uint32_t)ld_cur + 4u * (lane & 31)) * 4u, off_pre = off_prev;   // < 4 GiB: checked by the launcher
+      const uint32_t off_cur = ((uint32_t)row_f * (uint32_t)ld_cur + 4u * (lane % LPR)) * 4u, off_pre = off_prev;   // < 4 GiB: checked by the launcher
       layer_h16x2<KS, LNTP, decltype(posc)::value, TC_QUEUE>(
           st, ringlane, biaslane + l * W_HID,
           [&](int ks, int pl) {

@@ -1105,7 +1105,7 @@ int launch_tgemm(const GemmArgs& a, hipStream_t s) {
 // `in` counts the columns of X; with gap >= 0 column `gap` of X is padding and dW has in - 1 columns
 // defer != NULL: if the split-fp16 kernel is the one to use, its arguments and grid go to *defer instead of a launch (layer_bwd dispatches it
 // together with the layer's input-gradient product)
-struct DwDefer { DwhArgs args; int tiles, splits; bool set; };
+struct DwDefer { DwhArgs args; int tiles, splits; bool set; int wgs = 128; };      // wgs (in): workgroups the deferred gradient should spread over
 int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, const float* dz_amax, float* dW, float* db, int in, int gap, int out,
             int64_t R, hipStream_t s, DwDefer* defer = nullptr) {
   PNRF_REQUIRE(out <= DB_MAX_OUT, PNRF_E_SHAPE, "pnrf_trainer: layer output %d wider than the bias-partial buffer (%d)", out, DB_MAX_OUT);
@@ -1128,7 +1128,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
     splits = R / 128 < HEAD_MAX_SPLITS ? R / 128 : HEAD_MAX_SPLITS;      // partials are a few KB each: as many workgroups as there are CUs
   } else if (use_h) {
     tiles = ((out + 127) / 128) * ((in + 127) / 128);
-    splits = ((defer ? 128 : 256) + tiles - 1) / tiles;         // one workgroup per CU (half of the CUs when the launch is shared with the dX product) ...
+    splits = ((defer ? defer->wgs : 256) + tiles - 1) / tiles;         // one workgroup per CU (half of the CUs when the launch is shared with the dX product) ...
     if (splits > by_traffic) splits = by_traffic;               // ... unless the partials would outweigh the operands
     const int64_t by_rows = (R + DH_KC - 1) / DH_KC;
     if (splits > by_rows) splits = by_rows;
@@ -1798,6 +1798,9 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     const TLin& lf = t->L[L_FEAT];
     auto dw_job = [&](const float* X, int ldx, const float* dZ, int ldz, const float* amax_slot, const TLin& l) -> int {
       DwDefer d;
+      // partials per gradient: at 32 768 rows 16 splits (the reduction of the partials is what shrinks: iteration 0.985 -> 0.960 ms), at 262 144 rows
+      // 32 (16: 4.29 -> 4.50 ms — the grouped launch is bound by HBM there and wants the parallelism)
+      d.wgs = R >= 65536 ? 128 : 64;
       int rc = gemm_dw(t, X, ldx, dZ, ldz, amax_slot, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, R, s, &d);
       if (rc || !d.set) return rc;                           // (not set: gemm_dw launched another kernel itself)
       return group_dw(t, d);
@@ -1873,6 +1876,7 @@ int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, 
     for (int k = 5; k >= 0; --k) {
       const TLin& l = t->L[first + k];
       DwDefer d;
+      d.wgs = 64;
       T_RC(gemm_dw(t, k ? h[k - 1] : x0, k ? 256 : in0, dh[k], 256, m + k * HG_SLOT, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, N, s, &d));
       PNRF_REQUIRE(d.set, PNRF_E_STATE, "pnrf_trainer: a hidden layer of an ELU net did not take the split-fp16 weight-gradient kernel");
       T_RC(group_dw(t, d));

@@ -151,3 +151,35 @@ def test_exploration_iteration_at_config4_size(work, dev):
     # one optimizer step of each kind leaves finite parameters
     wk.stage2_step(); wk.explore_step(n_mult)
     assert all(bool(torch.isfinite(p).all()) for i in range(26) for p in tr.read('param', i))
+
+
+@pytest.mark.parametrize('offset', [1e-3, 1.0, 300.0])
+def test_backward_chain_gradient_range(dev, offset):
+    """The backward chain carries gradients as per-row power-of-two-scaled fp16 planes (pnrf_tchain.h): image gradients of 1e-7 per pixel (a target 1e-3 from
+    the rendered image: the products' own 1e-6 differences in the image are then 1e-3 of the gradient signal), of the usual size and of 0.1 (a target 300 away) have to come out fp32-grade — against the exact-fp32 products and
+    against one launch per layer — with rows whose gradient is dominated by the alpha branch and rows without any.  8192 sample rows: the
+    smallest batch that takes the engine path."""
+    from pronerf_amd import workloads as wl
+    wk = wl.TrainWorkload(dev, n_rays=1024, n_views=6, H=96, W=128, focal=110.0, max_samples=8, seed=3)
+    tr = wk.trainer
+    tr.set_products('f32')
+    _, rgb = wk.stage2_step(want_rgb=True, adam=False)
+    g = torch.Generator(device='cpu').manual_seed(7)
+    delta = torch.randn(rgb.shape, generator=g).to(dev) * offset
+    delta[::5] = 0                                                            # every fifth ray: no image gradient at all
+    wk.target = (rgb + delta).contiguous()
+    res = {}
+    for kind in ('f32', 'f16x2', 'f16x2_unchained'):
+        tr.set_products(kind)
+        loss, _ = wk.stage2_step(want_rgb=True, adam=False)
+        res[kind] = (float(loss[1]), _grads(tr))
+    tr.set_products('f16x2')
+    assert all(bool(torch.isfinite(x).all()) for x in res['f16x2'][1])
+    assert abs(res['f16x2'][0] - res['f32'][0]) <= 5e-3 * res['f32'][0]
+    scale = max(float(x.abs().max()) for x in res['f32'][1])
+    worst32 = max(_rel(a, b) for a, b in zip(res['f16x2'][1], res['f32'][1]))
+    worstu = max(_rel(a, b) for a, b in zip(res['f16x2'][1], res['f16x2_unchained'][1]))
+    base = max(_rel(a, b) for a, b in zip(res['f16x2_unchained'][1], res['f32'][1]))
+    print(f'\n[gradient range] target offset {offset:g}: largest gradient entry {scale:.1e}; engine chains vs fp32 products {worst32:.1e} (one launch per layer vs '
+          f'fp32: {base:.1e}), vs one launch per layer {worstu:.1e}')
+    assert scale > 0 and worst32 < max(2e-2, 3 * base) and worstu < 1e-2

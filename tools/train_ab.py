@@ -1,19 +1,15 @@
 #!/usr/bin/env python3
-"""Times the training iterations of tests/perf_train_gpu.py's workload against several library builds, each in its own child process
-(python tools/train_ab.py <variant> [<variant> ...]; '' = the default build)."""
-import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-code = '''
-import ctypes as C, os, sys
-sys.path.insert(0, %r)
-from pronerf_amd import _lib
-name = %r
-if name:
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libpronerf_hip_' + name + '.so')
-sys.argv = ['perf_train_gpu.py', '--hip-only']
-__file__ = os.path.join(%r, 'tests', 'perf_train_gpu.py')
-exec(open(__file__).read())
-'''
-for v in sys.argv[1:] or ['']:
-    r = subprocess.run([sys.executable, '-c', code % (ROOT, v, ROOT)], capture_output=True, text=True)
-    print(repr(v), r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:])
+"""Interleaved timing of library builds on the two training workloads:  python tools/train_ab.py <lib> <lib> ...   ('' = the default build)"""
+import ctypes, json, os, subprocess, sys
+libs = sys.argv[1:] or ['']
+res = {l: [] for l in libs}
+for rnd in range(3):
+    for l in libs:
+        for w in ('stage2_iteration', 'stage1_explore_64'):
+            cmd = [sys.executable, os.path.join(os.path.dirname(__file__), 'train_iter.py'), '--workload', w, '--iters', '40', '--warmup', '5'] + (['--lib', l] if l else [])
+            out = subprocess.run(cmd, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+            res[l].append((w, json.loads(out)['ms']))
+for l in libs:
+    for w in ('stage2_iteration', 'stage1_explore_64'):
+        v = sorted(ms for ww, ms in res[l] if ww == w)
+        print(f'{l or "default":10s} {w:20s} median {v[len(v) // 2]:.4f} min {v[0]:.4f}')
