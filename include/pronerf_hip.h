@@ -266,7 +266,10 @@ int pnrf_ctx_profile_end(pnrf_ctx_t* ctx, float* ms, int* frames);
  * products carry bias + activation (forward) and the activation derivative of the layer below (backward) in their epilogues and
  * multiply either in split fp16 (default: both operands as hi + 2^-11 lo fp16 pairs, 22 significand bits, three fp16 MFMAs per
  * block, gradients scaled by a power of two from their recorded maximum) or in exact fp32 on v_mfma_f32_16x16x4_f32
- * (pnrf_trainer_set_products); a layer's input-gradient product and weight gradient are one launch; the 1-4 wide heads, sort,
+ * (pnrf_trainer_set_products).  From 8192 sample rows on the fine net runs as two launches on the fused-MLP engine of the inference
+ * path — forward pts0 .. feature, views with every activation saved once; backward the ten input-gradient products with per-row
+ * scaled fp16 planes — and the 256-wide weight gradients of all three nets as one grouped launch per iteration; below that, and
+ * for the 4096-row sampler / refine nets, a layer's products are launches or 16-row layer chains.  The 1-4 wide heads, sort,
  * interval refinement, jitter, encodings, compositing, losses and Adam are per-ray / streaming kernels. */
 
 /* Operator-level backward passes (each mirrors what torch.autograd derives for the forward it names). */
@@ -359,12 +362,13 @@ int pnrf_trainer_set_graph(pnrf_trainer_t* t, int enable);
 /* Arithmetic of the layer products X W^T and dZ W.  kind 0 (default): split-fp16 MFMA — both operands as hi + 2^-11 lo fp16 pairs (22
    significand bits), three fp16 MFMAs per product block, fp32 accumulation; gradients are scaled by a power of two taken from their
    recorded maximum before the split.  kind 1: exact-fp32 MFMA products everywhere (the reference trains in fp32; torch's fp32 GEMMs are
-   this).  From 8192 rows on kind 0 runs the fine net's forward pass (pts0 .. pts7, feature_linear) as ONE launch on the fused-MLP engine of the
-   inference path: 128 rows per workgroup stay in registers through the nine layers, the weights stream through LDS once per 128 rows, each
-   layer's activation is written once for the backward pass (same split-fp16 arithmetic, the engine's contraction order: fp32 round-off
-   apart from the per-layer products).  kind 2: one product launch per layer; kind 3: pts1-4 and pts6, pts7, feature as two 64-row layer chains
-   (kinds 2 and 3: bit-identical to each other; kept for A/B timing and tests).  The narrow heads (fewer than 64 output columns) always use
-   the fp32 kernel. */
+   this).  From 8192 rows on kind 0 runs the fine net on the fused-MLP engine of the inference path: forward (pts0 .. pts7, feature_linear,
+   views_linear) and backward (their input gradients) as ONE launch each — 128 rows per workgroup stay in registers through the layers, the
+   weights stream through LDS once per 128 rows, each activation / gradient is written once, ReLU derivatives travel as bit masks — and the
+   weight gradients as one grouped launch (same split-fp16 arithmetic, the engine's contraction order and per-row gradient scales: fp32
+   round-off apart from the per-layer products).  kind 2: one product launch per layer; kind 3: pts1-4 and pts6, pts7, feature forward as two
+   64-row layer chains (kinds 2 and 3: bit-identical to each other; kept for A/B timing and tests).  The narrow heads (fewer than 64 output
+   columns) always use the fp32 kernel. */
 int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind);
 /* optimizer.step() of torch.optim.Adam (L2 weight decay added to the gradient).  which 0: the joint optimizer over all
  * parameters (run_S_eS_eN_alter_base_refine2.py:394, 869; stage 1 s_optimizer); which 1: the NeRF-only optimizer of stage 1

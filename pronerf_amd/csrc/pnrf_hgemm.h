@@ -589,14 +589,24 @@ __global__ __launch_bounds__(512) void layer_bwd_kernel(HGemmArgs g, DwhArgs d, 
 // The weight gradients of several layers in one launch (their dZ / X buffers must all still exist): blocks [first[j], first[j + 1]) belong to
 // job j as (tile, split) = (b % tiles, b / tiles).
 constexpr int DH_GROUP_MAX = 24;
-struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int tiles[DH_GROUP_MAX]; int n; };
+struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int tiles[DH_GROUP_MAX]; int splits[DH_GROUP_MAX]; int n; };
+// Workgroups go to the XCDs round robin (blockIdx % 8) and every tile of a split reads the split's rows — of X or of dZ — again.  Jobs start at
+// multiples of 8 and, where the split count is one too, block b of a job is (tile (b / 8) % tiles, split b % 8 + 8 (b / (8 tiles))): the tiles of a
+// split run on ONE XCD at about the same time and its L2 fetches the rows once (at 262 144 rows the grouped launch is bound by HBM; FETCH_SIZE
+// said 10.1 GB per launch for 5.4 GB of operands).
+#ifndef PNRF_DWG_PLAIN
+#define PNRF_DWG_PLAIN 0
+#endif
 __global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DH_BYTES];
   __shared__ float s_red[16];
   int j = 0;
   while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
-  const int b = (int)blockIdx.x - g.first[j];
-  dwh_body(g.j[j], b % g.tiles[j], b / g.tiles[j], smem, s_red);
+  const int b = (int)blockIdx.x - g.first[j], tiles = g.tiles[j], splits = g.splits[j];
+  if (b >= tiles * splits) return;                             // padding up to the next multiple of 8
+  int tile = b % tiles, split = b / tiles;
+  if (!PNRF_DWG_PLAIN && splits % 8 == 0) { const int q = b >> 3; tile = q % tiles; split = (b & 7) + 8 * (q / tiles); }
+  dwh_body(g.j[j], tile, split, smem, s_red);
 }
 
 // ------------------------------------------------------------------------------------------ layer chains of the 4096-row nets, handed over in LDS

@@ -1188,8 +1188,8 @@ void begin_dw(pnrf_trainer* t) { t->jobs.n = 0; t->pool_used = 0; t->grp.n = 0; 
 int group_dw(pnrf_trainer* t, const DwDefer& d) {
   PNRF_REQUIRE(t->grp.n < DH_GROUP_MAX, PNRF_E_STATE, "pnrf_trainer: more than %d grouped weight gradients", DH_GROUP_MAX);
   DwhGroupArgs& g = t->grp;
-  g.j[g.n] = d.args; g.first[g.n] = t->grp_blocks; g.tiles[g.n] = d.tiles;
-  t->grp_blocks += d.tiles * d.splits;
+  g.j[g.n] = d.args; g.first[g.n] = t->grp_blocks; g.tiles[g.n] = d.tiles; g.splits[g.n] = d.splits;
+  t->grp_blocks += (d.tiles * d.splits + 7) & ~7;               // jobs start on XCD 0 (dwh_group_kernel)
   ++g.n;
   return 0;
 }
