@@ -247,8 +247,9 @@ def train_pmc(workload):
 
 def train_block(dev, eager=True):
     """Training iterations at configs[3] / configs[4] size (pronerf_amd.workloads): HIP trainer vs the oracle's eager torch autograd graph +
-    torch.optim.Adam on the same GPU (checker-side, after the timed region).  The iteration is HBM-bound by the builder's own analysis
-    (fp32 activations of the 256-wide layers: DESIGN.md, training), so `frac_of_hbm_roof` = measured HBM bytes per iteration / ms / 8 TB/s."""
+    torch.optim.Adam on the same GPU (checker-side, after the timed region).  `frac_of_hbm_roof` = measured HBM bytes per iteration / ms / 8 TB/s:
+    the largest launch of an iteration (the grouped weight gradients) is HBM-bound, the two chain launches of the fine net are bound by
+    their stores and the split-fp16 MFMA rate."""
     from pronerf_amd import workloads as wl
     HBM_PEAK = 8.0e12
     wk = wl.TrainWorkload(dev, max_samples=256)
