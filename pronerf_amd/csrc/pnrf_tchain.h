@@ -89,7 +89,7 @@ __global__ void tchain_pack_kernel(TChainPackArgs a) {
 
 // Store of saved activations: 2.4 GB per launch at 262 144 rows that nobody reads before the backward pass.  Left in the L2 (plain stores) they
 // turn it over every ~13 us and evict the 2.2 MB weight stream between two batches of a workgroup (FETCH_SIZE: 0.3 GB per launch for 67 MB of
-// input).  Measured per launch at 262 144 rows: plain 954 us, sc1 945, sc0 sc1 939, nt 802 (no stores at all: 695).
+// input).  Measured per launch at 262 144 rows: plain 954 us, sc1 945, sc0 sc1 939, nt 802 (no stores at all: 695); sc1 nt / sc0 nt / sc0 sc1 nt: as nt.
 #ifndef PNRF_TC_STORE_MODE
 #define PNRF_TC_STORE_MODE 3
 #endif
@@ -100,6 +100,12 @@ __device__ __forceinline__ void tc_store(float* p, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v));
 #elif PNRF_TC_STORE_MODE == 2
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v));
+#elif PNRF_TC_STORE_MODE == 4        // (asm forms for timing the remaining policies: the s_nop covers the store-data hazard the compiler cannot see)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v));
+#elif PNRF_TC_STORE_MODE == 5
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 nt\n\ts_nop 1" ::"v"(p), "v"(v));
+#elif PNRF_TC_STORE_MODE == 6
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v));
 #else
   __builtin_nontemporal_store(v, (f32x4*)p);       // (the compiler's own store: as inline asm it ran, but its data-register hazards were nobody's business)
 #endif

@@ -1057,6 +1057,7 @@ struct pnrf_trainer {
   TChainPackArgs tc_pack;
   _Float16* tb_stream = nullptr;                 // ... and the transposed layers' stream of the input-gradient chain (tchain_bwd_kernel)
   TChainBwdPackArgs tb_pack;
+  bool tc_ok = true;                             // workspaces small enough for the chains' 32-bit row offsets
   uint2* tc_mask = nullptr;                      // ReLU masks of pts0 .. pts7 (written by the forward chain, read by the backward chain)
   float* dz_x[6] = {};                           // dZ5 .. dZ0 of the backward chain (dZ7 = d_a, dZ6 = d_b)
   int nerf_fwd = 0;                              // fine net's forward from 8192 rows on: 0 one engine launch (tchain_fwd_kernel), 3 two 64-row layer chains
@@ -1548,7 +1549,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->emb, R * 90);
   // the chain kernels (pnrf_tchain.h) write whole batches of TC_ROWS rows: their buffers hold the row count rounded up
   const int64_t Rp = (R + TC_ROWS - 1) / TC_ROWS * TC_ROWS;
-  PNRF_REQUIRE(Rp * LD_C5 * 4 < ((int64_t)1 << 32), PNRF_E_ARG, "pnrf_trainer_create: %lld sample rows exceed the 32-bit row offsets of the layer chains", (long long)Rp);
+  t->tc_ok = Rp * LD_C5 * 4 < ((int64_t)1 << 32);    // the chains address rows with 32-bit byte offsets; beyond that the per-layer products take over
   for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], Rp * 256);
   T_ALLOC(t->n_c5, Rp * LD_C5); T_ALLOC(t->n_a5, Rp * 256); T_ALLOC(t->n_a6, Rp * 256); T_ALLOC(t->n_a7, Rp * 256);
   T_ALLOC(t->n_cv, Rp * LD_CV); T_ALLOC(t->n_hv, Rp * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
@@ -1709,7 +1710,7 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   // not far enough ahead of an L2 under this load, and the 16 x 64-byte stores of the register epilogue cost 23 % (no-store probe build:
   // 411 vs 535 us per launch).  A first version on hgemm_rchain_kernel<4> (LDS round trip in the epilogue, one workgroup per CU) was 2 % slower.
   bool chained = false, engine = false;
-  if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192) {
+  if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->tc_ok) {
     // pts0 .. pts7 and feature_linear in one launch on the fused-MLP engine: 128 rows per workgroup stay in registers through the nine layers
     TChainArgs c = {};
     c.blob = t->tc_stream;
@@ -1787,7 +1788,7 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   // one max-|gradient| slot per gradient buffer write (the two products that add up d_a share one)
   float* m = t->amax + slot0 * HG_SLOT;
   T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
-  const bool engine = t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->dw_tile == 0;
+  const bool engine = t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->dw_tile == 0 && t->tc_ok;
   if (!engine) T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0 * HG_SLOT, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   if (engine) {
     // The ten input-gradient products from the view layer down as ONE launch (tchain_bwd_kernel): the rows' gradients stay in registers from
