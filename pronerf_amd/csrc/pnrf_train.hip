@@ -606,35 +606,25 @@ __global__ void dw_reduce_kernel(const DwJobs jobs) {
 }
 
 // ------------------------------------------------------------------------------------------ positional encoding
-// The NeRF's inputs in one launch: gamma(x) (10 octaves, 63 values) into the first layer's input rows AND into the head of the skip layer's
-// concatenated rows, gamma(v) (4 octaves, 27 values; the direction of ray row / rep) behind the feature columns of the views layer's rows.
-__global__ void nerf_inputs_kernel(const float* __restrict__ pts, const float* __restrict__ dirs, int dir_stride, int rep, float* __restrict__ emb,
-                                   int ld_emb, float* __restrict__ c5, int ld_c5, float* __restrict__ cv, int ld_cv, int cv_col, int64_t rows) {
-  const int64_t total = rows * 3;
+// The NeRF's inputs in one launch: gamma(x) (10 octaves, 63 values) into the head of the skip layer's concatenated rows — which are also the
+// first layer's input rows (row stride ld_c5) —, gamma(v) (4 octaves, 27 values; the direction of ray row / rep) behind the feature columns of
+// the views layer's rows.  One thread per (row, column of 64): a wave writes 256 contiguous bytes of a row (the first version, one thread per
+// (row, coordinate) with 51 strided 4-byte stores and a second 90-wide copy of the embedding, took 85 us at 262 144 rows).  Column j of an
+// embedding = [x(3), sin 2^0 x, cos 2^0 x, sin 2^1 x, ...]: the same expressions as Embedder.embed (run_nerf_helpers.py:666-671).
+__global__ void nerf_inputs_kernel(const float* __restrict__ pts, const float* __restrict__ dirs, int dir_stride, int rep, float* __restrict__ c5, int ld_c5,
+                                   float* __restrict__ cv, int ld_cv, int cv_col, int64_t rows) {
+  const int64_t total = rows * 64;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / 3;
-    const int c = (int)(i - row * 3);
-    {
-      const float v = pts[i];
-      float* o = emb + row * ld_emb;
-      float* o2 = c5 + row * ld_c5;
-      o[c] = v; o2[c] = v;
-      for (int k = 0; k < 10; ++k) {
-        const float arg = v * (float)(1u << k), sn = sinf(arg), cs = cosf(arg);
-        o[3 + 6 * k + c] = sn; o2[3 + 6 * k + c] = sn;
-        o[3 + 6 * k + 3 + c] = cs; o2[3 + 6 * k + 3 + c] = cs;
-      }
-    }
-    {
-      const float v = dirs[(row / rep) * dir_stride + c];
-      float* o = cv + row * ld_cv + cv_col;
-      o[c] = v;
-      for (int k = 0; k < 4; ++k) {
-        const float arg = v * (float)(1u << k);
-        o[3 + 6 * k + c] = sinf(arg);
-        o[3 + 6 * k + 3 + c] = cosf(arg);
-      }
-    }
+    const int64_t row = i >> 6;
+    const int col = (int)(i & 63);
+    auto emb = [](const float* x, int col) {
+      if (col < 3) return x[col];
+      const int j = col - 3, k = j / 6, r = j - 6 * k, c = r < 3 ? r : r - 3;
+      const float arg = x[c] * (float)(1u << k);
+      return r < 3 ? sinf(arg) : cosf(arg);
+    };
+    if (col < 63) c5[row * ld_c5 + col] = emb(pts + row * 3, col);
+    if (col < 27) cv[row * ld_cv + cv_col + col] = emb(dirs + (row / rep) * dir_stride, col);
   }
 }
 // dx[row, c] = sum over the two gradient sources (either may be NULL) of  dE[c] + sum_k 2^k (cos(2^k x) dE[sin_k] - sin(2^k x) dE[cos_k])
@@ -1045,7 +1035,7 @@ struct pnrf_trainer {
   float *mm_input, *s_h[6], *s_y, *depth_sorted, *add_s, *mul_s, *mm_rgb;
   int64_t* sort_idx;
   float *refine_in, *r_h[6], *r_y, *z_pre, *z, *pts, *rgb0;
-  float *emb, *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
+  float *n_a[4], *n_c5, *n_a5, *n_a6, *n_a7, *n_cv, *n_hv, *raw, *rgb_map, *wts;
   float *d_rgb_map, *d_raw, *d_hv, *d_cv, *d_a, *d_b, *d_c5, *d_e0, *d_pts, *d_z, *d_add, *d_mul, *d_depth, *d_ry, *d_sy, *d_rgb0, *d_mmrgb,
       *d_h0, *d_h1, *d_hk[6], *dw_pool, *loss;   // d_hk: one gradient buffer per hidden layer of an ELU net (layer chains); d_h0 / d_h1 = d_hk[0 / 1]
   float* w_gapped = nullptr;                     // fp32 copy [out][in + 1] of the skip layer's weights with the zero column of its input layout
@@ -1546,7 +1536,6 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   T_ALLOC(t->s_y, N * 27); T_ALLOC(t->depth_sorted, N * 8); T_ALLOC(t->add_s, N * 8); T_ALLOC(t->mul_s, N * 8); T_ALLOC(t->mm_rgb, N * 3);
   T_ALLOC(t->sort_idx, N * 8);
   T_ALLOC(t->refine_in, N * 144); T_ALLOC(t->r_y, N * 35); T_ALLOC(t->z_pre, N * 8); T_ALLOC(t->z, R); T_ALLOC(t->pts, R * 3); T_ALLOC(t->rgb0, N * 3);
-  T_ALLOC(t->emb, R * 90);
   // the chain kernels (pnrf_tchain.h) write whole batches of TC_ROWS rows: their buffers hold the row count rounded up
   const int64_t Rp = (R + TC_ROWS - 1) / TC_ROWS * TC_ROWS;
   t->tc_ok = Rp * LD_C5 * 4 < ((int64_t)1 << 32);    // the chains address rows with 32-bit byte offsets; beyond that the per-layer products take over
@@ -1697,7 +1686,7 @@ int sampler_refine_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, hipStr
 // query points t->pts [N*S,3] + view directions -> raw [N*S,4]  (NeRF class, run_nerf_helpers.py:824-847)
 int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream_t s) {
   const int64_t R = bt->n * S;
-  hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->emb, 90, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
+  hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 64)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
   PNRF_LAUNCH_CHECK();
   // Rows are independent through the layers, so the 256 -> 256 layers run as two layer chains (hgemm_wchain_kernel, pnrf_hgemm.h): a workgroup
   // keeps its 64 rows on chip from layer to layer — a chained layer writes its activation (the backward pass and the weight gradient need it)
@@ -1732,7 +1721,7 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
     // pts0 and pts5 (63 / 320 inputs) as products of their own; the 256 -> 256 layers behind each as a chain
     RChainArgs ca = {}, cb = {};
     HGemmArgs h0{}, h5{};
-    bool ok = fwd_hgemm_args(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, &h0) &&
+    bool ok = fwd_hgemm_args(t, L_N + 0, t->n_c5, LD_C5, t->n_a[0], 256, R, T_ACT_RELU, &h0) &&
               fwd_hgemm_args(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, &h5);
     float* outa[4] = {t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H};
     const float* ina[4] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3]};
@@ -1764,7 +1753,7 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
     }
   }
   if (!chained) {
-    T_RC(layer_fwd(t, L_N + 0, t->emb, 90, t->n_a[0], 256, R, T_ACT_RELU, s));
+    T_RC(layer_fwd(t, L_N + 0, t->n_c5, LD_C5, t->n_a[0], 256, R, T_ACT_RELU, s));
     for (int k = 1; k < 4; ++k) T_RC(layer_fwd(t, L_N + k, t->n_a[k - 1], 256, t->n_a[k], 256, R, T_ACT_RELU, s));
     T_RC(layer_fwd(t, L_N + 4, t->n_a[3], 256, t->n_c5 + C5_H, LD_C5, R, T_ACT_RELU, s));                                   // skip: cat[pts, h]
     T_RC(layer_fwd(t, L_N + 5, t->n_c5, LD_C5, t->n_a5, 256, R, T_ACT_RELU, s));
@@ -1820,8 +1809,8 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     const int ncu = trainer_num_cu();
     hipLaunchKernelGGL(tchain_bwd_kernel, dim3((unsigned)(c.nbatch < ncu ? c.nbatch : ncu)), dim3(512), TB_LDS_BYTES, s, c);
     PNRF_LAUNCH_CHECK();
-    const float* xin[8] = {t->emb, t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5, t->n_a5, t->n_a6};
-    const int ldx[8] = {90, 256, 256, 256, 256, LD_C5, 256, 256};
+    const float* xin[8] = {t->n_c5, t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5, t->n_a5, t->n_a6};
+    const int ldx[8] = {LD_C5, 256, 256, 256, 256, LD_C5, 256, 256};
     // the ten wide weight gradients join the iteration's grouped launch (flush_dw_group): at 32 768 rows each of them alone is a 30 us launch
     for (int k = 7; k >= 0; --k) T_RC(dw_job(xin[k], ldx[k], dz[k], 256, c.slot[k], t->L[L_N + k]));
     if (want_dpts) {
@@ -1845,7 +1834,7 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   T_RC(layer_bwd(t, L_N + 3, t->d_a, 256, m + 6 * HG_SLOT, t->n_a[2], 256, t->d_b, 256, m + 7 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[2], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 2, t->d_b, 256, m + 7 * HG_SLOT, t->n_a[1], 256, t->d_a, 256, m + 8 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[1], 256, 0, s));
   T_RC(layer_bwd(t, L_N + 1, t->d_a, 256, m + 8 * HG_SLOT, t->n_a[0], 256, t->d_b, 256, m + 9 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_a[0], 256, 0, s));
-  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9 * HG_SLOT, t->emb, 90, want_dpts ? t->d_e0 : nullptr, 64, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));   // 63 columns in rows of 64
+  T_RC(layer_bwd(t, L_N + 0, t->d_b, 256, m + 9 * HG_SLOT, t->n_c5, LD_C5, want_dpts ? t->d_e0 : nullptr, 64, nullptr, 0.f, R, T_ACT_NONE, none, 0, 0, s));   // 63 columns in rows of 64
   if (want_dpts) {
     hipLaunchKernelGGL(posenc_bwd_kernel, dim3(grid_for(R * 3)), dim3(TPB), 0, s, t->pts, t->d_e0, 64, t->d_c5, LD_C5, t->d_pts, R, 10);
     PNRF_LAUNCH_CHECK();
