@@ -16,13 +16,14 @@
 // whole number of ring revolutions so that all of them start at ring position 0.
 #pragma once
 
-constexpr int TC_NL = 10;                                  // pts0 .. pts7, feature, views
-__host__ __device__ constexpr int tc_ks(int l) { return l == 0 ? 2 : (l == 5 ? 10 : (l == 9 ? 9 : 8)); }   // k-steps of 32: 63 (+1) | 256 | 64 + 256 | 256 + 27 (+5) inputs
-__host__ __device__ constexpr int tc_ntp(int l) { return l == 9 ? 4 : 8; }                       // tile pairs of 32 outputs: 256, views_linear 128
+constexpr int TC_NL = 10;                                  // layers with saved outputs: pts0 .. pts7, feature, views
+constexpr int TC_NSL = 11;                                 // stream layers: those and rgb_linear; alpha_linear rides as a ninth tile pair of the feature layer
+__host__ __device__ constexpr int tc_ks(int l) { return l == 0 ? 2 : (l == 5 ? 10 : (l == 9 ? 9 : (l == 10 ? 4 : 8))); }   // k-steps of 32: 63 (+1) | 256 | 64 + 256 | 256 + 27 (+5) | 128 inputs
+__host__ __device__ constexpr int tc_ntp(int l) { return l == 8 ? 9 : (l == 9 ? 4 : (l == 10 ? 1 : 8)); }   // tile pairs of 32 outputs: 256; feature 256 + alpha; views 128; rgb 3
 __host__ __device__ constexpr int tc_frags(int l) { return tc_ntp(l) * tc_ks(l) * 4; }
 __host__ __device__ constexpr int tc_frag0(int l) { int s = 0; for (int i = 0; i < l; ++i) s += tc_frags(i); return s; }
-constexpr int TC_NFRAGS = tc_frag0(TC_NL);                 // 2320
-constexpr int TC_PAD_SLOTS = (NSLOTS - (TC_NFRAGS / SLOT_FRAGS) % NSLOTS) % NSLOTS;            // 3: a batch is a whole number of ring revolutions
+constexpr int TC_NFRAGS = tc_frag0(TC_NSL);                // 2368
+constexpr int TC_PAD_SLOTS = (NSLOTS - (TC_NFRAGS / SLOT_FRAGS) % NSLOTS) % NSLOTS;            // 0: a batch is a whole number of ring revolutions
 constexpr int TC_NSLOTS = TC_NFRAGS / SLOT_FRAGS + TC_PAD_SLOTS;                               // 148 slots of 16 KiB
 constexpr int TC_ROWS = 128;                               // rows per workgroup and batch
 #ifndef PNRF_TC_QUEUE
@@ -37,9 +38,12 @@ constexpr int TC_RING_BYTES = TC_RING * SLOT_BYTES;
 constexpr int TC_GROUP_PAIRS = PNRF_TC_GROUP_PAIRS;        // forward chain: tile pairs per staged group (4: 512-byte row segments, 2: 256-byte)
 constexpr int TC_STG_ROW = 128 + 4;                        // floats per staged row: 128 features + padding (bank spread of the 16-byte accesses)
 constexpr int TC_STG_BYTES = 8 * 16 * TC_STG_ROW * 4;      // eight waves x 16 rows
-constexpr int TC_LDS_BYTES = TC_RING_BYTES + TC_NL * W_HID * 4 + TC_STG_BYTES;
+constexpr int TC_BIAS_LD = W_HID + 32;                     // bias table [stream layer][288]: entry 256 of the feature layer is alpha_linear's bias
+constexpr int TC_BIAS_BYTES = TC_NSL * TC_BIAS_LD * 4;
+constexpr int TC_LDS_BYTES = TC_RING_BYTES + TC_BIAS_BYTES + TC_STG_BYTES;
 __host__ __device__ constexpr int tc_pos(int l) { return (tc_frag0(l) / SLOT_FRAGS) % TC_RING; }   // ring position of layer l's first slot
-static_assert(tc_frags(0) % SLOT_FRAGS == 0 && tc_frags(1) % SLOT_FRAGS == 0 && tc_frags(5) % SLOT_FRAGS == 0 && tc_frags(9) % SLOT_FRAGS == 0 && TC_NSLOTS % TC_RING == 0,
+static_assert(tc_frags(0) % SLOT_FRAGS == 0 && tc_frags(1) % SLOT_FRAGS == 0 && tc_frags(5) % SLOT_FRAGS == 0 && tc_frags(8) % SLOT_FRAGS == 0 && tc_frags(9) % SLOT_FRAGS == 0 &&
+              tc_frags(10) % SLOT_FRAGS == 0 && TC_NSLOTS % TC_RING == 0,
               "whole slots per layer, whole ring revolutions per batch");
 static_assert(H16_PIECES == 8, "tchain_fwd_kernel's epilogue pieces are written for one accumulator register per piece");
 
@@ -47,8 +51,9 @@ typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
 
 struct TChainPackArgs {
   const float* P;                    // the trainer's flat parameters
-  size_t w[TC_NL];                   // offset of layer l's weights [256][in_dim]
-  int in_dim[TC_NL];                 // 63 | 256 | 319 (skip layer: [embedding 63 | h 256], run_nerf_helpers.py:829-831) | 283 (views: [feature 256 | view embedding 27], :842-843)
+  size_t w[TC_NSL];                  // offset of layer l's weights [out][in_dim]
+  size_t w_alpha;                    // alpha_linear [1][256]
+  int in_dim[TC_NSL];                // 63 | 256 | 319 (skip layer: [embedding 63 | h 256], run_nerf_helpers.py:829-831) | 283 (views: [feature 256 | view embedding 27], :842-843)
   _Float16* stream;                  // TC_NFRAGS KiB
 };
 // one thread per 16-byte piece of the stream (lane `lane` of fragment F)
@@ -64,10 +69,12 @@ __global__ void tchain_pack_kernel(TChainPackArgs a) {
     return;
   }
   int l = 0;
-  while (l + 1 < TC_NL && F >= tc_frag0(l + 1)) ++l;
+  while (l + 1 < TC_NSL && F >= tc_frag0(l + 1)) ++l;
   const int f = F - tc_frag0(l), pl = f & 1, t = (f >> 1) & 1, KS = tc_ks(l), ks = (f >> 2) % KS, tp = (f >> 2) / KS;
   const int out = 32 * tp + 16 * t + (lane & 15), g = lane >> 4;
-  const float* W = a.P + a.w[l] + (size_t)out * a.in_dim[l];
+  // rows past a layer's outputs are zero: the feature layer's ninth tile pair holds alpha_linear in its first row, rgb_linear has 3 rows
+  const bool row_ok = l == 8 ? out <= 256 : (l == 10 ? out < 3 : true);
+  const float* W = l == 8 && out == 256 ? a.P + a.w_alpha : a.P + a.w[l] + (size_t)out * a.in_dim[l];
   f16x8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -80,7 +87,7 @@ __global__ void tchain_pack_kernel(TChainPackArgs a) {
     } else {
       in = hidden_feat_h16(l == 5 ? ks - 2 : ks, g, j) + (l == 5 ? 63 : 0);
     }
-    const float x = in >= 0 ? W[in] : 0.f;
+    const float x = in >= 0 && row_ok ? W[in] : 0.f;
     const _Float16 h = (_Float16)x;
     v[j] = pl ? (_Float16)((x - (float)h) * H16_LO_SCALE) : h;
   }
@@ -113,10 +120,12 @@ __device__ __forceinline__ void tc_store(float* p, const f32x4& v) {
 
 struct TChainArgs {
   const void* blob;                  // TC_NSLOTS slots
-  const float* bias[TC_NL];
+  const float* bias[TC_NSL];         // [10]: rgb_linear's
+  const float* bias_alpha;
+  float* raw;                        // [n rounded up to TC_ROWS][4]: rgb (pre-sigmoid) and alpha (pre-activation) of every row (run_nerf_helpers.py:838-846)
   const float* X0; int ldx0;         // [n][ldx0] fp32, 16-byte aligned rows: columns 0 .. 63 = position embedding (63) + one zero
   const float* XV; int ldxv;         // [n][ldxv]: columns 0 .. 31 = view embedding (27) + zeros
-  float* out[TC_NL]; int ldo[TC_NL]; // saved activations [n rounded up to TC_ROWS][ldo], 16-byte aligned rows: whole batches are written, no row predicate —
+  float* out[TC_NSL]; int ldo[TC_NSL]; // saved activations ([10]: unused) [n rounded up to TC_ROWS][ldo], 16-byte aligned rows: whole batches are written, no row predicate —
                                      // a predicated store is a branch, and eight of them in a row serialise the flush of a staged group
   uint2* mask;                       // [batch][wave][layer][lane]: two words (tile pairs 0-3 | 4-7), bit 31 - (8 (tp & 3) + 4 t + r) = (activation of the lane's row, feature 32 tp + 16 t
                                      // + 4 g + r) > 0 — what
@@ -128,7 +137,11 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
   constexpr int NW = 8, NTP = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + TC_RING_BYTES);        // [layer][256]
-  for (int i = threadIdx.x; i < TC_NL * W_HID; i += 512) bias_lds[i] = (i >> 8) == 9 && (i & 255) >= 128 ? 0.f : a.bias[i >> 8][i & 255];
+  for (int i = threadIdx.x; i < TC_NSL * TC_BIAS_LD; i += 512) {
+    const int l = i / TC_BIAS_LD, c = i - l * TC_BIAS_LD;
+    const int n_out = l == 9 ? 128 : (l == 10 ? 3 : 256);
+    bias_lds[i] = c < n_out ? a.bias[l][c] : (l == 8 && c == 256 ? a.bias_alpha[0] : 0.f);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, g = lane >> 4;
   WStream<NW> st;
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     // written out as whole 512-byte row segments (one store instruction = 2 rows x 512 B).  Stored straight from the accumulators — lane
     // (column, g) holds 4 features of ONE row, an instruction covers 16 rows x 64 B — the same bytes reached HBM in 128-byte pieces at a 1 KiB
     // stride and the launch ran at 2.3 TB/s of writes (1.06 ms at 262 144 rows; 0.65 ms without the stores; a plain fill writes 6.8 TB/s).
-    float* const stage = (float*)(smem + TC_RING_BYTES + TC_NL * W_HID * 4) + wave * (16 * TC_STG_ROW);
+    float* const stage = (float*)(smem + TC_RING_BYTES + TC_BIAS_BYTES) + wave * (16 * TC_STG_ROW);
     float* const stage_w = stage + col * TC_STG_ROW + 4 * g;                       // this lane's accumulator tiles go here (+ 32 (tp & 3) + 16 t)
     constexpr int GP = TC_GROUP_PAIRS, LPR = 8 * GP, RPI = 64 / LPR;                 // tile pairs per staged group; lanes per row, rows per store instruction
     const float* const stage_r = stage + (lane / LPR) * TC_STG_ROW + 4 * (lane % LPR);   // ... and it reads rows RPI i + lane / LPR, 16 bytes at 4 (lane % LPR)
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
     uint32_t off_prev = 0;
     uint2* const m_lane = a.mask + ((int64_t)batch * 8 + wave) * TC_NL * 64 + lane;      // ReLU masks of this lane: + 64 l
     int l_prev = 0;                                // ... and its layer (for the mask)
+    float alpha_v = 0.f;                           // alpha_linear's output of this lane's row (lanes of group 0)
     uint32_t mb0 = 0, mb1 = 0;                     // mask bits of the layer whose pieces are running (tile pairs 0-3 | 4-7)
 
     // piece pcx = accumulator register pcx & 3 of tile pcx >> 2 of a tile pair: bias is in the accumulator; combine, activate (floor = 0: ReLU,
@@ -215,43 +229,55 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
       }
     };
     // one layer: KSc = its k-steps (2: from the input columns; 10: input columns, then the hidden planes; 8: hidden planes)
-    auto layer = [&](auto ksc, auto posc, f16x8(&ih)[NTP], f16x8(&il)[NTP], f16x8(&oh)[NTP], f16x8(&ol)[NTP], int l, float floor_prev, float floor_) {
-      constexpr int KS = decltype(ksc)::value;
-      constexpr int LNTP = KS == 9 ? 4 : NTP;        // views_linear: 128 outputs
+    // LNTP: the layer's tile pairs (9: feature + the alpha pair).  PRE: what its first pieces finish — 0 nothing, 1 the previous layer's last
+    // pair (index PTP), 2 the alpha pair (one value per row: kept in alpha_v)
+    auto layer = [&](auto ksc, auto posc, auto ntpc, auto prec, auto ptpc, f16x8(&ih)[NTP], f16x8(&il)[NTP], f16x8(&oh)[NTP], f16x8(&ol)[NTP], int l,
+                     float floor_prev, float floor_) {
+      constexpr int KS = decltype(ksc)::value, LNTP = decltype(ntpc)::value, PRE = decltype(prec)::value, PTP = decltype(ptpc)::value;
+      constexpr int LTP = LNTP == 9 ? 7 : LNTP - 1;  // last pair of the layer that is an activation of the net
       f32x4 nm[2], nc[2];
       const int ld_cur = a.ldo[l], ld_pre = ld_prev, l_pre = l_prev;
       float* const o_cur = a.out[l];
       float* const o_pre = o_prev;
       const uint32_t off_cur = ((uint32_t)row_f * (uint32_t)ld_cur + 4u * (lane % LPR)) * 4u, off_pre = off_prev;   // < 4 GiB: checked by the launcher
       layer_h16x2<KS, LNTP, decltype(posc)::value, TC_QUEUE>(
-          st, ringlane, biaslane + l * W_HID,
+          st, ringlane, biaslane + l * TC_BIAS_LD,
           [&](int ks, int pl) {
             if constexpr (KS == 2) return pl == 0 ? Gh[ks & 1] : Gl[ks & 1];
             else if constexpr (KS == 10) return ks < 2 ? (pl == 0 ? Gh[ks & 1] : Gl[ks & 1]) : (pl == 0 ? ih[(ks - 2) & 7] : il[(ks - 2) & 7]);
             else if constexpr (KS == 9) return ks < 8 ? (pl == 0 ? ih[ks & 7] : il[ks & 7]) : (pl == 0 ? Gh[0] : Gl[0]);      // views: G holds the view embedding
+            else if constexpr (KS == 4) return pl == 0 ? ih[ks & 3] : il[ks & 3];
             else return pl == 0 ? ih[ks] : il[ks];
           },
-          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { piece(oh, ol, tp, pcx, mn, cr, floor_, o_cur, off_cur, ld_cur, l, LNTP - 1); },
-          [&](int pcx) { if constexpr (KS != 2) piece(ih, il, NTP - 1, pcx, pm, pc, floor_prev, o_pre, off_pre, ld_pre, l_pre); }, nm, nc);
+          [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { piece(oh, ol, tp, pcx, mn, cr, floor_, o_cur, off_cur, ld_cur, l, LTP); },
+          [&](int pcx) {
+            if constexpr (PRE == 1) piece(ih, il, PTP, pcx, pm, pc, floor_prev, o_pre, off_pre, ld_pre, l_pre, PTP);
+            else if constexpr (PRE == 2) { if (pcx == 0) alpha_v = fmaf(pc[0][0], INV, pm[0][0]); }
+          }, nm, nc);
 #pragma unroll
       for (int t = 0; t < 2; ++t) { pm[t] = nm[t]; pc[t] = nc[t]; }
       o_prev = o_cur; ld_prev = ld_cur; off_prev = off_cur; l_prev = l;
     };
     const float NEG = -__builtin_inff();
 #define POS(l) std::integral_constant<int, tc_pos(l)>{}
-    layer(std::integral_constant<int, 2>{}, POS(0), Yh, Yl, Xh, Xl, 0, 0.f, 0.f);                       // pts0: input columns -> X
     using K8 = std::integral_constant<int, 8>;
+    using N8 = std::integral_constant<int, 8>;
+    using Pre0 = std::integral_constant<int, 0>;
+    using Pre1 = std::integral_constant<int, 1>;
+    using P7 = std::integral_constant<int, 7>;
+    layer(std::integral_constant<int, 2>{}, POS(0), N8{}, Pre0{}, P7{}, Yh, Yl, Xh, Xl, 0, 0.f, 0.f);   // pts0: input columns -> X
     static_assert(tc_pos(1) == tc_pos(3) && tc_pos(2) == tc_pos(4), "pts1 .. pts4 as a loop of two layers");
 #pragma nounroll
     for (int p = 0; p < 2; ++p) {                                                               // pts1 .. pts4
-      layer(K8{}, POS(1), Xh, Xl, Yh, Yl, 2 * p + 1, 0.f, 0.f);
-      layer(K8{}, POS(2), Yh, Yl, Xh, Xl, 2 * p + 2, 0.f, 0.f);
+      layer(K8{}, POS(1), N8{}, Pre1{}, P7{}, Xh, Xl, Yh, Yl, 2 * p + 1, 0.f, 0.f);
+      layer(K8{}, POS(2), N8{}, Pre1{}, P7{}, Yh, Yl, Xh, Xl, 2 * p + 2, 0.f, 0.f);
     }
     load_inputs();
-    layer(std::integral_constant<int, 10>{}, POS(5), Xh, Xl, Yh, Yl, 5, 0.f, 0.f);                      // the skip layer: [input columns | pts4's planes]
-    layer(K8{}, POS(6), Yh, Yl, Xh, Xl, 6, 0.f, 0.f);
-    layer(K8{}, POS(7), Xh, Xl, Yh, Yl, 7, 0.f, 0.f);
-    layer(K8{}, POS(8), Yh, Yl, Xh, Xl, 8, 0.f, NEG);                                                   // feature_linear has no activation
+    layer(std::integral_constant<int, 10>{}, POS(5), N8{}, Pre1{}, P7{}, Xh, Xl, Yh, Yl, 5, 0.f, 0.f);  // the skip layer: [input columns | pts4's planes]
+    layer(K8{}, POS(6), N8{}, Pre1{}, P7{}, Yh, Yl, Xh, Xl, 6, 0.f, 0.f);
+    layer(K8{}, POS(7), N8{}, Pre1{}, P7{}, Xh, Xl, Yh, Yl, 7, 0.f, 0.f);
+    // feature_linear (no activation) with alpha_linear as the first row of a ninth tile pair: both read pts7's activations
+    layer(K8{}, POS(8), std::integral_constant<int, 9>{}, Pre1{}, P7{}, Yh, Yl, Xh, Xl, 8, 0.f, NEG);
     {   // views_linear reads [feature | view embedding]: the embedding's k-step comes from the rows the rgb branch's weight gradient reads
       const float4* x = (const float4*)(a.XV + rr * a.ldxv + 8 * g);
       const float4 lo = x[0], hi = x[1];
@@ -263,10 +289,14 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
         Gl[0][j] = (_Float16)((v[j] - (float)h) * H16_LO_SCALE);
       }
     }
-    layer(std::integral_constant<int, 9>{}, POS(9), Xh, Xl, Yh, Yl, 9, NEG, 0.f);                       // views_linear (ReLU)
-    // the last layer's last tile pair (its planes go to Y, which nobody reads)
+    layer(std::integral_constant<int, 9>{}, POS(9), std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, P7{}, Xh, Xl, Yh, Yl, 9, NEG, 0.f);   // views_linear (ReLU)
+    // rgb_linear: 4 k-steps of views' activations, one tile pair whose first three rows are r, g, b.  Its fourth k-step reads views' last tile
+    // pair: finished here, not among rgb_linear's own MFMAs (a layer of fewer than 8 k-steps runs its deferred pieces behind its last k-step)
 #pragma unroll
     for (int pcx = 0; pcx < 8; ++pcx) piece(Yh, Yl, 3, pcx, pm, pc, 0.f, o_prev, off_prev, ld_prev, l_prev, 3);
+    layer(std::integral_constant<int, 4>{}, POS(10), std::integral_constant<int, 1>{}, Pre0{}, P7{}, Yh, Yl, Xh, Xl, 10, 0.f, NEG);
+    if (g == 0 && valid)
+      *(float4*)(a.raw + row * 4) = make_float4(fmaf(pc[0][0], INV, pm[0][0]), fmaf(pc[0][1], INV, pm[0][1]), fmaf(pc[0][2], INV, pm[0][2]), alpha_v);
 #pragma unroll
     for (int i = 0; i < TC_PAD_SLOTS; ++i) st.begin();
   }

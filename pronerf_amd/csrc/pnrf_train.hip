@@ -1515,12 +1515,14 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     T_ALLOC(t->tc_stream, (size_t)TC_NSLOTS * SLOT_BYTES / sizeof(_Float16));
     memset(&t->tc_pack, 0, sizeof(t->tc_pack));
     t->tc_pack.P = t->P; t->tc_pack.stream = t->tc_stream;
-    for (int l = 0; l < TC_NL; ++l) {
-      const TLin& tl = t->L[l < 8 ? L_N + l : (l == 8 ? L_FEAT : L_VIEWS)];
-      PNRF_REQUIRE(tl.out == (l == 9 ? 128 : 256) && tl.in == (l == 0 ? 63 : l == 5 ? 319 : l == 9 ? 283 : 256), PNRF_E_SHAPE,
+    for (int l = 0; l < TC_NSL; ++l) {
+      const TLin& tl = t->L[l < 8 ? L_N + l : (l == 8 ? L_FEAT : (l == 9 ? L_VIEWS : L_RGB))];
+      PNRF_REQUIRE(tl.out == (l == 9 ? 128 : l == 10 ? 3 : 256) && tl.in == (l == 0 ? 63 : l == 5 ? 319 : l == 9 ? 283 : l == 10 ? 128 : 256), PNRF_E_SHAPE,
                    "pnrf_trainer: fine-net layer %d is %d -> %d", l, tl.in, tl.out);
       t->tc_pack.w[l] = tl.w; t->tc_pack.in_dim[l] = tl.in;
     }
+    PNRF_REQUIRE(t->L[L_ALPHA].in == 256 && t->L[L_ALPHA].out == 1, PNRF_E_SHAPE, "pnrf_trainer: alpha_linear is %d -> %d", t->L[L_ALPHA].in, t->L[L_ALPHA].out);
+    t->tc_pack.w_alpha = t->L[L_ALPHA].w;
     T_ALLOC(t->tb_stream, (size_t)TB_NSLOTS * SLOT_BYTES / sizeof(_Float16));
     memset(&t->tb_pack, 0, sizeof(t->tb_pack));
     t->tb_pack.P = t->P; t->tb_pack.stream = t->tb_stream;
@@ -1703,11 +1705,12 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
     // pts0 .. pts7 and feature_linear in one launch on the fused-MLP engine: 128 rows per workgroup stay in registers through the nine layers
     TChainArgs c = {};
     c.blob = t->tc_stream;
-    float* outs[TC_NL] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H, t->n_a5, t->n_a6, t->n_a7, t->n_cv, t->n_hv};
-    for (int l = 0; l < TC_NL; ++l) {
-      c.bias[l] = t->P + t->L[l < 8 ? L_N + l : (l == 8 ? L_FEAT : L_VIEWS)].b;
-      c.out[l] = outs[l]; c.ldo[l] = l == 4 ? LD_C5 : (l == 8 ? LD_CV : (l == 9 ? 128 : 256));
+    float* outs[TC_NSL] = {t->n_a[0], t->n_a[1], t->n_a[2], t->n_a[3], t->n_c5 + C5_H, t->n_a5, t->n_a6, t->n_a7, t->n_cv, t->n_hv, t->n_hv};
+    for (int l = 0; l < TC_NSL; ++l) {
+      c.bias[l] = t->P + t->L[l < 8 ? L_N + l : (l == 8 ? L_FEAT : (l == 9 ? L_VIEWS : L_RGB))].b;
+      c.out[l] = outs[l]; c.ldo[l] = l == 4 ? LD_C5 : (l == 8 ? LD_CV : (l >= 9 ? 128 : 256));
     }
+    c.bias_alpha = t->P + t->L[L_ALPHA].b; c.raw = t->raw;
     c.XV = t->n_cv + 256; c.ldxv = LD_CV;
     c.X0 = t->n_c5; c.ldx0 = LD_C5; c.mask = t->tc_mask; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
     const size_t lds = TC_LDS_BYTES;
@@ -1761,9 +1764,11 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
     T_RC(layer_fwd(t, L_N + 7, t->n_a6, 256, t->n_a7, 256, R, T_ACT_RELU, s));
     T_RC(layer_fwd(t, L_FEAT, t->n_a7, 256, t->n_cv, LD_CV, R, T_ACT_NONE, s));
   }
-  T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
-  if (!engine) T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));            // (the engine launch ran views_linear as its tenth layer)
-  T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
+  if (!engine) {                                     // (the engine launch ran alpha_linear, views_linear and rgb_linear too and wrote raw itself)
+    T_RC(layer_fwd(t, L_ALPHA, t->n_a7, 256, t->raw + 3, 4, R, T_ACT_NONE, s));
+    T_RC(layer_fwd(t, L_VIEWS, t->n_cv, LD_CV, t->n_hv, 128, R, T_ACT_RELU, s));
+    T_RC(layer_fwd(t, L_RGB, t->n_hv, 128, t->raw, 4, R, T_ACT_NONE, s));
+  }
   return 0;
 }
 
