@@ -317,15 +317,8 @@ __global__ __launch_bounds__(256) void head_dx_kernel(HeadArgs a) {
 #pragma unroll
   for (int j = 0; j < HEAD_MAX; ++j) w[j] = j < a.n ? *(const f32x4_t*)(a.W + (size_t)j * a.K + 4 * cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   float amax = 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * rows_b + rl; r < a.M; r += (int64_t)gridDim.x * rows_b) {
-    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < HEAD_MAX; ++j)
-      if (j < a.n) v += a.dZ[r * a.ldz + j] * w[j];
-    float* dst = a.dX + r * a.lddx + 4 * cq;
-    if (a.beta != 0.f) v += *(const f32x4_t*)dst;
+  auto finish = [&](int64_t r, f32x4_t v, const f32x4_t& h) {
     if (a.act != T_ACT_NONE) {
-      const f32x4_t h = *(const f32x4_t*)(a.H + r * a.ldh + 4 * cq);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (a.act == T_ACT_RELU) v[e] = h[e] > 0.f ? v[e] : 0.f;
@@ -333,7 +326,34 @@ __global__ __launch_bounds__(256) void head_dx_kernel(HeadArgs a) {
       }
     }
     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    *(f32x4_t*)dst = v;
+    *(f32x4_t*)(a.dX + r * a.lddx + 4 * cq) = v;
+  };
+  const int64_t stride = (int64_t)gridDim.x * rows_b;
+  int64_t r = (int64_t)blockIdx.x * rows_b + rl;
+  for (; r + 3 * stride < a.M; r += 4 * stride) {            // four rows' loads in flight per thread (as head_dw_kernel)
+    f32x4_t v[4], h[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t ru = r + u * stride;
+      v[u] = a.beta != 0.f ? *(const f32x4_t*)(a.dX + ru * a.lddx + 4 * cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      h[u] = a.act != T_ACT_NONE ? *(const f32x4_t*)(a.H + ru * a.ldh + 4 * cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < HEAD_MAX; ++j)
+        if (j < a.n) s += a.dZ[ru * a.ldz + j] * w[j];
+      v[u] = s + v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) finish(r + u * stride, v[u], h[u]);
+  }
+  for (; r < a.M; r += stride) {
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX; ++j)
+      if (j < a.n) v += a.dZ[r * a.ldz + j] * w[j];
+    if (a.beta != 0.f) v += *(const f32x4_t*)(a.dX + r * a.lddx + 4 * cq);
+    const f32x4_t h = a.act != T_ACT_NONE ? *(const f32x4_t*)(a.H + r * a.ldh + 4 * cq) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    finish(r, v, h);
   }
   if (a.dx_amax) hg_slot_write(a.dx_amax, amax, red, blockIdx.x);
 }
@@ -348,7 +368,25 @@ __global__ __launch_bounds__(256) void head_dw_kernel(HeadArgs a) {
   float sz[HEAD_MAX];
 #pragma unroll
   for (int j = 0; j < HEAD_MAX; ++j) { acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; sz[j] = 0.f; }
-  for (int64_t r = r_begin + rl; r < r_end; r += rows_b) {
+  // four rows' loads in flight per thread (one row at a time the loop waited out a memory latency per 16 bytes: 132 us for 268 MB at 262 144
+  // rows); the sums keep their row order
+  int64_t r = r_begin + rl;
+  for (; r + 3 * rows_b < r_end; r += 4 * rows_b) {
+    f32x4_t x[4];
+    float z[4][HEAD_MAX];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = *(const f32x4_t*)(a.X + (r + u * rows_b) * a.ldx + 4 * cq);
+#pragma unroll
+      for (int j = 0; j < HEAD_MAX; ++j) z[u][j] = j < a.n ? a.dZ[(r + u * rows_b) * a.ldz + j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < HEAD_MAX; ++j)
+        if (j < a.n) { acc[j] += z[u][j] * x[u]; sz[j] += z[u][j]; }
+  }
+  for (; r < r_end; r += rows_b) {
     const f32x4_t x = *(const f32x4_t*)(a.X + r * a.ldx + 4 * cq);
 #pragma unroll
     for (int j = 0; j < HEAD_MAX; ++j)
@@ -608,23 +646,35 @@ __global__ void dw_reduce_kernel(const DwJobs jobs) {
 // ------------------------------------------------------------------------------------------ positional encoding
 // The NeRF's inputs in one launch: gamma(x) (10 octaves, 63 values) into the head of the skip layer's concatenated rows — which are also the
 // first layer's input rows (row stride ld_c5) —, gamma(v) (4 octaves, 27 values; the direction of ray row / rep) behind the feature columns of
-// the views layer's rows.  One thread per (row, column of 64): a wave writes 256 contiguous bytes of a row (the first version, one thread per
-// (row, coordinate) with 51 strided 4-byte stores and a second 90-wide copy of the embedding, took 85 us at 262 144 rows).  Column j of an
-// embedding = [x(3), sin 2^0 x, cos 2^0 x, sin 2^1 x, ...]: the same expressions as Embedder.embed (run_nerf_helpers.py:666-671).
+// the views layer's rows.  One thread per (row, q of 32): q < 30 is the (octave q / 3, coordinate q % 3) pair of gamma(x) — one argument, its
+// sine and its cosine —, q < 12 also that pair of gamma(v), q = 30 / 31 copy the raw x / v.  (The first version, one thread per (row,
+// coordinate) with 51 strided stores and a second 90-wide copy of the embedding, took 85 us at 262 144 rows.)  Column order of an embedding =
+// [x(3), sin 2^0 x, cos 2^0 x, sin 2^1 x, ...], the same expressions as Embedder.embed (run_nerf_helpers.py:666-671).
 __global__ void nerf_inputs_kernel(const float* __restrict__ pts, const float* __restrict__ dirs, int dir_stride, int rep, float* __restrict__ c5, int ld_c5,
                                    float* __restrict__ cv, int ld_cv, int cv_col, int64_t rows) {
-  const int64_t total = rows * 64;
+  const int64_t total = rows * 32;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i >> 6;
-    const int col = (int)(i & 63);
-    auto emb = [](const float* x, int col) {
-      if (col < 3) return x[col];
-      const int j = col - 3, k = j / 6, r = j - 6 * k, c = r < 3 ? r : r - 3;
+    const int64_t row = i >> 5;
+    const int q = (int)(i & 31);
+    const float* x = pts + row * 3;
+    const float* v = dirs + (row / rep) * dir_stride;
+    float* o = c5 + row * ld_c5;
+    float* ov = cv + row * ld_cv + cv_col;
+    if (q < 30) {
+      const int k = q / 3, c = q - 3 * k;
       const float arg = x[c] * (float)(1u << k);
-      return r < 3 ? sinf(arg) : cosf(arg);
-    };
-    if (col < 63) c5[row * ld_c5 + col] = emb(pts + row * 3, col);
-    if (col < 27) cv[row * ld_cv + cv_col + col] = emb(dirs + (row / rep) * dir_stride, col);
+      o[3 + 6 * k + c] = sinf(arg);
+      o[3 + 6 * k + 3 + c] = cosf(arg);
+      if (q < 12) {
+        const float argv = v[c] * (float)(1u << k);
+        ov[3 + 6 * k + c] = sinf(argv);
+        ov[3 + 6 * k + 3 + c] = cosf(argv);
+      }
+    } else if (q == 30) {
+      o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+    } else {
+      ov[0] = v[0]; ov[1] = v[1]; ov[2] = v[2];
+    }
   }
 }
 // dx[row, c] = sum over the two gradient sources (either may be NULL) of  dE[c] + sum_k 2^k (cos(2^k x) dE[sin_k] - sin(2^k x) dE[cos_k])
@@ -1688,7 +1738,7 @@ int sampler_refine_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, hipStr
 // query points t->pts [N*S,3] + view directions -> raw [N*S,4]  (NeRF class, run_nerf_helpers.py:824-847)
 int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream_t s) {
   const int64_t R = bt->n * S;
-  hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 64)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
+  hipLaunchKernelGGL(nerf_inputs_kernel, dim3(grid_for(R * 32)), dim3(TPB), 0, s, t->pts, bt->rays + 8, 11, S, t->n_c5, LD_C5, t->n_cv, LD_CV, 256, R);
   PNRF_LAUNCH_CHECK();
   // Rows are independent through the layers, so the 256 -> 256 layers run as two layer chains (hgemm_wchain_kernel, pnrf_hgemm.h): a workgroup
   // keeps its 64 rows on chip from layer to layer — a chained layer writes its activation (the backward pass and the weight gradient need it)
