@@ -1921,7 +1921,7 @@ int elu_net_backward(pnrf_trainer* t, int first, const float* dy, int out_last, 
     for (int k = 5; k >= 0; --k) {
       const TLin& l = t->L[first + k];
       DwDefer d;
-      d.wgs = 64;
+      d.wgs = 32;                                              // 4096 rows: 8 splits (stage-2 iteration 0.955 -> 0.942 ms against 16; 4 splits: 0.957)
       T_RC(gemm_dw(t, k ? h[k - 1] : x0, k ? 256 : in0, dh[k], 256, m + k * HG_SLOT, t->G + l.w, t->G + l.b, l.in_x(), l.gap, l.out, N, s, &d));
       PNRF_REQUIRE(d.set, PNRF_E_STATE, "pnrf_trainer: a hidden layer of an ELU net did not take the split-fp16 weight-gradient kernel");
       T_RC(group_dw(t, d));
