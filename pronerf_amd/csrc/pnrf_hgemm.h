@@ -1,6 +1,7 @@
 // Split-fp16 kernels of the trainer (included by pnrf_train.hip inside its anonymous namespace): the layer products (hgemm_kernel), the weight
-// gradients (dwh_kernel), a layer's backward as one launch (layer_bwd_kernel), the layer chains of the 4096-row nets (hgemm_rchain_kernel) and
-// their grouped weight gradients (dwh_group_kernel), and the kernel that keeps the fp16 weight planes current (split_weights_kernel).
+// gradients (dwh_kernel), a layer's backward as one launch (layer_bwd_kernel), the layer chains of the 4096-row nets (hgemm_rchain_kernel), the
+// 64-row chains of the wide layers (hgemm_wchain_kernel; an A/B alternative since pnrf_tchain.h), the iteration's grouped weight gradients
+// (dwh_group_kernel), and the kernel that keeps the fp16 weight planes current (split_weights_kernel).
 //
 // Y = act(X W^T + b) and dX = (dZ W [+ dX]) * act'(H) with fp32-grade results at 3/16 of the fp32 MFMA cycles: both operands are split
 //   x = x_hi + 2^-11 x_lo',  x_hi = fp16(x),  x_lo' = fp16((x - x_hi) 2^11)          (22 significand bits per operand)

@@ -3,15 +3,15 @@
 // Reference: run_S_eS_eN_alter_base_refine2.py — render_rays :525-680 (forward), loss / backward / optimizer.step :858-869,
 // create_nerf :337-395 (one Adam over fine net + sampler + refine net, betas (0.9, 0.999), eps 1e-8, L2 weight decay).
 //
-// Everything is fp32, like the reference's training.  The layer products (Y = X W^T, dX = dY W, dW = dY^T X) are plain
-// library GEMMs (rocBLAS); every other stage is a hand-written kernel here: bias + activation and its backward with the
-// bias-gradient column sums, the sampler head (sigmoid, depth affine, stable 8-sort, gathers) and its scatter backward,
-// the refine head (interval refinement, depth jitter, query points) and its backward, positional-encoding forward /
-// backward, alpha-compositing backward (suffix products, no division by the transmittance factors), the MSE losses and
-// Adam.  The projection into the training views carries no gradient in the reference (`torch.no_grad`, :576) and the
-// Pluecker moment does not depend on the depth along the ray, so no gradient reaches refine_in or mm_input and the first
-// layers of the sampler / refine nets need no dX.  A trainer owns parameters, gradients, Adam moments and workspaces;
-// nothing is allocated per step and every launch goes to the caller's stream.
+// Storage and accumulation are fp32, like the reference's training.  No library GEMM: the layer products (Y = X W^T, dX = dY W, dW = dY^T X)
+// are kernels of this library — split-fp16 MFMA (pnrf_hgemm.h; the fine net from 8192 rows on as two launches on the inference path's fused-MLP
+// engine, pnrf_tchain.h) or exact-fp32 MFMA (tgemm_kernel below) — and so is every other stage: bias + activation and its backward, the
+// sampler head (sigmoid, depth affine, stable 8-sort, gathers) and its scatter backward, the refine head (interval refinement, depth jitter,
+// query points) and its backward, positional-encoding forward / backward, alpha-compositing backward (suffix products, no division by the
+// transmittance factors), the MSE losses and Adam.  The projection into the training views carries no gradient in the reference
+// (`torch.no_grad`, :576) and the Pluecker moment does not depend on the depth along the ray, so no gradient reaches refine_in or mm_input and
+// the first layers of the sampler / refine nets need no dX.  A trainer owns parameters, gradients, Adam moments and workspaces; nothing is
+// allocated per step and every launch goes to the caller's stream.
 #include <string.h>
 
 #include <type_traits>
