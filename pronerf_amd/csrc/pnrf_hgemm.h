@@ -637,6 +637,10 @@ struct RChainArgs {
 // MI = 4 (64-row tiles, the NeRF layers' 32 768 .. 1 M rows: a quarter of the weight traffic of 16-row tiles) keeps ONE operand region and
 // rewrites it in place — the next layer's planes are written behind the barrier that follows the last MFMA of the current one, so nobody
 // reads the old planes any more — which brings the workgroup to 134 KB of LDS; MI <= 2 alternate between two regions as before.
+// PNRF_RC_PROBE (timing builds only; results are wrong): 1 no MFMA steps, 2 no stores, 4 no weight fetches
+#ifndef PNRF_RC_PROBE
+#define PNRF_RC_PROBE 0
+#endif
 template <int MI>
 __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
   constexpr int ROWS = 16 * MI, QN = 2 * MI;
@@ -659,6 +663,9 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
   int64_t rr[QN];
 #pragma unroll
   for (int q = 0; q < QN; ++q) { const int64_t r = row0 + rl0 + 8 * q; rr[q] = r < c.M ? r : c.M - 1; }
+  int64_t rrow[MI];                                            // rows of this lane's accumulator tiles
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) { const int64_t r = row0 + 16 * mi + m16; rrow[mi] = r < c.M ? r : c.M - 1; }
   float in_scale = 1.f;
   {
     if (c.x0_amax) in_scale = hg_scale_for(hg_slot_read(c.x0_amax, s_red));
@@ -674,11 +681,11 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
       *(f16x4_t*)(sX + XPLANE + off) = l;
     }
   }
-  // weight stream: step s of layer i = global step 8 i + s; four rotating register sets, three steps ahead
+  // weight stream: step s of layer i = global step 8 i + s
   struct WFrag { f16x8_t h[2], l[2]; };
   int w_layer = 0, w_ks = 0;
   auto load_w = [&](WFrag& w) {
-    if (w_layer < c.n) {
+    if (!(PNRF_RC_PROBE & 4) && w_layer < c.n) {
       const RChainLayer& L = c.l[w_layer];
       const int plane_bytes = L.n_pad * L.ldb * 2;
       const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc((void*)L.Bh, 0, plane_bytes, HG_BUF_FLAGS);
@@ -692,8 +699,17 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
     }
     if (++w_ks == 8) { w_ks = 0; ++w_layer; }
   };
+#ifdef PNRF_RC_PREFETCH3
   WFrag w0, w1, w2, w3;
   load_w(w0); load_w(w1); load_w(w2);
+#else
+  // eight register sets = one layer of this wave's fragments: a set is refilled with the NEXT layer's step the moment its step has run, so a
+  // layer's weights have the whole previous layer (steps + epilogue) to arrive.  (Three steps ahead — 0.2 us of MFMA steps — every step waited
+  // out most of an L2 round trip: a layer took 6.3 us for 0.6 us of MFMAs.)
+  WFrag w[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) load_w(w[s]);
+#endif
   __syncthreads();                                             // the first resident operand planes are complete
   for (int i = 0; i < c.n; ++i) {
     const RChainLayer& L = c.l[i];
@@ -701,10 +717,12 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
     const _Float16* xl = xh + XPLANE;
     const int ldc = L.ldc ? L.ldc : 256, ldh = L.ldh ? L.ldh : 256;
     const bool use_h = c.bwd && L.act != T_ACT_NONE;
-    f32x4_t hv[QN];
+    f32x4_t hv[MI][2];                                         // act'(H) of this lane's accumulator elements (requested now, used in the epilogue)
     if (use_h) {
 #pragma unroll
-      for (int q = 0; q < QN; ++q) hv[q] = *(const f32x4_t*)(L.H + rr[q] * ldh + cl);
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) hv[mi][j] = *(const f32x4_t*)(L.H + rrow[mi] * ldh + wave * 32 + 16 * j + 4 * g);
     }
     f32x4_t accm[MI][2], accx[MI][2];
 #pragma unroll
@@ -712,6 +730,7 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) { accm[mi][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accx[mi][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     auto step = [&](const WFrag& w, int s) {
+      if (PNRF_RC_PROBE & 1) return;                             // timing probe: no MFMA steps
       f16x8_t ah[MI], al[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -731,53 +750,62 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
         for (int j = 0; j < 2; ++j) accx[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[j], ah[mi], accx[mi][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     };
+#ifdef PNRF_RC_PREFETCH3
     load_w(w3); step(w0, 0); load_w(w0); step(w1, 1); load_w(w1); step(w2, 2); load_w(w2); step(w3, 3);
     load_w(w3); step(w0, 4); load_w(w0); step(w1, 5); load_w(w1); step(w2, 6); load_w(w2); step(w3, 7);
-    // ---- epilogue.  All fetches in flight (the next layer's first weight fragments, the rows of H) are drained before the first store
-    // (cf. hgemm_body: one counter for loads and stores).
+#else
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { step(w[s], s); load_w(w[s]); }
+#endif
+    // ---- epilogue from the accumulators: D register e of lane (m16, g) of tile (mi, j) = C[row 16 mi + m16][column 32 wave + 16 j + 4 g + e] —
+    // 16 contiguous bytes of a row per lane: bias / activation / act'(H) / store / split into the next layer's planes without an LDS round
+    // trip (through LDS, with the row-contiguous thread mapping, the epilogue was 3.4 of a layer's 6.2 us: three barriers more per layer).
+    // All fetches in flight (the next layer's weight fragments, the rows of H) are drained before the first store (cf. hgemm_body: one counter
+    // for loads and stores).
     __builtin_amdgcn_s_waitcnt(0x0F70);
     const float inv = 1.f / in_scale;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *(f32x4_t*)(sC + (16 * mi + m16) * HG_LDC + wave * 32 + 16 * j + 4 * g) = (accm[mi][j] + accx[mi][j] * HG_LO_INV) * inv;
-    __syncthreads();
-    f32x4_t v[QN];
+    f32x4_t v[MI][2];
     float amax = 0.f;
-    const f32x4_t b4 = !c.bwd && L.bias ? *(const f32x4_t*)(L.bias + cl) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < QN; ++q) {
-      v[q] = *(const f32x4_t*)(sC + (rl0 + 8 * q) * HG_LDC + cl) + b4;
+    for (int j = 0; j < 2; ++j) {
+      const int col = wave * 32 + 16 * j + 4 * g;
+      const f32x4_t b4 = !c.bwd && L.bias ? *(const f32x4_t*)(L.bias + col) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (!c.bwd) {
-          if (L.act == T_ACT_ELU) v[q][e] = v[q][e] > 0.f ? v[q][e] : expm1f(v[q][e]);
-          else if (L.act == T_ACT_RELU) v[q][e] = fmaxf(v[q][e], 0.f);
-        } else if (use_h) {
-          if (L.act == T_ACT_ELU) v[q][e] = hv[q][e] > 0.f ? v[q][e] : v[q][e] * (hv[q][e] + 1.f);
-          else v[q][e] = hv[q][e] > 0.f ? v[q][e] : 0.f;
+      for (int mi = 0; mi < MI; ++mi) {
+        f32x4_t x = (accm[mi][j] + accx[mi][j] * HG_LO_INV) * inv + b4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!c.bwd) {
+            if (L.act == T_ACT_ELU) x[e] = x[e] > 0.f ? x[e] : expm1f(x[e]);
+            else if (L.act == T_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+          } else if (use_h) {
+            if (L.act == T_ACT_ELU) x[e] = hv[mi][j][e] > 0.f ? x[e] : x[e] * (hv[mi][j][e] + 1.f);
+            else x[e] = hv[mi][j][e] > 0.f ? x[e] : 0.f;
+          }
+        }
+        v[mi][j] = x;
+        if (row0 + 16 * mi + m16 < c.M) {
+          amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+          if (!(PNRF_RC_PROBE & 2)) *(f32x4_t*)(L.C + rrow[mi] * ldc + col) = x;
         }
       }
-      if (row0 + rl0 + 8 * q < c.M) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[q][0]), fabsf(v[q][1]))), fmaxf(fabsf(v[q][2]), fabsf(v[q][3])));
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // (the bias fetch)
-#pragma unroll
-    for (int q = 0; q < QN; ++q)
-      if (row0 + rl0 + 8 * q < c.M) *(f32x4_t*)(L.C + rr[q] * ldc + cl) = v[q];
     in_scale = 1.f;
     if (c.bwd) in_scale = hg_scale_for(hg_slot_write(L.c_amax, amax, s_red, blockIdx.x));   // the workgroup's own maximum
     if (i + 1 < c.n) {
+      if (REGIONS == 1) __syncthreads();                       // one region: every wave is done reading this layer's planes
       _Float16* nh = sX + ((i + 1) & (REGIONS - 1)) * 2 * XPLANE;
 #pragma unroll
-      for (int q = 0; q < QN; ++q) {
-        f16x4_t h, l;
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float x = v[q][e] * in_scale; const _Float16 xh_ = (_Float16)x; h[e] = xh_; l[e] = (_Float16)((x - (float)xh_) * HG_LO_SCALE); }
-        const int off = (rl0 + 8 * q) * RC_LDX + cl;
-        *(f16x4_t*)(nh + off) = h;
-        *(f16x4_t*)(nh + XPLANE + off) = l;
-      }
+        for (int j = 0; j < 2; ++j) {
+          f16x4_t h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float x = v[mi][j][e] * in_scale; const _Float16 xh_ = (_Float16)x; h[e] = xh_; l[e] = (_Float16)((x - (float)xh_) * HG_LO_SCALE); }
+          const int off = (16 * mi + m16) * RC_LDX + wave * 32 + 16 * j + 4 * g;
+          *(f16x4_t*)(nh + off) = h;
+          *(f16x4_t*)(nh + XPLANE + off) = l;
+        }
     }
     __syncthreads();
   }
