@@ -536,8 +536,8 @@ class Trainer:
         256 -> 256 layers as two 64-row layer chains (bit-identical to 'f16x2_unchained'; pnrf_trainer_set_products)."""
         kinds = {'f16x2': 0, 'f32': 1, 'f16x2_unchained': 2, 'f16x2_wchain': 3}
         if kind not in kinds:
-            raise PnrfError(f"Trainer.set_products: kind must be 'f16x2' (split-fp16 MFMA products, default) or 'f32' (exact-fp32 MFMA products), got {kind!r} "
-                            '(the training drivers read it from PNRF_TRAIN_PRODUCTS)')
+            raise PnrfError(f"Trainer.set_products: kind must be one of {sorted(kinds)} ('f16x2': split-fp16 MFMA products, the default; 'f32': exact-fp32 "
+                            f'MFMA products), got {kind!r} (the training drivers read it from PNRF_TRAIN_PRODUCTS)')
         k = kinds[kind]
         check(_lib.load().pnrf_trainer_set_products(self.handle, k), 'pnrf_trainer_set_products')
 
