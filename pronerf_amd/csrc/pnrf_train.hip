@@ -609,12 +609,51 @@ __global__ void dw_reduce_kernel(const DwJobs jobs) {
   while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
   const DwJob& J = jobs.j[k];
   const int b = (int)blockIdx.x - J.block0, dw_blocks = J.blocks - J.db_blocks;
+  // Many splits (the 1 .. 4-wide heads write 256 partials of a few hundred values): eight lanes share an element — lane `sub` sums its eighth of
+  // the splits in order, the eight sums are added as a fixed tree — instead of one thread walking 256 partials (that walk was 15 of this
+  // launch's 38 us at 32 768 rows).  Fewer splits: one thread per element, in split order.  Either way the order is fixed: run-to-run identical.
+  constexpr int SUB = 8, MANY = 64;
   if (b >= dw_blocks) {
+    if (J.splits >= MANY) {
+      const int t = (b - dw_blocks) * (int)blockDim.x + (int)threadIdx.x, j = t / SUB, sub = t % SUB, per = (J.splits + SUB - 1) / SUB;
+      float s = 0.f;
+      if (j < J.out)
+        for (int q = sub * per; q < (sub + 1) * per && q < J.splits; ++q) s += J.db_part[(size_t)q * J.out + j];
+#pragma unroll
+      for (int o = 1; o < SUB; o <<= 1) s += __shfl_xor(s, o);
+      if (j < J.out && sub == 0) J.db[j] = s;
+      return;
+    }
     const int j = (b - dw_blocks) * (int)blockDim.x + (int)threadIdx.x;
     if (j < J.out) {
       float s = 0.f;
       for (int q = 0; q < J.splits; ++q) s += J.db_part[(size_t)q * J.out + j];
       J.db[j] = s;
+    }
+    return;
+  }
+  if (J.gap < 0 && J.numel % 4 == 0 && J.splits >= MANY) {
+    const int n4 = J.numel >> 2, per = (J.splits + SUB - 1) / SUB;
+    const f32x4_t* part = (const f32x4_t*)J.part;
+    const int total = (n4 * SUB + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x;      // whole blocks: the lanes of a group stay together
+    for (int t = b * (int)blockDim.x + (int)threadIdx.x; t < total; t += dw_blocks * (int)blockDim.x) {
+      const int i = t / SUB, sub = t % SUB;
+      f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+      if (i < n4) {
+        const int q1 = (sub + 1) * per < J.splits ? (sub + 1) * per : J.splits;
+        int q = sub * per;
+        for (; q + 4 <= q1; q += 4) {
+          const f32x4_t p0 = part[(size_t)q * n4 + i], p1 = part[(size_t)(q + 1) * n4 + i], p2 = part[(size_t)(q + 2) * n4 + i],
+                        p3 = part[(size_t)(q + 3) * n4 + i];
+          s = (((s + p0) + p1) + p2) + p3;
+        }
+        for (; q < q1; ++q) s += part[(size_t)q * n4 + i];
+      }
+#pragma unroll
+      for (int o = 1; o < SUB; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += __shfl_xor(s[e], o);
+      if (i < n4 && sub == 0) ((f32x4_t*)J.dW)[i] = s;
     }
     return;
   }
@@ -1218,7 +1257,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   DwJob& J = t->jobs.j[t->jobs.n];
   J.part = part; J.db_part = db_part; J.dW = dW; J.db = db; J.numel = numel; J.splits = (int)splits; J.out = out;
   J.in_src = in; J.in_dst = gap >= 0 ? in - 1 : in; J.gap = gap;
-  J.db_blocks = (out + TPB - 1) / TPB;
+  J.db_blocks = (out * (splits >= 64 ? 8 : 1) + TPB - 1) / TPB;   // dw_reduce_kernel: eight lanes per element from 64 splits on
   J.blocks = grid_for(gap < 0 && numel % 4 == 0 ? numel / 4 : numel) + J.db_blocks;
   J.block0 = t->jobs.n ? t->jobs.j[t->jobs.n - 1].block0 + t->jobs.j[t->jobs.n - 1].blocks : 0;
   ++t->jobs.n;
