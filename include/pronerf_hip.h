@@ -274,8 +274,8 @@ int pnrf_ctx_profile_end(pnrf_ctx_t* ctx, float* ms, int* frames);
 
 /* Operator-level backward passes (each mirrors what torch.autograd derives for the forward it names). */
 /* raw2outputs backward for d rgb_map [n,3]: arguments as pnrf_composite_fwd; outputs d_raw dev [n,s,4], d_z dev [n,s] (NULL to
- * skip), d_add / d_mul dev [n,s] (NULL to skip).  Any s >= 1 (two passes per ray, O(1) registers; d_raw doubles as scratch between
- * them).  (run_S_eS_eN_alter_base_refine2.py:475-522) */
+ * skip), d_add / d_mul dev [n,s] (NULL to skip).  Any s >= 1 (a wave per ray, a lane per sample, two recurrences in sample order).
+ * (run_S_eS_eN_alter_base_refine2.py:475-522) */
 int pnrf_composite_bwd(const float* raw, const float* z, const float* rays_d, int d_stride, const float* add,
                        const float* mul, const float* noise, float clamp, int white_bkgd, const float* d_rgb,
                        float* d_raw, float* d_z, float* d_add, float* d_mul, int64_t n, int s, void* stream);

@@ -423,7 +423,8 @@ __global__ void explore_kernel(ExploreArgs a, const float* __restrict__ z8, cons
 }
 
 // ---------------------------------------------------------------- raw2outputs (trt.py:564-597; base.py:501-551; refine2.py:475-522)
-__global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
+// One thread per ray: the form for many rays (from 65 536 on every SIMD has waves to hide the latencies with).
+__global__ void composite_thread_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
                                  const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
                                  int white_bkgd, float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc_out,
                                  float* __restrict__ weights, float* __restrict__ depth, int64_t n, int S) {
@@ -477,6 +478,67 @@ __global__ void composite_kernel(const float* __restrict__ raw, const float* __r
       }
     }
     if (white_bkgd) { const float bg = ieee_sub(1.f, sa); s0 = ieee_add(s0, bg); s1 = ieee_add(s1, bg); s2 = ieee_add(s2, bg); }
+    if (rgb) { rgb[i * 3] = s0; rgb[i * 3 + 1] = s1; rgb[i * 3 + 2] = s2; }
+    if (depth) depth[i] = sd;
+    if (acc_out) acc_out[i] = sa;
+    if (disp) disp[i] = ieee_div(1.f, fmaxf(1e-10f, ieee_div(sd, sa)));
+  }
+}
+
+// One WAVE per ray, lane = sample (chunks of 64 for S > 64): the per-sample work (loads, exp, sigmoids) runs in parallel, the transmittance
+// product and the five sums run over the lanes in sample order through v_readlane — the same operations in the same order as a thread walking
+// the ray, without its S memory latencies (thread per ray: 41 us for 4096 rays x 64 samples; 4096 threads do not fill 1024 SIMDs).
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
+                                 const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
+                                 int white_bkgd, float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ acc_out,
+                                 float* __restrict__ weights, float* __restrict__ depth, int64_t n, int S) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;                                                          // wave-uniform
+  const float* d = rays_d + i * d_stride;
+  const float dn = ieee_sqrt(ieee_add(ieee_add(ieee_mul(d[0], d[0]), ieee_mul(d[1], d[1])), ieee_mul(d[2], d[2])));
+  float T = 1.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, sd = 0.f, sa = 0.f;            // uniform: every lane carries the same running values
+  auto lane_val = [](float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
+  for (int c0 = 0; c0 < S; c0 += 64) {
+    const int m = S - c0 < 64 ? S - c0 : 64;
+    const int s = c0 + lane;
+    const bool on = lane < m;
+    const int64_t e = i * S + (on ? s : c0);
+    const float4 rw = *(const float4*)(raw + e * 4);
+    const float zc = z[e];
+    const float zn = (on && s + 1 < S) ? z[e + 1] : 0.f;
+    float r0 = rw.x, r1 = rw.y, r2 = rw.z, r3 = rw.w;
+    if (clampv > 0.f) {
+      r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv);
+      r2 = fminf(fmaxf(r2, -clampv), clampv); r3 = fminf(fmaxf(r3, -clampv), clampv);
+    }
+    float dist = (s + 1 < S) ? ieee_sub(zn, zc) : 1e10f;
+    dist = ieee_mul(dist, dn);
+    float sg = r3;
+    if (noise) sg = ieee_add(sg, noise[e]);
+    if (add) sg = ieee_add(sg, add[e]);
+    sg = fmaxf(sg, 0.f);
+    float alpha = ieee_sub(1.f, expf(ieee_mul(-sg, dist)));
+    if (mul) alpha = ieee_mul(alpha, fmaxf(mul[e], 0.f));
+    const float x = ieee_add(ieee_sub(1.f, alpha), 1e-10f);
+    float Tl = 0.f;                                                            // exclusive product up to this lane's sample
+    for (int j = 0; j < m; ++j) {
+      Tl = lane == j ? T : Tl;
+      T = ieee_mul(T, lane_val(x, j));
+    }
+    const float w = ieee_mul(alpha, Tl);
+    const float c0v = ieee_mul(w, sigmoid_f(r0)), c1v = ieee_mul(w, sigmoid_f(r1)), c2v = ieee_mul(w, sigmoid_f(r2)), cdv = ieee_mul(w, zc);
+    for (int j = 0; j < m; ++j) {
+      s0 = ieee_add(s0, lane_val(c0v, j));
+      s1 = ieee_add(s1, lane_val(c1v, j));
+      s2 = ieee_add(s2, lane_val(c2v, j));
+      sd = ieee_add(sd, lane_val(cdv, j));
+      sa = ieee_add(sa, lane_val(w, j));
+    }
+    if (weights && on) weights[e] = w;
+  }
+  if (white_bkgd) { const float bg = ieee_sub(1.f, sa); s0 = ieee_add(s0, bg); s1 = ieee_add(s1, bg); s2 = ieee_add(s2, bg); }
+  if (lane == 0) {
     if (rgb) { rgb[i * 3] = s0; rgb[i * 3 + 1] = s1; rgb[i * 3 + 2] = s2; }
     if (depth) depth[i] = sd;
     if (acc_out) acc_out[i] = sa;
@@ -598,8 +660,13 @@ extern "C" int pnrf_composite_fwd(const float* raw, const float* z, const float*
   PNRF_REQUIRE(n >= 0 && s >= 1 && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_fwd: bad sizes");
   if (n == 0) return 0;
   PNRF_REQUIRE(raw && z && rays_d, PNRF_E_ARG, "pnrf_composite_fwd: null pointer");
-  hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise,
-                     clampv, white_bkgd, rgb, disp, acc, weights, depth, n, s);
+  // few rays (a training batch): a wave per ray; many rays (a frame): a thread per ray.  Same operations in the same order either way.
+  if (n < 65536)
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise,
+                       clampv, white_bkgd, rgb, disp, acc, weights, depth, n, s);
+  else
+    hipLaunchKernelGGL(composite_thread_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise,
+                       clampv, white_bkgd, rgb, disp, acc, weights, depth, n, s);
   PNRF_LAUNCH_CHECK();
   return 0;
 }

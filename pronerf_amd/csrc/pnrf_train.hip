@@ -931,108 +931,103 @@ __global__ void refine_head_bwd_kernel(const float* __restrict__ y, const float*
 
 // ------------------------------------------------------------------------------------------ compositing backward
 // raw2outputs (refine2.py:475-522) backward for d rgb_map [n,3]: d raw [n,S,4], d z [n,S], d add / d mul [n,S] (NULL to skip).
-// Any S (a runtime value; the reference's exploration goes to 64, BASELINE.json's stress bound is 256): two passes per ray with O(1)
-// registers.  Pass 1 (ascending) leaves alpha_s and the exclusive transmittance T_s = prod_{k<s} x_k, x_k = 1 - alpha_k + 1e-10, in the first
-// two channels of d_raw (scratch, overwritten by pass 2).  Pass 2 (descending) carries Q_s = sum_{j>s} dw_j alpha_j prod_{s<k<j} x_k through
+// Any S (a runtime value; the reference's exploration goes to 64, BASELINE.json's stress bound is 256).  Pass 1 (ascending) forms alpha_s and the
+// exclusive transmittance T_s = prod_{k<s} x_k, x_k = 1 - alpha_k + 1e-10.  Pass 2 (descending) carries Q_s = sum_{j>s} dw_j alpha_j prod_{s<k<j} x_k through
 // the recurrence Q_{s-1} = dw_s alpha_s + x_s Q_s, so that  d alpha_s = T_s (dw_s - Q_s)  — the derivative of the transmittance products
 // without ever dividing by a factor x_k that can be 1e-10.
-__global__ void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
+// One WAVE per ray, lane = sample (chunks of 64 for S > 64), as composite_kernel (pnrf_ops.hip): per-sample work in parallel, the two
+// recurrences over the lanes in sample order through v_readlane.  (A thread per ray walked 2 S memory latencies: 51 us for 4096 rays x 64
+// samples.)  d_raw is no scratch any more: alpha and T stay in registers (the chunks are walked from the last to the first for Q; for
+// S > 64 the transmittance at a chunk's start is recomputed from the chunks before it).
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int d_stride,
                                      const float* __restrict__ add, const float* __restrict__ mul, const float* __restrict__ noise, float clampv,
                                      int white_bkgd, const float* __restrict__ d_rgb, float* __restrict__ d_raw, float* __restrict__ d_z,
                                      float* __restrict__ d_add, float* __restrict__ d_mul, int64_t n, int S) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float* d = rays_d + i * d_stride;
-    const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    const float g0 = d_rgb[i * 3], g1 = d_rgb[i * 3 + 1], g2 = d_rgb[i * 3 + 2];
-    const float gsum = white_bkgd ? (g0 + g1 + g2) : 0.f;                       // rgb_map += 1 - sum_s w_s
-    const bool clamped = clampv > 0.f;
-    // Both passes keep four samples' inputs in flight per thread and then run the recurrence over them in order (one sample per loop iteration
-    // waited out a memory latency per sample: 80 us for 4096 rays x 64 samples); same operations in the same order.
-    // pass 1
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;                                                          // wave-uniform
+  const float* d = rays_d + i * d_stride;
+  const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float g0 = d_rgb[i * 3], g1 = d_rgb[i * 3 + 1], g2 = d_rgb[i * 3 + 2];
+  const float gsum = white_bkgd ? (g0 + g1 + g2) : 0.f;                         // rgb_map += 1 - sum_s w_s
+  const bool clamped = clampv > 0.f;
+  auto lane_val = [](float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
+  const int nchunks = (S + 63) / 64;
+  // per-sample quantities of one chunk (this lane's sample): everything both passes need
+  struct Smp { float r0, r1, r2, raw3, sg, dist, al, a, ml; bool on; int64_t e; int s; };
+  auto load = [&](int c0) {
+    Smp q;
+    const int m = S - c0 < 64 ? S - c0 : 64;
+    q.s = c0 + lane; q.on = lane < m;
+    q.e = i * S + (q.on ? q.s : c0);
+    const float4 rw = *(const float4*)(raw + q.e * 4);
+    q.r0 = rw.x; q.r1 = rw.y; q.r2 = rw.z; q.raw3 = rw.w;
+    float r3 = rw.w;
+    if (clamped) r3 = fminf(fmaxf(r3, -clampv), clampv);
+    float sg = r3;
+    if (noise) sg += noise[q.e];
+    if (add) sg += add[q.e];
+    q.sg = sg;
+    const float zc = z[q.e], zn = (q.on && q.s + 1 < S) ? z[q.e + 1] : 0.f;
+    q.dist = ((q.s + 1 < S) ? (zn - zc) : 1e10f) * dn;
+    q.a = 1.f - expf(-fmaxf(sg, 0.f) * q.dist);
+    q.ml = mul ? mul[q.e] : 1.f;
+    q.al = mul ? q.a * fmaxf(q.ml, 0.f) : q.a;
+    return q;
+  };
+  // T at the start of chunk c = the product over the chunks before it, in sample order (one chunk for S <= 64: nothing to do)
+  auto t_start = [&](int c) {
     float T = 1.f;
-    for (int sb = 0; sb < S; sb += 4) {
-      const int64_t e0 = i * S + sb;
-      const int m = S - sb < 4 ? S - sb : 4;
-      float r3v[4], zz[5], nz[4], ad[4], ml[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t e = e0 + (u < m ? u : m - 1);
-        r3v[u] = raw[e * 4 + 3]; zz[u] = z[e];
-        nz[u] = noise ? noise[e] : 0.f; ad[u] = add ? add[e] : 0.f; ml[u] = mul ? mul[e] : 0.f;
-      }
-      zz[4] = sb + 4 < S ? z[e0 + 4] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u >= m) break;
-        const int s = sb + u;
-        const int64_t e = e0 + u;
-        float r3 = r3v[u];
-        if (clamped) r3 = fminf(fmaxf(r3, -clampv), clampv);
-        float sg = r3;
-        if (noise) sg += nz[u];
-        if (add) sg += ad[u];
-        const float dist = ((s + 1 < S) ? (zz[u + 1] - zz[u]) : 1e10f) * dn;
-        const float a = 1.f - expf(-fmaxf(sg, 0.f) * dist);
-        const float al = mul ? a * fmaxf(ml[u], 0.f) : a;
-        d_raw[e * 4] = T; d_raw[e * 4 + 1] = al;
-        T *= 1.f - al + 1e-10f;
-      }
+    for (int k = 0; k < c; ++k) {
+      const Smp q = load(64 * k);
+      const float x = 1.f - q.al + 1e-10f;
+      for (int j = 0; j < 64; ++j) T *= lane_val(x, j);
     }
-    // pass 2
-    float Q = 0.f, dd_next = 0.f;
-    for (int sb = S - 1; sb >= 0; sb -= 4) {                     // samples sb, sb - 1, .. (descending)
-      const int m = sb + 1 < 4 ? sb + 1 : 4;
-      float4 rw[4];
-      float Tp[4], alv[4], zz0[4], zz1[4], nz[4], ad[4], ml[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int su = sb - (u < m ? u : m - 1);
-        const int64_t e = i * S + su;
-        Tp[u] = d_raw[e * 4]; alv[u] = d_raw[e * 4 + 1];
-        rw[u] = *(const float4*)(raw + e * 4);
-        zz0[u] = z[e]; zz1[u] = su + 1 < S ? z[e + 1] : 0.f;
-        nz[u] = noise ? noise[e] : 0.f; ad[u] = add ? add[e] : 0.f; ml[u] = mul ? mul[e] : 1.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u >= m) break;
-        const int s = sb - u;
-        const int64_t e = i * S + s;
-        const float Tpre = Tp[u], al = alv[u];
-        float r0 = rw[u].x, r1 = rw[u].y, r2 = rw[u].z;
-        const bool in0 = !clamped || fabsf(r0) <= clampv, in1 = !clamped || fabsf(r1) <= clampv, in2 = !clamped || fabsf(r2) <= clampv;
-        if (clamped) { r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv); r2 = fminf(fmaxf(r2, -clampv), clampv); }
-        const float c0 = sigmoid_f(r0), c1 = sigmoid_f(r1), c2 = sigmoid_f(r2);
-        const float dws = g0 * c0 + g1 * c1 + g2 * c2 - gsum;
-        const float dal = Tpre * (dws - Q);
-        Q = dws * al + (1.f - al + 1e-10f) * Q;
-        const float w = al * Tpre;
-        d_raw[e * 4] = in0 ? g0 * w * c0 * (1.f - c0) : 0.f;
-        d_raw[e * 4 + 1] = in1 ? g1 * w * c1 * (1.f - c1) : 0.f;
-        d_raw[e * 4 + 2] = in2 ? g2 * w * c2 * (1.f - c2) : 0.f;
-        // alpha = a * relu(mul); a = 1 - exp(-relu(sig) dist)
-        float r3 = rw[u].w;
-        const bool in3 = !clamped || fabsf(r3) <= clampv;
-        if (clamped) r3 = fminf(fmaxf(r3, -clampv), clampv);
-        float sg = r3;
-        if (noise) sg += nz[u];
-        if (add) sg += ad[u];
-        const float dist = ((s + 1 < S) ? (zz1[u] - zz0[u]) : 1e10f) * dn;
-        const float ee = fmaxf(sg, 0.f);
-        const float ex = expf(-ee * dist);
-        const float a = 1.f - ex;
-        const float mm = ml[u];
-        const float da = mul ? dal * fmaxf(mm, 0.f) : dal;
-        if (d_mul) d_mul[e] = (mul && mm > 0.f) ? dal * a : 0.f;
-        const float dsg = sg > 0.f ? da * dist * ex : 0.f;
-        d_raw[e * 4 + 3] = in3 ? dsg : 0.f;
-        if (d_add) d_add[e] = add ? dsg : 0.f;
-        const float ddist = (s + 1 < S) ? da * ee * ex * dn : 0.f;          // the last interval (1e10) does not depend on z
-        if (d_z) {                                                          // d z_s = d dist_{s-1} dn - d dist_s dn
-          if (s + 1 < S) d_z[e + 1] = ddist - dd_next;
-          if (s == 0) d_z[e] = -ddist;
-        }
-        dd_next = ddist;
+    return T;
+  };
+  // pass 2 (descending)
+  float Q = 0.f, dd_next = 0.f;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int c0 = 64 * c, m = S - c0 < 64 ? S - c0 : 64;
+    const Smp q = load(c0);
+    const float x = 1.f - q.al + 1e-10f;
+    float Tpre = 0.f, Tr = t_start(c);
+    for (int j = 0; j < m; ++j) { Tpre = lane == j ? Tr : Tpre; Tr *= lane_val(x, j); }
+    float r0 = q.r0, r1 = q.r1, r2 = q.r2;
+    const bool in0 = !clamped || fabsf(r0) <= clampv, in1 = !clamped || fabsf(r1) <= clampv, in2 = !clamped || fabsf(r2) <= clampv;
+    if (clamped) { r0 = fminf(fmaxf(r0, -clampv), clampv); r1 = fminf(fmaxf(r1, -clampv), clampv); r2 = fminf(fmaxf(r2, -clampv), clampv); }
+    const float c0v = sigmoid_f(r0), c1v = sigmoid_f(r1), c2v = sigmoid_f(r2);
+    const float dws = g0 * c0v + g1 * c1v + g2 * c2v - gsum;
+    // Q_s (the value the thread-per-ray loop had when it reached sample s) for this lane, then Q <- dws al + x Q, sample by sample from the top
+    float Ql = 0.f;
+    for (int j = m - 1; j >= 0; --j) {
+      Ql = lane == j ? Q : Ql;
+      Q = lane_val(dws, j) * lane_val(q.al, j) + lane_val(x, j) * Q;
+    }
+    const float dal = Tpre * (dws - Ql);
+    const float w = q.al * Tpre;
+    const bool in3 = !clamped || fabsf(q.raw3) <= clampv;
+    const float ee = fmaxf(q.sg, 0.f);
+    const float ex = expf(-ee * q.dist);
+    const float da = mul ? dal * fmaxf(q.ml, 0.f) : dal;
+    const float dsg = q.sg > 0.f ? da * q.dist * ex : 0.f;
+    const float ddist = (q.s + 1 < S) ? da * ee * ex * dn : 0.f;               // the last interval (1e10) does not depend on z
+    // d z_{s+1} = ddist_s - ddist_{s+1}: the neighbour's value from the next lane (the next chunk's first sample across a chunk boundary)
+    float dd_up = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(ddist)));
+    if (lane == m - 1) dd_up = dd_next;
+    dd_next = lane_val(ddist, 0);
+    if (q.on) {
+      float4 o;
+      o.x = in0 ? g0 * w * c0v * (1.f - c0v) : 0.f;
+      o.y = in1 ? g1 * w * c1v * (1.f - c1v) : 0.f;
+      o.z = in2 ? g2 * w * c2v * (1.f - c2v) : 0.f;
+      o.w = in3 ? dsg : 0.f;
+      *(float4*)(d_raw + q.e * 4) = o;
+      if (d_mul) d_mul[q.e] = (mul && q.ml > 0.f) ? dal * q.a : 0.f;
+      if (d_add) d_add[q.e] = add ? dsg : 0.f;
+      if (d_z) {
+        if (q.s + 1 < S) d_z[q.e + 1] = ddist - dd_up;
+        if (q.s == 0) d_z[q.e] = -ddist;
       }
     }
   }
@@ -1511,7 +1506,7 @@ extern "C" int pnrf_composite_bwd(const float* raw, const float* z, const float*
   if (n == 0) return 0;
   PNRF_REQUIRE(raw && z && rays_d && d_rgb && d_raw, PNRF_E_ARG, "pnrf_composite_bwd: null pointer");
   PNRF_REQUIRE((add == nullptr) == (mul == nullptr), PNRF_E_ARG, "pnrf_composite_bwd: add and mul go together");
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise, clampv,
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise, clampv,
                      white_bkgd, d_rgb, d_raw, d_z, d_add, d_mul, n, s);
   PNRF_LAUNCH_CHECK();
   return 0;
