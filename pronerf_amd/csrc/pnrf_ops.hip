@@ -378,47 +378,63 @@ struct ExploreArgs {
   int n_mult, dir1, dir2, S;          // S = 8 * n_mult
   float mults[32];                    // torch.linspace(0, 1 - 1/n_mult, n_mult)
 };
-// One thread per ray: replicate each of the 8 refined depths n_mult times toward the next (dir1 > 0) or previous sample,
-// sort, jitter toward the neighbour (dir2), and lift to query points o + d*z.  S <= 256 samples per ray.
-__global__ void explore_kernel(ExploreArgs a, const float* __restrict__ z8, const float* __restrict__ rays, const float* __restrict__ jitter,
+// One WAVE per ray, lane l = samples l, l + 64, ...: replicate each of the 8 refined depths n_mult times toward the next (dir1 > 0) or previous
+// sample, sort, jitter toward the neighbour (dir2), and lift to query points o + d*z.  S <= 256 samples per ray.  The sort is a rank sort — rank
+// = number of smaller values + number of equal values before it: the order a stable insertion sort leaves — over the wave's copy of the S values
+// in LDS.  (A thread per ray with a 256-entry private array and an insertion sort: 54 us for 4096 rays x 64 samples.)
+__global__ __launch_bounds__(256) void explore_kernel(ExploreArgs a, const float* __restrict__ z8, const float* __restrict__ rays, const float* __restrict__ jitter,
                                float* __restrict__ z_out, float* __restrict__ pts_out, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float* r = rays + i * 11;
-    const float near = r[6], far = r[7];
-    float zz[256];
-    float z[8];
+  __shared__ float lds[4][2][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  if (i >= n) return;                                                          // wave-uniform
+  float* zz = lds[wv][0];
+  float* zs = lds[wv][1];
+  const float* r = rays + i * 11;
+  const float near = r[6], far = r[7];
+  float z[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) z[s] = z8[i * 8 + s];
-    const int S = a.S;
-    if (a.n_mult > 1) {
-      for (int s = 0; s < 8; ++s) {
-        const float nb = a.dir1 > 0 ? (s < 7 ? z[s + 1] : far) : (s > 0 ? z[s - 1] : near);
-        const float diff = fabsf(ieee_sub(z[s], nb));
-        for (int j = 0; j < a.n_mult; ++j) {
-          const float m = a.dir1 > 0 ? a.mults[j] : -a.mults[j];
-          zz[s * a.n_mult + j] = ieee_add(z[s], ieee_mul(m, diff));
-        }
-      }
-      for (int u = 1; u < S; ++u) {               // insertion sort (ascending), S <= 256
-        const float v = zz[u];
-        int w = u - 1;
-        while (w >= 0 && zz[w] > v) { zz[w + 1] = zz[w]; --w; }
-        zz[w + 1] = v;
-      }
+  for (int s = 0; s < 8; ++s) z[s] = z8[i * 8 + s];
+  const int S = a.S, nm = a.n_mult;
+  for (int u = lane; u < S; u += 64) {
+    float v;
+    if (nm > 1) {
+      const int s = u / nm, j = u - s * nm;
+      float zc = z[0], nb = a.dir1 > 0 ? z[1] : near;
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (s == k) { zc = z[k]; nb = a.dir1 > 0 ? (k < 7 ? z[k < 7 ? k + 1 : 7] : far) : z[k - 1]; }
+      const float diff = fabsf(ieee_sub(zc, nb));
+      const float m = a.dir1 > 0 ? a.mults[j] : -a.mults[j];
+      v = ieee_add(zc, ieee_mul(m, diff));
     } else {
-      for (int s = 0; s < 8; ++s) zz[s] = z[s];
+      v = z[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) if (u == k) v = z[k];
     }
-    float prev = near;                             // jitter uses the un-jittered neighbours (base.py:721-727)
-    for (int u = 0; u < S; ++u) {
-      const float cur = zz[u];
-      const float nb = a.dir2 > 0 ? (u + 1 < S ? zz[u + 1] : far) : prev;
-      const float jv = jitter[i * S + u];
-      const float zo = ieee_add(cur, ieee_mul(a.dir2 > 0 ? jv : -jv, fabsf(ieee_sub(cur, nb))));
-      prev = cur;
-      z_out[i * S + u] = zo;
-      float* p = pts_out + (i * S + u) * 3;
-      p[0] = ieee_add(r[0], ieee_mul(r[3], zo)); p[1] = ieee_add(r[1], ieee_mul(r[4], zo)); p[2] = ieee_add(r[2], ieee_mul(r[5], zo));
+    zz[u] = v;
+  }
+  if (nm > 1) {
+    for (int u = lane; u < S; u += 64) {
+      const float v = zz[u];
+      int rank = 0;
+      for (int k = 0; k < S; ++k) {
+        const float o = zz[k];
+        rank += (o < v || (o == v && k < u)) ? 1 : 0;
+      }
+      zs[rank] = v;
     }
+  } else {
+    for (int u = lane; u < S; u += 64) zs[u] = zz[u];
+  }
+  for (int u = lane; u < S; u += 64) {                                         // jitter uses the un-jittered neighbours (base.py:721-727)
+    const float cur = zs[u];
+    const float nb = a.dir2 > 0 ? (u + 1 < S ? zs[u + 1] : far) : (u > 0 ? zs[u - 1] : near);
+    const float jv = jitter[i * S + u];
+    const float zo = ieee_add(cur, ieee_mul(a.dir2 > 0 ? jv : -jv, fabsf(ieee_sub(cur, nb))));
+    z_out[i * S + u] = zo;
+    float* p = pts_out + (i * S + u) * 3;
+    p[0] = ieee_add(r[0], ieee_mul(r[3], zo)); p[1] = ieee_add(r[1], ieee_mul(r[4], zo)); p[2] = ieee_add(r[2], ieee_mul(r[5], zo));
   }
 }
 
@@ -704,7 +720,7 @@ extern "C" int pnrf_explore_fwd(const float* z8, const float* rays, const float*
   ExploreArgs a;
   a.n_mult = n_mult; a.dir1 = dir1; a.dir2 = dir2; a.S = 8 * n_mult;
   pnrf_linspace(0.f, (float)(1.0 - 1.0 / n_mult), n_mult, a.mults);
-  hipLaunchKernelGGL(explore_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, a, z8, rays, jitter, z_out, pts_out, n);
+  hipLaunchKernelGGL(explore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, z8, rays, jitter, z_out, pts_out, n);
   PNRF_LAUNCH_CHECK();
   return 0;
 }
