@@ -1157,7 +1157,9 @@ struct pnrf_trainer {
   float* w_gapped = nullptr;                     // fp32 copy [out][in + 1] of the skip layer's weights with the zero column of its input layout
   _Float16* planes = nullptr;                    // fp16 hi / lo planes of every layer's weights, both orientations (pnrf_hgemm.h)
   SplitArgs split;
-  bool planes_stale = true;                      // parameters changed since the planes were last written
+  bool planes_stale = true;                      // parameters changed since the planes were last written (set through params_changed())
+  bool nerf_planes_stale = true;                 // ... the fine net's planes (not refreshed while both of its chains run on the engine: nobody reads them)
+  bool streams_stale = true;                     // ... the chains' fragment streams
   bool use_f16 = true;                           // split-fp16 layer products (default) or the exact-fp32 MFMA kernels throughout
   _Float16* tc_stream = nullptr;                 // the fine net's pts0 .. feature weights as the fused-MLP engine's fragment stream (pnrf_tchain.h)
   TChainPackArgs tc_pack;
@@ -1177,6 +1179,8 @@ struct pnrf_trainer {
 };
 
 namespace {
+
+inline void params_changed(pnrf_trainer* t) { t->planes_stale = true; t->nerf_planes_stale = true; t->streams_stale = true; }
 
 template <class T>
 int dev_alloc(pnrf_trainer* t, T** p, size_t count) {
@@ -1627,7 +1631,7 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     T_ALLOC(t->w_gapped, (size_t)g.out * g.in_x());
     PNRF_HIP(hipMemset(t->w_gapped, 0, (size_t)g.out * g.in_x() * 4));
     t->split.n = N_LAYERS; t->split.P = t->P; t->split.planes = t->planes; t->split.total = t->nparam; t->split.gapped = t->w_gapped;
-    t->planes_stale = true;
+    params_changed(t);
     T_ALLOC(t->tc_stream, (size_t)TC_NSLOTS * SLOT_BYTES / sizeof(_Float16));
     memset(&t->tc_pack, 0, sizeof(t->tc_pack));
     t->tc_pack.P = t->P; t->tc_pack.stream = t->tc_stream;
@@ -1725,7 +1729,7 @@ extern "C" int pnrf_trainer_write(pnrf_trainer_t* t, int kind, int layer, const 
   if (W) PNRF_HIP(hipMemcpyAsync(base + l.w, W, (size_t)l.in * l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
   if (b) PNRF_HIP(hipMemcpyAsync(base + l.b, b, (size_t)l.out * 4, hipMemcpyDefault, (hipStream_t)stream));
   PNRF_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (kind == 0) t->planes_stale = true;
+  if (kind == 0) params_changed(t);
   return 0;
 }
 // Device address and element count of one of the flat arrays (kind as pnrf_trainer_read) — e.g. to all-reduce the gradients of
@@ -1734,7 +1738,7 @@ extern "C" int pnrf_trainer_flat(pnrf_trainer_t* t, int kind, float** ptr, int64
   PNRF_REQUIRE(t && ptr && count && kind >= 0 && kind <= 5, PNRF_E_ARG, "pnrf_trainer_flat: bad arguments");
   *ptr = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : kind == 3 ? t->V : kind == 4 ? t->M2 : t->V2;
   *count = (int64_t)t->nparam;
-  if (kind == 0) t->planes_stale = true;        // the caller may write the parameters through this pointer (before the next iteration is submitted)
+  if (kind == 0) params_changed(t);        // the caller may write the parameters through this pointer (before the next iteration is submitted)
   return 0;
 }
 
@@ -1774,7 +1778,7 @@ extern "C" int pnrf_trainer_adam_step(pnrf_trainer_t* t, int which, float lr, fl
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(TPB), 0, (hipStream_t)stream, t->P + first, t->G + first, (which == 0 ? t->M : t->M2) + first,
                      (which == 0 ? t->V : t->V2) + first, count, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   PNRF_LAUNCH_CHECK();
-  t->planes_stale = true;
+  params_changed(t);
   return 0;
 }
 
@@ -2087,16 +2091,28 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     PNRF_HIP(hipEventRecord(t->ev_in, caller));
     PNRF_HIP(hipStreamWaitEvent(s, t->ev_in, 0));
   }
-  if (t->planes_stale) {
-    hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)t->nparam)), dim3(TPB), 0, s, t->split);
-    PNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
-    PNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tchain_pack_bwd_kernel, dim3(TB_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tb_pack);
-    PNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tchain_norms_kernel, dim3(TB_NS, 16), dim3(256), 0, s, t->tb_pack);
-    PNRF_LAUNCH_CHECK();
-    t->planes_stale = false;
+  {
+    // which of the derived weight forms this iteration reads: the fp16 planes of the sampler / refine nets always; the fine net's planes
+    // unless both of its chains run on the engine; the chains' fragment streams if the forward chain does
+    const int64_t R = N * S;
+    const bool eng_f = t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->tc_ok, eng = eng_f && t->dw_tile == 0;
+    if (t->planes_stale || (!eng && t->nerf_planes_stale)) {
+      SplitArgs sp = t->split;
+      if (eng) sp.total = t->L[L_N].w;                         // the parameters before the fine net's
+      hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)sp.total)), dim3(TPB), 0, s, sp);
+      PNRF_LAUNCH_CHECK();
+      t->planes_stale = false;
+      if (!eng) t->nerf_planes_stale = false;
+    }
+    if (eng_f && t->streams_stale) {
+      hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
+      PNRF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(tchain_pack_bwd_kernel, dim3(TB_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tb_pack);
+      PNRF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(tchain_norms_kernel, dim3(TB_NS, 16), dim3(256), 0, s, t->tb_pack);
+      PNRF_LAUNCH_CHECK();
+      t->streams_stale = false;
+    }
   }
   StageArgs sa = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
                   t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S, t->amax, N_AMAX * HG_SLOT};
@@ -2170,7 +2186,7 @@ extern "C" int pnrf_trainer_set_products(pnrf_trainer_t* t, int kind) {
   drop_graphs(t);
   t->use_f16 = kind != 1;
   t->nerf_fwd = kind == 1 ? 0 : kind;
-  if (t->use_f16) t->planes_stale = true;
+  params_changed(t);                               // (also the fp32 kernels' gapped copy of the skip layer's weights is written with the planes)
   return 0;
 }
 
