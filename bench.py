@@ -68,6 +68,8 @@ def parse():
     ap.add_argument('--eager-reps', type=int, default=5)
     ap.add_argument('--no-chunked', action='store_true', help='skip the 745 x 1024-ray rendering of the frame (rank 0, N=1)')
     ap.add_argument('--no-variants', action='store_true', help='skip the frame with the single-pass split-fp16 sampler (rank 0, N=1)')
+    ap.add_argument('--no-shard-rehearsal', action='store_true', help='skip the one-GPU rehearsal of the 1/2, 1/4, 1/8-frame shards and small calls (rank 0, N=1)')
+    ap.add_argument('--steady-seconds', type=float, default=2.0, help='seconds of back-to-back frames after the timed region (steady_state block; 0 = skip)')
     ap.add_argument('--no-train', action='store_true', help='skip the training-iteration block (rank 0, N=1)')
     ap.add_argument('--no-train-eager', action='store_true', help='training block without the eager-torch legs')
     ap.add_argument('--launch-timeout', type=float, default=900.0, help='N>1 started without a launcher: seconds before the ranks are stopped')
@@ -166,22 +168,48 @@ def sustained_mfma_peak():
         return None
 
 
+def csrc_digest():
+    """Digest of the kernel sources + build flags (pronerf_amd.build._digest: what the library's .sha256 stamp holds).  Profiles record it
+    (tools/pmc_summary.py, tools/train_pmc_summary.py); a number read from a profile is reported only while it still matches."""
+    try:
+        from pronerf_amd import build as b
+        return b._digest()
+    except Exception:
+        return None
+
+
+def profile_provenance(summary):
+    """(usable, provenance) of a committed PMC summary: usable only if it was taken from the kernel sources of this tree."""
+    have, now = summary.get('csrc_digest'), csrc_digest()
+    prov = {'file': summary.get('_file'), 'commit': summary.get('commit'), 'csrc_digest': have}
+    if not have:
+        return False, dict(prov, refused='the profile predates digest stamping (cannot tell whether csrc/ changed since)')
+    if have != now:
+        return False, dict(prov, refused='csrc/ changed since the profile was taken (digest mismatch): re-run tools/profile_round.sh')
+    return True, prov
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (profiles/r<round>_v<version>_pmc_summary.json,
     newest = highest (round, version), not lexicographic: v9 < v11): separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2
-    correction applied there.  None when there is no summary or it does not list the kernel."""
+    correction applied there.  -> (bytes or None, provenance): None when there is no summary, it does not list the kernel, or it was taken
+    from other kernel sources than this tree's (the reason is in the provenance)."""
     import re
 
     def key(f):
         m = re.search(r'r(\d+)(?:_v(\d+))?_pmc_summary\.json$', os.path.basename(f))
         return (int(m.group(1)), int(m.group(2) or 0)) if m else (-1, -1)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')), key=key)
+    files = [f for f in files if '_train_' not in os.path.basename(f)]
     if not files:
-        return None
+        return None, {'refused': 'no profiles/r*_pmc_summary.json'}
     try:
-        return json.load(open(files[-1]))['per_kernel'][kernel]['hbm_bytes_per_launch']
-    except Exception:
-        return None
+        d = json.load(open(files[-1]))
+        d['_file'] = os.path.relpath(files[-1], ROOT)
+        ok, prov = profile_provenance(d)
+        return (d['per_kernel'][kernel]['hbm_bytes_per_launch'] if ok else None), prov
+    except Exception as e:
+        return None, {'refused': f'{type(e).__name__}: {e}'}
 
 
 def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2):
@@ -233,16 +261,19 @@ def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2):
 
 def train_pmc(workload):
     """HBM bytes per training iteration from the committed profile of tools/profile_train.sh (profiles/r<NN>_train_pmc_summary.json,
-    newest round): sum over the iteration's kernels of 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)."""
+    newest round): sum over the iteration's kernels of 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction).  -> (entry or None, provenance)."""
     import re
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_pmc_summary.json')),
                    key=lambda f: int(re.search(r'r(\d+)_train', os.path.basename(f)).group(1)))
     if not files:
-        return None
+        return None, {'refused': 'no profiles/r*_train_pmc_summary.json'}
     try:
-        return json.load(open(files[-1]))['workloads'][workload]
-    except Exception:
-        return None
+        d = json.load(open(files[-1]))
+        d['_file'] = os.path.relpath(files[-1], ROOT)
+        ok, prov = profile_provenance(d)
+        return (d['workloads'][workload] if ok else None), prov
+    except Exception as e:
+        return None, {'refused': f'{type(e).__name__}: {e}'}
 
 
 def train_block(dev, eager=True):
@@ -261,9 +292,10 @@ def train_block(dev, eager=True):
     def entry(name, fn, iters, warm, flop, extra=None):
         ms, wall = wl.timed_ms(fn, iters, warm)
         e = {'ms': ms, 'host_ms': wall, 'iters': iters, 'rays_per_s': wk.n / (ms * 1e-3), 'algorithmic_tflop': flop / 1e12, 'tflops': flop / (ms * 1e-3) / 1e12}
-        pm = train_pmc(name)
+        pm, prov = train_pmc(name)
+        e['hbm_bytes_per_iter'] = pm['hbm_bytes_per_iter'] if pm else None
+        e['hbm_bytes_source'] = prov
         if pm:
-            e['hbm_bytes_per_iter'] = pm['hbm_bytes_per_iter']
             e['hbm_TBps'] = pm['hbm_bytes_per_iter'] / (ms * 1e-3) / 1e12
             e['frac_of_hbm_roof'] = e['hbm_TBps'] * 1e12 / HBM_PEAK
             e['launches_per_iter'] = pm.get('launches_per_iter')
@@ -525,8 +557,9 @@ def main():
                        'nerf_kernel': 'nerf16_kernel<false, 2, (anonymous namespace)::PrecBf16>'}
             for k in kern:
                 kern[k]['symbol'] = symbols[k]
+            traffic, traffic_src = pmc_traffic(dom)
             res['roofline'] = {'bound': 'mfma', 'kernel': symbols[dom], 'stage': dom, 'achieved': kern[dom]['achieved_tflops'], 'peak': peaks[dom],
-                               'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': pmc_traffic(dom),
+                               'unit': 'TFLOP/s', 'frac': kern[dom]['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                                'launch_ms': prof[dom], 'flop_per_launch': flops[dom] * n_total,
                                'timing': f'HIP events on the launch stream around every kernel of the first {prof_frames} timed steps'}
             res['kernels'] = kern
@@ -538,6 +571,22 @@ def main():
                                        'what': 'rays whose depth order the plain-fp16 pass could not decide (adjacent sorted gap <= kappa x its own '
                                                'error bound): re-rendered by the split-fp16 kernel'}
             one_call = outs[0][:count].clone()
+            if args.steady_seconds > 0:
+                # the driver fixes --steps (20 frames = 90 ms): the same loop over >= steady_seconds of back-to-back frames, where the chip sits at
+                # the clock its power limit allows.  `value` stays the driver's K steps; DESIGN.md quotes the steady figure when they differ by > 3 %.
+                nfr = max(args.steps, int(args.steady_seconds * 1e3 / ms) + 1)
+                t1 = time.perf_counter()
+                for _ in range(nfr):
+                    step()
+                fence()
+                sdt = time.perf_counter() - t1
+                sms = sdt / nfr * 1e3
+                res['steady_state'] = {'ms_per_frame': sms, 'rays_per_s': n_total * nfr / sdt, 'frames': nfr, 'seconds': sdt,
+                                       'vs_timed_region': sms / ms,
+                                       'what': 'the timed loop again over >= %.1f s of back-to-back frames (host clock around barrier + synchronize)' % args.steady_seconds}
+            if not args.no_shard_rehearsal:
+                from pronerf_amd.workloads import shard_rehearsal
+                res['shard_rehearsal'] = shard_rehearsal(weights, scene, H, W, dev, reps=40)
             if not args.no_chunked:
                 res['chunked_1024'] = dict(chunked_1024(rend, rays, or_rays, one_call), one_call_ms_per_frame=ms)
             var_rgb = {}

@@ -96,6 +96,22 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 #define PNRF_VARIANT_BF16 6
 #define PNRF_VARIANT_F16 7
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
+/* Workgroup shape of the fused stages (sampler passes, projection + refine, NeRF) launched from this handle — how a launch's columns (rays or
+ * ray samples) are cut into batches and spread over the 256 CUs.  The reference renders any ray count through the same modules
+ * (run_S_eS_eN_alter_trt.py:223: `chunk` is accepted and unused); here a whole frame and a 1/8-frame shard or a 1024-ray chunk want different shapes:
+ *   WIDE    one 8-wave workgroup per CU (two waves per SIMD) walking batches of 256 columns (128 rays in the split-fp16 sampler kernel):
+ *           every weight fragment streamed into the CU feeds 8 waves.  Whole frames.
+ *   NARROW  two independent 4-wave workgroups per CU, each with its own LDS ring, walking batches of half the width: twice the weight stream
+ *           (5-7 % slower on whole frames), but the last round of a launch is finer and a CU left with one workgroup gives each wave a SIMD.
+ *           Launches of fewer than two rounds of wide batches: the 95 256-ray shard of an 8-GPU frame, ray chunks (a 1024-ray call is
+ *           8 / 16 / 8 / 64 workgroups in the four kernels, each alone on its CU).
+ *   AUTO    (what pack / deserialize produce) chosen per launch from the column count by the rules above.
+ * Every ray's instruction stream is the same in all shapes: results are bit-identical (tests/test_render_gpu.py).  Configuration like the
+ * variant: set before the handle is used; the single-kernel test variants (SAMPLER_F32*, BF16_32X32, NERF_4X64) have one shape. */
+#define PNRF_SHAPE_AUTO 0
+#define PNRF_SHAPE_NARROW 4
+#define PNRF_SHAPE_WIDE 8
+int pnrf_mlp_set_shape(pnrf_mlp_t* h, int shape);
 
 /* Module-level forward y = net(x), [m, out_dim].  head_act = 0: the raw output of the last Linear
  * (MinMaxRay_Net.forward, DoNeRFTRT.forward); head_act = 1: with the head activations of the TRT
@@ -251,6 +267,10 @@ int pnrf_ctx_free(pnrf_ctx_t* ctx);
 int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_rays,
                          const float* img4, const float* proj, int nb, int Hf, int Wf, float eps,
                          float* rgbd, int64_t* sort_idx, int64_t n, void* stream);
+/* Threshold of the two-pass sampler for this context's calls (pnrf_sampler_fwd_ws's kappa): negative = PNRF_SAMPLER_KAPPA (what a new
+ * context has), 0 = only the fp32 round-off allowance; NaN and values >= 1e30 are refused.  A larger kappa sends more rays through the
+ * fp32-grade second pass; PNRF_VARIANT_SAMPLER_SPLIT on the sampler handle sends all of them (the exact path). */
+int pnrf_ctx_set_sampler_kappa(pnrf_ctx_t* ctx, float kappa);
 /* Rays the sampler's second pass rendered in the context's most recent pnrf_render_rays_fwd (waits for the device; diagnostics). */
 int pnrf_ctx_sampler_stats(pnrf_ctx_t* ctx, int64_t* rays_second_pass);
 /* Per-stage device time of pnrf_render_rays_fwd (what the reference gets from line_profiler / the cuda events around

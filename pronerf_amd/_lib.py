@@ -36,6 +36,7 @@ SIGNATURES = {
     'pnrf_mlp_deserialize': (_i, [_p, _i64, C.POINTER(_p)]),
     'pnrf_mlp_kind': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'pnrf_mlp_set_variant': (_i, [_p, _i]),
+    'pnrf_mlp_set_shape': (_i, [_p, _i]),
     'pnrf_mlp_fwd': (_i, [_p, _p, _p, _p, _i64, _i, _p]),
     'pnrf_posenc_fwd': (_i, [_p, _p, _i64, _i, _p]),
     'pnrf_plucker_fwd': (_i, [_p, _p, _p, _i64, _p]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     'pnrf_ctx_free': (_i, [_p]),
     'pnrf_render_rays_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
     'pnrf_ctx_sampler_stats': (_i, [_p, C.POINTER(_i64)]),
+    'pnrf_ctx_set_sampler_kappa': (_i, [_p, _f]),
     'pnrf_ctx_profile_begin': (_i, [_p, _i]),
     'pnrf_ctx_profile_end': (_i, [_p, C.POINTER(C.c_float), C.POINTER(_i)]),
     'pnrf_linspace': (_i, [_f, _f, _i, C.POINTER(_f)]),

@@ -74,4 +74,10 @@ struct pnrf_mlp {
   float* d_tvals;        // sampler only: t = torch.linspace(0,1,48) of the ray points (trt.py:556-557)
   int device;
   int variant;           // PNRF_VARIANT_* (pnrf_mlp_set_variant); 0 = default kernels
+  int shape;             // workgroup shape of the fused stages (pnrf_mlp_set_shape): PNRF_SHAPE_AUTO = per launch from the column count, or one forced
 };
+
+// pnrf_sampler_fwd_ws with the caller's word that the workspace's counters are zero (a context's workspace): no memset on the stream
+int pnrf_sampler_fwd_ws_impl(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
+                             int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, int64_t workspace_bytes, float kappa,
+                             bool ws_clean, void* stream);

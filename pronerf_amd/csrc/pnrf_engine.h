@@ -67,11 +67,14 @@ __host__ __device__ constexpr bool queue_refill(int f, int ahead, int nf) {  // 
   return f + ahead < nf && (XSLOT ? true : ((f + ahead) / SLOT_FRAGS == f / SLOT_FRAGS && (f % SLOT_FRAGS) + ahead < SLOT_FRAGS));
 }
 // PD_ slots in flight in a ring of NS_ = PD_ + 1 (the inference kernels: 3 of 4; the trainer's forward chain, whose per-layer stores share
-// vmcnt with the LDS-DMA and have to have completed PD_ - 1 slots after their issue, runs 7 of 8)
+// vmcnt with the LDS-DMA and have to have completed PD_ - 1 slots after their issue, runs 7 of 8; so do the inference kernels' one-batch
+// shapes — a single 4-wave workgroup with a SIMD per wave consumes a 16 KiB slot in ~0.25 us, and three slots in flight over a ~1.1 us
+// L2 round trip deliver 44 GB/s where the MFMAs ask for 64: with seven in flight the stream keeps up)
 template <int NW, int PD_ = PD, int NS_ = NSLOTS>
 struct WStream {
   static_assert(NS_ == PD_ + 1 && (NS_ & (NS_ - 1)) == 0, "ring protocol assumes one free slot and a power-of-two ring");
   static constexpr int RING_SLOTS = NS_;
+  static constexpr int RING_BYTES = NS_ * SLOT_BYTES;
   static constexpr int LOADS_PER_WAVE = SLOT_FRAGS / NW;
   const char* g;       // packed blob
   char* ring;          // LDS ring base
@@ -240,7 +243,7 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
   constexpr int AHEAD = KS < 8 ? KS : 8;
   using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   auto frag_ptr = [&](int g) {
-    return (const frag_t*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+    return (const frag_t*)(ringlane + ((POS0 + g / SLOT_FRAGS) % ST::RING_SLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
   f32x16 pend[NCB];
   frag_t aq[AHEAD];
@@ -320,7 +323,7 @@ __device__ __forceinline__ void layer_f32(ST& st, const char* ringlane, const fl
   constexpr int NF = KS4 * NT;                 // fragments in the layer
   constexpr int AHEAD = KS4 < 8 ? KS4 : 8;     // A fragments in flight ahead of the MFMAs
   auto frag_ptr = [&](int g) {
-    return (const f32x4*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+    return (const f32x4*)(ringlane + ((POS0 + g / SLOT_FRAGS) % ST::RING_SLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
   f32x4 pend;
   f32x4 aq[AHEAD];                             // rotating prefetch queue (static indices after unrolling)
@@ -490,7 +493,7 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
   constexpr int NF = NTP * KS * 2;
   constexpr int AHEAD = NF < PNRF_B16_AHEAD ? NF : PNRF_B16_AHEAD;
   auto frag_ptr = [&](int g) {
-    return (const VT*)(ringlane + ((POS0 + g / SLOT_FRAGS) % NSLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+    return (const VT*)(ringlane + ((POS0 + g / SLOT_FRAGS) % ST::RING_SLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
   };
   f32x4 pend[2][NCB];
   VT aq[AHEAD];

@@ -650,7 +650,6 @@ __global__ __launch_bounds__(512) void hgemm_rchain_kernel(RChainArgs c) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[HgShape<MI>::BYTES > XBYTES + ROWS * HG_LDC * 4 ? HgShape<MI>::BYTES : XBYTES + ROWS * HG_LDC * 4];
   __shared__ float s_red[16];
   _Float16* const sX = (_Float16*)smem;                        // [region][plane hi / lo][ROWS][RC_LDX]
-  float* const sC = (float*)(smem + XBYTES);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m16 = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   if (c.has_first) {

@@ -322,18 +322,23 @@ __device__ __forceinline__ void split_h16(const float (&v)[8], f16x8& hi, f16x8&
   }
 }
 
-__global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
-  constexpr int TPB = 512, NW = 8;
+// NW = 8: 128 rays per workgroup batch, one workgroup per CU (two waves per SIMD).  NW = 4: 64 rays per batch, two independent workgroups
+// per CU with a ring each (launch_mlp's wg_per_cu): the same instruction stream per wave — results are bit-identical — at half the batch
+// granularity, for calls with few batches per CU (ray shards, ray chunks, the short list of pass 2).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) {
+  constexpr int TPB = 64 * NW;
+  PrecF16::enter();               // packed activations saturate at +-65 504 instead of overflowing to inf (see PrecF16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();                  // the first slots are on their way while the bias table is fetched
   // the handle's bias table is shared with the exact-fp32 kernels (true scale); this kernel's stream is packed for log2(e)-scaled
   // activations (elu_scaled): the biases of the six ELU layers are scaled here, the output layer's stay as they are
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = i < (1 + S_NHID) * W_HID ? a.bias[i] * LOG2E : a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
-  WStream<NW> st;
-  st.init(a.blob, a.nslots, smem);
-  st.prologue();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * q;
@@ -474,6 +479,11 @@ __global__ __launch_bounds__(512, 2) void sampler_h16_kernel(SamplerArgs a) {
     }
   }
   st.drain();
+  // two-pass scheme: the last workgroup to finish leaves the counters at zero for the next call on this workspace (every workgroup has
+  // read counters[0] by now; stream order makes the stores visible to the next launch) — no memset on the stream per call
+  if (a.list && threadIdx.x == 0) {
+    if (atomicAdd(a.counters + 2, 1) == (int)gridDim.x - 1) { a.counters[0] = 0; a.counters[2] = 0; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ sampler, pass 1 of two
@@ -508,16 +518,18 @@ struct P1Epi {
   }
 };
 
-__global__ __launch_bounds__(512, 2) void sampler_p1_kernel(SamplerArgs a) {
-  constexpr int TPB = 512, NW = 8;
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
+  constexpr int TPB = 64 * NW;
+  PrecF16::enter();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
-  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
@@ -756,13 +768,13 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
   P::enter();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   constexpr int COLS = 32 * NCB;
-  WStream<NW> st;
-  st.init(a.blob, a.nslots, smem);
-  st.prologue();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
@@ -1341,14 +1353,19 @@ struct HiddenEpi16 {
 // CLS = false: DoNeRFTRT; CLS = true: the NeRF class (layer sequence as nerf_kernel<.., CLS>, feature_linear folded, alpha as a 9th tile)
 // NCB = 2: 8 waves of 32 columns, two waves per SIMD (the default).  NCB = 4: 4 waves of 64 columns, one wave per SIMD: every weight fragment read
 // from LDS feeds four MFMAs instead of two (tools/lds_mfma_probe.hip: 1.57 -> 1.81 PFLOP/s for the bare hidden-layer loop).
-template <bool CLS, int NCB = 2, class P = PrecBf16>
-__global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfArgs a) {
-  constexpr int NW = 16 / NCB, TPB = 64 * NW;
+// NW: waves per workgroup.  16 / NCB (the default) = one workgroup per CU; NCB = 2, NW = 4: two independent 4-wave workgroups per CU,
+// 128 rows per batch (as sampler_h16_kernel<4>).
+template <bool CLS, int NCB = 2, class P = PrecBf16, int NW = 16 / NCB>
+__global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfArgs a) {
+  constexpr int TPB = 64 * NW;
   using Epi = HiddenEpi16<NCB, P>;
   using v8 = typename P::v8;
   P::enter();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = (float*)(smem + RING_BYTES);
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
@@ -1362,9 +1379,6 @@ __global__ __launch_bounds__(1024 / NCB, NCB == 2 ? 2 : 1) void nerf16_kernel(Ne
   }
   const float pe_vs = (float)(1 << g);
   const int64_t nrows = a.n * a.S;
-  WStream<NW> st;
-  st.init(a.blob, a.nslots, smem);
-  st.prologue();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * g;
@@ -1549,7 +1563,7 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
   // the ring + bias region exceeds the 64 KiB default dynamic-LDS limit.  The attribute is per device, and the call is a table update in
   // the runtime, so it is simply made on every launch (a per-process "done" cache skipped it on a second GPU).
   {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RING_BYTES + 8192));
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((lds + 8191) & ~(size_t)4095));
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -1566,11 +1580,29 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
   return 0;
 }
 
+// Workgroup shape of a fused stage for one launch (include/pronerf_hip.h, pnrf_mlp_set_shape):
+//   WIDE    8 waves, one workgroup per CU, two waves per SIMD, the widest batch (every weight fragment the workgroup streams feeds 8 waves);
+//   NARROW  4 waves, two independent workgroups per CU, each with its own ring: half the batch granularity, and a CU left with one workgroup
+//           (the last round of a launch, or a call with fewer batches than CUs) runs it with a SIMD per wave.
+// Same results bit for bit (a wave's instruction stream per batch does not depend on the shape).  Measured on whole frames (profiles/r04_*):
+// NARROW is 5-8 % slower than WIDE in every stage (twice the weight stream per CU; the ELU kernels are bound by their VALU issue cycles, not
+// by a phase lock of their waves: tools/elu_chain_probe.hip), so it is chosen only below two rounds of wide batches.
+enum { SHAPE_WIDE = PNRF_SHAPE_WIDE, SHAPE_NARROW = PNRF_SHAPE_NARROW };
+#ifndef PNRF_NARROW_ROUNDS
+#define PNRF_NARROW_ROUNDS 2
+#endif
+// cols: columns of the launch (rays or ray samples); cpw: columns per wave of the stage's engine
+int stage_shape(const pnrf_mlp_t* h, int64_t cols, int cpw) {
+  if (h->shape == SHAPE_WIDE || h->shape == SHAPE_NARROW) return h->shape;
+  const int64_t nb8 = (cols + 8 * cpw - 1) / (8 * cpw);
+  return nb8 < (int64_t)PNRF_NARROW_ROUNDS * num_cu() ? SHAPE_NARROW : SHAPE_WIDE;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
 static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
-                          int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, float kappa, void* stream) {
+                          int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, bool ws_clean, float kappa, void* stream) {
   SamplerArgs a = {};
   a.bias = h->d_bias; a.nbias = h->nbias;
   a.n = n; a.nbatch = (int)((n + 127) / 128);
@@ -1579,18 +1611,38 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
   a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   hipStream_t st = (hipStream_t)stream;
+  // split-fp16 kernel (16 columns per wave): 128 / 64 rays per workgroup batch.  expect: rays the launch is expected to render (pass 2: the
+  // list's length is known on the device only; about a tenth of the rays on the frames measured, an eighth is assumed for the shape)
+  auto launch_h16 = [&](SamplerArgs& x, int64_t rows, int64_t expect) {
+    if (stage_shape(h, expect, 16) == SHAPE_NARROW) {
+      x.nbatch = (int)((rows + 63) / 64);
+      return launch_mlp(sampler_h16_kernel<4>, x, 256, lds, x.nbatch, st, 2);
+    }
+    x.nbatch = (int)((rows + 127) / 128);
+    return launch_mlp(sampler_h16_kernel<8>, x, 512, lds, x.nbatch, st);
+  };
   if (workspace) {                      // two passes: plain fp16 for every ray, split fp16 for the rays pass 1 cannot decide
     int* counters = (int*)workspace;
-    PNRF_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+    // counters[0] rays on the list, [1] the same for pnrf_ctx_sampler_stats, [2] finished workgroups of pass 2.  Pass 2's last workgroup leaves
+    // [0] and [2] at zero, so a workspace that has been through a call (or was cleared once, as a context's is) needs no memset.
+    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
     SamplerArgs p = a;
     p.blob = h->d_blob_p1; p.nslots = h->nslots_p1; p.bias = h->d_bias_p1; p.nbias = h->nbias_p1;
-    p.nbatch = (int)((n + 255) / 256);
     p.list = counters + 16; p.counters = counters; p.p1c = h->d_p1c; p.kappa = kappa;
-    int rc = launch_mlp(sampler_p1_kernel, p, 512, RING_BYTES + (size_t)h->nbias_p1 * 4, p.nbatch, st);
+    const size_t lds1 = RING_BYTES + (size_t)h->nbias_p1 * 4;
+    int rc;
+    if (stage_shape(h, n, 32) == SHAPE_NARROW) {
+      p.nbatch = (int)((n + 127) / 128);
+      rc = launch_mlp(sampler_p1_kernel<4>, p, 256, lds1, p.nbatch, st, 2);
+    } else {
+      p.nbatch = (int)((n + 255) / 256);
+      rc = launch_mlp(sampler_p1_kernel<8>, p, 512, lds1, p.nbatch, st);
+    }
     if (rc) return rc;
     a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
     a.list = counters + 16; a.counters = counters;
-    return launch_mlp(sampler_h16_kernel, a, 512, lds, a.nbatch, st);        // grid sized for all rays: the count is known on the device only
+    // the grid is sized for a list of every ray (workgroups beyond the list leave at once)
+    return launch_h16(a, n, (n + 7) / 8);
   }
   if (h->variant == PNRF_VARIANT_SAMPLER_F32_FULL) {
     a.blob = h->d_blob; a.nslots = h->nslots;
@@ -1601,7 +1653,7 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
     return launch_mlp(sampler_kernel<2>, a, 512, lds, a.nbatch, st);
   }
   a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
-  return launch_mlp(sampler_h16_kernel, a, 512, lds, a.nbatch, st);
+  return launch_h16(a, n, n);
 }
 
 extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted,
@@ -1610,14 +1662,15 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd: handle is not a sampler net");
   PNRF_REQUIRE(n >= 0 && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG, "pnrf_sampler_fwd: null pointer / negative n");
   if (n == 0) return 0;
-  return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, 0.f, stream);
+  return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, false, 0.f, stream);
 }
 
 extern "C" int64_t pnrf_sampler_workspace_bytes(int64_t n) { return n < 0 ? 0 : (int64_t)(16 + n) * (int64_t)sizeof(int); }
 
-extern "C" int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
-                                   float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,
-                                   int64_t workspace_bytes, float kappa, void* stream) {
+// ws_clean: the workspace's counters are known to be zero (a context's workspace: cleared at creation, left clean by every call)
+int pnrf_sampler_fwd_ws_impl(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
+                             int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, int64_t workspace_bytes, float kappa,
+                             bool ws_clean, void* stream) {
   PNRF_REQUIRE(h && h->net == PNRF_NET_SAMPLER, PNRF_E_ARG, "pnrf_sampler_fwd_ws: handle is not a sampler net");
   PNRF_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (rays && depth_sorted && add_sorted && mul_sorted)), PNRF_E_ARG,
                "pnrf_sampler_fwd_ws: null pointer / negative n / more than 2^31 rays");
@@ -1625,11 +1678,34 @@ extern "C" int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64
   PNRF_REQUIRE(workspace && workspace_bytes >= pnrf_sampler_workspace_bytes(n) && ((uintptr_t)workspace & 15) == 0, PNRF_E_ARG,
                "pnrf_sampler_fwd_ws: workspace of %lld bytes (16-byte aligned) needed for %lld rays, got %lld", (long long)pnrf_sampler_workspace_bytes(n),
                (long long)n, (long long)workspace_bytes);
-  PNRF_REQUIRE(kappa != kappa || kappa < 1e30f, PNRF_E_ARG, "pnrf_sampler_fwd_ws: bad kappa");
+  PNRF_REQUIRE(kappa == kappa && kappa < 1e30f, PNRF_E_ARG, "pnrf_sampler_fwd_ws: kappa must be a number below 1e30 (negative = default), got %g", (double)kappa);
   if (h->variant != PNRF_VARIANT_DEFAULT)      // the single-kernel variants of a handle (parity tests, A/B timing) ignore the workspace
-    return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, 0.f, stream);
-  return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, workspace,
+    return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, false, 0.f, stream);
+  return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, workspace, ws_clean,
                         kappa < 0.f ? PNRF_SAMPLER_KAPPA : kappa, stream);
+}
+
+extern "C" int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
+                                   float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,
+                                   int64_t workspace_bytes, float kappa, void* stream) {
+  return pnrf_sampler_fwd_ws_impl(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, workspace, workspace_bytes, kappa,
+                                  false, stream);
+}
+
+// The fused refine stage in its two workgroup shapes (256 / 128 rays per batch; stage_shape) and two operand types
+template <int MODE, int HEAD>
+static int refine_launch(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
+  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
+  const bool bf16 = h->variant == PNRF_VARIANT_BF16;
+  if (!bf16) { a.blob = h->d_blob_f16; a.nslots = h->nslots_f16; }
+  if (stage_shape(h, n, 32) == SHAPE_NARROW) {
+    a.nbatch = (int)((n + 127) / 128);
+    if (bf16) return launch_mlp(refine_kernel<1, 4, MODE, HEAD>, a, 256, lds, a.nbatch, st, 2);
+    return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecF16>, a, 256, lds, a.nbatch, st, 2);
+  }
+  a.nbatch = (int)((n + 255) / 256);
+  if (bf16) return launch_mlp(refine_kernel<1, 8, MODE, HEAD>, a, 512, lds, a.nbatch, st);
+  return launch_mlp(refine_kernel<1, 8, MODE, HEAD, PrecF16>, a, 512, lds, a.nbatch, st);
 }
 
 extern "C" int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays, const float* depth_sorted,
@@ -1643,11 +1719,7 @@ extern "C" int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in
   a.n = n;
   a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
   a.jitter = jitter; a.jitter_dir = jitter_dir; a.rgb0 = rgb0;
-  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  a.nbatch = (int)((n + 255) / 256);
-  if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 8, 2>, a, 512, lds, a.nbatch, (hipStream_t)stream);
-  a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
-  return launch_mlp(refine_kernel<1, 8, 2, 0, PrecF16>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  return refine_launch<2, 0>(h, a, n, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
@@ -1659,11 +1731,7 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = n;
   a.x = refine_in; a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
-  const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
-  a.nbatch = (int)((n + 255) / 256);      // 256 columns per workgroup batch
-  if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 8, 1>, a, 512, lds, a.nbatch, (hipStream_t)stream);
-  a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
-  return launch_mlp(refine_kernel<1, 8, 1, 0, PrecF16>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  return refine_launch<1, 0>(h, a, n, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
@@ -1679,10 +1747,7 @@ extern "C" int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, c
   a.n = n;
   a.or_rays = or_rays; a.img4 = (const float4*)img4; a.proj = proj; a.Hf = Hf; a.Wf = Wf; a.eps = eps;
   a.rays = rays; a.depth_sorted = depth_sorted; a.z = z; a.pts = pts;
-  a.nbatch = (int)((n + 255) / 256);
-  if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 8, 1, 1>, a, 512, RING_BYTES + (size_t)h->nbias * 4, a.nbatch, (hipStream_t)stream);
-  a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
-  return launch_mlp(refine_kernel<1, 8, 1, 1, PrecF16>, a, 512, RING_BYTES + (size_t)h->nbias * 4, a.nbatch, (hipStream_t)stream);
+  return refine_launch<1, 1>(h, a, n, (hipStream_t)stream);
 }
 
 extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
@@ -1716,16 +1781,24 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
     a.blob = f16 ? h->d_blob_f16 : h->d_blob_b16; a.nslots = f16 ? h->nslots_f16 : h->nslots_b16; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
   }
   const size_t lds16 = RING_BYTES + (size_t)h->nbias_b16 * 4;
+  hipStream_t st = (hipStream_t)stream;
+  // the 16x16x32 engine (two 16-column blocks per wave) in its two workgroup shapes: 256 rows (8 waves) or 128 rows (4 waves) per batch
+  const bool narrow = b16 && h->variant != PNRF_VARIANT_NERF_4X64 && stage_shape(h, n * S, 32) == SHAPE_NARROW;
+  if (narrow) a.nbatch = (int)((n * S + 127) / 128);
   if (h->net == PNRF_NET_NERFCLS) {
-    if (f16) return launch_mlp(nerf16_kernel<true, 2, PrecF16>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
-    if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<true, 4>, a, 256, lds16, a.nbatch, (hipStream_t)stream);
-    if (b16) return launch_mlp(nerf16_kernel<true, 2>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
-    return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+    if (narrow) return f16 ? launch_mlp(nerf16_kernel<true, 2, PrecF16, 4>, a, 256, lds16, a.nbatch, st, 2)
+                           : launch_mlp(nerf16_kernel<true, 2, PrecBf16, 4>, a, 256, lds16, a.nbatch, st, 2);
+    if (f16) return launch_mlp(nerf16_kernel<true, 2, PrecF16>, a, 512, lds16, a.nbatch, st);
+    if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<true, 4>, a, 256, lds16, a.nbatch, st);
+    if (b16) return launch_mlp(nerf16_kernel<true, 2>, a, 512, lds16, a.nbatch, st);
+    return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, st);
   }
-  if (f16) return launch_mlp(nerf16_kernel<false, 2, PrecF16>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
-  if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<false, 4>, a, 256, lds16, a.nbatch, (hipStream_t)stream);
-  if (b16) return launch_mlp(nerf16_kernel<false, 2>, a, 512, lds16, a.nbatch, (hipStream_t)stream);
-  return launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, (hipStream_t)stream);
+  if (narrow) return f16 ? launch_mlp(nerf16_kernel<false, 2, PrecF16, 4>, a, 256, lds16, a.nbatch, st, 2)
+                         : launch_mlp(nerf16_kernel<false, 2, PrecBf16, 4>, a, 256, lds16, a.nbatch, st, 2);
+  if (f16) return launch_mlp(nerf16_kernel<false, 2, PrecF16>, a, 512, lds16, a.nbatch, st);
+  if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<false, 4>, a, 256, lds16, a.nbatch, st);
+  if (b16) return launch_mlp(nerf16_kernel<false, 2>, a, 512, lds16, a.nbatch, st);
+  return launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, st);
 }
 
 extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_views, float* y, int64_t m, int head_act, void* stream) {

@@ -733,11 +733,13 @@ struct pnrf_ctx {
   int64_t max_rays;
   float* ws;             // one allocation: depth[8] add[8] mul[8] z[8] pts[24] per ray, then the two-pass sampler's workspace
   void* sampler_ws;      // inside ws: pnrf_sampler_workspace_bytes(max_rays)
+  bool sampler_ws_clean; // its counters are zero: cleared at creation, left at zero by every completed call (sampler_h16_kernel's last workgroup)
   int device;
   // per-stage timing (pnrf_ctx_profile_begin / _end): 4 events per profiled call, recorded on the caller's stream
   hipEvent_t* ev;
   int prof_cap, prof_n;
   bool prof_on;
+  float kappa;           // two-pass sampler threshold (pnrf_ctx_set_sampler_kappa); < 0 = PNRF_SAMPLER_KAPPA
 };
 static constexpr int PROF_EVENTS = 4;
 static constexpr int PROF_MAX_FRAMES = 4096;
@@ -758,6 +760,7 @@ extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refi
   pnrf_ctx* c = new pnrf_ctx();
   c->sampler = sampler; c->refine = refine; c->nerf = nerf; c->max_rays = max_rays; c->ws = nullptr;
   c->ev = nullptr; c->prof_cap = 0; c->prof_n = 0; c->prof_on = false;
+  c->kappa = -1.f; c->sampler_ws_clean = false;
   hipError_t e = hipGetDevice(&c->device);
   PNRF_REQUIRE(max_rays < ((int64_t)1 << 31), PNRF_E_ARG, "pnrf_ctx_create: at most 2^31 - 1 rays per context");
   const size_t ws_rays = (((size_t)max_rays * WS_FLOATS_PER_RAY * sizeof(float)) + 255) & ~(size_t)255;
@@ -765,6 +768,7 @@ extern "C" int pnrf_ctx_create(const pnrf_mlp_t* sampler, const pnrf_mlp_t* refi
   if (e == hipSuccess) {
     c->sampler_ws = (char*)c->ws + ws_rays;
     e = hipMemset(c->sampler_ws, 0, 64);
+    c->sampler_ws_clean = e == hipSuccess;
   }
   if (e != hipSuccess) {
     set_error("pnrf_ctx_create: workspace allocation failed: %s", hipGetErrorString(e));
@@ -805,8 +809,11 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
   hipEvent_t* ev = (c->prof_on && c->prof_n < c->prof_cap) ? c->ev + (size_t)c->prof_n * PROF_EVENTS : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (ev) PNRF_HIP(hipEventRecord(ev[0], st));
-  if ((rc = pnrf_sampler_fwd_ws(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, c->sampler_ws,
-                                pnrf_sampler_workspace_bytes(c->max_rays), -1.f, stream))) return rc;                  // trt.py:628-635
+  const bool clean = c->sampler_ws_clean;
+  c->sampler_ws_clean = false;                       // a call that fails between the two passes leaves the counters set: the next one clears them
+  if ((rc = pnrf_sampler_fwd_ws_impl(c->sampler, rays, n, depth, add, mul, sort_idx, nullptr, nullptr, c->sampler_ws,
+                                     pnrf_sampler_workspace_bytes(c->max_rays), c->kappa, clean, stream))) return rc;       // trt.py:628-635
+  c->sampler_ws_clean = true;
   if (ev) PNRF_HIP(hipEventRecord(ev[1], st));
   if ((rc = pnrf_refine_project_fwd(c->refine, rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, z, pts, n, stream))) return rc;   // :637-681
   if (ev) PNRF_HIP(hipEventRecord(ev[2], st));
@@ -815,6 +822,13 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
     PNRF_HIP(hipEventRecord(ev[3], st));
     c->prof_n += 1;
   }
+  return 0;
+}
+
+extern "C" int pnrf_ctx_set_sampler_kappa(pnrf_ctx_t* c, float kappa) {
+  PNRF_REQUIRE(c, PNRF_E_ARG, "pnrf_ctx_set_sampler_kappa: null context");
+  PNRF_REQUIRE(kappa == kappa && kappa < 1e30f, PNRF_E_ARG, "pnrf_ctx_set_sampler_kappa: kappa must be a number below 1e30 (negative = default), got %g", (double)kappa);
+  c->kappa = kappa;
   return 0;
 }
 

@@ -880,6 +880,14 @@ extern "C" int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant) {
   return 0;
 }
 
+extern "C" int pnrf_mlp_set_shape(pnrf_mlp_t* h, int shape) {
+  PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_set_shape: null handle");
+  PNRF_REQUIRE(shape == PNRF_SHAPE_AUTO || shape == PNRF_SHAPE_WIDE || shape == PNRF_SHAPE_NARROW, PNRF_E_ARG,
+               "pnrf_mlp_set_shape: PNRF_SHAPE_AUTO (0), _WIDE (8) or _NARROW (4), got %d", shape);
+  h->shape = shape;
+  return 0;
+}
+
 extern "C" int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int* out_dim) {
   PNRF_REQUIRE(h, PNRF_E_ARG, "pnrf_mlp_kind: null handle");
   if (net) *net = h->net;

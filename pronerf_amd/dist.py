@@ -66,16 +66,22 @@ class FrameGather:
     that last used a buffer is done).  Shards are padded to the largest one (they differ by at most one ray); ``frame(b)`` is the
     assembled [n_total, C] frame of buffer ``b``.  ``bench.py`` times exactly this at N > 1."""
 
-    def __init__(self, n_total: int, channels: int = 4, device=None, dtype=torch.float32, depth: int = 2, pipelined: bool = True):
+    def __init__(self, n_total: int, channels: int = 4, device=None, dtype=torch.float32, depth: int = 2, pipelined: bool = True,
+                 collective=None):
+        """collective: None = the all-gather runs when there is more than one rank; True = also in a one-rank process group (the RCCL launch
+        path on a one-GPU box: tests/test_dist_gpu.py)."""
         self.rank, self.world = world()
         self.n_total, self.channels = int(n_total), int(channels)
         self.counts = [shard_range(n_total, r, self.world)[1] for r in range(self.world)]
         self.first, self.count = shard_range(n_total, self.rank, self.world)
         self.cmax = max(self.counts) if self.counts else 0
-        self.pipelined = bool(pipelined) and self.world > 1
+        self.collective = self.world > 1 if collective is None else bool(collective)
+        if self.collective and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('FrameGather(collective=True) needs an initialised process group')
+        self.pipelined = bool(pipelined) and self.collective
         self.depth = depth if self.pipelined else 1
         self.outs = [torch.zeros(self.cmax, channels, device=device, dtype=dtype) for _ in range(self.depth)]
-        self.fulls = [torch.empty(self.world * self.cmax, channels, device=device, dtype=dtype) if self.world > 1 else None for _ in range(self.depth)]
+        self.fulls = [torch.empty(self.world * self.cmax, channels, device=device, dtype=dtype) if self.collective else None for _ in range(self.depth)]
         self.pending = [None] * self.depth
         self._next = 0
 
@@ -87,7 +93,7 @@ class FrameGather:
         return b
 
     def submit(self, b: int):
-        if self.world == 1:
+        if not self.collective:
             return
         if self.pipelined:
             self.pending[b] = dist.all_gather_into_tensor(self.fulls[b], self.outs[b], async_op=True)
@@ -106,7 +112,7 @@ class FrameGather:
     def frame(self, b: int):
         """The gathered frame of buffer ``b`` ([n_total, C]; a view when the shards are equal)."""
         self._wait(b)
-        if self.world == 1:
+        if not self.collective:
             return self.outs[b][:self.count]
         full = self.fulls[b]
         if self.cmax * self.world == self.n_total:

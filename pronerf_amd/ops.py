@@ -66,6 +66,17 @@ class PackedMLP:
         self.variant = variant
         return self
 
+    SHAPES = {'auto': 0, 'narrow': 4, 'wide': 8}
+
+    def set_shape(self, shape):
+        """Workgroup shape of the fused stages launched from this handle (pnrf_mlp_set_shape): 'auto' (per launch, the default), 'wide',
+        'narrow', or the PNRF_SHAPE_* integer — bit-identical results, A/B timing."""
+        v = self.SHAPES.get(shape, shape) if isinstance(shape, str) else shape
+        if isinstance(v, str):
+            raise PnrfError(f'unknown workgroup shape {shape!r}; one of {sorted(self.SHAPES)}')
+        check(_lib.load().pnrf_mlp_set_shape(self.handle, int(v)), 'pnrf_mlp_set_shape')
+        return self
+
     def __del__(self):
         try:
             if getattr(self, 'handle', None):
@@ -362,6 +373,11 @@ class RenderContext:
         v = C.c_int64()
         check(_lib.load().pnrf_ctx_sampler_stats(self.handle, C.byref(v)), 'pnrf_ctx_sampler_stats')
         return int(v.value)
+
+    def set_sampler_kappa(self, kappa):
+        """Threshold of the two-pass sampler for this context (pnrf_ctx_set_sampler_kappa): negative = the library default (4), 0 = only the
+        fp32 round-off allowance; NaN / inf are refused."""
+        check(_lib.load().pnrf_ctx_set_sampler_kappa(self.handle, float(kappa)), 'pnrf_ctx_set_sampler_kappa')
 
     def profile_begin(self, max_frames=64):
         """Record per-stage events on the next ``max_frames`` render_rays calls (pnrf_ctx_profile_begin)."""

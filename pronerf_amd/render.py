@@ -51,9 +51,10 @@ class Renderer:
     ``ops.PackedMLP`` (a module's ``packed()``, or one loaded from an engine file).
     """
 
-    def __init__(self, weights, max_rays: int, device='cuda:0', variants=None):
+    def __init__(self, weights, max_rays: int, device='cuda:0', variants=None, shape=None):
         """variants: optional {'sampler' | 'refine' | 'nerf': kernel variant} (``ops.PackedMLP.set_variant``; parity tests and A/B
-        timing — the default kernels are the product path)."""
+        timing — the default kernels are the product path).  shape: optional workgroup shape for the three nets ('wide' | 'narrow' |
+        'auto', or a dict per net; ``ops.PackedMLP.set_shape``) — default: chosen per launch from the ray count."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise ops.PnrfError('Renderer needs a GPU device (pronerf_amd has no CPU path)')
@@ -71,6 +72,11 @@ class Renderer:
             self.nerf = pack((ops.NET_NERF, ops.NET_NERFCLS), weights['nerf'])
             for k, v in (variants or {}).items():
                 getattr(self, k).set_variant(v)
+            if shape is not None:
+                for k in ('sampler', 'refine', 'nerf'):
+                    w = shape.get(k) if isinstance(shape, dict) else shape
+                    if w is not None:
+                        getattr(self, k).set_shape(w)
             self.ctx = ops.RenderContext(self.sampler, self.refine, self.nerf, max_rays)
         self.img4 = None
         self.proj = None

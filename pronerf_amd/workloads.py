@@ -104,3 +104,61 @@ def timed_ms(fn, iters, warm, stream_sync=torch.cuda.synchronize):
         fn()
     e1.record(); stream_sync()
     return e0.elapsed_time(e1) / iters, (time.perf_counter() - t0) * 1e3 / iters
+
+
+def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), call_rays=(1024, 4096), reps=40, shape=None, check=True, stages=False):
+    """One-GPU rehearsal of what a rank of an N-GPU run and a chunked caller execute, on the kernels of THIS build: ``pnrf_render_rays_fwd`` on the
+    first / middle / last contiguous ray shard of 1/N of the frame (``shard_range``), no collective; and on single calls of ``call_rays`` rays
+    (the frame's first rays), launched back to back on one stream.  Reports per world size the slowest of the three shards and the implied
+    kernel-only strong-scaling bound frame_ms / shard_ms.  ``check``: every shard / call equals the same rows of the one-call frame bit for bit
+    (rays are independent).  ``stages``: a second pass per size with the context's per-stage events (sampler / refine / NeRF ms)."""
+    from .render import Renderer, shard_range
+
+    def stage_ms(fn, n):
+        rend.ctx.profile_begin(n)
+        for _ in range(n):
+            fn()
+        return rend.ctx.profile_end()[0]
+    dev = torch.device(device)
+    n_total = H * W
+    rend = Renderer(weights, max_rays=n_total, device=dev, shape=shape)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W)
+    ref = torch.empty(n_total, 4, device=dev)
+    rend.render_rays(rays, or_rays, out=ref)
+    out = torch.empty_like(ref)
+    res = {'what': 'one GPU, current kernels: ms per pnrf_render_rays_fwd call on the first / middle / last contiguous shard of 1/N of the 762 048-ray '
+                   'frame (no collective) and on single small calls; speedup_bound = frame ms / slowest shard ms',
+           'reps': reps, 'shape': shape if shape is not None else 'auto (per launch: the default)', 'shards': {}, 'calls': {}}
+    identical = True
+    frame_ms = None
+    for world in worlds:
+        per = {}
+        for rank in sorted({0, world // 2, world - 1}):
+            first, count = shard_range(n_total, rank, world)
+            r, o, dst = rays[first:first + count], or_rays[first:first + count], out[first:first + count]
+            ms = timed_ms(lambda: rend.render_rays(r, o, out=dst), reps, 5)[0]
+            per[f'rank{rank}'] = ms
+            if stages and rank == 0:
+                per['rank0_stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), min(reps, 64))
+            if check:
+                identical = identical and bool(torch.equal(dst, ref[first:first + count]))
+        worst = max(v for k, v in per.items() if not k.endswith('_stages'))
+        if world == 1:
+            frame_ms = worst
+        res['shards'][str(world)] = {'rays': shard_range(n_total, 0, world)[1], 'ms': per, 'ms_slowest': worst,
+                                     'speedup_bound': (frame_ms / worst) if frame_ms else None,
+                                     'rays_per_s_x_world': n_total / worst * 1e3}
+    for c in call_rays:
+        r, o, dst = rays[:c], or_rays[:c], out[:c]
+        ms, wall = timed_ms(lambda: rend.render_rays(r, o, out=dst), 200, 20)
+        res['calls'][str(c)] = {'ms_per_call': ms, 'host_ms_per_call': wall, 'rays_per_s': c / ms * 1e3,
+                                'frame_ms_at_this_rate': ms * ((n_total + c - 1) // c)}
+        if stages:
+            res['calls'][str(c)]['stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), 64)
+        if check:
+            identical = identical and bool(torch.equal(dst, ref[:c]))
+    if check:
+        res['bit_identical_to_one_call_frame'] = identical
+    del rend
+    return res

@@ -29,3 +29,20 @@ def test_self_launch_reports_a_failed_rank():
 def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2'], cwd=ROOT, env=dict(_env(), WORLD_SIZE='4', RANK='0'), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'does not match' in r.stderr
+
+
+def test_profile_numbers_are_refused_when_the_kernel_sources_changed():
+    """roofline.traffic / train.hbm_bytes_per_iter come from committed rocprofv3 --pmc summaries: quoted only while the summary's csrc digest
+    equals this tree's (pronerf_amd.build._digest), otherwise null with the reason."""
+    sys.path.insert(0, ROOT)
+    import bench
+    now = bench.csrc_digest()
+    assert isinstance(now, str) and len(now) == 64
+    ok, prov = bench.profile_provenance({'csrc_digest': now, 'commit': 'abc1234', '_file': 'profiles/x.json'})
+    assert ok and prov == {'file': 'profiles/x.json', 'commit': 'abc1234', 'csrc_digest': now}
+    ok, prov = bench.profile_provenance({'csrc_digest': '0' * 64, 'commit': 'abc1234'})
+    assert not ok and 'changed since the profile' in prov['refused']
+    ok, prov = bench.profile_provenance({'round': 'r03_v3'})
+    assert not ok and 'predates' in prov['refused']
+    val, prov = bench.pmc_traffic('nerf_kernel')              # whatever is committed: either a byte count with its source, or a reason
+    assert (val is None and 'refused' in prov) or (val > 0 and prov['csrc_digest'] == now)

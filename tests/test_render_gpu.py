@@ -161,3 +161,85 @@ def test_ray_counts_past_two_gib_of_workspace(dev):
     for k in range(reps):
         assert torch.equal(out[k * n:(k + 1) * n], one[0]) and torch.equal(idx[k * n:(k + 1) * n], one[1]), k
     assert torch.equal(out[reps * n:], one[0][:tail]) and torch.equal(idx[reps * n:], one[1][:tail])
+
+
+def test_workgroup_shapes_agree_bit_for_bit(dev):
+    """pnrf_mlp_set_shape: wide (8 waves, one workgroup per CU) and narrow (4 waves, two per CU, half-width batches) launches of every fused
+    stage run the same instruction stream per ray — rgb, depth and the sampler indices are identical, at ragged sizes, on both fine-net classes
+    and operand types; the per-launch default equals both."""
+    from pronerf_amd import synthetic
+    from pronerf_amd.render import Renderer
+    Hh, Ww = 150, 209                                # 31 350 rays: 245 narrow sampler batches + a ragged tail
+    scene = synth.make_scene(3, H=Hh, W=Ww, rotate=True)
+    w = synth.make_weights(3, 'trained')
+    c = synthetic.make_nerfcls_weights(3, head_scale=0.3)      # NeRF-class fine net in pack order: pts 0..7, feature, alpha, views, rgb
+    order = list(c['pts_linears']) + [c['feature_linear'], c['alpha_linear'], c['views_linears'][0], c['rgb_linear']]
+    wc = dict(w, nerf={'W': [a for a, _ in order], 'b': [b for _, b in order]})
+    for weights, variants in ((w, None), (w, {'nerf': 'f16', 'refine': 'bf16'}), (wc, None), (w, {'sampler': 'sampler_split'})):
+        outs = []
+        for shape in ('wide', 'narrow', None):
+            rend = Renderer(weights, max_rays=Hh * Ww, device=dev, variants=variants, shape=shape)
+            rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+            rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+            rgbd, idx = rend.render_rays(rays, or_rays, want_idx=True)
+            for n in (1000, 1, 129):
+                part, _ = rend.render_rays(rays[:n].contiguous(), or_rays[:n].contiguous())
+                assert torch.equal(part, rgbd[:n]), (shape, n)
+            outs.append((rgbd.clone(), idx.clone(), rend.ctx.sampler_stats()))
+            del rend
+        for rgbd, idx, n2 in outs[1:]:
+            assert torch.equal(rgbd, outs[0][0]) and torch.equal(idx, outs[0][1]) and n2 == outs[0][2]
+        assert bool(torch.isfinite(outs[0][0]).all())
+    with pytest.raises(Exception):
+        Renderer(w, max_rays=8, device=dev, shape=3)
+    with pytest.raises(Exception):
+        Renderer(w, max_rays=8, device=dev, shape='tall')
+
+
+def test_two_pass_workspace_needs_no_memset_between_calls(dev):
+    """The context clears the two-pass sampler's counters once; every call leaves them at zero (last workgroup of pass 2).  Calls of
+    different sizes back to back on one context give the same rows and the same second-pass counts as fresh contexts."""
+    from pronerf_amd.render import Renderer
+    Hh, Ww = 64, 90
+    scene = synth.make_scene(1, H=Hh, W=Ww, rotate=True)
+    w = synth.make_weights(1, 'trained')
+    rend = Renderer(w, max_rays=Hh * Ww, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+    full, _ = rend.render_rays(rays, or_rays)
+    full = full.clone()
+    n_full = rend.ctx.sampler_stats()
+    assert 0 < n_full < Hh * Ww
+    counts = []
+    for n in (Hh * Ww, 1, 700, Hh * Ww, 129, 4097):
+        part, _ = rend.render_rays(rays[:n].contiguous(), or_rays[:n].contiguous())
+        assert torch.equal(part, full[:n]), n
+        counts.append(rend.ctx.sampler_stats())
+    assert counts[0] == n_full and counts[3] == n_full
+    fresh = Renderer(w, max_rays=Hh * Ww, device=dev)
+    fresh.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    for n, c in zip((1, 700, 129, 4097), (counts[1], counts[2], counts[4], counts[5])):
+        fresh.render_rays(rays[:n].contiguous(), or_rays[:n].contiguous())
+        assert fresh.ctx.sampler_stats() == c
+
+
+def test_context_kappa_setter(dev):
+    """pnrf_ctx_set_sampler_kappa: a larger kappa sends more rays through the second pass, kappa = 0 fewer; NaN / inf are refused; the
+    sort indices do not move between the default and a very large kappa (every ray through the split kernel)."""
+    from pronerf_amd import _lib
+    from pronerf_amd.render import Renderer
+    Hh, Ww = 64, 90
+    scene = synth.make_scene(1, H=Hh, W=Ww, rotate=True)
+    rend = Renderer(synth.make_weights(1, 'trained'), max_rays=Hh * Ww, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+    res = {}
+    for k in (-1.0, 0.0, 16.0, 1e20):
+        rend.ctx.set_sampler_kappa(k)
+        _, idx = rend.render_rays(rays, or_rays, want_idx=True)
+        res[k] = (idx.clone(), rend.ctx.sampler_stats())
+    assert res[0.0][1] < res[-1.0][1] < res[16.0][1] <= res[1e20][1] == Hh * Ww
+    assert torch.equal(res[-1.0][0], res[1e20][0]) and torch.equal(res[16.0][0], res[1e20][0])
+    for bad in (float('nan'), float('inf'), 1e31):
+        with pytest.raises(_lib.PnrfError):
+            rend.ctx.set_sampler_kappa(bad)

@@ -5,7 +5,8 @@
 
 A config selects a library build (lib=<name> -> pronerf_amd/lib/libpronerf_hip_<name>.so, empty = the default build; see
 `python -m pronerf_amd.build --variant <name> [flags]`) and the kernel variants of its handles (pnrf_mlp_set_variant: sampler=
-default (two passes) | sampler_split | sampler_f32 | sampler_f32_full, refine= default (fp16) | bf16, nerf= default (fp16) | bf16 | bf16_32x32 | nerf_4x64) — explicit configuration, the library reads no environment.
+default (two passes) | sampler_split | sampler_f32 | sampler_f32_full, refine= default (fp16) | bf16, nerf= default (fp16) | bf16 | bf16_32x32 | nerf_4x64) — explicit configuration, the library reads no environment.  shape=wide|narrow|single forces the workgroup shape of all three
+stages (pnrf_mlp_set_shape).
 Every round renders `--frames` frames per config through pnrf_render_rays_fwd with the context's per-kernel events
 (pnrf_ctx_profile_begin / _end); reports median / min over the rounds per stage kernel on the bench workload (one 1008x756 frame).
 path=ops times the operator-level sequence instead (sampler, refine_input, refine on refine_in, NeRF: four kernels with the [n,144]
@@ -53,7 +54,7 @@ def main():
             libs[n] = load_lib(n)
         _lib._lib = libs[n]
         var = {k: v for k, v in (('sampler', c.get('sampler', 'default')), ('refine', c.get('refine', 'default')), ('nerf', c.get('nerf', 'default'))) if v != 'default'}
-        r = Renderer(weights, max_rays=H * W, device=dev, variants=var)
+        r = Renderer(weights, max_rays=H * W, device=dev, variants=var, shape=(c.get('shape') or None))
         r.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
         rends.append(r)
     _lib._lib = libs[cfgs[0].get('lib', '')]

@@ -23,6 +23,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, 'profiles')
 
 
+def provenance(src):
+    """csrc digest recorded on the GPU box when the passes ran (tools/profile_*.sh) and the commit being summarised (with a dirty mark)."""
+    import subprocess
+    out = {}
+    f = os.path.join(src, 'csrc_digest.txt')
+    if os.path.exists(f):
+        out['csrc_digest'] = open(f).read().strip()
+    try:
+        c = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'pronerf_amd/csrc', 'include'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        out['commit'] = c + ('+uncommitted csrc changes' if dirty else '')
+    except Exception:
+        pass
+    return out
+
+
+
 def short(name):
     if 'nerf16_kernel' in name:
         return 'nerf_kernel'
@@ -72,6 +89,7 @@ summary = {
     'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over launches); see tools/pmc_summary.py for the derived fields',
     'per_kernel': per,
 }
+summary.update(provenance(src))
 path = os.path.join(out_dir, f'{tag}_pmc_summary.json')
 json.dump(summary, open(path, 'w'), indent=1)
 print(path)

@@ -6,6 +6,7 @@ TAG=${1:?tag}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+python3 -c "from pronerf_amd import build; print(build._digest())" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
 python3 bench.py --steps 10 --warmup 2 --no-chunked --no-train > "$OUT/bench.json"
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gpu-eager-baseline --no-sustained --no-chunked --no-variants --no-train > "$OUT/bench_under_rocprof.json"

@@ -16,6 +16,23 @@ import sys
 tag, src = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, 'profiles')
+
+
+def provenance(src):
+    """csrc digest recorded on the GPU box when the passes ran (tools/profile_*.sh) and the commit being summarised (with a dirty mark)."""
+    import subprocess
+    out = {}
+    f = os.path.join(src, 'csrc_digest.txt')
+    if os.path.exists(f):
+        out['csrc_digest'] = open(f).read().strip()
+    try:
+        c = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'pronerf_amd/csrc', 'include'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        out['commit'] = c + ('+uncommitted csrc changes' if dirty else '')
+    except Exception:
+        pass
+    return out
+
 A, B = 2, 8
 
 
@@ -51,5 +68,6 @@ for w in ('stage2_iteration', 'stage1_explore_64', 'stage1_explore_256'):
     if st:
         shutil.copy(st[0], os.path.join(out_dir, f'{tag}_train_{w}_kernel_stats.csv'))
     res['workloads'][w] = e
+res.update(provenance(src))
 json.dump(res, open(os.path.join(out_dir, f'{tag}_train_pmc_summary.json'), 'w'), indent=1)
 print(json.dumps(res, indent=1))
