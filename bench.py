@@ -212,17 +212,16 @@ def pmc_traffic(kernel):
         return None, {'refused': f'{type(e).__name__}: {e}'}
 
 
-def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2):
+def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2, streams=4):
     """configs[1] read literally: the frame as ceil(n / 1024) pnrf_render_rays_fwd calls of <= 1024 rays each (744 x 1024 + 192 for the Fern
-    frame), launched back to back on the stream, and the same call sequence replayed as ONE hipGraph.  Every chunk must equal the
-    corresponding rows of the one-call frame `ref` bit for bit (rays are independent; the kernels walk the same 128 / 256-column batches)."""
+    frame), (a) launched back to back on ONE stream, (b) the same call sequence replayed as ONE hipGraph, (c) / (d) the same calls round-robin
+    over `streams` HIP streams with a context each (pronerf_amd.render.ChunkedRenderer: a 1024-ray call is four dependent one-batch kernels on
+    8 / 16 / 8 / 64 of the 256 CUs, so its time is latency and several chunks fit side by side), eager and as one hipGraph.  Every variant
+    must equal the one-call frame `ref` bit for bit (rays are independent; a ray's instruction stream does not depend on the launch shape)."""
+    from pronerf_amd.render import ChunkedRenderer
     n = rays.shape[0]
     out = torch.empty_like(ref)
     bounds = [(a, min(n, a + chunk)) for a in range(0, n, chunk)]
-
-    def frame():
-        for a, b in bounds:
-            rend.render_rays(rays[a:b], or_rays[a:b], out=out[a:b])
 
     def timed(fn):
         fn(); torch.cuda.synchronize()
@@ -232,30 +231,47 @@ def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2):
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps, (time.perf_counter() - t0) * 1e3 / reps
+
+    def graphed(fn, key):
+        try:
+            out.zero_()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()                                       # warm-up on a side stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                fn()
+            gms, gwall = timed(g.replay)
+            res[key + 'graph_ms_per_frame'] = gms
+            res[key + 'graph_host_ms_per_frame'] = gwall
+            res[key + 'graph_bit_identical_to_one_call'] = bool(torch.equal(out, ref))
+            del g
+        except Exception as e:                                # capture is best effort: report why instead of failing the bench line
+            res[key + 'graph_ms_per_frame'] = None
+            res[key + 'graph_error'] = f'{type(e).__name__}: {e}'[:300]
+
     res = {'chunk_rays': chunk, 'calls_per_frame': len(bounds), 'reps': reps}
-    ms, wall = timed(frame)
+    one = ChunkedRenderer(rend, chunk, 1)
+    ms, wall = timed(lambda: one.render_rays(rays, or_rays, out))
     res['calls_ms_per_frame'] = ms
     res['calls_host_ms_per_frame'] = wall
     res['calls_bit_identical_to_one_call'] = bool(torch.equal(out, ref))
-    try:
+    graphed(lambda: one.render_rays(rays, or_rays, out), '')
+    del one
+    if streams > 1:
+        many = ChunkedRenderer(rend, chunk, streams)
         out.zero_()
-        g = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            frame()                                       # warm-up on the capture stream
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            frame()
-        gms, gwall = timed(g.replay)
-        res['graph_ms_per_frame'] = gms
-        res['graph_host_ms_per_frame'] = gwall
-        res['graph_bit_identical_to_one_call'] = bool(torch.equal(out, ref))
-        del g
-    except Exception as e:                                # capture is best effort: report why instead of failing the bench line
-        res['graph_ms_per_frame'] = None
-        res['graph_error'] = f'{type(e).__name__}: {e}'[:300]
+        ms, wall = timed(lambda: many.render_rays(rays, or_rays, out))
+        key = f'streams{streams}_'
+        res['streams'] = streams
+        res[key + 'calls_ms_per_frame'] = ms
+        res[key + 'calls_host_ms_per_frame'] = wall
+        res[key + 'calls_bit_identical_to_one_call'] = bool(torch.equal(out, ref))
+        graphed(lambda: many.render_rays(rays, or_rays, out), key)
+        del many
     return res
 
 

@@ -98,16 +98,17 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 /* Workgroup shape of the fused stages (sampler passes, projection + refine, NeRF) launched from this handle — how a launch's columns (rays or
  * ray samples) are cut into batches and spread over the 256 CUs.  The reference renders any ray count through the same modules
- * (run_S_eS_eN_alter_trt.py:223: `chunk` is accepted and unused); here a whole frame and a 1/8-frame shard or a 1024-ray chunk want different shapes:
+ * (run_S_eS_eN_alter_trt.py:223: `chunk` is accepted and unused); here a whole frame and a 1024-ray chunk want different shapes:
  *   WIDE    one 8-wave workgroup per CU (two waves per SIMD) walking batches of 256 columns (128 rays in the split-fp16 sampler kernel):
- *           every weight fragment streamed into the CU feeds 8 waves.  Whole frames.
- *   NARROW  two independent 4-wave workgroups per CU, each with its own LDS ring, walking batches of half the width: twice the weight stream
- *           (5-7 % slower on whole frames), but the last round of a launch is finer and a CU left with one workgroup gives each wave a SIMD.
- *           Launches of fewer than two rounds of wide batches: the 95 256-ray shard of an 8-GPU frame, ray chunks (a 1024-ray call is
- *           8 / 16 / 8 / 64 workgroups in the four kernels, each alone on its CU).
- *   AUTO    (what pack / deserialize produce) chosen per launch from the column count by the rules above.
- * Every ray's instruction stream is the same in all shapes: results are bit-identical (tests/test_render_gpu.py).  Configuration like the
- * variant: set before the handle is used; the single-kernel test variants (SAMPLER_F32*, BF16_32X32, NERF_4X64) have one shape. */
+ *           every weight fragment streamed into the CU feeds 8 waves.  Whole frames, ray shards.
+ *   NARROW  one 4-wave workgroup per CU (a SIMD per wave) on batches of half the width: a call of at most one such batch per CU takes the
+ *           latency of one batch through the layers, and a wave that has its SIMD to itself gets through them in 0.7 of the time
+ *           (a 1024-ray call: 8 / 16 / 8 / 64 workgroups in the four kernels; 0.148 -> 0.114 ms).
+ *   AUTO    (what pack / deserialize produce) NARROW when the launch has at most one narrow batch per CU, else WIDE.
+ * Every ray's instruction stream is the same in both shapes: results are bit-identical (tests/test_render_gpu.py).  In both shapes a CU
+ * holds at most ONE workgroup of these kernels (registers exclude a second wide one, the LDS request a second narrow one), whatever runs on
+ * other streams.  Configuration like the variant: set before the handle is used; the single-kernel test variants (SAMPLER_F32*, BF16_32X32,
+ * NERF_4X64) have one shape. */
 #define PNRF_SHAPE_AUTO 0
 #define PNRF_SHAPE_NARROW 4
 #define PNRF_SHAPE_WIDE 8
@@ -196,12 +197,22 @@ int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* d
  * fp32-grade wherever two of them are close — and only there.  Pass 1 renders every ray in plain fp16 (one v_mfma_f32_32x32x16_f16 per
  * product, a third of the split kernel's MFMA work) and carries, per ray, a bound s_k on the standard deviation of its own rounding error
  * in depth k (variance propagation through the layers from |x_l|^2 and the weights' column norms); a ray is "undecided" when
- * some adjacent sorted gap is not larger than kappa (s_i + s_i+1) + 2e-6 (far - near), or not finite.  Pass 2 renders the undecided rays
- * with the split-fp16 kernel of pnrf_sampler_fwd and overwrites their rows.  Result: sort indices as pnrf_sampler_fwd's on every ray;
- * depths / add / mul of the undecided rays identical to pnrf_sampler_fwd's, of the others within a few s_k (fp16-grade, <= 1e-3 (far - near)).
- * kappa < 0 selects PNRF_SAMPLER_KAPPA; kappa = 0 leaves only the fp32 round-off allowance (tests); +inf is refused.
- * workspace: dev, 16-byte aligned, >= pnrf_sampler_workspace_bytes(n) bytes, contents irrelevant (two counters are reset on the stream
- * by every call); concurrent calls need separate workspaces.  Handles set to a SAMPLER_* variant run that single kernel instead. */
+ * some adjacent sorted gap is not larger than kappa (s_i + s_i+1) + 2e-6 (far - near), when a depth is not finite, or when one of its
+ * activations reached the fp16 limit.  Pass 2 renders the undecided rays with the split-fp16 kernel of pnrf_sampler_fwd and overwrites
+ * their rows.  Pass 3 (a few workgroups that leave at once when there is nothing to do) renders with the exact-fp32 kernel
+ * (PNRF_VARIANT_SAMPLER_F32's) the rays of pass 2 in which a hidden activation saturated at 65 504 — fp16 range is DEFINED: every kernel
+ * runs with MODE.FP16_OVFL (saturation instead of inf), a saturated ray is detected and re-rendered in fp32, nothing becomes NaN.
+ * Guarantee: the depths / add / mul of the rays of passes 2 and 3 are identical to pnrf_sampler_fwd's (split fp16 resp. exact fp32:
+ * fp32-grade); those of the other rays are fp16-grade (measured <= 6e-4 (far - near), tested <= 2e-3) and their SORT INDICES equal
+ * pnrf_sampler_fwd's under the error model — a statistical bound (fp16 roundings treated as independent zero-mean errors; subnormals and
+ * fp32 accumulation error are covered by the 2e-6 allowance), not a proof: kappa = 4 is >= 4x the largest margin any ray has needed on
+ * synthetic, heavy-tailed, x4-scaled and optimizer-trained weights (0 index mismatches on 762 048 rays each down to kappa = 1;
+ * tools/kappa_scan.py, tests/test_fullframe_gpu.py).  Where exactness matters more than 0.5 ms per frame, PNRF_VARIANT_SAMPLER_SPLIT
+ * renders every ray fp32-grade.
+ * kappa < 0 selects PNRF_SAMPLER_KAPPA; kappa = 0 leaves only the fp32 round-off allowance (tests); NaN and values >= 1e30 are refused.
+ * workspace: dev, 16-byte aligned, >= pnrf_sampler_workspace_bytes(n) bytes, contents irrelevant (its counters are reset on the stream
+ * by every call); concurrent calls need separate workspaces.  Handles set to SAMPLER_SPLIT run the split kernel for every ray + pass 3;
+ * SAMPLER_F32* handles run their single kernel. */
 #define PNRF_SAMPLER_KAPPA 4.0f
 int64_t pnrf_sampler_workspace_bytes(int64_t n);
 int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
@@ -273,6 +284,10 @@ int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_ray
 int pnrf_ctx_set_sampler_kappa(pnrf_ctx_t* ctx, float kappa);
 /* Rays the sampler's second pass rendered in the context's most recent pnrf_render_rays_fwd (waits for the device; diagnostics). */
 int pnrf_ctx_sampler_stats(pnrf_ctx_t* ctx, int64_t* rays_second_pass);
+/* Rays whose hidden activations reached the fp16 limit in the split-fp16 kernel and were therefore rendered by the exact-fp32 kernel (the
+ * third pass) in the context's most recent pnrf_render_rays_fwd: 0 for every net whose activations stay below 65 504 / log2(e) (waits for the
+ * device; diagnostics). */
+int pnrf_ctx_sampler_saturated(pnrf_ctx_t* ctx, int64_t* rays_third_pass);
 /* Per-stage device time of pnrf_render_rays_fwd (what the reference gets from line_profiler / the cuda events around
  * render(), run_S_eS_eN_alter_trt.py:327-332, at frame granularity): after _begin, the next max_frames calls on this
  * context record an event before and after each of the three kernels on the caller's stream; _end waits for the last

@@ -63,6 +63,7 @@ SIGNATURES = {
     'pnrf_render_rays_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
     'pnrf_ctx_sampler_stats': (_i, [_p, C.POINTER(_i64)]),
     'pnrf_ctx_set_sampler_kappa': (_i, [_p, _f]),
+    'pnrf_ctx_sampler_saturated': (_i, [_p, C.POINTER(_i64)]),
     'pnrf_ctx_profile_begin': (_i, [_p, _i]),
     'pnrf_ctx_profile_end': (_i, [_p, C.POINTER(C.c_float), C.POINTER(_i)]),
     'pnrf_linspace': (_i, [_f, _f, _i, C.POINTER(_f)]),

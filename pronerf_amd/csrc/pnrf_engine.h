@@ -103,10 +103,14 @@ struct WStream {
 #pragma unroll
     for (int i = 0; i < LOADS_PER_WAVE; ++i) {
       uint32_t keep;
+      // s_nop 2: with the two s_mov in front of it, five wait states between whatever wrote the address SGPRs and the VMEM instruction that reads
+      // them.  The compiler cannot see a VMEM instruction in here, so it does not keep its "VALU writes SGPR -> VMEM reads it: 5 wait states"
+      // rule for us — and in the 4-wave kernels (four pieces per wave and slot: the address pairs are spilled) it restores them with
+      // v_readlane_b32 right in front of this statement (round 4: 36 such places in refine_kernel<1, 4, ..>, three wait states each).
       asm volatile(
           "s_mov_b32 %0, m0\n\t"
           "s_mov_b32 m0, %3\n\t"
-          "s_nop 0\n\t"
+          "s_nop 2\n\t"
           "global_load_lds_dwordx4 %1, %2\n\t"
           "s_mov_b32 m0, %0"
           : "=&s"(keep)
@@ -282,15 +286,18 @@ __device__ __forceinline__ void layer_bf16(ST& st, const char* ringlane, const f
         // k-step after which piece pc is issued.  PIECES = 16 (one activation each; the ELU nets): one piece per k-step, so that every MFMA
         // gap carries the same three or four VALU instructions (v_exp, v_fma, v_med3, every second time v_cvt_pk) — 8 + 16..20 issue cycles
         // inside the MFMA's 32.  In a layer's first tile the pieces are the previous layer's last tile, whose two fragments are read by
-        // k-steps 14 and 15: pieces 0..13 behind k-steps 0..13, the last two behind k-step 14; in the other tiles one k-step later (the
+        // k-steps 14 and 15: pieces 0..12 behind k-steps 0..12, the last three behind k-step 13; in the other tiles one k-step later (the
         // previous tile's last MFMA is still in flight at k-step 0).  PIECES = 8: one piece every second k-step.  PIECES = 2: two halves.
+        // The packed dword a piece writes is produced by an inline-asm conversion, which hipcc's hazard recogniser does not see as a VALU
+        // write: it is never the operand of the very next MFMA (one whole MFMA between the last conversion and its consumer, in every layer
+        // engine here).
 #ifndef PNRF_BF16_P8_AT0
 #define PNRF_BF16_P8_AT0 1
 #endif
 #ifndef PNRF_BF16_P8_STEP
 #define PNRF_BF16_P8_STEP 2
 #endif
-        const int at = PIECES == 16 ? (KS >= 16 ? (to == 0 ? (pc < 14 ? pc : 14) : (pc < 15 ? pc + 1 : 15)) : 1 + (pc * (KS - 1)) / PIECES)
+        const int at = PIECES == 16 ? (KS >= 16 ? (to == 0 ? (pc < 13 ? pc : 13) : (pc < 15 ? pc + 1 : 15)) : 1 + (pc * (KS - 1)) / PIECES)
                        : PIECES != 2 ? ((to == 0 || KS < 16) ? 1 + pc : PNRF_BF16_P8_AT0 + PNRF_BF16_P8_STEP * pc)
                                      : (KS >= 8 ? PNRF_BF16_AT0 + pc * PNRF_BF16_ATSTEP : (KS >= 4 ? 1 + pc * (KS / 4) : KS - 1));
         if (ks == (at < KS ? at : KS - 1)) {
@@ -445,7 +452,8 @@ __device__ __forceinline__ void layer_h16x2(ST& st, const char* ringlane, const 
 #pragma unroll
       for (int pc = 0; pc < H16_PIECES; ++pc) {
         const int at = KS < 8 ? KS - 1
-                       : H16_PIECES == 8 ? (tp == 0 ? (pc < 6 ? pc : 6) : pc)       // first pair of a layer: done before k-step 7 reads the result
+                       : H16_PIECES == 8 ? (tp == 0 ? (pc < 5 ? pc : 5) : pc)       // first pair of a layer: done a whole k-step before k-step 7 reads the
+                                                                                    // result (asm conversions: see layer_bf16's note on the consumer)
                                          : (tp == 0 ? 1 + pc : PNRF_H16_AT0 + pc * PNRF_H16_ATSTEP);
         if (ks == (at < KS ? at : KS - 1)) {
           if (tp == 0) pre1(pc);

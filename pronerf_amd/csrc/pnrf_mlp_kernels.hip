@@ -28,6 +28,7 @@ using namespace pnrf;
 namespace {
 
 
+
 // compile-time loop: f(std::integral_constant<int,I>) for I in [0,N) — keeps register-array indices static
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -38,6 +39,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 // hardware exp2 / reciprocal (1 ulp each): for the fused bf16 kernels' epilogues
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -106,11 +108,7 @@ struct PrecF16 {
   // switch, and a volatile statement could not be interleaved with the engine's other asm statements)
   static __device__ __forceinline__ int cvt_pk(float a, float b) {
     int pk;
-#ifdef PNRF_F16_CVT_VOLATILE
-    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
-#else
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
-#endif
     return pk;
   }
 };
@@ -134,6 +132,10 @@ struct SamplerArgs {
   // two-pass scheme: pass 1 (sampler_p1_kernel) appends the rays it cannot decide to list[] (count in counters[0]); pass 2
   // (sampler_h16_kernel with list != NULL) renders exactly those rays and leaves the count in counters[1]
   int* list; int* counters; const float* p1c; float kappa;
+  // list_count: where the length of list[] is (pass 2: counters; pass 3: counters + 3).  sat_list (sampler_h16_kernel, NULL = off): rays with a
+  // hidden activation at the fp16 limit (the conversion saturates at 65 504: MODE.FP16_OVFL) are appended here, count in counters[3], and
+  // rendered again by the exact-fp32 kernel (pass 3, sampler_kernel<2> with list = sat_list)
+  const int* list_count; int* sat_list;
 };
 
 #define PNRF_CSWAP(i, j)                                                              \
@@ -165,6 +167,16 @@ template <int MODE>
 __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
   constexpr bool FUSED = MODE != 0;
   constexpr int TPB = 512, NW = 8;
+  // pass 3 of the sampler (MODE 2 with a list): the rays whose fp16 activations saturated in the split kernel.  Almost always none: leave
+  // before anything is fetched
+  int64_t total = a.n;
+  int nbatch = a.nbatch;
+  if (MODE == 2 && a.list) {
+    const int cnt = __builtin_amdgcn_readfirstlane(*a.list_count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[5] = cnt;              // kept for pnrf_ctx_sampler_stats
+    if (cnt == 0) return;
+    total = cnt; nbatch = (cnt + NW * 16 - 1) / (NW * 16);
+  }
   constexpr int KS0 = MODE == 2 ? 4 * SF_KS4_0 : S_KS0;
   constexpr int KS4_0 = MODE == 2 ? SF_KS4_0 : S_KS4_0;
   constexpr int POS_H = MODE == 2 ? SF_POS_H : S_POS_H;
@@ -182,10 +194,11 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * q;
 
-  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
-    const int64_t row = (int64_t)batch * (NW * 16) + wave * 16 + col;
-    const bool valid = row < a.n;
-    const int64_t rr = valid ? row : a.n - 1;
+  for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int64_t pos = (int64_t)batch * (NW * 16) + wave * 16 + col;
+    const bool valid = pos < total;
+    const int64_t row = (MODE == 2 && a.list) ? (int64_t)a.list[valid ? pos : total - 1] : pos;
+    const int64_t rr = (valid || (MODE == 2 && a.list)) ? row : a.n - 1;
     float B0[KS0];
     float near = 0.f, far = 1.f;
     if (FUSED) {
@@ -309,6 +322,9 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
     }
   }
   st.drain();
+  if (MODE == 2 && a.list && threadIdx.x == 0) {          // pass 3: the last workgroup leaves its counters at zero for the next call
+    if (atomicAdd(a.counters + 4, 1) == (int)gridDim.x - 1) { a.counters[3] = 0; a.counters[4] = 0; }
+  }
 }
 
 // Sampler in split fp16 (layer_h16x2): same producer geometry (16 columns per wave, lane quarter q), same fused epilogue;
@@ -322,9 +338,9 @@ __device__ __forceinline__ void split_h16(const float (&v)[8], f16x8& hi, f16x8&
   }
 }
 
-// NW = 8: 128 rays per workgroup batch, one workgroup per CU (two waves per SIMD).  NW = 4: 64 rays per batch, two independent workgroups
-// per CU with a ring each (launch_mlp's wg_per_cu): the same instruction stream per wave — results are bit-identical — at half the batch
-// granularity, for calls with few batches per CU (ray shards, ray chunks, the short list of pass 2).
+// NW = 8: 128 rays per workgroup batch, two waves per SIMD.  NW = 4: 64 rays per batch, a SIMD per wave: the same instruction stream per
+// wave — results are bit-identical — at half the batch latency, for calls with at most one batch per CU (ray chunks, the short list of pass 2).
+// One workgroup per CU in both shapes (stage_shape).
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) {
   constexpr int TPB = 64 * NW;
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
   int64_t total = a.n;
   int nbatch = a.nbatch;
   if (a.list) {
-    const int cnt = __builtin_amdgcn_readfirstlane(a.counters[0]);
+    const int cnt = __builtin_amdgcn_readfirstlane(*a.list_count);
     total = cnt; nbatch = (cnt + NW * 16 - 1) / (NW * 16);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[1] = cnt;            // kept for pnrf_ctx_sampler_stats
   }
@@ -372,6 +388,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
     // activations ping-pong between X and Y: per 32-feature k-step one hi and one lo plane
     f16x8 Xh[SH_KS_H], Xl[SH_KS_H], Yh[SH_KS_H], Yl[SH_KS_H];
     f32x4 pm[2], pc[2];                   // pending (deferred) tile pair of the previous layer
+    // largest packed high plane seen, as 16-bit integers: hidden activations are >= -log2(e), so only the positive limit 0x7bff (65 504, where
+    // the conversion saturates) can be reached — one v_pk_max_i16 per pair of activations
+    i16x2_t amax = {0, 0};
     // pair (t, p) of tile pair tp: registers 2p, 2p+1 of tile t -> dword 2t + p of k-step tp of the next layer's
     // planes.  Per activation: combine (v_fma), ELU on the log2(e) scale (v_exp, v_fma, v_med3), then per PAIR one v_cvt_pk_f16_f32 for the
     // high plane and per value v_mul (x 2^11) + v_fma_mix{lo,hi}_f16 for the low plane ((v - hi) 2^11 in one fused step: hi 2^11 and v 2^11 are
@@ -392,6 +411,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
       }
       int hi, lo;
       asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+      amax = __builtin_elementwise_max(amax, __builtin_bit_cast(i16x2_t, hi));
       const float s0 = v0 * H16_LO_SCALE, s1 = v1 * H16_LO_SCALE, sc = H16_LO_SCALE;
       asm("v_fma_mixlo_f16 %0, -%1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(sc), "v"(s0));
       asm("v_fma_mixhi_f16 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(sc), "v"(s1));
@@ -477,6 +497,21 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
         p[1] = make_float4(perm[4], perm[5], perm[6], perm[7]);
       }
     }
+    // rays with a saturated hidden activation (any of the column's four lane groups): to the exact-fp32 pass
+    if (a.sat_list) {
+      int sat = (amax[0] >= 0x7bff) | (amax[1] >= 0x7bff);
+      sat |= __shfl_xor(sat, 16);
+      sat |= __shfl_xor(sat, 32);
+      const bool flag = q == 0 && valid && sat;
+      const uint64_t m = __ballot(flag);
+      if (m) {
+        int base = 0;
+        const int leader = __builtin_ctzll(m);
+        if (lane == leader) base = atomicAdd(a.counters + 3, __builtin_popcountll(m));
+        base = __shfl(base, leader);
+        if (flag) a.sat_list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)row;
+      }
+    }
   }
   st.drain();
   // two-pass scheme: the last workgroup to finish leaves the counters at zero for the next call on this workspace (every workgroup has
@@ -556,6 +591,10 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
     f16x8 Bo[KS_HID], Bn[KS_HID];
     f32x16 pend[1];
     float sq_a = 0.f, sq_b = 0.f, V = 0.f;   // |x_l|^2 of the layer being written / the one before it (per-lane partial sums), error variance
+    // an activation at the fp16 limit (the pack saturates at 65 504) shows in its layer's |x|^2 >= 65 504^2: such a ray is undecided whatever
+    // its gaps (its pass-1 values are wrong; the split kernel and, if that saturates too, the exact-fp32 kernel render it)
+    constexpr float OVF2 = 65504.f * 65504.f;
+    bool ovf = false;
 
     // ---- layer 0: 8 tiles x (W_hi P_hi | W_hi P_lo + W_lo P_hi), one slot; tile t's activation runs behind tile t+1's MFMAs
     {
@@ -592,6 +631,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
       layer_bf16<1, KS_HID, NT_HID, P1_POS_H, 16, true>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int, int ks) { return in[ks]; }, P1Epi{out, sq_out},
                                                          [&](int pc) { P1Epi{in, sq_in}(NT_HID - 1, pc, pend); }, np);
       pend[0] = np[0];
+      ovf |= sq_in >= OVF2;
       V = a.p1c[l] * fmaf(C2, sq_in, V);
       sq_in = 0.f;
     };
@@ -606,6 +646,8 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
                                                      [&](int, int, f32x16(&)[1]) {}, [&](int pc) { P1Epi{Bo, sq_b}(NT_HID - 1, pc, pend); }, fin);
 #pragma unroll
     for (int i = 0; i < P1_SLOTS_PAD; ++i) st.begin();
+    ovf |= sq_b >= OVF2;
+    ovf |= (bool)__shfl_xor((int)ovf, 32);
     // variance bound of a depth logit: both halves of a column hold partial sums over their rows
     float U = fmaf(C2, sq_b, V);
     U = ieee_add(U, __shfl_xor(U, 32));
@@ -629,7 +671,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
     for (int i = 0; i < 8; ++i) dep[i] = ieee_add(ieee_mul(dep[i], span), near);      // trt.py:631
     PNRF_SORT8                                                                             // trt.py:632-635
     // decidable?  every adjacent gap must exceed kappa x (std bound of the two depths) + an fp32 round-off allowance
-    bool undecided = false;
+    bool undecided = ovf;
     {
       const float inv_span = 1.f / span;
       float sdev[8];
@@ -1319,7 +1361,6 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
 // ReLU after the conversion, on the packed pair: as 16-bit integers the bf16 patterns of negative values (and -0) are negative, so one
 // v_pk_max_i16 against 0 clears them — the same bits as converting max(x, 0), with one instruction per two values instead of two.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef short i16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int relu_pack_bf16(float a, float b) {
 #ifdef PNRF_RELU_F32
   return __builtin_bit_cast(int, bf16x2_t{(__bf16)act_fast(a, ACT_RELU), (__bf16)act_fast(b, ACT_RELU)});
@@ -1353,8 +1394,7 @@ struct HiddenEpi16 {
 // CLS = false: DoNeRFTRT; CLS = true: the NeRF class (layer sequence as nerf_kernel<.., CLS>, feature_linear folded, alpha as a 9th tile)
 // NCB = 2: 8 waves of 32 columns, two waves per SIMD (the default).  NCB = 4: 4 waves of 64 columns, one wave per SIMD: every weight fragment read
 // from LDS feeds four MFMAs instead of two (tools/lds_mfma_probe.hip: 1.57 -> 1.81 PFLOP/s for the bare hidden-layer loop).
-// NW: waves per workgroup.  16 / NCB (the default) = one workgroup per CU; NCB = 2, NW = 4: two independent 4-wave workgroups per CU,
-// 128 rows per batch (as sampler_h16_kernel<4>).
+// NW: waves per workgroup.  16 / NCB (the default); NCB = 2, NW = 4: 128 rows per batch, a SIMD per wave (as sampler_h16_kernel<4>).
 template <bool CLS, int NCB = 2, class P = PrecBf16, int NW = 16 / NCB>
 __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfArgs a) {
   constexpr int TPB = 64 * NW;
@@ -1559,7 +1599,7 @@ int num_cu() {
 // Kernel variants are a property of the packed handle (pnrf_mlp_set_variant, include/pronerf_hip.h); nothing on the launch path reads the
 // process environment.  Default: split-fp16 sampler with the folded first layer, refine and NeRF stages on v_mfma_f32_16x16x32_bf16.
 template <class K, class A>
-int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream, int wg_per_cu = 1) {
+int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t stream) {
   // the ring + bias region exceeds the 64 KiB default dynamic-LDS limit.  The attribute is per device, and the call is a table update in
   // the runtime, so it is simply made on every launch (a per-process "done" cache skipped it on a second GPU).
   {
@@ -1569,7 +1609,7 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
       return (int)e;
     }
   }
-  const int ncu = num_cu() * wg_per_cu;
+  const int ncu = num_cu();
   const int grid = nbatch < ncu ? nbatch : ncu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(tpb), lds, stream, a);
   hipError_t e = hipGetLastError();
@@ -1582,21 +1622,26 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
 
 // Workgroup shape of a fused stage for one launch (include/pronerf_hip.h, pnrf_mlp_set_shape):
 //   WIDE    8 waves, one workgroup per CU, two waves per SIMD, the widest batch (every weight fragment the workgroup streams feeds 8 waves);
-//   NARROW  4 waves, two independent workgroups per CU, each with its own ring: half the batch granularity, and a CU left with one workgroup
-//           (the last round of a launch, or a call with fewer batches than CUs) runs it with a SIMD per wave.
-// Same results bit for bit (a wave's instruction stream per batch does not depend on the shape).  Measured on whole frames (profiles/r04_*):
-// NARROW is 5-8 % slower than WIDE in every stage (twice the weight stream per CU; the ELU kernels are bound by their VALU issue cycles, not
-// by a phase lock of their waves: tools/elu_chain_probe.hip), so it is chosen only below two rounds of wide batches.
+//   NARROW  4 waves, half-width batches, ONE workgroup per CU (a SIMD per wave): for calls of at most one narrow batch per CU (ray chunks),
+//           whose time is the latency of one batch through the layers — two waves sharing a SIMD double it.
+// Same results bit for bit (a wave's instruction stream per batch does not depend on the shape).
+// A CU never holds two fused-MLP workgroups: wide ones exclude each other by registers (2 x 240 per SIMD lane), narrow ones by LDS (their
+// request is padded to NARROW_LDS_BYTES > 80 KiB).  Round 4 measured why: two 4-wave workgroups per CU ("paired" narrow launches) are 5-8 %
+// slower than WIDE on whole frames in every stage (twice the weight stream per CU; the ELU kernels are bound by their VALU issue cycles,
+// not by a phase lock of their waves: tools/elu_chain_probe.hip) and 5 % faster on a 1/8-frame shard — and, when calls on DIFFERENT streams
+// put workgroups of different kernels on one CU, a refine workgroup beside a NeRF / sampler one returned, a few times per thousand calls,
+// wrong rows for columns 16..31 of a wave (lanes 16-31 / 48-63 of loads issued in its batch head came back with other rays' data;
+// a delay or a full vmcnt wait behind the loads hid it, the cause inside the memory pipeline was not found: NOTEBOOK.md, round 4).  One
+// workgroup per CU is immune by construction and was clean over 10^5 concurrent calls (tests/test_render_gpu.py, tools/dbg_chunk*.py).
 enum { SHAPE_WIDE = PNRF_SHAPE_WIDE, SHAPE_NARROW = PNRF_SHAPE_NARROW };
-#ifndef PNRF_NARROW_ROUNDS
-#define PNRF_NARROW_ROUNDS 2
-#endif
+constexpr size_t NARROW_LDS_BYTES = 84 * 1024;      // two of them do not fit a CU's 160 KiB
 // cols: columns of the launch (rays or ray samples); cpw: columns per wave of the stage's engine
 int stage_shape(const pnrf_mlp_t* h, int64_t cols, int cpw) {
   if (h->shape == SHAPE_WIDE || h->shape == SHAPE_NARROW) return h->shape;
-  const int64_t nb8 = (cols + 8 * cpw - 1) / (8 * cpw);
-  return nb8 < (int64_t)PNRF_NARROW_ROUNDS * num_cu() ? SHAPE_NARROW : SHAPE_WIDE;
+  const int64_t nb4 = (cols + 4 * cpw - 1) / (4 * cpw);
+  return nb4 <= num_cu() ? SHAPE_NARROW : SHAPE_WIDE;
 }
+size_t narrow_lds(size_t lds) { return lds > NARROW_LDS_BYTES ? lds : NARROW_LDS_BYTES; }
 
 }  // namespace
 
@@ -1616,16 +1661,26 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
   auto launch_h16 = [&](SamplerArgs& x, int64_t rows, int64_t expect) {
     if (stage_shape(h, expect, 16) == SHAPE_NARROW) {
       x.nbatch = (int)((rows + 63) / 64);
-      return launch_mlp(sampler_h16_kernel<4>, x, 256, lds, x.nbatch, st, 2);
+      return launch_mlp(sampler_h16_kernel<4>, x, 256, narrow_lds(lds), x.nbatch, st);
     }
     x.nbatch = (int)((rows + 127) / 128);
     return launch_mlp(sampler_h16_kernel<8>, x, 512, lds, x.nbatch, st);
   };
+  // pass 3: a few workgroups (the saturated list is empty on every net whose activations stay inside the fp16 range: they leave at once)
+  auto launch_f32_list = [&](SamplerArgs& f, int* counters, int* sat_list) {
+    f.blob = h->d_blob_fold; f.nslots = h->nslots_fold;
+    f.list = sat_list; f.list_count = counters + 3; f.counters = counters; f.sat_list = nullptr;
+    const int nb = (int)((n + 127) / 128);
+    return launch_mlp(sampler_kernel<2>, f, 512, lds, nb < 16 ? nb : 16, st);
+  };
+  void* workspace_split = nullptr;
+  if (workspace && h->variant == PNRF_VARIANT_SAMPLER_SPLIT) { workspace_split = workspace; workspace = nullptr; }
   if (workspace) {                      // two passes: plain fp16 for every ray, split fp16 for the rays pass 1 cannot decide
     int* counters = (int*)workspace;
-    // counters[0] rays on the list, [1] the same for pnrf_ctx_sampler_stats, [2] finished workgroups of pass 2.  Pass 2's last workgroup leaves
-    // [0] and [2] at zero, so a workspace that has been through a call (or was cleared once, as a context's is) needs no memset.
-    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+    // counters[0] rays on the list, [1] the same for pnrf_ctx_sampler_stats, [2] finished workgroups of pass 2, [3] rays on the saturated list,
+    // [4] finished workgroups of pass 3, [5] = [3] for the stats.  The last workgroups of passes 2 / 3 leave [0], [2] / [3], [4] at zero, so a
+    // workspace that has been through a call (or was cleared once, as a context's is) needs no memset.
+    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), st));
     SamplerArgs p = a;
     p.blob = h->d_blob_p1; p.nslots = h->nslots_p1; p.bias = h->d_bias_p1; p.nbias = h->nbias_p1;
     p.list = counters + 16; p.counters = counters; p.p1c = h->d_p1c; p.kappa = kappa;
@@ -1633,16 +1688,28 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
     int rc;
     if (stage_shape(h, n, 32) == SHAPE_NARROW) {
       p.nbatch = (int)((n + 127) / 128);
-      rc = launch_mlp(sampler_p1_kernel<4>, p, 256, lds1, p.nbatch, st, 2);
+      rc = launch_mlp(sampler_p1_kernel<4>, p, 256, narrow_lds(lds1), p.nbatch, st);
     } else {
       p.nbatch = (int)((n + 255) / 256);
       rc = launch_mlp(sampler_p1_kernel<8>, p, 512, lds1, p.nbatch, st);
     }
     if (rc) return rc;
+    SamplerArgs f = a;                                    // pass 3 (exact fp32, folded first layer) on the rays pass 2 reports as saturated
     a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
-    a.list = counters + 16; a.counters = counters;
+    a.list = counters + 16; a.counters = counters; a.list_count = counters; a.sat_list = counters + 16 + n;
     // the grid is sized for a list of every ray (workgroups beyond the list leave at once)
-    return launch_h16(a, n, (n + 7) / 8);
+    if ((rc = launch_h16(a, n, (n + 7) / 8))) return rc;
+    return launch_f32_list(f, counters, counters + 16 + n);
+  }
+  if (workspace_split) {                // PNRF_VARIANT_SAMPLER_SPLIT with a workspace: the split kernel for every ray + the exact-fp32 pass for saturated ones
+    int* counters = (int*)workspace_split;
+    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), st));
+    SamplerArgs f = a;
+    a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
+    a.counters = counters; a.sat_list = counters + 16 + n;
+    int rc;
+    if ((rc = launch_h16(a, n, n))) return rc;
+    return launch_f32_list(f, counters, counters + 16 + n);
   }
   if (h->variant == PNRF_VARIANT_SAMPLER_F32_FULL) {
     a.blob = h->d_blob; a.nslots = h->nslots;
@@ -1665,7 +1732,8 @@ extern "C" int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t 
   return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, false, 0.f, stream);
 }
 
-extern "C" int64_t pnrf_sampler_workspace_bytes(int64_t n) { return n < 0 ? 0 : (int64_t)(16 + n) * (int64_t)sizeof(int); }
+// 16 counters, the list of pass 2 (n entries), the list of pass 3 (n entries)
+extern "C" int64_t pnrf_sampler_workspace_bytes(int64_t n) { return n < 0 ? 0 : (int64_t)(16 + 2 * n) * (int64_t)sizeof(int); }
 
 // ws_clean: the workspace's counters are known to be zero (a context's workspace: cleared at creation, left clean by every call)
 int pnrf_sampler_fwd_ws_impl(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
@@ -1679,7 +1747,7 @@ int pnrf_sampler_fwd_ws_impl(const pnrf_mlp_t* h, const float* rays, int64_t n, 
                "pnrf_sampler_fwd_ws: workspace of %lld bytes (16-byte aligned) needed for %lld rays, got %lld", (long long)pnrf_sampler_workspace_bytes(n),
                (long long)n, (long long)workspace_bytes);
   PNRF_REQUIRE(kappa == kappa && kappa < 1e30f, PNRF_E_ARG, "pnrf_sampler_fwd_ws: kappa must be a number below 1e30 (negative = default), got %g", (double)kappa);
-  if (h->variant != PNRF_VARIANT_DEFAULT)      // the single-kernel variants of a handle (parity tests, A/B timing) ignore the workspace
+  if (h->variant != PNRF_VARIANT_DEFAULT && h->variant != PNRF_VARIANT_SAMPLER_SPLIT)      // the exact-fp32 variants of a handle ignore the workspace
     return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, nullptr, false, 0.f, stream);
   return sampler_launch(h, rays, n, depth_sorted, add_sorted, mul_sorted, sort_idx, mm_rgb, depth_raw, workspace, ws_clean,
                         kappa < 0.f ? PNRF_SAMPLER_KAPPA : kappa, stream);
@@ -1700,8 +1768,8 @@ static int refine_launch(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStrea
   if (!bf16) { a.blob = h->d_blob_f16; a.nslots = h->nslots_f16; }
   if (stage_shape(h, n, 32) == SHAPE_NARROW) {
     a.nbatch = (int)((n + 127) / 128);
-    if (bf16) return launch_mlp(refine_kernel<1, 4, MODE, HEAD>, a, 256, lds, a.nbatch, st, 2);
-    return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecF16>, a, 256, lds, a.nbatch, st, 2);
+    if (bf16) return launch_mlp(refine_kernel<1, 4, MODE, HEAD>, a, 256, narrow_lds(lds), a.nbatch, st);
+    return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecF16>, a, 256, narrow_lds(lds), a.nbatch, st);
   }
   a.nbatch = (int)((n + 255) / 256);
   if (bf16) return launch_mlp(refine_kernel<1, 8, MODE, HEAD>, a, 512, lds, a.nbatch, st);
@@ -1786,15 +1854,15 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   const bool narrow = b16 && h->variant != PNRF_VARIANT_NERF_4X64 && stage_shape(h, n * S, 32) == SHAPE_NARROW;
   if (narrow) a.nbatch = (int)((n * S + 127) / 128);
   if (h->net == PNRF_NET_NERFCLS) {
-    if (narrow) return f16 ? launch_mlp(nerf16_kernel<true, 2, PrecF16, 4>, a, 256, lds16, a.nbatch, st, 2)
-                           : launch_mlp(nerf16_kernel<true, 2, PrecBf16, 4>, a, 256, lds16, a.nbatch, st, 2);
+    if (narrow) return f16 ? launch_mlp(nerf16_kernel<true, 2, PrecF16, 4>, a, 256, narrow_lds(lds16), a.nbatch, st)
+                           : launch_mlp(nerf16_kernel<true, 2, PrecBf16, 4>, a, 256, narrow_lds(lds16), a.nbatch, st);
     if (f16) return launch_mlp(nerf16_kernel<true, 2, PrecF16>, a, 512, lds16, a.nbatch, st);
     if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<true, 4>, a, 256, lds16, a.nbatch, st);
     if (b16) return launch_mlp(nerf16_kernel<true, 2>, a, 512, lds16, a.nbatch, st);
     return launch_mlp(nerf_kernel<1, 8, true, true>, a, 512, lds, a.nbatch, st);
   }
-  if (narrow) return f16 ? launch_mlp(nerf16_kernel<false, 2, PrecF16, 4>, a, 256, lds16, a.nbatch, st, 2)
-                         : launch_mlp(nerf16_kernel<false, 2, PrecBf16, 4>, a, 256, lds16, a.nbatch, st, 2);
+  if (narrow) return f16 ? launch_mlp(nerf16_kernel<false, 2, PrecF16, 4>, a, 256, narrow_lds(lds16), a.nbatch, st)
+                         : launch_mlp(nerf16_kernel<false, 2, PrecBf16, 4>, a, 256, narrow_lds(lds16), a.nbatch, st);
   if (f16) return launch_mlp(nerf16_kernel<false, 2, PrecF16>, a, 512, lds16, a.nbatch, st);
   if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<false, 4>, a, 256, lds16, a.nbatch, st);
   if (b16) return launch_mlp(nerf16_kernel<false, 2>, a, 512, lds16, a.nbatch, st);

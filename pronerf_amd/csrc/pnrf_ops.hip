@@ -840,6 +840,14 @@ extern "C" int pnrf_ctx_sampler_stats(pnrf_ctx_t* c, int64_t* rays_second_pass) 
   return 0;
 }
 
+extern "C" int pnrf_ctx_sampler_saturated(pnrf_ctx_t* c, int64_t* rays_third_pass) {
+  PNRF_REQUIRE(c && rays_third_pass, PNRF_E_ARG, "pnrf_ctx_sampler_saturated: null argument");
+  int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PNRF_HIP(hipMemcpy(v, c->sampler_ws, sizeof(v), hipMemcpyDeviceToHost));       // synchronises with the device: diagnostics only
+  *rays_third_pass = v[5];
+  return 0;
+}
+
 extern "C" int pnrf_ctx_profile_begin(pnrf_ctx_t* c, int max_frames) {
   PNRF_REQUIRE(c && max_frames > 0 && max_frames <= PROF_MAX_FRAMES, PNRF_E_ARG, "pnrf_ctx_profile_begin: need a context and 1..%d frames", PROF_MAX_FRAMES);
   if (max_frames > c->prof_cap) {

@@ -300,7 +300,8 @@ def composite(raw, z, rays_d, add=None, mul=None, noise=None, clamp=0.0, white_b
 
 def sampler_fwd(mlp: PackedMLP, rays, want_idx=True, want_rgb=True, want_raw=False, two_pass=False, kappa=None):
     """pnrf_sampler_fwd; two_pass=True: pnrf_sampler_fwd_ws (plain-fp16 pass for every ray + split-fp16 pass for the undecided ones, what
-    the fused path runs) and the number of rays of the second pass as a seventh return value (a 0-d int32 tensor on the device)."""
+    the fused path runs) and the numbers of rays of the second (split fp16) and third (exact fp32: saturated activations) pass as a seventh
+    and eighth return value (0-d int32 tensors on the device)."""
     rays = _chk(rays, 'rays', (11,))
     n, dev = rays.shape[0], rays.device
     depth = torch.empty(n, 8, device=dev, dtype=f32); add = torch.empty_like(depth); mul = torch.empty_like(depth)
@@ -313,7 +314,7 @@ def sampler_fwd(mlp: PackedMLP, rays, want_idx=True, want_rgb=True, want_raw=Fal
         ws = torch.empty(max(nb, 64) // 4, device=dev, dtype=torch.int32)
         check(lib.pnrf_sampler_fwd_ws(mlp.handle, _ptr(rays), n, _ptr(depth), _ptr(add), _ptr(mul), _ptr(idx), _ptr(rgb), _ptr(draw), _ptr(ws), nb,
                                       -1.0 if kappa is None else float(kappa), _stream()), 'pnrf_sampler_fwd_ws')
-        return depth, idx, add, mul, rgb, draw, ws[1]
+        return depth, idx, add, mul, rgb, draw, ws[1], ws[5]
     check(_lib.load().pnrf_sampler_fwd(mlp.handle, _ptr(rays), n, _ptr(depth), _ptr(add), _ptr(mul), _ptr(idx), _ptr(rgb), _ptr(draw), _stream()),
           'pnrf_sampler_fwd')
     return depth, idx, add, mul, rgb, draw
@@ -372,6 +373,12 @@ class RenderContext:
         """Rays the sampler's second (split-fp16) pass rendered in the most recent render_rays call; waits for the device."""
         v = C.c_int64()
         check(_lib.load().pnrf_ctx_sampler_stats(self.handle, C.byref(v)), 'pnrf_ctx_sampler_stats')
+        return int(v.value)
+
+    def sampler_saturated(self):
+        """Rays the exact-fp32 third pass rendered in the most recent render_rays call (activations at the fp16 limit); waits for the device."""
+        v = C.c_int64()
+        check(_lib.load().pnrf_ctx_sampler_saturated(self.handle, C.byref(v)), 'pnrf_ctx_sampler_saturated')
         return int(v.value)
 
     def set_sampler_kappa(self, kappa):

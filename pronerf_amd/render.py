@@ -126,3 +126,44 @@ class Renderer:
             raise ops.PnrfError('Renderer.render_rays: call set_views() first')
         with torch.cuda.device(self.device):
             return self.ctx.render_rays(rays, or_rays, self.img4, self.proj, eps=eps, want_idx=want_idx, out=out)
+
+
+class ChunkedRenderer:
+    """A frame as calls of at most ``chunk`` rays (BASELINE.json configs[1]: "1024-ray chunks"; the reference's ``chunk`` argument,
+    run_S_eS_eN_alter_trt.py:223, which its TRT path accepts and ignores).  A small call is latency-bound — four dependent kernels of one
+    batch each, a few of the 256 CUs busy — so the chunks go round-robin over ``streams`` HIP streams, each with its own context (workspace):
+    ``streams`` chunks are in flight at a time, fork / join by events on the caller's stream, which also captures into one hipGraph.
+    Same kernels, same rows: the result equals the one-call frame bit for bit."""
+
+    def __init__(self, renderer: Renderer, chunk: int = 1024, streams: int = 4):
+        self.r, self.chunk, self.k = renderer, int(chunk), max(1, int(streams))
+        with torch.cuda.device(renderer.device):
+            self.ctxs = [ops.RenderContext(renderer.sampler, renderer.refine, renderer.nerf, self.chunk) for _ in range(self.k)]
+            self.streams = [torch.cuda.Stream(device=renderer.device) for _ in range(self.k)] if self.k > 1 else [None]
+            self.fork = torch.cuda.Event()
+            self.joins = [torch.cuda.Event() for _ in range(self.k)]
+
+    def render_rays(self, rays, or_rays, out, eps=1e-5):
+        r = self.r
+        if r.img4 is None:
+            raise ops.PnrfError('ChunkedRenderer.render_rays: call Renderer.set_views() first')
+        n = rays.shape[0]
+        with torch.cuda.device(r.device):
+            cur = torch.cuda.current_stream()
+            if self.k == 1:
+                for a in range(0, n, self.chunk):
+                    b = min(n, a + self.chunk)
+                    self.ctxs[0].render_rays(rays[a:b], or_rays[a:b], r.img4, r.proj, eps=eps, out=out[a:b])
+                return out
+            self.fork.record(cur)
+            for i, st in enumerate(self.streams):
+                st.wait_event(self.fork)
+            for j, a in enumerate(range(0, n, self.chunk)):
+                b = min(n, a + self.chunk)
+                i = j % self.k
+                with torch.cuda.stream(self.streams[i]):
+                    self.ctxs[i].render_rays(rays[a:b], or_rays[a:b], r.img4, r.proj, eps=eps, out=out[a:b])
+            for i, st in enumerate(self.streams):
+                self.joins[i].record(st)
+                cur.wait_event(self.joins[i])
+        return out

@@ -367,7 +367,7 @@ def test_two_pass_sampler_arguments(dev):
     rays = cu(orc.frame_setup(scene)['rays'], dev)
     n = rays.shape[0]
     need = int(lib.pnrf_sampler_workspace_bytes(n))
-    assert need == (16 + n) * 4 and int(lib.pnrf_sampler_workspace_bytes(-5)) == 0
+    assert need == (16 + 2 * n) * 4 and int(lib.pnrf_sampler_workspace_bytes(-5)) == 0            # counters + the lists of passes 2 and 3
     d = torch.empty(n, 8, device=dev); a = torch.empty_like(d); m = torch.empty_like(d)
     ws = torch.empty(need // 4 + 8, device=dev, dtype=torch.int32)
     p = lambda t: C.c_void_p(t.data_ptr())
@@ -376,6 +376,7 @@ def test_two_pass_sampler_arguments(dev):
     assert call(C.c_void_p(ws.data_ptr() + 4), need, -1.0) == -1                                   # not 16-byte aligned
     assert call(None, need, -1.0) == -1
     assert call(p(ws), need, float('inf')) == -1 and b'kappa' in lib.pnrf_last_error()
+    assert call(p(ws), need, float('nan')) == -1 and b'kappa' in lib.pnrf_last_error()              # a NaN threshold would flag every ray
     assert call(p(ws), need, -1.0) == 0
     for k in (1, 255, 257):
         r = rays[:k].contiguous()
@@ -383,8 +384,45 @@ def test_two_pass_sampler_arguments(dev):
         one = ops.sampler_fwd(mlps['sampler'], r, want_raw=True)
         assert torch.equal(two[1], one[1])                                                         # indices (no ties on these weights)
         np.testing.assert_allclose(two[0].cpu().numpy(), one[0].cpu().numpy(), rtol=0, atol=2e-3)
-        assert 0 <= int(two[6]) <= k
+        assert 0 <= int(two[6]) <= k and int(two[7]) == 0                                          # nothing saturates on these weights
     split = ops.PackedMLP(ops.NET_SAMPLER, w['sampler']['W'], w['sampler']['b'], variant='sampler_split')
     s2 = ops.sampler_fwd(split, rays, two_pass=True, want_raw=True)                                # variant handles run their one kernel
     s1 = ops.sampler_fwd(split, rays, want_raw=True)
     assert all(torch.equal(x, y) for x, y in zip(s2[:6], s1[:6]) if x is not None)
+
+
+def test_sampler_fp16_range_is_defined(dev):
+    """Activations beyond the fp16 range: with two of the sampler's hidden layers scaled x300 (activations up to ~4e5) the
+    plain-fp16 pass flags every such ray (|x|^2 at the saturation limit), the split kernel saturates (MODE.FP16_OVFL: no inf / NaN), reports
+    them, and the exact-fp32 third pass renders them: every output finite, indices and depths equal to the exact-fp32 variant's on every ray
+    that saturated; on the untouched weights the third pass renders nothing."""
+    from pronerf_amd import ops
+    w = synth.make_weights(0, 'trained')['sampler']
+    scene = synth.make_scene(0, H=40, W=52, rotate=True)
+    rays = cu(orc.frame_setup(scene)['rays'], dev)
+    n = rays.shape[0]
+    for gain, expect_sat in ((1.0, False), (300.0, True)):
+        W = [x.copy() for x in w['W']]; b = [x.copy() for x in w['b']]
+        W[2] = W[2] * gain; W[3] = W[3] * gain; W[-1] = W[-1] / (gain * gain)            # hidden activations x gain^2, logits of the usual size
+        f32 = ops.PackedMLP(ops.NET_SAMPLER, W, b, variant='sampler_f32')
+        ref = ops.sampler_fwd(f32, rays, want_raw=True)
+        for variant in ('default', 'sampler_split'):
+            mlp = ops.PackedMLP(ops.NET_SAMPLER, W, b, variant=variant)
+            out = ops.sampler_fwd(mlp, rays, two_pass=True, want_raw=True)
+            n2, n3 = int(out[6]), int(out[7])
+            for t in out[:6]:
+                assert t is None or bool(torch.isfinite(t.float()).all())
+            assert (n3 > 0) == expect_sat, (gain, variant, n2, n3)
+            tie = (ref[0][:, 1:] - ref[0][:, :-1]).min(1)[0] <= 1e-6
+            assert bool((out[1][~tie] == ref[1][~tie]).all()), (gain, variant)
+            if expect_sat:
+                # the split kernel alone (no workspace: saturating arithmetic, no third pass) is finite but differs from fp32 on the saturated rays ...
+                lone = ops.sampler_fwd(ops.PackedMLP(ops.NET_SAMPLER, W, b, variant='sampler_split'), rays, want_raw=True)
+                assert bool(torch.isfinite(lone[0]).all())
+                moved = (lone[5] - ref[5]).abs().max(1)[0] > 1e-4
+                assert int(moved.sum()) > 0
+                # ... and exactly those rows carry the exact-fp32 kernel's values after the third pass
+                assert n3 >= int(moved.sum())
+                assert torch.equal(out[5][moved], ref[5][moved]) and torch.equal(out[2][moved], ref[2][moved]) and torch.equal(out[3][moved], ref[3][moved])
+            else:
+                assert n3 == 0 and float((out[5] - ref[5]).abs().max()) <= 2e-3

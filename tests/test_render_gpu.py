@@ -243,3 +243,60 @@ def test_context_kappa_setter(dev):
     for bad in (float('nan'), float('inf'), 1e31):
         with pytest.raises(_lib.PnrfError):
             rend.ctx.set_sampler_kappa(bad)
+
+
+def test_chunked_renderer_streams_equal_the_one_call_frame(dev):
+    """ChunkedRenderer (configs[1]'s ray chunks): calls of <= chunk rays, serial on one stream or round-robin over several streams with a
+    context each, eager and replayed as one hipGraph — the same rows as the one-call frame, bit for bit, with a ragged last chunk."""
+    from pronerf_amd.render import ChunkedRenderer, Renderer
+    Hh, Ww = 90, 131                                 # 11 790 rays = 11 chunks of 1024 + 526
+    scene = synth.make_scene(2, H=Hh, W=Ww, rotate=True)
+    rend = Renderer(synth.make_weights(2, 'trained'), max_rays=Hh * Ww, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+    ref, _ = rend.render_rays(rays, or_rays)
+    ref = ref.clone()
+    for streams in (1, 3):
+        ch = ChunkedRenderer(rend, 1024, streams)
+        out = torch.zeros_like(ref)
+        ch.render_rays(rays, or_rays, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), streams
+        out.zero_()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ch.render_rays(rays, or_rays, out)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            ch.render_rays(rays, or_rays, out)
+        out.zero_()
+        g.replay(); g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), ('graph', streams)
+        del g, ch
+
+
+def test_concurrent_streams_never_change_a_row(dev):
+    """Regression test of round 4: calls on four streams at once (a context each) with the narrow shape forced and with the per-launch default —
+    250 x 1024-ray calls per frame, three frames each: every row equals the one-call frame.  (Two 4-wave workgroups of different fused kernels
+    on one CU returned wrong rows a few times per thousand calls; a CU now holds at most one fused-MLP workgroup.)"""
+    from pronerf_amd.render import ChunkedRenderer, Renderer
+    Hh, Ww = 400, 640
+    scene = synth.make_scene(4, H=Hh, W=Ww, rotate=True)
+    for shape in ('narrow', None):
+        rend = Renderer(synth.make_weights(4, 'trained'), max_rays=Hh * Ww, device=dev, shape=shape)
+        rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+        rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+        ref, _ = rend.render_rays(rays, or_rays)
+        ref = ref.clone()
+        ch = ChunkedRenderer(rend, 1024, 4)
+        for rep in range(3):
+            out = torch.zeros_like(ref)
+            ch.render_rays(rays, or_rays, out)
+            torch.cuda.synchronize()
+            bad = int((out != ref).any(1).sum())
+            assert bad == 0, (shape, rep, bad)
+        del ch, rend
