@@ -75,12 +75,29 @@ def make_weights(seed: int = 0, kind: str = 'trained'):
                  (tie-free sort-index test).
       'trained'  signal-preserving hidden layers and head biases chosen so that depths
                  spread over (0,1), alpha/weights are non-degenerate and rgb spans [0,1].
+      'heavy'    'trained' with Student-t(3) heavy-tailed sampler hidden weights (same variance);
+      'x4'       'trained' with the sampler's hidden layers scaled x4 each (activations up to the fp16
+                 range) and its output layer scaled back: adversarial sets for the two-pass sampler.
     """
-    assert kind in ('default', 'spread', 'trained')
+    assert kind in ('default', 'spread', 'trained', 'heavy', 'x4')
+    adversarial, kind = kind, ('trained' if kind in ('heavy', 'x4') else kind)
     rs = np.random.RandomState(1000003 * (seed + 1) + {'default': 0, 'spread': 1, 'trained': 2}[kind])
     S = N_SAMPLES
     sW, sb = _mlp(rs, SAMPLER_DIMS, 'default' if kind != 'trained' else 'trained')
     rW, rb = _mlp(rs, REFINE_DIMS, 'default' if kind != 'trained' else 'trained')
+    if adversarial == 'heavy':
+        # the sampler's hidden weights redrawn from Student's t with 3 degrees of freedom at the variance of the 'trained' draw: a few
+        # weights per row 5-20 x the rest (what the column-norm constants of the two-pass sampler's error model have to cover)
+        ts = np.random.RandomState(7000003 * (seed + 1))
+        for i in range(len(sW) - 1):
+            fi = SAMPLER_DIMS[i]
+            sW[i] = (ts.standard_t(3, size=sW[i].shape) * np.sqrt(2.0 / fi / 3.0)).astype(np.float32)
+    if adversarial == 'x4':
+        # the sampler's hidden layers x4 each (weights and biases), its output layer / 4^6: activations up to the fp16 range (the saturated
+        # rays go through the exact-fp32 pass), logits of the usual size
+        for i in range(len(sW) - 1):
+            sW[i] = sW[i] * 4.0; sb[i] = sb[i] * 4.0
+        sW[-1] = sW[-1] / 4.0 ** (len(sW) - 1)
     nW, nb = [], []
     for fi, fo in nerf_layer_dims():
         nW.append((rs.randn(fo, fi) * np.sqrt(2.0 / fi)).astype(np.float32))
@@ -199,3 +216,23 @@ def make_scene(seed: int = 0, H: int = 24, W: int = 32, Hf: int | None = None, W
     poses = np.stack([pose(sigma_t) for _ in range(n_views)], 0)
     images = rs.rand(n_views, Hf, Wf, 3).astype(np.float32)
     return {'H': H, 'W': W, 'focal': float(focal), 'K': K, 'c2w': c2w, 'poses': poses, 'images': images}
+
+
+def load_trained_fixture(path=None):
+    """The optimizer-trained nets of tests/golden/trained_synth_scene.npz (tools/make_trained_fixture.py: this package's stage-1 and stage-2
+    drivers on the synthetic LLFF scene) as weight dicts: 'sampler', 'refine' (stacks of 7), 'nerf' = the NeRF-class fine net in pack order
+    (pts_linears 0..7, feature, alpha, views, rgb: what ``Renderer`` takes) and 'nerfcls' = the same by name (what the oracle takes)."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'trained_synth_scene.npz')
+    g = np.load(path)
+    L = [(g[f'W{i}'], g[f'b{i}']) for i in range(26)]
+    stack = lambda a, b: {'W': [W for W, _ in L[a:b]], 'b': [x for _, x in L[a:b]]}
+    return {'sampler': stack(0, 7), 'refine': stack(7, 14), 'nerf': stack(14, 26),
+            'nerfcls': {'pts_linears': L[14:22], 'feature_linear': L[22], 'alpha_linear': L[23], 'views_linears': [L[24]], 'rgb_linear': L[25]},
+            'info': {k: g[k] for k in ('stage1_iters', 'stage2_iters', 'stage1_loss', 'stage2_loss')}}
+
+
+def weight_set(seed: int, kind: str):
+    """``make_weights(seed, kind)``, or the optimizer-trained fixture for kind 'optimizer' (the seed then only names the scene)."""
+    return load_trained_fixture() if kind == 'optimizer' else make_weights(seed, kind)

@@ -9,7 +9,7 @@
 * rgb / depth of the whole frame against the oracle's eager fp32 graph run on the device, three weight seeds.
 
 Tolerances: BASELINE.json north_star / BASELINE.md §4 — indices identical; RGB error PSNR >= 46.4 dB (moves a 27 dB image PSNR by
-<= 0.05 dB); depth within 2e-2; sampler depths within 2e-6.
+<= 0.05 dB); depth map within 1e-2 absolute (measured 2e-3 .. 5e-3) and 2e-3 relative RMS; sampler depths within 2e-6.
 """
 import os
 
@@ -25,7 +25,10 @@ pytestmark = pytest.mark.gpu
 H, W, FOCAL = 756, 1008, 815.13
 N = H * W
 TIE = 1e-6
-WEIGHT_SETS = [(0, 'trained'), (2, 'spread'), (3, 'trained'), (1, 'default')]
+# 'heavy' / 'x4': adversarial sets for the two-pass sampler (Student-t(3) hidden weights; hidden layers x4 each = activations up to the fp16 range);
+# 'optimizer': the nets this package's own trainers produced on the synthetic LLFF scene (tests/golden/trained_synth_scene.npz)
+WEIGHT_SETS = [(0, 'trained'), (2, 'spread'), (3, 'trained'), (1, 'default'), (0, 'heavy'), (0, 'x4'), (0, 'optimizer')]
+NEW_KINDS = ('heavy', 'x4', 'optimizer')
 
 
 @pytest.fixture(scope='module')
@@ -39,6 +42,13 @@ def dev():
 _ORACLE = {}
 
 
+def depth_relrms(a, b):
+    """RMS error of a depth map relative to the RMS of the depths (NDC depths in [0, 1])."""
+    a = a.double(); b = b.double()
+    return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
+
+
+
 def oracle_sampler_full_frame(seed, kind):
     """The oracle's frame set-up and sampler for all 762 048 rays on the host (0.3 TFLOP of fp32 torch CPU GEMMs), in chunks of 65 536 rays.
     Cached per weight set: both kernel variants are compared with the same oracle run."""
@@ -46,7 +56,7 @@ def oracle_sampler_full_frame(seed, kind):
     if key not in _ORACLE:
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         scene = synth.make_scene(seed, H=H, W=W, focal=FOCAL, rotate=True)
-        w = synth.make_weights(seed, kind)
+        w = synth.weight_set(seed, kind)
         rays_o, rays_d = orc.get_rays(H, W, scene['K'], scene['c2w'])
         vd = (rays_d / rays_d.norm(dim=-1, keepdim=True)).reshape(-1, 3)
         o, d = orc.ndc_rays(H, W, float(scene['K'][0, 0]), 1.0, rays_o, rays_d)
@@ -102,9 +112,12 @@ def test_full_frame_sampler_indices(dev, seed, kind, variant):
               f'max |depth - oracle| on the other rows {float(derr_row[coarse].max()) if bool(coarse.any()) else 0.0:.2e}, on the identical rows '
               f'{float(derr_row[same].max()) if bool(same.any()) else 0.0:.2e}')
         assert 0 < n2 <= int(same.sum()) <= n2 + 64 or kind == 'spread'          # (rows of pass 1 that coincide with the split result in all 24 values: a handful at most)
-        assert n2 <= 0.35 * N                                                    # the second pass stays a minority
+        # the second pass stays a minority — except on the heavy-tailed set, whose largest column norms make the error bound flag every ray
+        # (safe: everything is then rendered fp32-grade, at the split kernel's speed)
+        assert n2 <= (1.0 if kind == 'heavy' else 0.6 if kind in NEW_KINDS else 0.35) * N
+        assert int(out[7]) == 0 or kind == 'x4'                                  # the exact-fp32 third pass has nothing to do unless activations reach the fp16 limit
         assert float(derr_row[same].max()) <= 2e-6 if bool(same.any()) else True
-        assert float(derr_row[coarse].max()) <= 2e-3
+        assert float(derr_row[coarse].max()) <= 2e-3 if bool(coarse.any()) else True
         assert bool((gap[tie] <= TIE).all()) and bool(same[tie].all())          # every tie-set ray went through the fp32-grade pass
         # the check has teeth: with kappa = 0 (pass 1 decides everything but fp32 round-off ties) indices DO differ on these weights
         o0 = ops.sampler_fwd(mlp, rays, want_idx=True, want_rgb=False, want_raw=False, two_pass=True, kappa=0.0)
@@ -115,7 +128,7 @@ def test_full_frame_sampler_indices(dev, seed, kind, variant):
     else:
         assert derr <= 2e-6
     # the tie set is small for weights with spread depths; with default-initialised weights all 8 depths of a ray sit within ~1e-2
-    assert n_tie <= (2e-4 if kind != 'default' else 2e-2) * N, n_tie
+    assert n_tie <= (2e-2 if kind == 'default' else 2e-3 if kind in NEW_KINDS else 2e-4) * N, n_tie
     # inside the tie set: still a sorting permutation of the kernel's own depths, and equal to the oracle's up to transpositions of depths
     # closer than the tie threshold (so the sorted depth vectors agree)
     assert bool((g_ds[:, 1:] >= g_ds[:, :-1]).all())
@@ -128,7 +141,7 @@ def test_full_frame_sampler_indices(dev, seed, kind, variant):
     if variant != 'default':
         return
     # (2) end to end from (K, c2w): rays generated on the device, whole path in one call; same indices wherever the depths are apart
-    rend = Renderer(w, max_rays=N, device=dev)
+    rend = Renderer({k: w[k] for k in ('sampler', 'refine', 'nerf')}, max_rays=N, device=dev)
     rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     r2, o2 = rend.frame_rays(scene['K'], scene['c2w'], H, W)
     np.testing.assert_array_equal(r2.cpu().numpy(), oc['rays'].numpy())        # the device's rays ARE the oracle's: 0 ulp on all 762 048 x 11 values
@@ -162,10 +175,46 @@ def test_fern_8k_rays_vs_the_reference(dev, golden_dir):
     rel = float(((got[m, :3].double() - torch.from_numpy(g['rgb'])[m].double()) ** 2).mean().sqrt() / (torch.from_numpy(g['rgb'])[m].double() ** 2).mean().sqrt())
     print(f'[fern 8k] rgb PSNR vs the reference {ps:.1f} dB, rel. RMS {rel:.2e}, max depth error {float((got[m, 3] - torch.from_numpy(g["depth"])[m]).abs().max()):.2e}')
     assert ps > 46.4 and rel < 1e-2
-    np.testing.assert_allclose(got[m, 3].numpy(), g['depth'][tie_free], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(got[m, 3].numpy(), g['depth'][tie_free], rtol=0, atol=1e-2)
+    assert depth_relrms(got[m, 3], torch.from_numpy(g['depth'])[m]) < 2e-3
     # the border rays alone (their epi features are partly zero-padded): same bar
     border = torch.from_numpy((g['oob_taps'] > 0) & tie_free)
     assert orc.psnr(got[border, :3], torch.from_numpy(g['rgb'])[border]) > 46.4
+
+
+def test_full_frame_with_optimizer_trained_nets(dev):
+    """The whole frame with the nets an optimizer produced (sampler, refine and the NeRF-CLASS fine net the trainers save: tests/golden/
+    trained_synth_scene.npz) against the oracle's eager fp32 graph on the device: indices, rgb, depth — the acceptance the reference applies to
+    a trained Fern checkpoint (run_S_eS_eN_alter_trt.py:351-373), on the weights that exist here."""
+    from pronerf_amd.render import Renderer
+    torch.backends.cuda.matmul.allow_tf32 = False
+    scene = synth.make_scene(0, H=H, W=W, focal=FOCAL, rotate=True)
+    w = synth.load_trained_fixture()
+    rend = Renderer({k: w[k] for k in ('sampler', 'refine', 'nerf')}, max_rays=N, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    fr = orc.frame_setup(scene)
+    rays, or_rays = fr['rays'].to(dev), fr['or_rays'].to(dev)
+    rgbd, idx = rend.render_rays(rays, or_rays, want_idx=True)
+    td = lambda x: torch.as_tensor(x).to(dev)
+    wd = {k: {'W': [td(x) for x in w[k]['W']], 'b': [td(x) for x in w[k]['b']]} for k in ('sampler', 'refine')}
+    c = w['nerfcls']
+    pair = lambda p: (td(p[0]), td(p[1]))
+    wd['nerfcls'] = {'pts_linears': [pair(p) for p in c['pts_linears']], 'feature_linear': pair(c['feature_linear']), 'alpha_linear': pair(c['alpha_linear']),
+                     'views_linears': [pair(c['views_linears'][0])], 'rgb_linear': pair(c['rgb_linear'])}
+    with torch.no_grad():
+        ref = orc.render_rays_infer(wd, rays, or_rays, fr['images'].to(dev), fr['proj'].to(dev), mm_input=fr['mm_input'].to(dev), nerf='nerfcls')
+    gap = (ref['depth_sorted'][:, 1:] - ref['depth_sorted'][:, :-1]).min(dim=1)[0]
+    free = gap > 4e-6
+    mism = int((idx[free] != ref['sort_idx'][free]).any(1).sum())
+    ps = orc.psnr(rgbd[free, :3], ref['rgb'][free])
+    rel = float(((rgbd[free, :3].double() - ref['rgb'][free].double()) ** 2).mean().sqrt() / (ref['rgb'][free].double() ** 2).mean().sqrt())
+    derr = float((rgbd[free, 3] - ref['depth'][free]).abs().max())
+    n2, n3 = rend.ctx.sampler_stats(), rend.ctx.sampler_saturated()
+    print(f'\n[full frame, optimizer-trained nets] {int(free.sum())} of {N} rays compared, index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
+          f'max depth error {derr:.2e}, depth rel. RMS {depth_relrms(rgbd[free, 3], ref["depth"][free]):.2e}; second pass {n2 / N:.2%}, third pass {n3} rays')
+    assert int((~free).sum()) <= 2e-3 * N and mism == 0
+    assert ps > 46.4 and rel < 2e-2 and derr < 2e-2
+    assert bool(torch.isfinite(rgbd).all())
 
 
 @pytest.mark.parametrize('seed', [0, 3, 5])
@@ -194,7 +243,7 @@ def test_full_frame_rgb_vs_eager_oracle_on_device(dev, seed):
           f'max depth error {derr:.2e}')
     assert int((~free).sum()) <= 1e-3 * N
     assert mism == 0
-    assert ps > 46.4 and rel < 1e-2 and derr < 2e-2
+    assert ps > 46.4 and rel < 1e-2 and derr < 1e-2 and depth_relrms(rgbd[free, 3], ref['depth'][free]) < 2e-3
     assert bool(torch.isfinite(rgbd).all())
 
 
@@ -224,4 +273,4 @@ def test_full_frame_rgb_vs_the_cpu_oracle(dev):
     print(f'\n[full frame vs CPU oracle] {int(free.sum())} of 65536 rays outside the tie set: index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
           f'max depth error {derr:.2e}')
     assert int((~free).sum()) <= 16 and mism == 0
-    assert ps > 46.4 and rel < 1e-2 and derr < 2e-2
+    assert ps > 46.4 and rel < 1e-2 and derr < 1e-2 and depth_relrms(got[free, 3], ref['depth'][free]) < 2e-3
