@@ -1887,13 +1887,18 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
     a.x = x; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
-    return launch_mlp(refine_kernel<1, 4, 0>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+    // operand type as the fused stage's (pnrf_refine_fwd / pnrf_refine_project_fwd): fp16 by default, bf16 for PNRF_VARIANT_BF16, so that a
+    // module-level parity check exercises the arithmetic the render path runs
+    if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 4, 0>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
+    a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
+    return launch_mlp(refine_kernel<1, 4, 0, 0, PrecF16>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
   }
   NerfArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = m; a.nbatch = (int)((m + 127) / 128);
   a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out; a.S = 8;
-  if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 4, false, true>, a, 256, lds, a.nbatch, (hipStream_t)stream);
-  return launch_mlp(nerf_kernel<1, 4, false, false>, a, 256, lds, a.nbatch, (hipStream_t)stream);
+  // (4-wave workgroups: LDS-exclusive like the narrow shapes of the fused stages — one fused-MLP workgroup per CU)
+  if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 4, false, true>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
+  return launch_mlp(nerf_kernel<1, 4, false, false>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
 }
 

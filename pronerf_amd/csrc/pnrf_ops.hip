@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256) void explore_kernel(ExploreArgs a, const float
       int rank = 0;
       for (int k = 0; k < S; ++k) {
         const float o = zz[k];
-        rank += (o < v || (o == v && k < u)) ? 1 : 0;
+        // a NaN ranks behind every number (and NaNs among themselves by index): every slot of zs[] is written exactly once, so a non-finite
+        // refined depth (a diverged step) comes out as NaN samples, the same ones on every run, instead of uninitialised LDS
+        rank += (o < v || (o == v && k < u) || (v != v && (o == o || k < u))) ? 1 : 0;
       }
       zs[rank] = v;
     }
@@ -676,6 +678,7 @@ extern "C" int pnrf_composite_fwd(const float* raw, const float* z, const float*
   PNRF_REQUIRE(n >= 0 && s >= 1 && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_fwd: bad sizes");
   if (n == 0) return 0;
   PNRF_REQUIRE(raw && z && rays_d, PNRF_E_ARG, "pnrf_composite_fwd: null pointer");
+  PNRF_REQUIRE(((uintptr_t)raw & 15) == 0, PNRF_E_ARG, "pnrf_composite_fwd: raw must be 16-byte aligned (the kernel reads [r, g, b, sigma] as one 16-byte load)");
   // few rays (a training batch): a wave per ray; many rays (a frame): a thread per ray.  Same operations in the same order either way.
   if (n < 65536)
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise,

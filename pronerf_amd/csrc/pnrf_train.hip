@@ -1181,6 +1181,11 @@ struct pnrf_trainer {
 namespace {
 
 inline void params_changed(pnrf_trainer* t) { t->planes_stale = true; t->nerf_planes_stale = true; t->streams_stale = true; }
+// Does the fine net's forward / backward pass of an iteration over R sample rows run on the fused-MLP engine (tchain_fwd_kernel /
+// tchain_bwd_kernel + the grouped weight gradients)?  ONE definition: nerf_forward, nerf_backward and run_iteration's refresh of the
+// derived weight forms (fp16 planes vs fragment streams) must agree, or an iteration reads stale weights.
+inline bool engine_fwd(const pnrf_trainer* t, int64_t R) { return t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->tc_ok; }
+inline bool engine_bwd(const pnrf_trainer* t, int64_t R) { return engine_fwd(t, R) && t->dw_tile == 0; }
 
 template <class T>
 int dev_alloc(pnrf_trainer* t, T** p, size_t count) {
@@ -1509,6 +1514,7 @@ extern "C" int pnrf_composite_bwd(const float* raw, const float* z, const float*
   PNRF_REQUIRE(n >= 0 && s >= 1 && d_stride >= 3, PNRF_E_ARG, "pnrf_composite_bwd: bad sizes");
   if (n == 0) return 0;
   PNRF_REQUIRE(raw && z && rays_d && d_rgb && d_raw, PNRF_E_ARG, "pnrf_composite_bwd: null pointer");
+  PNRF_REQUIRE((((uintptr_t)raw | (uintptr_t)d_raw) & 15) == 0, PNRF_E_ARG, "pnrf_composite_bwd: raw and d_raw must be 16-byte aligned (16-byte loads / stores per sample)");
   PNRF_REQUIRE((add == nullptr) == (mul == nullptr), PNRF_E_ARG, "pnrf_composite_bwd: add and mul go together");
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z, rays_d, d_stride, add, mul, noise, clampv,
                      white_bkgd, d_rgb, d_raw, d_z, d_add, d_mul, n, s);
@@ -1661,6 +1667,12 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
   // the chain kernels (pnrf_tchain.h) write whole batches of TC_ROWS rows: their buffers hold the row count rounded up
   const int64_t Rp = (R + TC_ROWS - 1) / TC_ROWS * TC_ROWS;
   t->tc_ok = Rp * LD_C5 * 4 < ((int64_t)1 << 32);    // the chains address rows with 32-bit byte offsets; beyond that the per-layer products take over
+  // the chain kernels' dynamic LDS exceeds the 64 KiB default limit: raised once per trainer (a per-device function attribute)
+  {
+    hipError_t ea = hipFuncSetAttribute((const void*)tchain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_LDS_BYTES);
+    if (ea == hipSuccess) ea = hipFuncSetAttribute((const void*)tchain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_BYTES);
+    if (ea != hipSuccess) { set_error("pnrf_trainer_create: hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea)); pnrf_trainer_free(t); return (int)ea; }
+  }
   for (int k = 0; k < 4; ++k) T_ALLOC(t->n_a[k], Rp * 256);
   T_ALLOC(t->n_c5, Rp * LD_C5); T_ALLOC(t->n_a5, Rp * 256); T_ALLOC(t->n_a6, Rp * 256); T_ALLOC(t->n_a7, Rp * 256);
   T_ALLOC(t->n_cv, Rp * LD_CV); T_ALLOC(t->n_hv, Rp * 128); T_ALLOC(t->raw, R * 4); T_ALLOC(t->rgb_map, N * 3); T_ALLOC(t->wts, R);
@@ -1821,7 +1833,7 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
   // not far enough ahead of an L2 under this load, and the 16 x 64-byte stores of the register epilogue cost 23 % (no-store probe build:
   // 411 vs 535 us per launch).  A first version on hgemm_rchain_kernel<4> (LDS round trip in the epilogue, one workgroup per CU) was 2 % slower.
   bool chained = false, engine = false;
-  if (t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->tc_ok) {
+  if (engine_fwd(t, R)) {
     // pts0 .. pts7 and feature_linear in one launch on the fused-MLP engine: 128 rows per workgroup stay in registers through the nine layers
     TChainArgs c = {};
     c.blob = t->tc_stream;
@@ -1834,7 +1846,6 @@ int nerf_forward(pnrf_trainer* t, const pnrf_train_batch_t* bt, int S, hipStream
     c.XV = t->n_cv + 256; c.ldxv = LD_CV;
     c.X0 = t->n_c5; c.ldx0 = LD_C5; c.mask = t->tc_mask; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
     const size_t lds = TC_LDS_BYTES;
-    PNRF_HIP(hipFuncSetAttribute((const void*)tchain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ncu = trainer_num_cu();
     hipLaunchKernelGGL(tchain_fwd_kernel, dim3((unsigned)(c.nbatch < ncu ? c.nbatch : ncu)), dim3(512), lds, s, c);
     PNRF_LAUNCH_CHECK();
@@ -1902,7 +1913,7 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
   // one max-|gradient| slot per gradient buffer write (the two products that add up d_a share one)
   float* m = t->amax + slot0 * HG_SLOT;
   T_RC(layer_bwd(t, L_RGB, t->d_raw, 4, none, t->n_hv, 128, t->d_hv, 128, m + 0 * HG_SLOT, 0.f, R, T_ACT_RELU, t->n_hv, 128, 0, s));
-  const bool engine = t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->dw_tile == 0 && t->tc_ok;
+  const bool engine = engine_bwd(t, R);
   if (!engine) T_RC(layer_bwd(t, L_VIEWS, t->d_hv, 128, m + 0 * HG_SLOT, t->n_cv, LD_CV, t->d_cv, LD_CV, m + 1 * HG_SLOT, 0.f, R, T_ACT_NONE, none, 0, 0, s));
   if (engine) {
     // The ten input-gradient products from the view layer down as ONE launch (tchain_bwd_kernel): the rows' gradients stay in registers from
@@ -1930,7 +1941,6 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     c.slot[8] = m + 1 * HG_SLOT;                         // d feature (the rows of d_cv)
     c.slot[9] = m + 10 * HG_SLOT;                        // scratch
     c.dg = t->d_c5; c.lddg = LD_C5; c.de0 = t->d_e0; c.n = R; c.nbatch = (int)((R + TC_ROWS - 1) / TC_ROWS);
-    PNRF_HIP(hipFuncSetAttribute((const void*)tchain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_BYTES));
     const int ncu = trainer_num_cu();
     hipLaunchKernelGGL(tchain_bwd_kernel, dim3((unsigned)(c.nbatch < ncu ? c.nbatch : ncu)), dim3(512), TB_LDS_BYTES, s, c);
     PNRF_LAUNCH_CHECK();
@@ -2095,7 +2105,8 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     // which of the derived weight forms this iteration reads: the fp16 planes of the sampler / refine nets always; the fine net's planes
     // unless both of its chains run on the engine; the chains' fragment streams if the forward chain does
     const int64_t R = N * S;
-    const bool eng_f = t->use_f16 && t->nerf_fwd == 0 && R >= 8192 && t->tc_ok, eng = eng_f && t->dw_tile == 0;
+    const bool eng_f = engine_fwd(t, R), eng = engine_bwd(t, R);
+    static_assert(L_N + 12 == N_LAYERS && L_S < L_R && L_R < L_N, "the fine net's parameters are the tail of the flat parameter array (sp.total below)");
     if (t->planes_stale || (!eng && t->nerf_planes_stale)) {
       SplitArgs sp = t->split;
       if (eng) sp.total = t->L[L_N].w;                         // the parameters before the fine net's

@@ -11,6 +11,7 @@ only and excluded by BASELINE.json's north_star; ``render_rays(use_trt=True)`` r
 from __future__ import annotations
 
 import os
+import time
 import struct
 import zlib
 
@@ -126,12 +127,20 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
                         f'(got {N_samples}, {num_neighbor}, {N_point_ray_enc})')
     if ray_batch.shape[-1] != 11 or or_ray_batch.shape[-1] != 11:
         raise PnrfError('render_rays: ray batches must be [N,11] (use_viewdirs=True)')
-    rend = _renderer(min_max_ray_net, refine_net, network_fine, ray_batch.shape[0], ray_batch.device)
-    img4, proj = _packed_views(kwargs['ref_rgb'], kwargs['ref_pose'], N_samples, num_neighbor)
-    with torch.cuda.device(rend.device):                     # the context's kernels go to ITS device's current stream
-        rgbd, _ = rend.ctx.render_rays(ray_batch, or_ray_batch, img4, proj)
+    rgbd = _render_rgbd(ray_batch, or_ray_batch, min_max_ray_net, refine_net, network_fine, kwargs['ref_rgb'], kwargs['ref_pose'], N_samples, num_neighbor,
+                        out=kwargs.get('out_rgbd'))
     rgb_map, depth_map = rgbd[:, :3], rgbd[:, 3]
     return {'rgb_map0': rgb_map, 'rgb_map1': rgb_map, 'depth_map': depth_map}
+
+
+def _render_rgbd(ray_batch, or_ray_batch, min_max_ray_net, refine_net, network_fine, ref_rgb, ref_pose, n_samples, num_neighbor, out=None):
+    """The packed [n, 4] = (rgb_map, depth_map) result of the fused path (into ``out`` if given): what ``render_rays`` slices its dict from
+    and what the sharded frame driver gathers (rgb_map0 and rgb_map1 are the same tensor at inference, trt.py:695)."""
+    rend = _renderer(min_max_ray_net, refine_net, network_fine, ray_batch.shape[0], ray_batch.device)
+    img4, proj = _packed_views(ref_rgb, ref_pose, n_samples, num_neighbor)
+    with torch.cuda.device(rend.device):                     # the context's kernels go to ITS device's current stream
+        rgbd, _ = rend.ctx.render_rays(ray_batch, or_ray_batch, img4, proj, out=out)
+    return rgbd
 
 
 def render(rays, or_rays, sh, **kwargs):
@@ -146,16 +155,19 @@ def render(rays, or_rays, sh, **kwargs):
 def render_sharded(rays, or_rays, sh, **kwargs):
     """``render`` with the frame's rays sharded over the ranks of the process group (not in the reference; the multi-GPU shape of
     SURVEY.md §8(e)): rank r renders the contiguous flat range ``shard_range(N, r, world)`` and one all-gather of the packed
-    [n, 7] = (rgb_map0, rgb_map1, depth_map) tiles rebuilds the frame on every rank.  Returns (rgb0, rgb1, depth) shaped like ``render``'s."""
+    [n, 4] = (rgb_map, depth_map) tiles rebuilds the frame on every rank (rgb_map0 is rgb_map1 at inference, trt.py:695: one copy travels).
+    Returns (rgb0, rgb1, depth) shaped like ``render``'s.  ``rays`` / ``or_rays`` are the whole frame's; ``render_path`` (which generates
+    only its own shard's rays and pipelines the gathers over frames) is what a run under torchrun uses."""
     from .dist import render_frame_sharded
 
     def part(first, count):
         r = render_rays(rays[first:first + count].contiguous(), or_rays[first:first + count].contiguous(), **kwargs)
-        return torch.cat([r['rgb_map0'], r['rgb_map1'], r['depth_map'][:, None]], 1)
+        return torch.cat([r['rgb_map1'], r['depth_map'][:, None]], 1)
 
-    full = render_frame_sharded(part, rays.shape[0], out_channels=7, device=rays.device)
+    full = render_frame_sharded(part, rays.shape[0], out_channels=4, device=rays.device)
     hw = list(sh[:-1])
-    return full[:, 0:3].reshape(hw + [3]), full[:, 3:6].reshape(hw + [3]), full[:, 6].reshape(hw)
+    rgb = full[:, 0:3].reshape(hw + [3])
+    return rgb, rgb, full[:, 3].reshape(hw)
 
 
 # ------------------------------------------------------------------------------------ model construction
@@ -261,27 +273,57 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
     ref_K = render_kwargs.get('ref_K', K)
     ref_Kh = np.asarray(ref_K.detach().cpu() if isinstance(ref_K, torch.Tensor) else ref_K, dtype=np.float32)
     dev = next(render_kwargs['network_fine'].parameters()).device
-    rgbs0, rgbs1, depths, psnrs, times = [], [], [], [], []
-    from .dist import world as _world
-    rank, world_size = _world()               # under torchrun every frame's rays are sharded over the ranks (render_sharded)
+    rgbs0, rgbs1, depths, psnrs, times, walls = [], [], [], [], [], []
+    from concurrent.futures import ThreadPoolExecutor
+    from .dist import FrameGather, world as _world
+    from .render import shard_range
+    rank, world_size = _world()               # under torchrun every frame's rays are sharded over the ranks
     verbose = verbose and rank == 0
     t1, t2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fwd = {k: render_kwargs[k] for k in ('network_fn', 'network_query_fn', 'N_samples', 'network_fine', 'min_max_ray_net', 'refine_net',
                                           'N_point_ray_enc', 'embed_fn', 'embeddirs_fn', 'num_neighbor', 'use_trt', 'embed_rays')
            if k in render_kwargs}
-    for i, c2w in enumerate(render_poses):
-        c2w_h = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)
-        rays, or_rays = ops.frame_rays(Kh, c2w_h, H, W, near=near, far=far, or_near=or_near, or_far=or_far, device=dev)   # :245-271
-        ref_nos = select_neighbors(c2w_h, poses_h, NB)                                                                     # :281-284
+    n_rays = H * W
+    first, count = shard_range(n_rays, rank, world_size)
+    # N > 1 = what bench.py times: this rank's rays only, the [n, 4] tiles gathered by RCCL on its own stream while the next render runs
+    # (FrameGather: two buffers in flight over the timing repetitions and over the poses), the next pose's neighbour images uploaded from
+    # pinned memory on a copy stream meanwhile, PNG encoding on a worker thread.
+    fg = FrameGather(n_rays, 4, device=dev, pipelined=True) if world_size > 1 else None
+    copy_stream = torch.cuda.Stream(device=dev)
+    png_pool = ThreadPoolExecutor(max_workers=1) if (savedir is not None and rank == 0) else None
+    png_jobs = []
+    poses_list = [np.asarray(c.detach().cpu() if isinstance(c, torch.Tensor) else c, dtype=np.float32) for c in render_poses]
+
+    def upload(i):
+        """Neighbour images / matrices of pose i -> device, asynchronously on the copy stream (trt.py:281-296)."""
+        ref_nos = select_neighbors(poses_list[i], poses_h, NB)                                                           # :281-284
         nb = images[ref_nos] if isinstance(images, np.ndarray) else images[torch.as_tensor(ref_nos)]
-        ref_rgb = torch.as_tensor(nb, dtype=torch.float32).permute(0, 3, 1, 2).contiguous().to(dev)                        # :286,296
-        ref_pose = torch.from_numpy(projection_matrices(ref_Kh, poses_h[ref_nos])).to(dev)                                  # :289-294
+        host = torch.as_tensor(nb, dtype=torch.float32)
+        if host.device.type == 'cpu':
+            host = host.contiguous().pin_memory()
+        with torch.cuda.stream(copy_stream):
+            ref_rgb = host.to(dev, non_blocking=True).permute(0, 3, 1, 2).contiguous()                                  # :286,296
+            ref_pose = torch.from_numpy(projection_matrices(ref_Kh, poses_h[ref_nos])).to(dev, non_blocking=True)     # :289-294
+            ev = torch.cuda.Event(); ev.record(copy_stream)
+        return ref_rgb, ref_pose, ev, host
+
+    nxt = upload(0) if poses_list else None
+    for i, c2w_h in enumerate(poses_list):
+        tw = time.perf_counter()
+        rays, or_rays = ops.frame_rays(Kh, c2w_h, H, W, near=near, far=far, or_near=or_near, or_far=or_far, first=first, count=count, device=dev)   # :245-271
+        ref_rgb, ref_pose, ev, _host = nxt
+        torch.cuda.current_stream(dev).wait_event(ev)
+        ref_rgb.record_stream(torch.cuda.current_stream(dev))
+        nxt = upload(i + 1) if i + 1 < len(poses_list) else None                 # overlaps this pose's renders
         sh = (H, W, 3)
         frame_ms = []
+        b = 0
         for _ in range(n_timing_reps):                                                                                     # :327-332
             t1.record()
-            if world_size > 1:
-                rgb0, rgb1, depth_map = render_sharded(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)
+            if fg is not None:
+                b = fg.acquire()
+                _render_rgbd(rays, or_rays, fwd['min_max_ray_net'], fwd['refine_net'], fwd['network_fine'], ref_rgb, ref_pose, S, NB, out=fg.outs[b][:count])
+                fg.submit(b)
             else:
                 rgb0, rgb1, depth_map, _ = render(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)
             t2.record()
@@ -289,14 +331,23 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
             frame_ms.append(t1.elapsed_time(t2))
             if verbose:
                 print('Render path time:', frame_ms[-1])
+        if fg is not None:
+            full = fg.frame(b)                                          # waits for the last repetition's gather
+            rgb1 = full[:, 0:3].reshape(H, W, 3); rgb0 = rgb1; depth_map = full[:, 3].reshape(H, W)
         times.append(frame_ms)
         rgbs0.append(rgb0.cpu().numpy()); rgbs1.append(rgb1.cpu().numpy()); depths.append(depth_map.cpu().numpy())
         if gt_imgs is not None and render_factor == 0:
             psnrs.append(mse2psnr(img2mse(rgb1, torch.as_tensor(gt_imgs[i], dtype=torch.float32).to(dev))))
-        if savedir is not None and rank == 0:
+        if png_pool is not None:
             os.makedirs(savedir, exist_ok=True)
-            _write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs1[-1]))
-            _write_png(os.path.join(savedir, 'depth_{:03d}.png'.format(i)), to8b(depths[-1] / np.max(depths[-1])))
+            png_jobs.append(png_pool.submit(_write_png, os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs1[-1])))
+            png_jobs.append(png_pool.submit(_write_png, os.path.join(savedir, 'depth_{:03d}.png'.format(i)), to8b(depths[-1] / np.max(depths[-1]))))
+        walls.append((time.perf_counter() - tw) * 1e3)
+    for j in png_jobs:
+        j.result()                                                      # re-raises a writer's exception
+    if png_pool is not None:
+        png_pool.shutdown()
+    render_kwargs['pose_wall_ms'] = walls                             # host wall time per pose: set-up, n_timing_reps renders, gather, read-back
     render_kwargs['render_ms'] = times
     if len(psnrs) > 0 and verbose:
         print(psnrs)

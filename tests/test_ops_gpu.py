@@ -426,3 +426,27 @@ def test_sampler_fp16_range_is_defined(dev):
                 assert torch.equal(out[5][moved], ref[5][moved]) and torch.equal(out[2][moved], ref[2][moved]) and torch.equal(out[3][moved], ref[3][moved])
             else:
                 assert n3 == 0 and float((out[5] - ref[5]).abs().max()) <= 2e-3
+
+
+def test_explore_with_a_non_finite_depth_is_deterministic(dev):
+    """pnrf_explore_fwd's rank sort with NaN depths (a diverged training step): NaNs rank behind every number, each output slot is written
+    exactly once — the same NaN / finite pattern on every run (the old rank left slots unwritten: uninitialised LDS), finite rays untouched."""
+    from pronerf_amd import ops
+    scene = synth.make_scene(0, H=9, W=11, rotate=True)
+    rays = cu(orc.frame_setup(scene)['rays'], dev)
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(0)
+    z8 = torch.sort(torch.rand(n, 8, generator=g), 1)[0]
+    clean = z8.clone()
+    z8[3, 2] = float('nan'); z8[5, :] = float('nan'); z8[7, 7] = float('inf')
+    for n_mult in (4, 8):
+        jit = (torch.rand(n, 8 * n_mult, generator=g) * 0.2)
+        runs = [ops.explore(cu(z8, dev), rays, cu(jit, dev), n_mult, 1, -1) for _ in range(3)]
+        ref = ops.explore(cu(clean, dev), rays, cu(jit, dev), n_mult, 1, -1)
+        for zo, po in runs[1:]:
+            assert torch.equal(torch.isnan(zo), torch.isnan(runs[0][0])) and torch.equal(torch.nan_to_num(zo), torch.nan_to_num(runs[0][0]))
+            assert torch.equal(torch.nan_to_num(po), torch.nan_to_num(runs[0][1]))
+        zo = runs[0][0]
+        ok = torch.ones(n, dtype=torch.bool); ok[[3, 5, 7]] = False
+        assert torch.equal(zo[ok.to(dev)], ref[0][ok.to(dev)])                    # rays without a non-finite depth: unchanged
+        assert bool(torch.isnan(zo[5]).all()) and int(torch.isnan(zo[3]).sum()) >= n_mult
