@@ -292,6 +292,53 @@ def train_pmc(workload):
         return None, {'refused': f'{type(e).__name__}: {e}'}
 
 
+def train_kernel_table(fn, n_rays, samples, iters=5, top=8):
+    """Per-kernel table of one training iteration, measured in this run: torch.profiler (roctracer) around `iters` iterations -> mean
+    microseconds per iteration of every kernel, the `top` largest listed; for the three launches that carry the fine net (forward chain,
+    backward chain, grouped weight gradients) the algorithmic bytes / FLOPs of the launch and what they amount to per second.
+    Kernels run ~5-10 % slower under the tracer than in the timed loop (`ms` of the block is the un-traced figure)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        fn(); torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+        rows = []
+        for e in prof.key_averages():
+            t = getattr(e, 'device_time_total', None)
+            if t is None:
+                t = getattr(e, 'cuda_time_total', 0.0)
+            if t > 0:
+                rows.append((e.key, e.count / iters, t / iters))
+    except Exception as e:                                   # the tracer is optional: report why instead of failing the bench line
+        return {'error': f'{type(e).__name__}: {e}'[:300]}
+    rows.sort(key=lambda r: -r[2])
+    R = n_rays * samples
+    # fine net (NeRF class): per-row floats the launches move by design, and MACs (pronerf_amd.workloads.layer_macs)
+    fine = [(63, 256)] + [(256, 256)] * 4 + [(319, 256)] + [(256, 256)] * 2 + [(256, 256), (256, 1), (283, 128), (128, 3)]
+    macs = sum(a * b for a, b in fine)
+    dx_macs = macs - 63 * 256                                # no input gradient through pts0's weights into ... the embedding: kept; through rgb: kept
+    act_out = 8 * 256 + 256 + 128 + 4                        # activations the forward chain writes once (fp32): pts0..7, feature, views hidden, raw
+    dz_out = 8 * 256 + 256 + 64                              # gradients the backward chain writes once: dZ of pts0..7, d feature, d embedding
+    dw_in = 64 + 4 * 512 + (320 + 256) + 2 * 512 + 512 + (288 + 128) + 256      # X and dZ rows the nine 256-wide weight gradients + views read
+    known = {
+        'tchain_fwd_kernel': {'bytes': R * 4.0 * (90 + act_out) + R * 40.0, 'flop': 2.0 * macs * R, 'bound': 'stores (fp32 activations written once) / split-fp16 MFMA rate'},
+        'tchain_bwd_kernel': {'bytes': R * 4.0 * (129 + dz_out) + R * 40.0, 'flop': 2.0 * dx_macs * R, 'bound': 'stores (fp32 gradients written once) / split-fp16 MFMA rate'},
+        'dwh_group_kernel': {'bytes': R * 4.0 * dw_in, 'flop': 2.0 * (macs - 256 - 128 * 3) * R, 'bound': 'hbm (re-reads every saved activation and gradient)'},
+    }
+    out = {'iters': iters, 'traced_us_per_iter': sum(r[2] for r in rows), 'kernels': []}
+    for name, launches, us in rows[:top]:
+        short = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].strip()
+        e = {'kernel': short[:60], 'launches_per_iter': launches, 'us_per_iter': us}
+        for k, v in known.items():
+            if k in name:
+                e.update(algorithmic_bytes=v['bytes'], algorithmic_tflop=v['flop'] / 1e12, TBps=v['bytes'] / (us * 1e-6) / 1e12,
+                         tflops=v['flop'] / (us * 1e-6) / 1e12, frac_of_8TBps=v['bytes'] / (us * 1e-6) / 8e12, bound=v['bound'])
+        out['kernels'].append(e)
+    return out
+
+
 def train_block(dev, eager=True):
     """Training iterations at configs[3] / configs[4] size (pronerf_amd.workloads): HIP trainer vs the oracle's eager torch autograd graph +
     torch.optim.Adam on the same GPU (checker-side, after the timed region).  `frac_of_hbm_roof` = measured HBM bytes per iteration / ms / 8 TB/s:
@@ -317,6 +364,7 @@ def train_block(dev, eager=True):
             e['launches_per_iter'] = pm.get('launches_per_iter')
             e['pmc_source'] = pm.get('source')
         e.update(extra or {})
+        e['per_kernel'] = train_kernel_table(fn, wk.n, (extra or {}).get('samples_per_ray', 8))
         out[name] = e
         return e
 

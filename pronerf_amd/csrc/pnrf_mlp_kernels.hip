@@ -821,7 +821,18 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
 
-  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+  // Batch order.  HEAD = 1 fetches the neighbour images: workgroups b and b + 8 share an XCD (its L2) under the round-robin placement the
+  // dispatcher is observed to use, so the workgroups of residue x walk the x-th EIGHTH of the batches — one band of the frame, whose samples
+  // project into one band of every neighbour image: each L2 fetches its band instead of all 48.8 MB (round 3: 503 MB of fetches per frame,
+  // 406 MB of them the images once per XCD).  Speed only: any placement gives the same rows.  Plain grid-stride order otherwise.
+  int jbase = 0, j0 = (int)blockIdx.x, jstep = (int)gridDim.x, jend = a.nbatch;
+  if (HEAD == 1 && (gridDim.x & 7) == 0 && a.nbatch >= (int)gridDim.x) {
+    const int per = (a.nbatch + 7) >> 3;
+    jbase = (int)(blockIdx.x & 7) * per; j0 = (int)(blockIdx.x >> 3); jstep = (int)(gridDim.x >> 3);
+    jend = a.nbatch - jbase < per ? a.nbatch - jbase : per;
+  }
+  for (int j = j0; j < jend; j += jstep) {
+    const int batch = jbase + j;
     int64_t row[NCB];
     bool valid[NCB];
     v8 Bo[NCB][KS_HID], Bn[NCB][KS_HID];

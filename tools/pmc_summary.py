@@ -41,6 +41,8 @@ def provenance(src):
 
 
 def short(name):
+    if 'sampler_kernel<2>' in name:
+        return 'sampler_p3_kernel'               # the exact-fp32 third pass: a few workgroups that leave at once when nothing saturated
     if 'nerf16_kernel' in name:
         return 'nerf_kernel'
     for k in ('nerf_kernel', 'refine_input_kernel', 'refine_kernel', 'sampler_p1_kernel', 'sampler_h16_kernel', 'sampler_kernel', 'frame_rays_kernel',
@@ -79,6 +81,11 @@ for k, c in acc.items():
         e['clock_GHz'] = round(cyc / durs[0], 3)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
             e['mfma_busy_frac'] = round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc), 3)
+    if m.get('SQ_WAVE_CYCLES', 0) > 0:           # where the waves' cycles go (quad-cycle units cancel in the ratios)
+        for src_n, dst_n in (('SQ_WAIT_ANY', 'wave_frac_parked'), ('SQ_WAIT_INST_ANY', 'wave_frac_issue_stall'), ('SQ_WAIT_INST_LDS', 'wave_frac_lds_issue_stall'),
+                             ('SQ_ACTIVE_INST_ANY', 'wave_frac_active'), ('SQ_ACTIVE_INST_VALU', 'wave_frac_valu'), ('SQ_ACTIVE_INST_LDS', 'wave_frac_lds')):
+            if src_n in m:
+                e[dst_n] = round(m[src_n] / m['SQ_WAVE_CYCLES'], 3)
     if m.get('SQ_INSTS_MFMA', 0) > 0 and 'SQ_INSTS_VALU' in m:
         e['valu_per_mfma'] = round((m['SQ_INSTS_VALU'] - m['SQ_INSTS_MFMA']) / m['SQ_INSTS_MFMA'], 3)
     per[k] = e
