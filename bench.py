@@ -73,6 +73,9 @@ def parse():
     ap.add_argument('--no-train', action='store_true', help='skip the training-iteration block (rank 0, N=1)')
     ap.add_argument('--no-train-eager', action='store_true', help='training block without the eager-torch legs')
     ap.add_argument('--launch-timeout', type=float, default=900.0, help='N>1 started without a launcher: seconds before the ranks are stopped')
+    ap.add_argument('--partition', default='cyclic', choices=('cyclic', 'contiguous'),
+                    help="N>1: how the frame's rays are dealt to the ranks: blocks of 1024 rays round-robin (every rank sees the frame's average share of "
+                         "second-pass rays) or contiguous ranges (SURVEY.md 8(e); the slowest shard then sets the frame rate)")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' to rehearse "
                     'the multi-rank path with several ranks sharing one GPU)')
     return ap.parse_args()
@@ -520,21 +523,22 @@ def main():
 
     dbg('process group up')
     from pronerf_amd import synthetic
-    from pronerf_amd.render import Renderer, shard_range
+    from pronerf_amd.render import RayPartition, Renderer
 
     weights = synthetic.make_weights(0, 'trained')
     scene = synthetic.make_scene(0, H=H, W=W, focal=FOCAL, rotate=True)
     n_total = H * W
-    first, count = shard_range(n_total, rank, world)
-    rend = Renderer(weights, max_rays=count, device=dev)
+    part = RayPartition(n_total, world, args.partition)           # world == 1: the whole frame
+    count = part.count(rank)
+    rend = Renderer(weights, max_rays=max(count, 1), device=dev)
     rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
-    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W, first=first, count=count)
-    counts = [shard_range(n_total, r, world)[1] for r in range(world)]
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W, **part.frame_rays_args(rank))
+    counts = list(part.counts)
     # N > 1: the gather of frame i runs on the collective's stream while frame i+1 renders (pronerf_amd.dist.FrameGather: two output /
     # frame buffers; the wait before a buffer is reused is a stream wait, the host never blocks).  Every frame is complete when fence() returns.
     from pronerf_amd.dist import FrameGather
     pipeline = world > 1 and os.environ.get('PNRF_BENCH_PIPELINE', '1') != '0'
-    fg = FrameGather(n_total, 4, device=dev, pipelined=pipeline)
+    fg = FrameGather(n_total, 4, device=dev, pipelined=pipeline, partition=part)
     outs = fg.outs
 
     def step():
@@ -599,7 +603,8 @@ def main():
                        'rays_per_step': n_total, 'rays_per_gpu': counts[0], 'rays_per_rank': counts,
                        'gather_bytes_per_rank_per_frame': (fg.cmax * 4 * 4 if world > 1 else 0),
                        'gather_bytes_per_frame': (fg.cmax * 4 * 4 * world if world > 1 else 0),
-                       'gather_pipelined': bool(pipeline), 'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
+                       'gather_pipelined': bool(pipeline), 'ray_partition': (part.kind + (f' (blocks of {part.block} rays round-robin)' if part.kind == 'cyclic' else '')),
+                       'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
             'outputs_finite': finite,
             'algorithmic_flop_per_ray': FLOP_PER_RAY,
             'e2e_mfma_tflops': value * FLOP_PER_RAY / 1e12,

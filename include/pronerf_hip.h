@@ -138,6 +138,13 @@ int pnrf_ray_encode_fwd(const float* rays, float* mm_input, int64_t n, int n_pts
 int pnrf_frame_rays_fwd(const float* K, const float* c2w, int H, int W, float near, float far,
                         float or_near, float or_far, int64_t first, int64_t count,
                         float* rays, float* or_rays, void* stream);
+/* The same for the pixels of a block-cyclic ray partition (multi-GPU frames; pronerf_amd.render.RayPartition): output row q is
+ * pixel first + (q / block) * stride + q % block — rank r of `world` ranks dealt blocks of `block` consecutive pixels round-robin passes
+ * first = r * block, stride = world * block and count = the number of pixels it owns.  stride = 0 with count <= block is the contiguous
+ * range of pnrf_frame_rays_fwd.  Blocks that leave the frame or overlap are refused. */
+int pnrf_frame_rays_blocks_fwd(const float* K, const float* c2w, int H, int W, float near, float far,
+                               float or_near, float or_far, int64_t first, int64_t block, int64_t stride,
+                               int64_t count, float* rays, float* or_rays, void* stream);
 /* ndc_rays on an arbitrary ray set: rays_o, rays_d dev [n,3] -> out_o, out_d dev [n,3]
  * (run_nerf_helpers.py:2776-2793). */
 int pnrf_ndc_rays_fwd(const float* rays_o, const float* rays_d, int H, int W, float focal, float near,

@@ -42,6 +42,7 @@ SIGNATURES = {
     'pnrf_plucker_fwd': (_i, [_p, _p, _p, _i64, _p]),
     'pnrf_ray_encode_fwd': (_i, [_p, _p, _i64, _i, _p]),
     'pnrf_frame_rays_fwd': (_i, [C.POINTER(_f), C.POINTER(_f), _i, _i, _f, _f, _f, _f, _i64, _i64, _p, _p, _p]),
+    'pnrf_frame_rays_blocks_fwd': (_i, [C.POINTER(_f), C.POINTER(_f), _i, _i, _f, _f, _f, _f, _i64, _i64, _i64, _i64, _p, _p, _p]),
     'pnrf_ndc_rays_fwd': (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _i64, _p]),
     'pnrf_warp_trt_fwd': (_i, [_p, _p, _p, _p, _i64, _p, _p, _i, _i, _i, _i64, _p]),
     'pnrf_warp_train_fwd': (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _i, _i, _i, _i64, _p]),

@@ -1667,8 +1667,10 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
   a.sort_idx = sort_idx; a.mm_rgb = mm_rgb; a.depth_raw = depth_raw;
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   hipStream_t st = (hipStream_t)stream;
-  // split-fp16 kernel (16 columns per wave): 128 / 64 rays per workgroup batch.  expect: rays the launch is expected to render (pass 2: the
-  // list's length is known on the device only; about a tenth of the rays on the frames measured, an eighth is assumed for the shape)
+  // split-fp16 kernel (16 columns per wave): 128 / 64 rays per workgroup batch.  Pass 2 renders a list whose length is known on the device
+  // only (a tenth of the rays on most frames, a quarter in places): its shape is chosen as if every ray were on it — a narrow launch that meets
+  // a long list walks two or three batches per workgroup at one-wave-per-SIMD latency (round 4: the last 1/8-frame shard took 0.707 ms, the
+  // others 0.63), a wide launch that meets a short one loses 9 us
   auto launch_h16 = [&](SamplerArgs& x, int64_t rows, int64_t expect) {
     if (stage_shape(h, expect, 16) == SHAPE_NARROW) {
       x.nbatch = (int)((rows + 63) / 64);
@@ -1709,7 +1711,7 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
     a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
     a.list = counters + 16; a.counters = counters; a.list_count = counters; a.sat_list = counters + 16 + n;
     // the grid is sized for a list of every ray (workgroups beyond the list leave at once)
-    if ((rc = launch_h16(a, n, (n + 7) / 8))) return rc;
+    if ((rc = launch_h16(a, n, n))) return rc;
     return launch_f32_list(f, counters, counters + 16 + n);
   }
   if (workspace_split) {                // PNRF_VARIANT_SAMPLER_SPLIT with a workspace: the split kernel for every ray + the exact-fp32 pass for saturated ones

@@ -74,10 +74,12 @@ struct FrameArgs {
   int H, W;
   float near, far, or_near, or_far;
   int64_t first, count;
+  int64_t block, stride;     // output row q is pixel first + (q / block) * stride + q % block (one contiguous range: block = count; a rank's blocks of a
+                             // block-cyclic partition: first = rank * block, stride = world * block)
 };
 __global__ void frame_rays_kernel(FrameArgs a, float* __restrict__ rays, float* __restrict__ or_rays) {
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < a.count; q += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = a.first + q;
+    const int64_t pix = a.first + (q / a.block) * a.stride + q % a.block;
     const int j = (int)(pix / a.W), i = (int)(pix - (int64_t)j * a.W);
     // dirs = ((i-cx)/fx, -(j-cy)/fy, -1);  rays_d[c] = sum_k dirs[k]*R[c][k]  (products, then a 3-term sum)
     const float d0 = ieee_div(ieee_sub((float)i, a.K02), a.K00);
@@ -614,20 +616,35 @@ extern "C" int pnrf_ray_encode_fwd(const float* rays, float* mm_input, int64_t n
   return 0;
 }
 
-extern "C" int pnrf_frame_rays_fwd(const float* K, const float* c2w, int H, int W, float near, float far, float or_near,
-                                   float or_far, int64_t first, int64_t count, float* rays, float* or_rays, void* stream) {
-  PNRF_REQUIRE(K && c2w && H > 0 && W > 0 && first >= 0 && count >= 0 && first + count <= (int64_t)H * W, PNRF_E_ARG,
-               "pnrf_frame_rays_fwd: bad arguments (H=%d W=%d first=%lld count=%lld)", H, W, (long long)first, (long long)count);
+extern "C" int pnrf_frame_rays_blocks_fwd(const float* K, const float* c2w, int H, int W, float near, float far, float or_near, float or_far,
+                                          int64_t first, int64_t block, int64_t stride, int64_t count, float* rays, float* or_rays, void* stream) {
+  PNRF_REQUIRE(K && c2w && H > 0 && W > 0 && first >= 0 && count >= 0 && block >= 1 && stride >= 0, PNRF_E_ARG,
+               "pnrf_frame_rays_blocks_fwd: bad arguments (H=%d W=%d first=%lld block=%lld stride=%lld count=%lld)", H, W, (long long)first,
+               (long long)block, (long long)stride, (long long)count);
   if (count == 0) return 0;
-  PNRF_REQUIRE(rays && or_rays, PNRF_E_ARG, "pnrf_frame_rays_fwd: null output");
+  {
+    const int64_t last = first + ((count - 1) / block) * stride + (count - 1) % block;          // the largest pixel index addressed
+    PNRF_REQUIRE(last < (int64_t)H * W && (stride == 0 ? count <= block : stride >= block), PNRF_E_ARG,
+                 "pnrf_frame_rays_blocks_fwd: the blocks leave the %d x %d frame or overlap (last pixel %lld)", H, W, (long long)last);
+  }
+  PNRF_REQUIRE(rays && or_rays, PNRF_E_ARG, "pnrf_frame_rays_blocks_fwd: null output");
   FrameArgs a;
   a.K00 = K[0]; a.K02 = K[2]; a.K11 = K[4]; a.K12 = K[5];
   a.sx = ndc_scale(W, K[0]); a.sy = ndc_scale(H, K[0]);
   for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) a.R[r * 3 + c] = c2w[r * 4 + c]; a.T[r] = c2w[r * 4 + 3]; }
   a.H = H; a.W = W; a.near = near; a.far = far; a.or_near = or_near; a.or_far = or_far; a.first = first; a.count = count;
+  a.block = block; a.stride = stride;
   hipLaunchKernelGGL(frame_rays_kernel, dim3(grid_for(count)), dim3(TPB), 0, (hipStream_t)stream, a, rays, or_rays);
   PNRF_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int pnrf_frame_rays_fwd(const float* K, const float* c2w, int H, int W, float near, float far, float or_near,
+                                   float or_far, int64_t first, int64_t count, float* rays, float* or_rays, void* stream) {
+  PNRF_REQUIRE(K && c2w && H > 0 && W > 0 && first >= 0 && count >= 0 && first + count <= (int64_t)H * W, PNRF_E_ARG,
+               "pnrf_frame_rays_fwd: bad arguments (H=%d W=%d first=%lld count=%lld)", H, W, (long long)first, (long long)count);
+  if (count == 0) return 0;
+  return pnrf_frame_rays_blocks_fwd(K, c2w, H, W, near, far, or_near, or_far, first, count, 0, count, rays, or_rays, stream);
 }
 
 extern "C" int pnrf_ndc_rays_fwd(const float* rays_o, const float* rays_d, int H, int W, float focal, float near,

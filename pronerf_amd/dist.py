@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from .render import shard_range
+from .render import RayPartition, shard_range
 
 
 def world():
@@ -67,14 +67,21 @@ class FrameGather:
     assembled [n_total, C] frame of buffer ``b``.  ``bench.py`` times exactly this at N > 1."""
 
     def __init__(self, n_total: int, channels: int = 4, device=None, dtype=torch.float32, depth: int = 2, pipelined: bool = True,
-                 collective=None):
+                 collective=None, partition=None):
         """collective: None = the all-gather runs when there is more than one rank; True = also in a one-rank process group (the RCCL launch
-        path on a one-GPU box: tests/test_dist_gpu.py)."""
+        path on a one-GPU box: tests/test_dist_gpu.py).  partition: a ``RayPartition`` (how the frame's rays are dealt to the ranks: this
+        rank renders ``partition.frame_rays_args(rank)``) or 'contiguous' / 'cyclic'; None = contiguous ranges (``shard_range``)."""
         self.rank, self.world = world()
         self.n_total, self.channels = int(n_total), int(channels)
-        self.counts = [shard_range(n_total, r, self.world)[1] for r in range(self.world)]
-        self.first, self.count = shard_range(n_total, self.rank, self.world)
-        self.cmax = max(self.counts) if self.counts else 0
+        if partition is None or isinstance(partition, str):
+            partition = RayPartition(n_total, self.world, partition or 'contiguous')
+        if partition.n_total != self.n_total or partition.world != self.world:
+            raise ValueError('FrameGather: the partition is for another frame size / world size')
+        self.partition = partition
+        self.counts = list(partition.counts)
+        self.first = shard_range(n_total, self.rank, self.world)[0] if partition.kind == 'contiguous' else None
+        self.count = partition.count(self.rank)
+        self.cmax = partition.cmax
         self.collective = self.world > 1 if collective is None else bool(collective)
         if self.collective and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('FrameGather(collective=True) needs an initialised process group')
@@ -84,6 +91,7 @@ class FrameGather:
         self.fulls = [torch.empty(self.world * self.cmax, channels, device=device, dtype=dtype) if self.collective else None for _ in range(self.depth)]
         self.pending = [None] * self.depth
         self._next = 0
+        self._index = partition.gather_index(device) if self.collective else None
 
     def acquire(self) -> int:
         """Index of the buffer the next frame renders into (``outs[b][:count]``), free of any gather still reading it."""
@@ -110,14 +118,13 @@ class FrameGather:
             self._wait(b)
 
     def frame(self, b: int):
-        """The gathered frame of buffer ``b`` ([n_total, C]; a view when the shards are equal)."""
+        """The gathered frame of buffer ``b`` ([n_total, C] in frame order; a view when the gathered buffer already is the frame: equal
+        contiguous shards — otherwise one index_select with the partition's ``gather_index``)."""
         self._wait(b)
         if not self.collective:
             return self.outs[b][:self.count]
         full = self.fulls[b]
-        if self.cmax * self.world == self.n_total:
-            return full
-        return torch.cat([full[r * self.cmax:r * self.cmax + c] for r, c in enumerate(self.counts)], 0)
+        return full if self._index is None else full.index_select(0, self._index)
 
 
 def allreduce_gradients(trainer, group=None):

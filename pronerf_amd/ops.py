@@ -158,16 +158,21 @@ def ray_encode(rays, n_pts=48):
     return out
 
 
-def frame_rays(K, c2w, H, W, near=0.0, far=1.0, or_near=1.0, or_far=10.0, first=0, count=None, device='cuda'):
-    """rays[count,11], or_rays[count,11] for flat pixel range [first, first+count)."""
+def frame_rays(K, c2w, H, W, near=0.0, far=1.0, or_near=1.0, or_far=10.0, first=0, count=None, device='cuda', block=None, stride=0):
+    """rays[count,11], or_rays[count,11] for flat pixel range [first, first+count); with ``block`` / ``stride``: row q is pixel
+    first + (q // block) * stride + q % block (a rank's share of a block-cyclic partition, pnrf_frame_rays_blocks_fwd)."""
     count = H * W - first if count is None else count
     Kh = np.ascontiguousarray(np.asarray(K.detach().cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float32).reshape(3, 3))
     Ch = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)[:3, :4])
     rays = torch.empty(count, 11, device=device, dtype=f32)
     orr = torch.empty(count, 11, device=device, dtype=f32)
     fp = C.POINTER(C.c_float)
-    check(_lib.load().pnrf_frame_rays_fwd(Kh.ctypes.data_as(fp), Ch.ctypes.data_as(fp), H, W, near, far, or_near, or_far,
-                                          first, count, _ptr(rays), _ptr(orr), _stream()), 'pnrf_frame_rays_fwd')
+    if block is None:
+        check(_lib.load().pnrf_frame_rays_fwd(Kh.ctypes.data_as(fp), Ch.ctypes.data_as(fp), H, W, near, far, or_near, or_far,
+                                              first, count, _ptr(rays), _ptr(orr), _stream()), 'pnrf_frame_rays_fwd')
+    else:
+        check(_lib.load().pnrf_frame_rays_blocks_fwd(Kh.ctypes.data_as(fp), Ch.ctypes.data_as(fp), H, W, near, far, or_near, or_far,
+                                                     first, int(block), int(stride), count, _ptr(rays), _ptr(orr), _stream()), 'pnrf_frame_rays_blocks_fwd')
     return rays, orr
 
 

@@ -276,7 +276,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
     rgbs0, rgbs1, depths, psnrs, times, walls = [], [], [], [], [], []
     from concurrent.futures import ThreadPoolExecutor
     from .dist import FrameGather, world as _world
-    from .render import shard_range
+    from .render import RayPartition
     rank, world_size = _world()               # under torchrun every frame's rays are sharded over the ranks
     verbose = verbose and rank == 0
     t1, t2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -284,11 +284,12 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
                                           'N_point_ray_enc', 'embed_fn', 'embeddirs_fn', 'num_neighbor', 'use_trt', 'embed_rays')
            if k in render_kwargs}
     n_rays = H * W
-    first, count = shard_range(n_rays, rank, world_size)
+    part = RayPartition(n_rays, world_size, os.environ.get('PNRF_RAY_PARTITION', 'cyclic'))      # blocks of 1024 rays round-robin: every rank gets the frame's
+    count = part.count(rank)                                                                      # average share of second-pass rays (render.RayPartition)
     # N > 1 = what bench.py times: this rank's rays only, the [n, 4] tiles gathered by RCCL on its own stream while the next render runs
     # (FrameGather: two buffers in flight over the timing repetitions and over the poses), the next pose's neighbour images uploaded from
     # pinned memory on a copy stream meanwhile, PNG encoding on a worker thread.
-    fg = FrameGather(n_rays, 4, device=dev, pipelined=True) if world_size > 1 else None
+    fg = FrameGather(n_rays, 4, device=dev, pipelined=True, partition=part) if world_size > 1 else None
     copy_stream = torch.cuda.Stream(device=dev)
     png_pool = ThreadPoolExecutor(max_workers=1) if (savedir is not None and rank == 0) else None
     png_jobs = []
@@ -310,7 +311,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
     nxt = upload(0) if poses_list else None
     for i, c2w_h in enumerate(poses_list):
         tw = time.perf_counter()
-        rays, or_rays = ops.frame_rays(Kh, c2w_h, H, W, near=near, far=far, or_near=or_near, or_far=or_far, first=first, count=count, device=dev)   # :245-271
+        rays, or_rays = ops.frame_rays(Kh, c2w_h, H, W, near=near, far=far, or_near=or_near, or_far=or_far, device=dev, **part.frame_rays_args(rank))   # :245-271
         ref_rgb, ref_pose, ev, _host = nxt
         torch.cuda.current_stream(dev).wait_event(ev)
         ref_rgb.record_stream(torch.cuda.current_stream(dev))
@@ -322,7 +323,8 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
             t1.record()
             if fg is not None:
                 b = fg.acquire()
-                _render_rgbd(rays, or_rays, fwd['min_max_ray_net'], fwd['refine_net'], fwd['network_fine'], ref_rgb, ref_pose, S, NB, out=fg.outs[b][:count])
+                if count > 0:
+                    _render_rgbd(rays, or_rays, fwd['min_max_ray_net'], fwd['refine_net'], fwd['network_fine'], ref_rgb, ref_pose, S, NB, out=fg.outs[b][:count])
                 fg.submit(b)
             else:
                 rgb0, rgb1, depth_map, _ = render(rays, or_rays, sh, ref_rgb=ref_rgb, ref_pose=ref_pose, **fwd)

@@ -112,7 +112,7 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
     (the frame's first rays), launched back to back on one stream.  Reports per world size the slowest of the three shards and the implied
     kernel-only strong-scaling bound frame_ms / shard_ms.  ``check``: every shard / call equals the same rows of the one-call frame bit for bit
     (rays are independent).  ``stages``: a second pass per size with the context's per-stage events (sampler / refine / NeRF ms)."""
-    from .render import Renderer, shard_range
+    from .render import RayPartition, Renderer, shard_range
 
     def stage_ms(fn, n):
         rend.ctx.profile_begin(n)
@@ -128,7 +128,7 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
     rend.render_rays(rays, or_rays, out=ref)
     out = torch.empty_like(ref)
     res = {'what': 'one GPU, current kernels: ms per pnrf_render_rays_fwd call on the first / middle / last contiguous shard of 1/N of the 762 048-ray '
-                   'frame (no collective) and on single small calls; speedup_bound = frame ms / slowest shard ms',
+                   'frame (no collective) — and, cyclic_*, on the same ranks\' share of the frame dealt in blocks of 1024 rays round-robin (what bench.py and the frame driver use at N > 1) — and on single small calls; speedup_bound = frame ms / slowest shard ms',
            'reps': reps, 'shape': shape if shape is not None else 'auto (per launch: the default)', 'shards': {}, 'calls': {}}
     identical = True
     frame_ms = None
@@ -139,8 +139,9 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
             r, o, dst = rays[first:first + count], or_rays[first:first + count], out[first:first + count]
             ms = timed_ms(lambda: rend.render_rays(r, o, out=dst), reps, 5)[0]
             per[f'rank{rank}'] = ms
-            if stages and rank == 0:
-                per['rank0_stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), min(reps, 64))
+            if stages:
+                per[f'rank{rank}_stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), min(reps, 64))
+                per[f'rank{rank}_stages']['rays_second_pass'] = rend.ctx.sampler_stats()
             if check:
                 identical = identical and bool(torch.equal(dst, ref[first:first + count]))
         worst = max(v for k, v in per.items() if not k.endswith('_stages'))
@@ -149,6 +150,23 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
         res['shards'][str(world)] = {'rays': shard_range(n_total, 0, world)[1], 'ms': per, 'ms_slowest': worst,
                                      'speedup_bound': (frame_ms / worst) if frame_ms else None,
                                      'rays_per_s_x_world': n_total / worst * 1e3}
+        if world > 1:
+            # the same ranks with the frame dealt in blocks of 1024 rays round-robin (RayPartition 'cyclic': what bench.py and the frame driver use at
+            # N > 1): every rank renders the frame's average share of second-pass rays
+            part = RayPartition(n_total, world, 'cyclic')
+            cyc = {}
+            for rank in sorted({0, world // 2, world - 1}):
+                rows = part.rows(rank).to(dev)
+                r, o = rays.index_select(0, rows), or_rays.index_select(0, rows)
+                dst = torch.empty(rows.shape[0], 4, device=dev)
+                cyc[f'rank{rank}'] = timed_ms(lambda: rend.render_rays(r, o, out=dst), reps, 5)[0]
+                if stages:
+                    cyc[f'rank{rank}_stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), min(reps, 64))
+                    cyc[f'rank{rank}_stages']['rays_second_pass'] = rend.ctx.sampler_stats()
+                if check:
+                    identical = identical and bool(torch.equal(dst, ref.index_select(0, rows)))
+            cw = max(v for k, v in cyc.items() if not k.endswith('_stages'))
+            res['shards'][str(world)].update(cyclic_ms=cyc, cyclic_ms_slowest=cw, cyclic_speedup_bound=frame_ms / cw)
     for c in call_rays:
         r, o, dst = rays[:c], or_rays[:c], out[:c]
         ms, wall = timed_ms(lambda: rend.render_rays(r, o, out=dst), 200, 20)

@@ -45,7 +45,7 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['steps'] == 3 and j['backend'] == 'gloo'
-    assert j['outputs_finite'] and j['value'] > 0 and j['config']['rays_per_gpu'] == 762048 // 2
+    assert j['outputs_finite'] and j['value'] > 0 and j['config']['rays_per_rank'] == [381120, 380928] and j['config']['ray_partition'].startswith('cyclic')
     assert 'roofline' not in j and 'cpu_baseline' not in j            # N = 1 only
 
 
@@ -53,12 +53,13 @@ def test_bench_two_ranks_without_a_launcher():
     """`python3 bench.py --gpus 2` as the driver starts the N = 1 bench (no torch.distributed.run): bench.py starts its own ranks before
     anything touches the GPU and relays rank 0's line."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
-    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--partition', 'contiguous']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert j['n_gpus'] == 2 and j['ranks'] == 2 and j['backend'] == 'gloo' and j['launcher'].startswith('self')
     assert j['config']['rays_per_rank'] == [381024, 381024] and j['config']['gather_bytes_per_rank_per_frame'] == 381024 * 16
+    assert j['config']['ray_partition'] == 'contiguous'
     assert j['outputs_finite'] and j['value'] > 0
 
 

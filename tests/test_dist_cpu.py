@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pronerf_amd.render import shard_range
+from pronerf_amd.render import RayPartition, shard_range
 
 
 def test_shard_range_partitions():
@@ -82,15 +82,43 @@ def test_sharded_render_matches_single_process(ws, H, W):
             assert root is None
 
 
-def _gather_worker(rank, ws, port, n_total, frames, pipelined, q):
+def test_ray_partition_properties():
+    """RayPartition: both kinds deal every ray exactly once; cyclic blocks of 1024 rays give the Fern frame 95 424 + 7 x 95 232 rays; the gather
+    index rebuilds the frame from the rank-major gathered buffer; frame_rays_args describe the same rows."""
+    for n, w, blk in ((762048, 8, 1024), (1000, 3, 64), (130, 4, 32), (64, 8, 16), (5, 8, 4), (762048, 2, 1024), (97, 1, 16), (768, 2, 1024)):
+        for kind in ('contiguous', 'cyclic'):
+            p = RayPartition(n, w, kind, blk)
+            rows = [p.rows(r) for r in range(w)]
+            assert [len(x) for x in rows] == p.counts and sum(p.counts) == n
+            assert sorted(torch.cat(rows).tolist()) == list(range(n))
+            buf = torch.full((w * p.cmax,), -1, dtype=torch.int64)
+            for r in range(w):
+                buf[r * p.cmax: r * p.cmax + p.counts[r]] = rows[r]
+                a = p.frame_rays_args(r)
+                q = torch.arange(a['count'])
+                pix = a['first'] + q if 'block' not in a else a['first'] + (q // a['block']) * a['stride'] + q % a['block']
+                assert torch.equal(pix, rows[r])
+            gi = p.gather_index()
+            assert torch.equal(buf if gi is None else buf[gi], torch.arange(n))
+    assert RayPartition(762048, 8, 'cyclic').counts == [95424] + [95232] * 7
+    assert RayPartition(762048, 8, 'contiguous').counts == [95256] * 8 and RayPartition(762048, 8, 'contiguous').gather_index() is None
+    assert RayPartition(100, 1, 'cyclic').kind == 'contiguous'                      # one rank: the whole frame
+    with pytest.raises(ValueError):
+        RayPartition(10, 2, 'striped')
+
+
+def _gather_worker(rank, ws, port, n_total, frames, pipelined, q, kind='contiguous'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=ws)
     try:
         from pronerf_amd.dist import FrameGather
-        fg = FrameGather(n_total, 4, device='cpu', pipelined=pipelined)
-        assert (fg.first, fg.count) == shard_range(n_total, rank, ws) and fg.depth == (2 if pipelined else 1)
-        rows = torch.arange(fg.first, fg.first + fg.count, dtype=torch.float32)[:, None] + torch.tensor([0., .25, .5, .75])
+        part = RayPartition(n_total, ws, kind, 32)
+        fg = FrameGather(n_total, 4, device='cpu', pipelined=pipelined, partition=part)
+        assert fg.count == part.count(rank) and fg.depth == (2 if pipelined else 1)
+        if kind == 'contiguous':
+            assert (fg.first, fg.count) == shard_range(n_total, rank, ws)
+        rows = part.rows(rank).to(torch.float32)[:, None] + torch.tensor([0., .25, .5, .75])
         got = []
         for f in range(frames):                       # frame f: pixel value = 1000 f + global row (+ channel / 4)
             b = fg.acquire()
@@ -106,14 +134,16 @@ def _gather_worker(rank, ws, port, n_total, frames, pipelined, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('ws,n_total,pipelined', [(2, 48, True), (3, 35, True), (2, 35, False)])
-def test_frame_gather_pipeline(ws, n_total, pipelined):
-    """pronerf_amd.dist.FrameGather (what bench.py times at N > 1): two buffers in flight, async all-gather, ragged shards."""
+@pytest.mark.parametrize('ws,n_total,pipelined,kind', [(2, 48, True, 'contiguous'), (3, 35, True, 'contiguous'), (2, 35, False, 'contiguous'),
+                                                       (3, 135, True, 'cyclic'), (2, 151, False, 'cyclic')])
+def test_frame_gather_pipeline(ws, n_total, pipelined, kind):
+    """pronerf_amd.dist.FrameGather (what bench.py times at N > 1): two buffers in flight, async all-gather, ragged shards; contiguous
+    ranges and the block-cyclic partition (blocks of 32 rays here), whose frame is rebuilt through the partition's gather index."""
     frames = 5
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gather_worker, args=(r, ws, port, n_total, frames, pipelined, q)) for r in range(ws)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, ws, port, n_total, frames, pipelined, q, kind)) for r in range(ws)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(ws)]

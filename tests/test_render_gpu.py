@@ -300,3 +300,31 @@ def test_concurrent_streams_never_change_a_row(dev):
             bad = int((out != ref).any(1).sum())
             assert bad == 0, (shape, rep, bad)
         del ch, rend
+
+
+def test_cyclic_partition_shards_equal_the_frame(dev):
+    """RayPartition('cyclic'): every rank's rays come out of pnrf_frame_rays_blocks_fwd as the rows partition.rows(rank) of the one-call frame's
+    rays (bit for bit), the rendered tiles put through the gather index give the one-call frame, and bad block arguments are refused."""
+    from pronerf_amd import _lib
+    from pronerf_amd.render import RayPartition, Renderer
+    Hh, Ww = 201, 333                                # 66 933 rays: 66 blocks of 1024 (the last one 373 rays) over 8 ranks
+    scene = synth.make_scene(5, H=Hh, W=Ww, rotate=True)
+    rend = Renderer(synth.make_weights(5, 'trained'), max_rays=Hh * Ww, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww)
+    ref, _ = rend.render_rays(rays, or_rays)
+    ref = ref.clone()
+    for world in (8, 3):
+        part = RayPartition(Hh * Ww, world, 'cyclic')
+        buf = torch.zeros(world * part.cmax, 4, device=dev)
+        for rank in range(world):
+            r, o = rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww, **part.frame_rays_args(rank))
+            rows = part.rows(rank).to(dev)
+            assert torch.equal(r, rays.index_select(0, rows)) and torch.equal(o, or_rays.index_select(0, rows))
+            tile, _ = rend.render_rays(r, o)
+            buf[rank * part.cmax: rank * part.cmax + part.count(rank)] = tile
+        assert torch.equal(buf.index_select(0, part.gather_index(dev)), ref)
+    with pytest.raises(_lib.PnrfError):
+        rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww, first=0, count=Hh * Ww, block=1024, stride=512)        # overlapping blocks
+    with pytest.raises(_lib.PnrfError):
+        rend.frame_rays(scene['K'], scene['c2w'], Hh, Ww, first=7 * 1024, count=9 * 1024, block=1024, stride=8 * 1024)   # leaves the frame
