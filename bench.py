@@ -171,19 +171,20 @@ def sustained_mfma_peak():
         return None
 
 
-def csrc_digest():
-    """Digest of the kernel sources + build flags (pronerf_amd.build._digest: what the library's .sha256 stamp holds).  Profiles record it
-    (tools/pmc_summary.py, tools/train_pmc_summary.py); a number read from a profile is reported only while it still matches."""
+def csrc_digest(scope='inference'):
+    """Digest of the kernel sources + build flags (pronerf_amd.build._digest; scope 'inference' leaves out the trainer-only sources, 'all' is
+    what the library's .sha256 stamp holds).  Profiles record it (tools/pmc_summary.py: inference, tools/train_pmc_summary.py: all); a number
+    read from a profile is reported only while it still matches."""
     try:
         from pronerf_amd import build as b
-        return b._digest()
+        return b._digest(scope)
     except Exception:
         return None
 
 
-def profile_provenance(summary):
+def profile_provenance(summary, scope='inference'):
     """(usable, provenance) of a committed PMC summary: usable only if it was taken from the kernel sources of this tree."""
-    have, now = summary.get('csrc_digest'), csrc_digest()
+    have, now = summary.get('csrc_digest'), csrc_digest(scope)
     prov = {'file': summary.get('_file'), 'commit': summary.get('commit'), 'csrc_digest': have}
     if not have:
         return False, dict(prov, refused='the profile predates digest stamping (cannot tell whether csrc/ changed since)')
@@ -289,7 +290,7 @@ def train_pmc(workload):
     try:
         d = json.load(open(files[-1]))
         d['_file'] = os.path.relpath(files[-1], ROOT)
-        ok, prov = profile_provenance(d)
+        ok, prov = profile_provenance(d, 'all')
         return (d['workloads'][workload] if ok else None), prov
     except Exception as e:
         return None, {'refused': f'{type(e).__name__}: {e}'}

@@ -41,12 +41,18 @@ def _layout_tag():
     return c & 0xffffffff
 
 
-def _digest():
+TRAINER_ONLY = ('pnrf_train.hip', 'pnrf_tchain.h', 'pnrf_hgemm.h')     # sources no inference kernel is built from
+
+
+def _digest(scope='all'):
+    """sha256 over the kernel sources + build flags.  scope 'all': every file (the library's .sha256 stamp, trainer profiles);
+    'inference': without the trainer-only sources — what the rendering kernels are built from (tools/profile_round.sh records it, bench.py
+    compares it before quoting a profile), so that work on the trainer does not void the frame's PMC profile."""
     h = hashlib.sha256()
     files = sorted(os.listdir(CSRC)) + ['../../include/pronerf_hip.h']
     for f in files:
         p = os.path.join(CSRC, f)
-        if os.path.isfile(p):
+        if os.path.isfile(p) and not (scope == 'inference' and f in TRAINER_ONLY):
             h.update(f.encode()); h.update(open(p, 'rb').read())
     h.update(' '.join(FLAGS).encode())
     return h.hexdigest()

@@ -6,7 +6,7 @@ TAG=${1:?tag}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 -c "from pronerf_amd import build; print(build._digest())" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
+python3 -c "from pronerf_amd import build; print(build._digest('inference'))" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
 python3 bench.py --steps 20 --warmup 10 --no-train > "$OUT/bench.json"
 python3 -c "import json,sys; j=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]); json.dump(j['shard_rehearsal'], open('$OUT/shard_rehearsal.json','w'), indent=1)"
 echo "bench done"
