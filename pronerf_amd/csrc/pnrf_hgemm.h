@@ -422,6 +422,9 @@ struct DwhArgs {
   int out, in; int64_t R, rows_per;
   const float* dz_amax;                        // max |dZ| slot (HG_SLOT floats) or NULL
 };
+#ifndef PNRF_DW_PROBE
+#define PNRF_DW_PROBE 0          // timing builds only (results are wrong): 1 no MFMAs, 2 no split on the way to LDS
+#endif
 constexpr int DH_KC = 32, DH_COL = DH_KC + 8;  // rows per chunk; halfs per column in LDS
 constexpr int DH_BYTES = 2 * 2 * 2 * 128 * DH_COL * 2;      // LDS of the weight-gradient body
 // workgroup (tile bx, split by) of the weight gradient
@@ -471,6 +474,14 @@ __device__ __forceinline__ void dwh_body(const DwhArgs& a, const int bx, const i
   auto store = [&](const f32x4_t (&st)[4], int buf) {
     _Float16* hi = sm + ((buf * 2 + op) * 2) * PLANE + sm_off;
     _Float16* lo = hi + PLANE;
+#if PNRF_DW_PROBE & 2                                           // timing build: the fetched bits go to LDS as they are (no split, no column sums)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *(f16x4_t*)(hi + e * DH_COL) = __builtin_bit_cast(f16x4_t, ((unsigned long long)__float_as_uint(st[0][e]) << 32 | __float_as_uint(st[1][e])));
+      *(f16x4_t*)(lo + e * DH_COL) = __builtin_bit_cast(f16x4_t, ((unsigned long long)__float_as_uint(st[2][e]) << 32 | __float_as_uint(st[3][e])));
+    }
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       f16x4_t h, l;
@@ -501,6 +512,10 @@ __device__ __forceinline__ void dwh_body(const DwhArgs& a, const int bx, const i
     for (int i = 0; i < 4; ++i) { const int o = frag_off(wm * 64 + 16 * i); ah[i] = *(const f16x8_t*)(zh + o); al[i] = *(const f16x8_t*)(zl + o); }
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int o = frag_off(wn * 32 + 16 * j); bh[j] = *(const f16x8_t*)(xh + o); bl[j] = *(const f16x8_t*)(xl + o); }
+#if PNRF_DW_PROBE & 1                                           // timing build: the fragments are read, one MFMA per chunk keeps them alive
+    accx[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0] + ah[1] + ah[2] + ah[3] + al[0] + al[1] + al[2] + al[3], bh[0] + bh[1] + bl[0] + bl[1], accx[0][0], 0, 0, 0);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
