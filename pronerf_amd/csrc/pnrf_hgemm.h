@@ -1,7 +1,7 @@
 // Split-fp16 kernels of the trainer (included by pnrf_train.hip inside its anonymous namespace): the layer products (hgemm_kernel), the weight
 // gradients (dwh_kernel), a layer's backward as one launch (layer_bwd_kernel), the layer chains of the 4096-row nets (hgemm_rchain_kernel), the
 // 64-row chains of the wide layers (hgemm_wchain_kernel; an A/B alternative since pnrf_tchain.h), the iteration's grouped weight gradients
-// (dwh_group_kernel), and the kernel that keeps the fp16 weight planes current (split_weights_kernel).
+// (dwh_group_kernel), and the body that keeps the fp16 weight planes current (split_weights_body, a block range of pnrf_train.hip's iter_prepare_kernel).
 //
 // Y = act(X W^T + b) and dX = (dZ W [+ dX]) * act'(H) with fp32-grade results at 3/16 of the fp32 MFMA cycles: both operands are split
 //   x = x_hi + 2^-11 x_lo',  x_hi = fp16(x),  x_lo' = fp16((x - x_hi) 2^11)          (22 significand bits per operand)
@@ -22,7 +22,7 @@
 //   * A [M, K] fp32 streams from HBM once: 512 threads fetch a chunk (16 bytes each, whole 256-byte row segments) two chunks ahead into
 //     registers, split it one chunk ahead and write the two fp16 planes [row][64 + 8] to LDS (double buffered; row stride 144 bytes: the
 //     ds_read_b128 of the 16 rows of a fragment cover all 64 banks once).
-//   * The weight planes are stored fragment-major (split_weights_kernel): the 16 columns x 32 k block that one MFMA consumes is one contiguous
+//   * The weight planes are stored fragment-major (split_weights_body): the 16 columns x 32 k block that one MFMA consumes is one contiguous
 //     KiB in lane order, so a fragment fetch is a single fully coalesced 16-byte-per-lane load from L2.  Fragments are fetched per 32-deep step,
 //     three steps ahead, into four rotating register sets.  Two orientations are kept: [out][in] for the forward product, [in][out] for dX.
 //   * Every fetch inside the loop is a buffer load — resource in scalar registers, a per-lane offset that never changes, a scalar offset per
@@ -384,9 +384,10 @@ __global__ __launch_bounds__(512) void hgemm_kernel(HGemmArgs a) {
 // One thread per weight.
 struct SplitLayer { size_t w; int in, out, gap; size_t fwd, bwd; int ld_fwd, ld_bwd; size_t plane_fwd, plane_bwd; };   // offsets in floats (w) / halfs
 struct SplitArgs { SplitLayer l[26]; int n; const float* P; _Float16* planes; size_t total; float* gapped; };
-__global__ void split_weights_kernel(SplitArgs a) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.total; i += stride) {
+// (bid, nblk): the block's index and the number of blocks that share the work — the kernel's own grid, or its share of iter_prepare_kernel's
+__device__ __forceinline__ void split_weights_body(const SplitArgs& a, unsigned bid, unsigned nblk) {
+  const size_t stride = (size_t)nblk * blockDim.x;
+  for (size_t i = bid * (size_t)blockDim.x + threadIdx.x; i < a.total; i += stride) {
     int li = 0;
     while (li + 1 < a.n && i >= a.l[li + 1].w) ++li;
     const SplitLayer& L = a.l[li];

@@ -12,7 +12,7 @@
 // Results agree with the per-layer products to fp32 round-off (different summation order), not bit for bit.
 //
 // Stream: the trainer's parameters change every iteration, so the engine's fragment stream is rebuilt on the device whenever the fp16 planes
-// are (tchain_pack_kernel): fragments (tile pair, k-step, tile of the pair, plane) of 16 output rows x 32 k, layer after layer, every layer a
+// are (tchain_pack_body, a block range of iter_prepare_kernel): fragments (tile pair, k-step, tile of the pair, plane) of 16 output rows x 32 k, layer after layer, every layer a
 // whole number of ring revolutions so that all of them start at ring position 0.
 #pragma once
 
@@ -57,8 +57,8 @@ struct TChainPackArgs {
   _Float16* stream;                  // TC_NFRAGS KiB
 };
 // one thread per 16-byte piece of the stream (lane `lane` of fragment F)
-__global__ void tchain_pack_kernel(TChainPackArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tchain_pack_body(const TChainPackArgs& a, unsigned bid) {
+  const int p = bid * blockDim.x + threadIdx.x;
   if (p >= TC_NSLOTS * SLOT_FRAGS * 64) return;
   const int F = p >> 6, lane = p & 63;
   if (F >= TC_NFRAGS) {                                      // the padding slots
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void tchain_fwd_kernel(TChainArgs a) {
 //   s4  pts5^T: 8 tile pairs of hidden columns -> dZ4, then 2 pairs of embedding columns -> d embedding          s9  pts0^T: 2 pairs -> d embedding
 // Gradient range.  Gradients are 1e-9 .. 1e-3; the planes carry them times a power of two PER ROW.  The first comes from the row's own maximum
 // (max |x| s in [2^13, 2^14)); from layer to layer the accumulators hold c' = (a s) W and |c'_j| <= |a s|_2 |W_:j|_2 <= |a s|_2 C with C^2 the
-// layer's largest column sum of squares (tchain_norms_kernel), so t = the power of two with |a s|_2 C t < 2^14 is known — before the first
+// layer's largest column sum of squares (tchain_norms_body), so t = the power of two with |a s|_2 C t < 2^14 is known — before the first
 // output is split — from the sum of squares of the row's planes, which the previous layer's epilogue accumulated; the next planes are c' t,
 // never above 2^14.  All factors are powers of two: undone exactly in the epilogue that stores the gradient.
 constexpr int TB_NS = 10;
@@ -352,9 +352,8 @@ __device__ __forceinline__ float tb_weight(const TChainBwdPackArgs& a, int s, in
   if (L == 0) return j < 63 ? a.P[a.w[0] + (size_t)k * 63 + j] : 0.f;
   return a.P[a.w[L] + (size_t)k * 256 + j];
 }
-__global__ void tchain_pack_bwd_kernel(TChainBwdPackArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < TB_NS) a.cmax[p] = 0.f;
+__device__ __forceinline__ void tchain_pack_bwd_body(const TChainBwdPackArgs& a, unsigned bid) {
+  const int p = bid * blockDim.x + threadIdx.x;
   if (p >= TB_NSLOTS * SLOT_FRAGS * 64) return;
   const int F = p >> 6, lane = p & 63;
   f16x8 v;
@@ -378,11 +377,13 @@ __global__ void tchain_pack_bwd_kernel(TChainBwdPackArgs a) {
   }
   *(f16x8*)(a.stream + (size_t)p * 8) = v;
 }
-// cmax[s] = max over the re-split output columns j of sum_k w(k, j)^2.  Block (s, b): columns 16 b .. 16 b + 15, 16 partial sums each; cmax is
-// zeroed by tchain_pack_bwd_kernel (the launch before this one)
-__global__ void tchain_norms_kernel(TChainBwdPackArgs a) {
-  __shared__ float red[256];
-  const int s = blockIdx.x, j = 16 * blockIdx.y + (threadIdx.x & 15), part = threadIdx.x >> 4;
+// cmax[s] = max over the re-split output columns j of sum_k w(k, j)^2.  Block (s, b) = index 16 s + b: columns 16 b .. 16 b + 15, 16 partial sums
+// each, atomicMax of the block's maximum into cmax[s].  The blocks run beside the packing blocks in ONE launch (iter_prepare_kernel), so nobody
+// can zero cmax ahead of them in that launch: the trainer alternates between two cmax arrays — this launch accumulates into one (zero since the
+// launch before) and clears the other (`zero`, which the chains of the iterations in between have finished reading).  red: 256 floats of LDS.
+__device__ __forceinline__ void tchain_norms_body(const TChainBwdPackArgs& a, int blk, float* red, float* zero) {
+  const int s = blk >> 4, j = 16 * (blk & 15) + (threadIdx.x & 15), part = threadIdx.x >> 4;
+  if (blk == 0 && threadIdx.x < 16) zero[threadIdx.x] = 0.f;
   float acc = 0.f;
   const int nk = s == 0 ? 128 : (s == 1 ? 257 : 256);
   if (s != 9)

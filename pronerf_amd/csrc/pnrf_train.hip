@@ -1097,14 +1097,37 @@ struct StageArgs {
   int64_t n; int S;
   float* amax; int n_amax;              // the iteration's max-|gradient| slots (hgemm_kernel operand scaling): cleared here
 };
-__global__ void stage_batch_kernel(StageArgs a) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+__device__ __forceinline__ void stage_batch_body(const StageArgs& a, unsigned bid, unsigned nblk) {
+  const int64_t stride = (int64_t)nblk * blockDim.x, t0 = bid * (int64_t)blockDim.x + threadIdx.x;
   for (int64_t i = t0; i < a.n_amax; i += stride) a.amax[i] = 0.f;
   for (int64_t i = t0; i < a.n * 11; i += stride) { a.d_rays[i] = a.rays[i]; a.d_or_rays[i] = a.or_rays[i]; }
   for (int64_t i = t0; i < a.n * 3; i += stride) a.d_target[i] = a.target[i];
   for (int64_t i = t0; i < a.n * 4; i += stride) a.d_ref_nos[i] = a.ref_nos[i];
   if (a.jitter) for (int64_t i = t0; i < a.n * a.S; i += stride) a.d_jitter[i] = a.jitter[i];
   if (a.noise) for (int64_t i = t0; i < a.n * a.S; i += stride) a.d_noise[i] = a.noise[i];
+}
+
+// The start of an iteration as ONE launch: whatever derived form of the parameters is stale — the fp16 planes (split_weights), the two chains'
+// fragment streams and the backward chain's column norms — and the copy of the batch into the staging buffers.  All of them read only the
+// parameters / the caller's batch and write disjoint buffers, so they are block ranges of one grid instead of five dependent launches of
+// 5-12 us each (the stage-2 iteration at 4096 rays is 35 launches without a gap between them; ~4.5 us of every small one is the launch itself).
+struct PrepArgs {
+  SplitArgs split; TChainPackArgs pack; TChainBwdPackArgs packb; StageArgs stage;
+  float* cmax_zero;                                             // the cmax array of the next refresh (tchain_norms_body)
+  unsigned n_split, n_pack, n_packb, n_norm, n_stage;          // blocks of each part (0: not this time)
+};
+__global__ __launch_bounds__(TPB) void iter_prepare_kernel(PrepArgs a) {
+  __shared__ float red[TPB];
+  unsigned b = blockIdx.x;
+  if (b < a.n_stage) { stage_batch_body(a.stage, b, a.n_stage); return; }
+  b -= a.n_stage;
+  if (b < a.n_norm) { tchain_norms_body(a.packb, (int)b, red, a.cmax_zero); return; }
+  b -= a.n_norm;
+  if (b < a.n_pack) { tchain_pack_body(a.pack, b); return; }
+  b -= a.n_pack;
+  if (b < a.n_packb) { tchain_pack_bwd_body(a.packb, b); return; }
+  b -= a.n_packb;
+  split_weights_body(a.split, b, a.n_split);
 }
 
 }  // namespace
@@ -1137,6 +1160,7 @@ struct pnrf_trainer {
     int64_t n;
     float eps, a_mmrgb, clamp;
     const void *img4, *poses, *K;
+    const void* cmax;                            // which of the two column-norm arrays the captured backward chain reads (tchain_norms_body)
     hipStream_t stream;
   };
   struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
@@ -1165,6 +1189,7 @@ struct pnrf_trainer {
   TChainPackArgs tc_pack;
   _Float16* tb_stream = nullptr;                 // ... and the transposed layers' stream of the input-gradient chain (tchain_bwd_kernel)
   TChainBwdPackArgs tb_pack;
+  float* cmax2 = nullptr;                        // the backward chain's column norms, two arrays used in turn (tb_pack.cmax = the current one)
   bool tc_ok = true;                             // workspaces small enough for the chains' 32-bit row offsets
   uint2* tc_mask = nullptr;                      // ReLU masks of pts0 .. pts7 (written by the forward chain, read by the backward chain)
   float* dz_x[6] = {};                           // dZ5 .. dZ0 of the backward chain (dZ7 = d_a, dZ6 = d_b)
@@ -1654,7 +1679,9 @@ static int trainer_init(pnrf_trainer* t, const float* const* W, const float* con
     t->tb_pack.P = t->P; t->tb_pack.stream = t->tb_stream;
     for (int l = 0; l < TC_NL; ++l) t->tb_pack.w[l] = t->tc_pack.w[l];
     t->tb_pack.w_alpha = t->L[L_ALPHA].w;
-    T_ALLOC(t->tb_pack.cmax, 16);
+    T_ALLOC(t->cmax2, 32);                                     // two arrays of 16: tchain_norms_body
+    PNRF_HIP(hipMemset(t->cmax2, 0, 32 * sizeof(float)));
+    t->tb_pack.cmax = t->cmax2;
     T_ALLOC(t->amax, N_AMAX * HG_SLOT);
     PNRF_HIP(hipMemset(t->amax, 0, N_AMAX * HG_SLOT * 4));
   }
@@ -2103,32 +2130,32 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
   }
   {
     // which of the derived weight forms this iteration reads: the fp16 planes of the sampler / refine nets always; the fine net's planes
-    // unless both of its chains run on the engine; the chains' fragment streams if the forward chain does
+    // unless both of its chains run on the engine; the chains' fragment streams if the forward chain does.  One launch with the batch copy.
     const int64_t R = N * S;
     const bool eng_f = engine_fwd(t, R), eng = engine_bwd(t, R);
     static_assert(L_N + 12 == N_LAYERS && L_S < L_R && L_R < L_N, "the fine net's parameters are the tail of the flat parameter array (sp.total below)");
+    static_assert(TPB == 256, "tchain_norms_body: 16 columns x 16 partial sums per block");
+    PrepArgs pa = {};
     if (t->planes_stale || (!eng && t->nerf_planes_stale)) {
-      SplitArgs sp = t->split;
-      if (eng) sp.total = t->L[L_N].w;                         // the parameters before the fine net's
-      hipLaunchKernelGGL(split_weights_kernel, dim3(grid_for((int64_t)sp.total)), dim3(TPB), 0, s, sp);
-      PNRF_LAUNCH_CHECK();
+      pa.split = t->split;
+      if (eng) pa.split.total = t->L[L_N].w;                   // the parameters before the fine net's
+      pa.n_split = (unsigned)grid_for((int64_t)pa.split.total);
       t->planes_stale = false;
       if (!eng) t->nerf_planes_stale = false;
     }
     if (eng_f && t->streams_stale) {
-      hipLaunchKernelGGL(tchain_pack_kernel, dim3(TC_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tc_pack);
-      PNRF_LAUNCH_CHECK();
-      hipLaunchKernelGGL(tchain_pack_bwd_kernel, dim3(TB_NSLOTS * SLOT_FRAGS * 64 / TPB), dim3(TPB), 0, s, t->tb_pack);
-      PNRF_LAUNCH_CHECK();
-      hipLaunchKernelGGL(tchain_norms_kernel, dim3(TB_NS, 16), dim3(256), 0, s, t->tb_pack);
-      PNRF_LAUNCH_CHECK();
+      pa.cmax_zero = t->tb_pack.cmax;                          // the array in use until now: cleared for the refresh after this one
+      t->tb_pack.cmax = t->cmax2 + (t->tb_pack.cmax == t->cmax2 ? 16 : 0);
+      pa.pack = t->tc_pack; pa.packb = t->tb_pack;
+      pa.n_pack = TC_NSLOTS * SLOT_FRAGS * 64 / TPB; pa.n_packb = TB_NSLOTS * SLOT_FRAGS * 64 / TPB; pa.n_norm = TB_NS * 16;
       t->streams_stale = false;
     }
+    pa.stage = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
+                t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S, t->amax, N_AMAX * HG_SLOT};
+    pa.n_stage = (unsigned)grid_for(N * 11);
+    hipLaunchKernelGGL(iter_prepare_kernel, dim3(pa.n_stage + pa.n_norm + pa.n_pack + pa.n_packb + pa.n_split), dim3(TPB), 0, s, pa);
+    PNRF_LAUNCH_CHECK();
   }
-  StageArgs sa = {bt->rays, bt->or_rays, bt->target, bt->jitter, bt->raw_noise, bt->ref_nos,
-                  t->st_rays, t->st_or_rays, t->st_target, t->st_jitter, t->st_noise, t->st_ref_nos, N, S, t->amax, N_AMAX * HG_SLOT};
-  hipLaunchKernelGGL(stage_batch_kernel, dim3(grid_for(N * 11)), dim3(TPB), 0, s, sa);
-  PNRF_LAUNCH_CHECK();
   pnrf_train_batch_t b = *bt;
   b.rays = t->st_rays; b.or_rays = t->st_or_rays; b.target = t->st_target; b.ref_nos = t->st_ref_nos;
   b.jitter = bt->jitter ? t->st_jitter : nullptr; b.raw_noise = bt->raw_noise ? t->st_noise : nullptr;
@@ -2144,7 +2171,7 @@ static int run_iteration(pnrf_trainer_t* t, const pnrf_train_batch_t* bt, int ki
     memset(&key, 0, sizeof(key));
     key.kind = kind; key.n_mult = n_mult; key.dir1 = dir1; key.jitter_dir = b.jitter_dir; key.white_bkgd = b.white_bkgd; key.layout = b.layout;
     key.nv = b.nv; key.Hf = b.Hf; key.Wf = b.Wf; key.has_jitter = b.jitter != nullptr; key.has_noise = b.raw_noise != nullptr; key.n = N;
-    key.eps = b.eps; key.a_mmrgb = b.a_mmrgb; key.clamp = b.clamp; key.img4 = b.img4; key.poses = b.poses; key.K = b.K; key.stream = s;
+    key.eps = b.eps; key.a_mmrgb = b.a_mmrgb; key.clamp = b.clamp; key.img4 = b.img4; key.poses = b.poses; key.K = b.K; key.cmax = t->tb_pack.cmax; key.stream = s;
     hipGraphExec_t exec = nullptr;
     for (auto& g : t->graphs)
       if (memcmp(&g.key, &key, sizeof(key)) == 0) exec = g.exec;

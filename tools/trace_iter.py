@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel timeline of the last complete training iteration in a rocprofv3 --kernel-trace CSV (iterations start at stage_batch_kernel):
+"""Kernel timeline of the last complete training iteration in a rocprofv3 --kernel-trace CSV (iterations start at iter_prepare_kernel):
     python tools/trace_iter.py <dir with *kernel_trace.csv> [--which -2]
 prints every launch with its grid, duration and the gap to its predecessor, then totals per kernel name."""
 import collections
