@@ -23,6 +23,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, 'profiles')
 
 
+
+def newest_per_dir(files):
+    """gpurun merges every call's outputs into the same local tree: a pass directory that was profiled twice holds two runs' CSVs (one per
+    profiler process id).  Keep, per directory, the newest."""
+    best = {}
+    for f in files:
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
 def provenance(src):
     """csrc digest recorded on the GPU box when the passes ran (tools/profile_*.sh) and the commit being summarised (with a dirty mark)."""
     import subprocess
@@ -53,7 +64,7 @@ def short(name):
 
 
 acc = defaultdict(lambda: defaultdict(list))
-for f in sorted(glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True)):
+for f in newest_per_dir(glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True)):
     names = set()
     disp = {}
     with open(f) as fh:

@@ -4,7 +4,7 @@
 set -eo pipefail
 TAG=${1:?tag}
 OUT=$PWD/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"      # a second run into the same tag must not leave the first one's CSVs beside its own
 export TMPDIR=/tmp
 python3 -c "from pronerf_amd import build; print(build._digest('inference'))" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
 python3 bench.py --steps 20 --warmup 10 --no-train > "$OUT/bench.json"

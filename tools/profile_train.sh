@@ -5,7 +5,7 @@
 set -eo pipefail
 TAG=${1:?tag}
 OUT=$PWD/gpurun_out/prof_train_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"      # a second run into the same tag must not leave the first one's CSVs beside its own
 export TMPDIR=/tmp
 python3 -c "from pronerf_amd import build; print(build._digest())" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
 for WLD in stage2_iteration stage1_explore_64 stage1_explore_256; do

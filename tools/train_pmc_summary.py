@@ -18,6 +18,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, 'profiles')
 
 
+
+def newest_per_dir(files):
+    """gpurun merges every call's outputs into the same local tree: a pass directory that was profiled twice holds two runs' CSVs (one per
+    profiler process id).  Keep, per directory, the newest."""
+    best = {}
+    for f in files:
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
 def provenance(src):
     """csrc digest recorded on the GPU box when the passes ran (tools/profile_*.sh) and the commit being summarised (with a dirty mark)."""
     import subprocess
@@ -38,7 +49,7 @@ A, B = 2, 8
 
 def total(workload, counter, iters):
     tot, n = 0.0, 0
-    for f in glob.glob(os.path.join(src, f'pmc_{workload}_{counter}_{iters}', '**', '*counter_collection.csv'), recursive=True):
+    for f in newest_per_dir(glob.glob(os.path.join(src, f'pmc_{workload}_{counter}_{iters}', '**', '*counter_collection.csv'), recursive=True)):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if r['Counter_Name'] == counter:
@@ -64,7 +75,7 @@ for w in ('stage2_iteration', 'stage1_explore_64', 'stage1_explore_256'):
                 e['ms_unprofiled' if name == f'{w}.json' else 'ms_under_kernel_trace'] = json.loads(open(p).read().strip().splitlines()[-1])['ms']
             except Exception:
                 pass
-    st = glob.glob(os.path.join(src, f'stats_{w}', '**', '*kernel_stats.csv'), recursive=True)
+    st = newest_per_dir(glob.glob(os.path.join(src, f'stats_{w}', '**', '*kernel_stats.csv'), recursive=True))
     if st:
         shutil.copy(st[0], os.path.join(out_dir, f'{tag}_train_{w}_kernel_stats.csv'))
     res['workloads'][w] = e
