@@ -114,6 +114,41 @@ def test_stage2_iteration_at_config3_size(work, dev):
     _forward_variants(wk, tr, lambda: wk.stage2_step(want_rgb=True, adam=False), range(26), loss, rgb, g16)
 
 
+def test_optimizer_steps_under_graph_replay_equal_kernel_by_kernel(work, dev):
+    """Iterations WITH their Adam steps, replayed as hipGraphs: every step refreshes the derived weight forms (one grouped launch in front of the captured
+    body) and the backward chain's column norms alternate between two arrays, which is part of the graph key — the losses of four consecutive steps
+    must equal, bit for bit, those of the same steps launched kernel by kernel from the same parameters and moments."""
+    wk, tr = work, work.trainer
+    tr.set_products('f16x2')
+    keep = {k: tr.flat(k).clone() for k in ('param', 'm', 'v')}
+    W0, b0 = tr.read('param', 0)
+
+    def restore():
+        for k, v in keep.items():
+            tr.flat(k).copy_(v)
+        tr.write('param', 0, W0, b0)                        # the write marks every derived form stale (the flat views do not)
+        tr.set_step(0, 0)
+
+    def run(graph):
+        restore()
+        tr.set_graph(graph)
+        out = []
+        for _ in range(4):
+            loss, _ = wk.stage2_step(adam=True)
+            out.append(loss.clone())
+        params = tr.flat('param').clone()
+        tr.set_graph(False)
+        return out, params
+
+    try:
+        a, pa = run(False)
+        b, pb = run(True)
+    finally:
+        restore()
+    assert all(bool(torch.isfinite(x).all()) for x in a) and float(a[0][0]) != float(a[3][0])            # the steps do change the loss
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(pa, pb)
+
+
 def test_exploration_iteration_at_config4_size(work, dev):
     """4096 rays x 256 samples per ray (n_mult = 32): 1 048 576 rows through the 12 NeRF layers, forward and backward."""
     wk, tr = work, work.trainer
