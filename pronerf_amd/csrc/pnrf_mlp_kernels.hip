@@ -1710,8 +1710,9 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
     SamplerArgs f = a;                                    // pass 3 (exact fp32, folded first layer) on the rays pass 2 reports as saturated
     a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
     a.list = counters + 16; a.counters = counters; a.list_count = counters; a.sat_list = counters + 16 + n;
-    // the grid is sized for a list of every ray (workgroups beyond the list leave at once)
-    if ((rc = launch_h16(a, n, n))) return rc;
+    // the grid is sized for a list of every ray (workgroups beyond the list leave at once); the shape for a sixth of them on it (8-27 % on the
+    // weight sets of tests/test_fullframe_gpu.py; a list of up to 40 % still costs a narrow launch no more than a wide one)
+    if ((rc = launch_h16(a, n, (n + 5) / 6))) return rc;
     return launch_f32_list(f, counters, counters + 16 + n);
   }
   if (workspace_split) {                // PNRF_VARIANT_SAMPLER_SPLIT with a workspace: the split kernel for every ray + the exact-fp32 pass for saturated ones

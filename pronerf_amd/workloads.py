@@ -106,6 +106,13 @@ def timed_ms(fn, iters, warm, stream_sync=torch.cuda.synchronize):
     return e0.elapsed_time(e1) / iters, (time.perf_counter() - t0) * 1e3 / iters
 
 
+def settled_ms(fn, reps):
+    """Device milliseconds per call once the chip has settled on this call size: the better of two measurements of ``reps`` back-to-back calls, each
+    behind ``reps`` // 2 untimed ones.  (A measurement taken right after calls of another size can sit 5 % high for its whole length — the clock the
+    power manager chose for the previous load — which is not what a rank that renders the same shard frame after frame sees.)"""
+    return min(timed_ms(fn, reps, max(5, reps // 2))[0] for _ in range(2))
+
+
 def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), call_rays=(1024, 4096), reps=40, shape=None, check=True, stages=False):
     """One-GPU rehearsal of what a rank of an N-GPU run and a chunked caller execute, on the kernels of THIS build: ``pnrf_render_rays_fwd`` on the
     first / middle / last contiguous ray shard of 1/N of the frame (``shard_range``), no collective; and on single calls of ``call_rays`` rays
@@ -128,7 +135,7 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
     rend.render_rays(rays, or_rays, out=ref)
     out = torch.empty_like(ref)
     res = {'what': 'one GPU, current kernels: ms per pnrf_render_rays_fwd call on the first / middle / last contiguous shard of 1/N of the 762 048-ray '
-                   'frame (no collective) — and, cyclic_*, on the same ranks\' share of the frame dealt in blocks of 1024 rays round-robin (what bench.py and the frame driver use at N > 1) — and on single small calls; speedup_bound = frame ms / slowest shard ms',
+                   'frame (no collective) — and, cyclic_*, on the same ranks\' share of the frame dealt in blocks of 1024 rays round-robin (what bench.py and the frame driver use at N > 1) — and on single small calls; every figure the better of two measurements of `reps` back-to-back calls, each behind reps / 2 untimed ones; speedup_bound = frame ms / slowest shard ms',
            'reps': reps, 'shape': shape if shape is not None else 'auto (per launch: the default)', 'shards': {}, 'calls': {}}
     identical = True
     frame_ms = None
@@ -137,7 +144,7 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
         for rank in sorted({0, world // 2, world - 1}):
             first, count = shard_range(n_total, rank, world)
             r, o, dst = rays[first:first + count], or_rays[first:first + count], out[first:first + count]
-            ms = timed_ms(lambda: rend.render_rays(r, o, out=dst), reps, 5)[0]
+            ms = settled_ms(lambda: rend.render_rays(r, o, out=dst), reps)
             per[f'rank{rank}'] = ms
             if stages:
                 per[f'rank{rank}_stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), min(reps, 64))
@@ -159,7 +166,7 @@ def shard_rehearsal(weights, scene, H, W, device='cuda:0', worlds=(1, 2, 4, 8), 
                 rows = part.rows(rank).to(dev)
                 r, o = rays.index_select(0, rows), or_rays.index_select(0, rows)
                 dst = torch.empty(rows.shape[0], 4, device=dev)
-                cyc[f'rank{rank}'] = timed_ms(lambda: rend.render_rays(r, o, out=dst), reps, 5)[0]
+                cyc[f'rank{rank}'] = settled_ms(lambda: rend.render_rays(r, o, out=dst), reps)
                 if stages:
                     cyc[f'rank{rank}_stages'] = stage_ms(lambda: rend.render_rays(r, o, out=dst), min(reps, 64))
                     cyc[f'rank{rank}_stages']['rays_second_pass'] = rend.ctx.sampler_stats()
