@@ -173,7 +173,7 @@ def sustained_mfma_peak():
 
 def csrc_digest(scope='inference'):
     """Digest of the kernel sources + build flags (pronerf_amd.build._digest; scope 'inference' leaves out the trainer-only sources, 'all' is
-    what the library's .sha256 stamp holds).  Profiles record it (tools/pmc_summary.py: inference, tools/train_pmc_summary.py: all); a number
+    what the library's .sha256 stamp holds).  Profiles record it (tools/pmc_summary.py: inference, tools/train_pmc_summary.py: training); a number
     read from a profile is reported only while it still matches."""
     try:
         from pronerf_amd import build as b
@@ -290,7 +290,7 @@ def train_pmc(workload):
     try:
         d = json.load(open(files[-1]))
         d['_file'] = os.path.relpath(files[-1], ROOT)
-        ok, prov = profile_provenance(d, 'all')
+        ok, prov = profile_provenance(d, 'training')
         return (d['workloads'][workload] if ok else None), prov
     except Exception as e:
         return None, {'refused': f'{type(e).__name__}: {e}'}

@@ -42,17 +42,19 @@ def _layout_tag():
 
 
 TRAINER_ONLY = ('pnrf_train.hip', 'pnrf_tchain.h', 'pnrf_hgemm.h')     # sources no inference kernel is built from
+INFERENCE_ONLY = ('pnrf_mlp_kernels.hip',)                           # ... and the one no trainer kernel is built from (the trainer has its own chains)
 
 
 def _digest(scope='all'):
     """sha256 over the kernel sources + build flags.  scope 'all': every file (the library's .sha256 stamp, trainer profiles);
     'inference': without the trainer-only sources — what the rendering kernels are built from (tools/profile_round.sh records it, bench.py
-    compares it before quoting a profile), so that work on the trainer does not void the frame's PMC profile."""
+    compares it before quoting a profile), so that work on the trainer does not void the frame's PMC profile; 'training': without the fused
+    inference kernels' source, for the trainer's profile (tools/profile_train.sh)."""
     h = hashlib.sha256()
     files = sorted(os.listdir(CSRC)) + ['../../include/pronerf_hip.h']
     for f in files:
         p = os.path.join(CSRC, f)
-        if os.path.isfile(p) and not (scope == 'inference' and f in TRAINER_ONLY):
+        if os.path.isfile(p) and not (scope == 'inference' and f in TRAINER_ONLY) and not (scope == 'training' and f in INFERENCE_ONLY):
             h.update(f.encode()); h.update(open(p, 'rb').read())
     h.update(' '.join(FLAGS).encode())
     return h.hexdigest()

@@ -48,4 +48,4 @@ def test_profile_numbers_are_refused_when_the_kernel_sources_changed():
     assert (val is None and 'refused' in prov) or (val > 0 and prov['csrc_digest'] == now)
     # the frame's profile is keyed to the sources the rendering kernels are built from; the trainer's to everything
     from pronerf_amd import build
-    assert now == build._digest('inference') != build._digest('all') == bench.csrc_digest('all')
+    assert now == build._digest('inference') != build._digest('all') == bench.csrc_digest('all') != build._digest('training')

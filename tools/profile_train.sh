@@ -7,7 +7,7 @@ TAG=${1:?tag}
 OUT=$PWD/gpurun_out/prof_train_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"      # a second run into the same tag must not leave the first one's CSVs beside its own
 export TMPDIR=/tmp
-python3 -c "from pronerf_amd import build; print(build._digest())" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
+python3 -c "from pronerf_amd import build; print(build._digest('training'))" > "$OUT/csrc_digest.txt"      # what bench.py checks before quoting this profile
 for WLD in stage2_iteration stage1_explore_64 stage1_explore_256; do
   python3 tools/train_iter.py --workload $WLD --iters 20 --warmup 3 > "$OUT/$WLD.json"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$WLD" -- python3 tools/train_iter.py --workload $WLD --iters 10 --warmup 2 > "$OUT/stats_$WLD.json"
