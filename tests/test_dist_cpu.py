@@ -107,6 +107,30 @@ def test_ray_partition_properties():
         RayPartition(10, 2, 'striped')
 
 
+def test_ray_partition_properties_random_sizes():
+    """The same properties on drawn (n, world, block, kind): every ray exactly once, counts consistent, the gather index inverts the rank-major buffer."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(n=st.integers(1, 5000), w=st.integers(1, 9), blk=st.sampled_from([4, 32, 64, 1024]), kind=st.sampled_from(['contiguous', 'cyclic']))
+    def check(n, w, blk, kind):
+        p = RayPartition(n, w, kind, blk)
+        rows = [p.rows(r) for r in range(w)]
+        assert [len(x) for x in rows] == p.counts and sum(p.counts) == n and max(p.counts) == p.cmax
+        assert sorted(torch.cat(rows).tolist()) == list(range(n))
+        buf = torch.full((w * p.cmax,), -1, dtype=torch.int64)
+        for r in range(w):
+            buf[r * p.cmax: r * p.cmax + p.counts[r]] = rows[r]
+            a = p.frame_rays_args(r)
+            q = torch.arange(a['count'])
+            pix = a['first'] + q if 'block' not in a else a['first'] + (q // a['block']) * a['stride'] + q % a['block']
+            assert torch.equal(pix, rows[r])
+        gi = p.gather_index()
+        assert torch.equal(buf if gi is None else buf[gi], torch.arange(n))
+
+    check()
+
+
 def _gather_worker(rank, ws, port, n_total, frames, pipelined, q, kind='contiguous'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.set_num_threads(1)
