@@ -216,6 +216,55 @@ def pmc_traffic(kernel):
         return None, {'refused': f'{type(e).__name__}: {e}'}
 
 
+
+class PowerPoll:
+    """`rocm-smi --showpower --showmaxpower --showclocks` every ~0.3 s on a thread while a loop runs on the GPU: socket power against the package cap and
+    the shader clock, for the `steady_state` block (the frame is power-limited: DESIGN.md 4.4).  Best effort: without rocm-smi, or if its output does
+    not parse, the block carries no `power` entry."""
+
+    def __init__(self):
+        import shutil
+        import threading
+        self.exe = shutil.which('rocm-smi') or ('/opt/rocm/bin/rocm-smi' if os.path.exists('/opt/rocm/bin/rocm-smi') else None)
+        self.samples, self.cap, self.stop = [], None, threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self.stop.is_set():
+            try:
+                out = subprocess.run([self.exe, '--showpower', '--showmaxpower', '--showclocks'], capture_output=True, text=True, timeout=10).stdout
+                w = re.search(r'GPU\[0\].*Current Socket Graphics Package Power \(W\):\s*([0-9.]+)', out)
+                c = re.search(r'GPU\[0\].*Max Graphics Package Power \(W\):\s*([0-9.]+)', out)
+                k = re.search(r'GPU\[0\].*sclk clock level:.*\((\d+)Mhz\)', out)
+                if c:
+                    self.cap = float(c.group(1))
+                if w:
+                    self.samples.append((float(w.group(1)), int(k.group(1)) if k else None))
+            except Exception:
+                return
+            self.stop.wait(0.3)
+
+    def __enter__(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.thread:
+            self.thread.join(timeout=15)
+
+    def result(self):
+        if not self.samples:
+            return None
+        ws = [w for w, _ in self.samples]
+        ks = [k for _, k in self.samples if k]
+        return {'socket_w_mean': sum(ws) / len(ws), 'socket_w_max': max(ws), 'package_cap_w': self.cap, 'sclk_mhz_mean': (sum(ks) / len(ks)) if ks else None,
+                'samples': len(ws), 'what': 'rocm-smi polled on a thread while the steady-state frames ran (GPU 0 of this process\'s view)'}
+
+
 def chunked_1024(rend, rays, or_rays, ref, chunk=1024, reps=2, streams=4):
     """configs[1] read literally: the frame as ceil(n / 1024) pnrf_render_rays_fwd calls of <= 1024 rays each (744 x 1024 + 192 for the Fern
     frame), (a) launched back to back on ONE stream, (b) the same call sequence replayed as ONE hipGraph, (c) / (d) the same calls round-robin
@@ -645,15 +694,18 @@ def main():
                 # the driver fixes --steps (20 frames = 90 ms): the same loop over >= steady_seconds of back-to-back frames, where the chip sits at
                 # the clock its power limit allows.  `value` stays the driver's K steps; DESIGN.md quotes the steady figure when they differ by > 3 %.
                 nfr = max(args.steps, int(args.steady_seconds * 1e3 / ms) + 1)
-                t1 = time.perf_counter()
-                for _ in range(nfr):
-                    step()
-                fence()
-                sdt = time.perf_counter() - t1
+                with PowerPoll() as pw:
+                    t1 = time.perf_counter()
+                    for _ in range(nfr):
+                        step()
+                    fence()
+                    sdt = time.perf_counter() - t1
                 sms = sdt / nfr * 1e3
                 res['steady_state'] = {'ms_per_frame': sms, 'rays_per_s': n_total * nfr / sdt, 'frames': nfr, 'seconds': sdt,
                                        'vs_timed_region': sms / ms,
                                        'what': 'the timed loop again over >= %.1f s of back-to-back frames (host clock around barrier + synchronize)' % args.steady_seconds}
+                if pw.result():
+                    res['steady_state']['power'] = pw.result()
             if not args.no_shard_rehearsal:
                 from pronerf_amd.workloads import shard_rehearsal
                 res['shard_rehearsal'] = shard_rehearsal(weights, scene, H, W, dev, reps=40)
