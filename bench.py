@@ -9,14 +9,15 @@ Workload (BASELINE.json configs[1], BASELINE.md Â§4): one 1008x756 LLFF-Fern-geo
 762 048 rays, 8 samples/ray, 4 neighbour views, 48 ray-encoding points; synthetic poses/images
 and seeded "trained-like" weights (no dataset/checkpoint ships).  A step = one pass of the hot
 path (sampler MLP in two passes: plain fp16 for every ray + fp32-grade split fp16 for the rays whose depth order the first pass cannot
-decide | neighbour projection + refine MLP bf16 | NeRF MLP bf16 + alpha compositing) over one frame: ONE pnrf_render_rays_fwd call renders the whole frame, as the reference
+decide | neighbour projection + refine MLP fp16 | NeRF MLP bf16 + alpha compositing) over one frame: ONE pnrf_render_rays_fwd call renders the whole frame, as the reference
 renders it in one render() call (run_S_eS_eN_alter_trt.py:329); the "1024-ray chunks" of BASELINE.json
 configs[1] are four of the 256-column workgroup batches each persistent kernel walks through inside its
 single launch.  Rays, images and weights are resident
 in HBM before the timed region, exactly like the reference's timed loop
-(run_S_eS_eN_alter_trt.py:327-332).  At N>1 the frame's rays are split into contiguous ranges,
-one per rank, and the per-rank [n,4] rgb+depth tiles are all-gathered over RCCL inside the timed
-region ("strong" scaling: the frame is fixed).
+(run_S_eS_eN_alter_trt.py:327-332).  At N>1 rank r renders the 1024-ray blocks r, r + N, r + 2N, ... of the frame
+(--partition cyclic, the default: contiguous ranges put the rays the sampler's second pass re-renders on one rank), and the per-rank
+[n,4] rgb+depth tiles are all-gathered over RCCL inside the timed region, the gather of frame i behind the render of frame i + 1
+("strong" scaling: the frame is fixed).
 
 Rank 0 prints ONE JSON line (see the driver contract); at N=1 it carries `roofline`, `cpu_baseline`
 (the CPU oracle on the host cores, 65 536 rays of the same frame) and `gpu_eager_baseline`: the oracle's
@@ -25,11 +26,14 @@ eager fp32 torch graph on the same GPU, whole frame in one call, device events â
 published number exists for the metric (BASELINE.md Â§1), so `vs_baseline` is value / that measured baseline
 and `vs_baseline_kind` says so.  Both baselines run after the timed region; oracle/ is imported only there.
 
-Also after the timed region, at N=1 (each can be switched off): `chunked_1024` â€” the same frame as 745 calls of <= 1024 rays (the literal
-reading of configs[1]) and the same through one hipGraph, next to the one-call figure; `variants` â€” the frame with the round-2 sampler
-(split fp16 for every ray); `train` â€” the training iterations of configs[3] / configs[4] (stage-2 iteration at 4096 rays x 17 views of
-756x1008; stage-1 exploration iterations at 64 and 256 samples per ray) with their algorithmic TFLOP/s, HBM bytes from the committed
-profiles/r03_train_pmc_summary.json and the same iteration as eager torch autograd + torch.optim.Adam on this GPU.
+Also after the timed region, at N=1 (each can be switched off): `steady_state` â€” the timed loop again over >= 2 s of frames, with socket power /
+package cap / shader clock polled from rocm-smi meanwhile (the path is power-limited: DESIGN.md 4.4); `shard_rehearsal` â€” this GPU's time on the
+first / middle / last rank's share of the frame at N = 2, 4, 8 (contiguous and block-cyclic) and on 1024- / 4096-ray calls; `chunked_1024` â€” the
+same frame as 745 calls of <= 1024 rays (the literal reading of configs[1]): on one stream, over four streams, and each as one hipGraph, next to
+the one-call figure; `variants` â€” the frame with other operand types / the round-2 sampler; `train` â€” the training iterations of configs[3] /
+configs[4] (stage-2 iteration at 4096 rays x 17 views of 756x1008; stage-1 exploration iterations at 64 and 256 samples per ray) with their
+algorithmic TFLOP/s, a per-kernel table measured in the run, HBM bytes from the newest committed profiles/r*_train_pmc_summary.json (quoted with
+its provenance, refused when the trainer's sources changed since) and the same iteration as eager torch autograd + torch.optim.Adam on this GPU.
 """
 from __future__ import annotations
 
