@@ -64,7 +64,7 @@ class FrameGather:
     ``submit()``; the all-gather of that frame then runs on the collective's stream while the next frame renders into the other buffer
     (``depth`` buffers, ``async_op=True``; ``acquire`` waits — a stream wait on GPU backends, the host does not block — until the gather
     that last used a buffer is done).  Shards are padded to the largest one (they differ by at most one ray); ``frame(b)`` is the
-    assembled [n_total, C] frame of buffer ``b``.  ``bench.py`` times exactly this at N > 1."""
+    assembled [n_total, C] frame of buffer ``b`` (in pixel order: see ``_set_index``).  ``bench.py`` times exactly this at N > 1."""
 
     def __init__(self, n_total: int, channels: int = 4, device=None, dtype=torch.float32, depth: int = 2, pipelined: bool = True,
                  collective=None, partition=None):
@@ -91,7 +91,17 @@ class FrameGather:
         self.fulls = [torch.empty(self.world * self.cmax, channels, device=device, dtype=dtype) if self.collective else None for _ in range(self.depth)]
         self.pending = [None] * self.depth
         self._next = 0
-        self._index = partition.gather_index(device) if self.collective else None
+        self._set_index(partition.gather_index(device) if self.collective else None, device, dtype)
+
+    def _set_index(self, index, device, dtype):
+        """Frame order of the gathered buffer (None: it already is the frame).  With an index and a GPU collective (RCCL) the reorder is part of
+        the frame's pipeline: one index_select into ``frames[b]`` on a side stream that waits for the gather — stream order, the host does not
+        block — so that what ``bench.py`` times at N > 1 ends with the frame assembled in pixel order; other backends reorder in ``frame()``."""
+        self._index = index
+        self._eager = index is not None and self.pipelined and dist.get_backend() == 'nccl'
+        self.frames = [torch.empty(self.n_total, self.channels, device=device, dtype=dtype) for _ in range(self.depth)] if self._eager else None
+        self._side = torch.cuda.Stream(device=device) if self._eager else None
+        self._done = [None] * self.depth
 
     def acquire(self) -> int:
         """Index of the buffer the next frame renders into (``outs[b][:count]``), free of any gather still reading it."""
@@ -105,6 +115,13 @@ class FrameGather:
             return
         if self.pipelined:
             self.pending[b] = dist.all_gather_into_tensor(self.fulls[b], self.outs[b], async_op=True)
+            if self._eager:
+                with torch.cuda.stream(self._side):
+                    self.pending[b].wait()                      # the side stream waits for the collective (no host block)
+                    torch.index_select(self.fulls[b], 0, self._index, out=self.frames[b])
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                self._done[b] = ev
         else:
             dist.all_gather_into_tensor(self.fulls[b], self.outs[b])
 
@@ -112,6 +129,9 @@ class FrameGather:
         if self.pending[b] is not None:
             self.pending[b].wait()
             self.pending[b] = None
+        if self._done[b] is not None:                           # the next gather into fulls[b] / reader of frames[b] comes behind the reorder
+            torch.cuda.current_stream().wait_event(self._done[b])
+            self._done[b] = None
 
     def fence(self):
         for b in range(self.depth):
@@ -123,6 +143,8 @@ class FrameGather:
         self._wait(b)
         if not self.collective:
             return self.outs[b][:self.count]
+        if self._eager:
+            return self.frames[b]
         full = self.fulls[b]
         return full if self._index is None else full.index_select(0, self._index)
 

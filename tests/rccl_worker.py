@@ -38,6 +38,23 @@ def main():
             same.append(bool(torch.equal(fg.frame(1 - b), ref)))
     fg.fence()
     same.append(bool(torch.equal(fg.frame(b), ref)))
+    # the stream-ordered reorder of a gathered buffer that is not in frame order (block-cyclic shards at N > 1): forced here with a permutation
+    # as the gather index — frame(b) must be the gathered rows in that order, for the frame whose reorder ran beside the next frame's kernels too
+    perm = torch.randperm(H * W, generator=torch.Generator().manual_seed(3)).to(dev)
+    fg2 = FrameGather(H * W, 4, device=dev, pipelined=True, collective=True)
+    fg2._set_index(perm, dev, torch.float32)
+    assert fg2._eager and fg2.frames[0].is_cuda
+    want = ref.index_select(0, perm)
+    reordered = []
+    for i in range(5):
+        b = fg2.acquire()
+        fg2.outs[b].zero_()
+        rend.render_rays(rays, or_rays, out=fg2.outs[b][:fg2.count])
+        fg2.submit(b)
+        if i >= 1:
+            reordered.append(bool(torch.equal(fg2.frame(1 - b), want)))
+    fg2.fence()
+    reordered.append(bool(torch.equal(fg2.frame(b), want)))
     # the plain collective on a device tensor, and an all-reduce (what allreduce_gradients issues), through the same communicator
     x = torch.arange(1024, device=dev, dtype=torch.float32)
     y = torch.empty_like(x)
@@ -48,7 +65,7 @@ def main():
     backend = dist.get_backend()
     dist.barrier()
     dist.destroy_process_group()
-    print(json.dumps({'backend': backend, 'world': 1, 'frames_equal': same, 'plain_collectives_ok': ok_plain,
+    print(json.dumps({'backend': backend, 'world': 1, 'frames_equal': same, 'reordered_frames_equal': reordered, 'plain_collectives_ok': ok_plain,
                       'rccl': getattr(torch.cuda, 'nccl', None) is not None and list(torch.cuda.nccl.version())}))
 
 

@@ -25,4 +25,4 @@ def test_rccl_all_gather_through_frame_gather_world_size_one():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert j['backend'] == 'nccl' and j['world'] == 1
-    assert j['frames_equal'] == [True] * 5 and j['plain_collectives_ok']
+    assert j['frames_equal'] == [True] * 5 and j['reordered_frames_equal'] == [True] * 5 and j['plain_collectives_ok']
