@@ -81,3 +81,7 @@ struct pnrf_mlp {
 int pnrf_sampler_fwd_ws_impl(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
                              int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, int64_t workspace_bytes, float kappa,
                              bool ws_clean, void* stream);
+// pnrf_nerf_train_fwd with a batch queue (two ints, zero between launches): the context's NeRF stage hands its batches out dynamically
+int pnrf_nerf_fwd_queue_impl(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z, const float* add_sorted,
+                             const float* mul_sorted, const float* noise, float clampv, int white_bkgd, int S, float* rgbd, float* raw,
+                             int64_t n, int* queue, void* stream);

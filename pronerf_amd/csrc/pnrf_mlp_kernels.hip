@@ -1081,6 +1081,7 @@ struct NerfArgs {
   const float* noise; int white_bkgd;                                // training-time compositing: sigma noise [n,8], white background
   float clampv; int S;                                               // raw clamp (stage 1: 10), samples per ray (8; stage-1 exploration: 8..256)
   float* y; const int* outmap;                      // module-level consumer
+  int* queue;                                       // nerf16_kernel: [0] batches handed out beyond the first round, [1] workgroups done; NULL = static stride
 };
 
 // sin / cos of scale * x, scale a power of two: hardware v_sin / v_cos on the fraction of the angle in revolutions (valid for any
@@ -1435,7 +1436,15 @@ __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfA
   const float* biaslane = bias_lds + 4 * g;
   const bool composite = a.S == 8 && a.rgbd;
 
-  for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+  // Batch hand-out.  Without a queue (operator-level calls): the static stride.  With one (a context's calls): a workgroup's first batch is its
+  // static one, every further one comes from an atomic counter — a workgroup that starts late because another stream's kernel held its CU (a
+  // collective beside the renderer at N > 1: tools/cu_steal_probe.py) then finds the work done instead of running its whole share of ~12-93
+  // batches after everybody else has finished.  The counter is fetched at the top of a batch and consumed at its end (its latency is hidden);
+  // the last workgroup to leave puts the two words back to zero for the next launch on this context.
+  __shared__ __attribute__((aligned(16))) int s_next[4];
+  for (int batch = blockIdx.x; batch < a.nbatch;) {
+    int q_pend = 0;
+    if (a.queue && threadIdx.x == 0) q_pend = atomicAdd(a.queue, 1);
     int64_t row[NCB];
     bool valid[NCB];
     v8 Bo[NCB][NB_KS_H], Bn[NCB][NB_KS_H], Bx[NCB];
@@ -1591,8 +1600,18 @@ __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfA
       }
       if (valid[cb] && g == 0 && s == 0) *(float4*)(a.rgbd + ray * 4) = make_float4(s0, s1, s2, s3);
     });
+    if (a.queue) {
+      if (threadIdx.x == 0) s_next[0] = (int)gridDim.x + q_pend;
+      __syncthreads();
+      batch = s_next[0];          // (rewritten at the end of the next batch, many slot barriers from here)
+    } else {
+      batch += gridDim.x;
+    }
   }
   st.drain();
+  if (a.queue && threadIdx.x == 0) {
+    if (atomicAdd(a.queue + 1, 1) == (int)gridDim.x - 1) { a.queue[0] = 0; a.queue[1] = 0; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
@@ -1693,7 +1712,7 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
     // counters[0] rays on the list, [1] the same for pnrf_ctx_sampler_stats, [2] finished workgroups of pass 2, [3] rays on the saturated list,
     // [4] finished workgroups of pass 3, [5] = [3] for the stats.  The last workgroups of passes 2 / 3 leave [0], [2] / [3], [4] at zero, so a
     // workspace that has been through a call (or was cleared once, as a context's is) needs no memset.
-    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), st));
+    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 16 * sizeof(int), st));      // (the whole header: words 8, 9 are the context's NeRF-stage queue)
     SamplerArgs p = a;
     p.blob = h->d_blob_p1; p.nslots = h->nslots_p1; p.bias = h->d_bias_p1; p.nbias = h->nbias_p1;
     p.list = counters + 16; p.counters = counters; p.p1c = h->d_p1c; p.kappa = kappa;
@@ -1717,7 +1736,7 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
   }
   if (workspace_split) {                // PNRF_VARIANT_SAMPLER_SPLIT with a workspace: the split kernel for every ray + the exact-fp32 pass for saturated ones
     int* counters = (int*)workspace_split;
-    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), st));
+    if (!ws_clean) PNRF_HIP(hipMemsetAsync(counters, 0, 16 * sizeof(int), st));      // (the whole header: words 8, 9 are the context's NeRF-stage queue)
     SamplerArgs f = a;
     a.blob = h->d_blob_h16; a.nslots = h->nslots_h16;
     a.counters = counters; a.sat_list = counters + 16 + n;
@@ -1842,6 +1861,14 @@ extern "C" int pnrf_nerf_fwd(const pnrf_mlp_t* h, const float* pts, const float*
 extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
                                    const float* add_sorted, const float* mul_sorted, const float* noise, float clampv, int white_bkgd,
                                    int S, float* rgbd, float* raw, int64_t n, void* stream) {
+  return pnrf_nerf_fwd_queue_impl(h, pts, rays, z, add_sorted, mul_sorted, noise, clampv, white_bkgd, S, rgbd, raw, n, nullptr, stream);
+}
+
+// queue: two ints of the caller's (a context's) device memory, zero before the first launch and left at zero by every launch (nerf16_kernel);
+// NULL = static batch stride
+int pnrf_nerf_fwd_queue_impl(const pnrf_mlp_t* h, const float* pts, const float* rays, const float* z,
+                             const float* add_sorted, const float* mul_sorted, const float* noise, float clampv, int white_bkgd,
+                             int S, float* rgbd, float* raw, int64_t n, int* queue, void* stream) {
   PNRF_REQUIRE(h && (h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS), PNRF_E_ARG, "pnrf_nerf_fwd: handle is not a nerf net");
   PNRF_REQUIRE(n >= 0 && S >= 1 && (n == 0 || (pts && rays)), PNRF_E_ARG, "pnrf_nerf_fwd: null pointer / negative n / bad S");
   PNRF_REQUIRE(n == 0 || (S == 8 ? ((rgbd && z) || raw) : (raw && !rgbd)), PNRF_E_ARG,
@@ -1853,6 +1880,7 @@ extern "C" int pnrf_nerf_train_fwd(const pnrf_mlp_t* h, const float* pts, const 
   a.n = n;
   a.pts = pts; a.rays = rays; a.z = z; a.add = add_sorted; a.mul = mul_sorted; a.rgbd = rgbd; a.raw = raw;
   a.noise = noise; a.white_bkgd = white_bkgd; a.clampv = clampv; a.S = S;
+  a.queue = h->variant == PNRF_VARIANT_BF16_32X32 ? nullptr : queue;          // (nerf_kernel, the 32x32x16 variant, keeps the static stride)
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
   a.nbatch = (int)((n * S + rows - 1) / rows);

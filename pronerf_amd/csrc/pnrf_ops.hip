@@ -837,7 +837,9 @@ extern "C" int pnrf_render_rays_fwd(pnrf_ctx_t* c, const float* rays, const floa
   if (ev) PNRF_HIP(hipEventRecord(ev[1], st));
   if ((rc = pnrf_refine_project_fwd(c->refine, rays, or_rays, depth, img4, proj, nb, Hf, Wf, eps, z, pts, n, stream))) return rc;   // :637-681
   if (ev) PNRF_HIP(hipEventRecord(ev[2], st));
-  if ((rc = pnrf_nerf_fwd(c->nerf, pts, rays, z, add, mul, rgbd, nullptr, n, stream))) return rc;                      // :691-694
+  // NeRF stage with its batches handed out dynamically (words 8, 9 of the sampler workspace's 16-word header: zero since creation, left at zero
+  // by every launch): a workgroup that another stream's kernel keeps off its CU for a while does not hold the frame up with its whole share
+  if ((rc = pnrf_nerf_fwd_queue_impl(c->nerf, pts, rays, z, add, mul, nullptr, 0.f, 0, 8, rgbd, nullptr, n, (int*)c->sampler_ws + 8, stream))) return rc;   // :691-694
   if (ev) {
     PNRF_HIP(hipEventRecord(ev[3], st));
     c->prof_n += 1;
