@@ -75,6 +75,7 @@ def parse():
     ap.add_argument('--no-shard-rehearsal', action='store_true', help='skip the one-GPU rehearsal of the 1/2, 1/4, 1/8-frame shards and small calls (rank 0, N=1)')
     ap.add_argument('--steady-seconds', type=float, default=2.0, help='seconds of back-to-back frames after the timed region (steady_state block; 0 = skip)')
     ap.add_argument('--no-train', action='store_true', help='skip the training-iteration block (rank 0, N=1)')
+    ap.add_argument('--no-optimizer-weights', action='store_true', help='skip the frame on the optimizer-trained nets (weights_optimizer block; rank 0, N=1)')
     ap.add_argument('--no-train-eager', action='store_true', help='training block without the eager-torch legs')
     ap.add_argument('--launch-timeout', type=float, default=900.0, help='N>1 started without a launcher: seconds before the ranks are stopped')
     ap.add_argument('--partition', default='cyclic', choices=('cyclic', 'contiguous'),
@@ -156,6 +157,61 @@ def gpu_eager_baseline(weights, scene, dev, reps=5):
     return {'value': n / mean * 1e3, 'unit': 'rays/s', 'ms_per_frame': mean, 'ms_per_frame_best': min(ms), 'reps': reps, 'rays': n, 'dtype': 'f32',
             'kind': 'port', 'what': 'oracle torch graph on the same GPU (eager, fp32, unfused, whole frame in one call; BASELINE.md §4 item 2)',
             'torch': torch.__version__}, rgb
+
+
+def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2):
+    """The frame on the only optimizer-shaped nets in the tree (tests/golden/trained_synth_scene.npz: this package's stage-1 + stage-2 drivers on the
+    synthetic LLFF scene; sampler, refine and the NeRF-CLASS fine net the trainers save — run_S_eS_eN_alter_trt.py:468-481 loads exactly such a
+    checkpoint): ms per frame, the share of rays the two-pass sampler sends through its second pass (27 % here against 15 % on the seeded set the
+    headline times), per-kernel ms, and rgb PSNR against the oracle's eager graph on the same nets.  After the timed region; rank 0, N = 1."""
+    from pronerf_amd import synthetic
+    from pronerf_amd.render import Renderer
+    from pronerf_amd.workloads import timed_ms
+    try:
+        w = synthetic.load_trained_fixture()
+    except (OSError, KeyError) as e:
+        return {'skipped': f'fixture not readable: {e}'}
+    rend = Renderer({k: w[k] for k in ('sampler', 'refine', 'nerf')}, max_rays=n_total, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W)
+    out = torch.empty(n_total, 4, device=dev)
+    ms = timed_ms(lambda: rend.render_rays(rays, or_rays, out=out), frames, 5)[0]
+    rend.ctx.profile_begin(frames)
+    for _ in range(frames):
+        rend.render_rays(rays, or_rays, out=out)
+    torch.cuda.synchronize()
+    prof, _ = rend.ctx.profile_end()
+    n2, n3 = rend.ctx.sampler_stats(), rend.ctx.sampler_saturated()
+    res = {'weights': 'tests/golden/trained_synth_scene.npz (optimizer-trained: stage-1 4000 + stage-2 3000 iterations; NeRF-class fine net)',
+           'ms_per_frame': ms, 'rays_per_s': n_total / ms * 1e3, 'kernels_ms': prof,
+           'sampler_two_pass': {'rays_second_pass': n2, 'fraction': n2 / n_total, 'rays_third_pass': n3}}
+    if eager_reps > 0:
+        from oracle import pronerf_oracle as orc                        # checker only, after every timed loop of this leg
+        torch.backends.cuda.matmul.allow_tf32 = False
+        td = lambda x: torch.as_tensor(x).to(dev)
+        wd = {k: {'W': [td(x) for x in w[k]['W']], 'b': [td(x) for x in w[k]['b']]} for k in ('sampler', 'refine')}
+        c = w['nerfcls']
+        pair = lambda p: (td(p[0]), td(p[1]))
+        wd['nerfcls'] = {'pts_linears': [pair(p) for p in c['pts_linears']], 'feature_linear': pair(c['feature_linear']), 'alpha_linear': pair(c['alpha_linear']),
+                         'views_linears': [pair(c['views_linears'][0])], 'rgb_linear': pair(c['rgb_linear'])}
+        fr = orc.frame_setup(scene)
+        t1, t2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ems = []
+        with torch.no_grad():
+            for i in range(eager_reps + 1):
+                t1.record()
+                ref = orc.render_rays_infer(wd, rays, or_rays, fr['images'].to(dev), fr['proj'].to(dev), mm_input=fr['mm_input'].to(dev), nerf='nerfcls')
+                t2.record(); torch.cuda.synchronize()
+                if i >= 1:
+                    ems.append(t1.elapsed_time(t2))
+        mse = float(((out[:, :3].double() - ref['rgb'].double()) ** 2).mean())
+        res['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse))) if mse > 0 else float('inf')
+        res['eager_ms_per_frame'] = sum(ems) / len(ems)
+        res['vs_eager'] = res['eager_ms_per_frame'] / ms
+        del ref, wd, fr
+    del rend, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def sustained_mfma_peak():
@@ -595,10 +651,13 @@ def main():
     fg = FrameGather(n_total, 4, device=dev, pipelined=pipeline, partition=part)
     outs = fg.outs
 
+    last_buf = [0]
+
     def step():
         b = fg.acquire()
         rend.render_rays(rays, or_rays, out=outs[b][:count])
         fg.submit(b)
+        last_buf[0] = b
 
     def fence():
         fg.fence()
@@ -630,6 +689,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     finite = bool(all(torch.isfinite(o).all().item() for o in outs))
+    # the assembled frame of the last timed step, as bytes: the same digest at every N (ray shards + gather change no row) — tests/test_dist_gpu.py,
+    # tests/test_bench_gpu.py compare it with the N = 1 line's
+    import hashlib
+    frame_sha = hashlib.sha256(fg.frame(last_buf[0]).contiguous().cpu().numpy().tobytes()).hexdigest() if rank == 0 else None
+    per_rank = None
+    if world > 1:
+        # after the timed region: where a frame's time goes on every rank — its render alone (device events) and the exchange alone (all-gather +
+        # reorder of an already rendered tile, host clock around fence) — so that a SCALE line explains itself
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            rend.render_rays(rays, or_rays, out=outs[0][:count])
+        e1.record(); torch.cuda.synchronize()
+        render_ms = e0.elapsed_time(e1) / reps
+        dist.barrier(); torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(reps):
+            fg.submit(fg.acquire())
+        fg.fence(); torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) / reps * 1e3
+        mine = {'rank': rank, 'device': f'{dev} ({torch.cuda.get_device_name(dev)})', 'rays': count, 'render_ms': render_ms, 'gather_ms': gather_ms,
+                'rays_second_pass': rend.ctx.sampler_stats()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     sampler_f32 = False                      # the product path: default kernel variants (the library reads no environment)
     res = None
@@ -660,6 +745,8 @@ def main():
                        'gather_pipelined': bool(pipeline), 'ray_partition': (part.kind + (f' (blocks of {part.block} rays round-robin)' if part.kind == 'cyclic' else '')),
                        'parallelism': f'ray-sharded x{world}' + (' + RCCL all-gather of [n,4] rgb+depth' if world > 1 else '')},
             'outputs_finite': finite,
+            'frame_sha256': frame_sha,
+            'per_rank': per_rank,
             'algorithmic_flop_per_ray': FLOP_PER_RAY,
             'e2e_mfma_tflops': value * FLOP_PER_RAY / 1e12,
         }
@@ -747,6 +834,8 @@ def main():
                 res['vs_baseline'] = value / eager['value']
                 res['vs_baseline_kind'] = ('value / gpu_eager_baseline.value, measured in this run (BASELINE.md §4 item 2: the denominator of the >= 10x '
                                            'target); the reference publishes no number for this metric')
+            if not args.no_optimizer_weights:
+                res['weights_optimizer'] = optimizer_weights_leg(scene, dev, n_total, eager_reps=0 if args.no_gpu_eager_baseline else min(2, args.eager_reps))
             if not args.no_train:
                 del rend
                 torch.cuda.empty_cache()

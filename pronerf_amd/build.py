@@ -22,7 +22,19 @@ LIB = os.path.join(LIBDIR, 'libpronerf_hip.so')
 SOURCES = ['pnrf_pack.hip', 'pnrf_ops.hip', 'pnrf_mlp_kernels.hip', 'pnrf_train.hip']
 LINK = []                    # no library dependencies: every kernel, the training step's layer products included, is in csrc/
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
+# No packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) in any kernel of the library.  Round 5 traced round 4's "co-residency
+# hazard" to them: in the fused refine kernel's scalar epilogue — where the SLP vectorizer had paired the fp32 arithmetic — a v_pk_mul_f32 returned 0 in one
+# 16-lane quarter of a wave a few times per thousand calls, but only while a workgroup of a DIFFERENT fused kernel shared the CU (loads, every layer's B
+# operand and the last accumulators bit-identical in the failing batches; 121 / 209 / 102 bad chunks per 29 800 with packed fp32, 0 per 134 100 without:
+# NOTEBOOK §19, profiles/r05_coresidency_*).  The feature is switched off for the device compilation (the host pass prints "not a recognized feature" for
+# it, filtered below); tests/test_abi_cpu.py disassembles the built library and fails on any packed-fp32 opcode.
+NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-Wno-pass-failed'] + NO_PACKED_FP32
+
+
+def _quiet(out: str) -> str:
+    """hipcc's output without the host pass's note about the device-only target feature."""
+    return '\n'.join(l for l in out.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l).strip()
 
 
 def _hipcc():
@@ -80,8 +92,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {s}:\n{out}')
-        if verbose and out.strip():
-            print(out)
+        if verbose and _quiet(out):
+            print(_quiet(out))
     cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs + LINK
     if verbose:
         print(' '.join(cmd), flush=True)
@@ -90,6 +102,49 @@ def build(force: bool = False, verbose: bool = True) -> str:
         os.remove(o)
     open(stamp, 'w').write(dig)
     return LIB
+
+
+def device_code_objects(lib: str = LIB):
+    """The gfx950 code objects inside a built library: clang offload bundles ("__CLANG_OFFLOAD_BUNDLE__": entry count, then per entry offset / size /
+    triple) found in the file, one per translation unit.  -> list of bytes.  (roc-obj-ls needs a perl module this image lacks.)"""
+    import struct
+    data = open(lib, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    out = []
+    pos = data.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from('<Q', data, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', data, q)
+            triple = data[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if ARCH in triple and size:
+                out.append(data[pos + off:pos + off + size])
+        pos = data.find(magic, pos + len(magic))
+    return out
+
+
+def device_opcodes(lib: str = LIB):
+    """Counter of the instruction mnemonics in every gfx950 code object of the library (llvm-objdump -d)."""
+    import collections
+    import tempfile
+    objdump = os.path.join(os.path.dirname(_hipcc()), '..', 'lib', 'llvm', 'bin', 'llvm-objdump')
+    if not os.path.exists(objdump):
+        objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    ops = collections.Counter()
+    for co in device_code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix='.co') as f:
+            f.write(co); f.flush()
+            txt = subprocess.run([objdump, '-d', f'--mcpu={ARCH}', f.name], stdout=subprocess.PIPE, text=True, check=True).stdout
+        for line in txt.splitlines():
+            t = line.split()
+            if len(t) >= 2 and line.startswith('\t') and (t[0].startswith(('v_', 's_', 'ds_', 'global_', 'buffer_', 'flat_', 'scratch_'))):
+                ops[t[0]] += 1
+    return ops
+
+
+PACKED_FP32_OPCODES = ('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32', 'v_pk_mov_b32')
 
 
 CEILING_SRC = os.path.join(os.path.dirname(HERE), 'tools', 'mfma_ceiling.hip')
@@ -107,19 +162,43 @@ def build_ceiling_probe(force: bool = False) -> str:
     return CEILING_BIN
 
 
+FOREIGN_SRC = os.path.join(os.path.dirname(HERE), 'tools', 'foreign_kernels.hip')
+FOREIGN_LIB = os.path.join(LIBDIR, 'libforeign_kernels.so')
+
+
+def build_foreign_kernels(force: bool = False) -> str:
+    """tools/foreign_kernels.hip -> pronerf_amd/lib/libforeign_kernels.so: the stand-in kernels of other streams that the co-residency stress
+    test (tests/test_coresidency_gpu.py, tools/coresidency_stress.py) runs beside the renderer.  Test infrastructure, not part of the product."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not os.path.exists(FOREIGN_SRC):
+        return ''
+    if force or not os.path.exists(FOREIGN_LIB) or os.path.getmtime(FOREIGN_LIB) < os.path.getmtime(FOREIGN_SRC):
+        subprocess.run([_hipcc(), '-O3', f'--offload-arch={ARCH}', '-shared', '-fPIC', FOREIGN_SRC, '-o', FOREIGN_LIB], check=True)
+    return FOREIGN_LIB
+
+
 def build_variant(name: str, extra_flags=(), csrc: str = CSRC, include: str = INCLUDE) -> str:
     """Build pronerf_amd/lib/libpronerf_hip_<name>.so with extra compiler flags (A/B timing, diagnostics)."""
     os.makedirs(LIBDIR, exist_ok=True)
     out = os.path.join(LIBDIR, f'libpronerf_hip_{name}.so')
     srcs = [os.path.join(csrc, s) for s in SOURCES]
     cmd = [_hipcc()] + FLAGS + list(extra_flags) + ['-shared', '-I', include, '-o', out] + srcs + LINK
-    subprocess.run(cmd, check=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if _quiet(r.stdout):
+        print(_quiet(r.stdout))
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed building variant {name}')
     return out
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '--variant':
-        print(build_variant(sys.argv[2], sys.argv[3:]))
+        # '+packed-fp32' as an extra flag re-enables the packed-fp32 instructions (reproducer builds of tools/coresidency_stage.py)
+        extra = [f for f in sys.argv[3:] if f != '+packed-fp32']
+        if '+packed-fp32' in sys.argv[3:]:
+            extra += ['-Xclang', '-target-feature', '-Xclang', '+packed-fp32-ops']
+        print(build_variant(sys.argv[2], extra))
     else:
         print(build(force='--force' in sys.argv))
         print(build_ceiling_probe(force='--force' in sys.argv))
+        print(build_foreign_kernels(force='--force' in sys.argv))

@@ -785,6 +785,28 @@ struct HiddenEpi {
   }
 };
 
+#ifdef PNRF_DEBUG_EHEAD
+// Diagnostic build only (tools/coresidency_repro.py): the fused refine epilogue records, per (ray, half), the ray / depth rows it holds in registers
+// since the batch head + where it ran, keyed by the ray's index in the frame (rays_base = first row of the frame's ray tensor).
+__device__ float* g_dbg_ehead;
+__device__ const float* g_dbg_rays_base;
+constexpr int DBG_STRIDE = 128;        // floats per (ray, half): [0,16) e_d / e_ray, [16,24) placement, [24,32) xor of the B operand after every layer, [32,48) last accumulators, [48,120) inputs
+template <int CNT, class V, int NK>
+__device__ __forceinline__ int dbg_xor(const V (&B)[NK]) {
+  int x = 0;
+#pragma unroll
+  for (int k = 0; k < CNT; ++k) {
+    const i32x4_t w = __builtin_bit_cast(i32x4_t, B[k]);
+    x ^= w[0] ^ w[1] ^ w[2] ^ w[3];
+  }
+  return x;
+}
+extern "C" int pnrf_debug_set_ehead(float* buf, const float* rays_base) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ehead), &buf, sizeof(buf));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_rays_base), &rays_base, sizeof(rays_base));
+  return (int)e;
+}
+#endif
 struct RefineArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
   int64_t n; int nbatch;
@@ -929,6 +951,13 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
             q[0] = hx; q[1] = hy; q[2] = hz; q[3] = m0; q[4] = m1; q[5] = m2;
           }
         }
+#ifdef PNRF_DEBUG_EHEAD
+        if (MODE == 1 && valid[cb] && g_dbg_ehead) {
+          float* d = g_dbg_ehead + (((a.rays - g_dbg_rays_base) / 11 + row[cb]) * 2 + h) * DBG_STRIDE;
+#pragma unroll
+          for (int i = 0; i < 72; ++i) d[48 + i] = feat[i];
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < R_KS0; ++ks) {
           float v[8];
@@ -945,14 +974,24 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
 #define PNRF_REFINE_PIECES 16
 #endif
     constexpr int RP = PNRF_REFINE_PIECES;      // pieces of the deferred hidden-layer epilogue (2, 8 or 16)
+#ifdef PNRF_DEBUG_EHEAD
+    float* dbgp = (MODE == 1 && valid[0] && g_dbg_ehead) ? g_dbg_ehead + (((a.rays - g_dbg_rays_base) / 11 + row[0]) * 2 + h) * DBG_STRIDE : nullptr;
+    auto dbg_cks = [&](int idx, int x) { if (dbgp) dbgp[24 + idx] = __int_as_float(x); };
+#endif
     auto hidden = [&](v8(&in)[NCB][KS_HID], v8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
       layer_bf16<NCB, KS_HID, NT_HID, R_POS_H, RP, F16>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
                                                    HiddenEpi<NCB, ACT_ELU, RP, P>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU, RP, P>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
+#ifdef PNRF_DEBUG_EHEAD
+      dbg_cks(1 + l, dbg_xor<KS_HID>(in[0]));        // `in` = the previous layer's output, complete since this call's first tile
+#endif
     };
     layer_bf16<NCB, R_KS0, NT_HID, 0, RP, F16>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU, RP, P>{Bn}, [](int) {}, pend);
+#ifdef PNRF_DEBUG_EHEAD
+    dbg_cks(0, dbg_xor<R_KS0>(Bo[0]));                 // the packed inputs
+#endif
     static_assert(R_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
     for (int l = 0; l < 4; l += 2) {
       hidden(Bn, Bo, l);
@@ -985,6 +1024,9 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
     }
     if constexpr (MODE == 1) {
       layer_bf16<NCB, KS_HID, 1, R_POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
+#ifdef PNRF_DEBUG_EHEAD
+      dbg_cks(6, dbg_xor<KS_HID>(Bo[0]));              // the last hidden layer's output
+#endif
 #pragma unroll
       for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
     } else {                   // training: tile 0 = refine + offsets, tile 1 = rgb head (rgb_map0, refine2.py:637)
@@ -1058,6 +1100,24 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         pp[3 * s4 + 1] = ieee_add(ieee_add(oy, ieee_mul(dy, zv)), ieee_mul(1e-2f, fy));
         pp[3 * s4 + 2] = ieee_add(ieee_add(oz, ieee_mul(dz, zv)), ieee_mul(1e-2f, fz));
       }
+#ifdef PNRF_DEBUG_EHEAD
+      if (MODE == 1 && valid[cb] && g_dbg_ehead) {
+        const int64_t g = (a.rays - g_dbg_rays_base) / 11 + row[cb];
+        float* d = g_dbg_ehead + (g * 2 + h) * DBG_STRIDE;
+        d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[8 + i] = r[i];
+        d[16] = __int_as_float((int)__builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_ID
+        d[17] = __int_as_float((int)__builtin_amdgcn_s_getreg((31 << 11) | 20));     // XCC_ID
+        d[18] = __int_as_float((int)blockIdx.x * 65536 + (int)threadIdx.x);
+        d[19] = __int_as_float((int)(__builtin_readcyclecounter() >> 8));
+        d[20] = __int_as_float(batch);
+        d[21] = __int_as_float((int)__builtin_amdgcn_s_getreg((31 << 11) | 6));      // LDS_ALLOC (physical base / size of the workgroup's LDS)
+        d[22] = __int_as_float((int)__builtin_amdgcn_s_getreg((31 << 11) | 5));      // GPR_ALLOC (physical VGPR / SGPR base and size of the wave)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[32 + i] = fin[cb][i];
+      }
+#endif
       if (valid[cb]) {
         *(float4*)(a.z + row[cb] * 8 + 4 * h) = make_float4(zz[0], zz[1], zz[2], zz[3]);
         float4* pq = (float4*)(a.pts + row[cb] * 24 + 12 * h);
@@ -1656,15 +1716,20 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
 //           whose time is the latency of one batch through the layers — two waves sharing a SIMD double it.
 // Same results bit for bit (a wave's instruction stream per batch does not depend on the shape).
 // A CU never holds two fused-MLP workgroups: wide ones exclude each other by registers (2 x 240 per SIMD lane), narrow ones by LDS (their
-// request is padded to NARROW_LDS_BYTES > 80 KiB).  Round 4 measured why: two 4-wave workgroups per CU ("paired" narrow launches) are 5-8 %
-// slower than WIDE on whole frames in every stage (twice the weight stream per CU; the ELU kernels are bound by their VALU issue cycles,
-// not by a phase lock of their waves: tools/elu_chain_probe.hip) and 5 % faster on a 1/8-frame shard — and, when calls on DIFFERENT streams
-// put workgroups of different kernels on one CU, a refine workgroup beside a NeRF / sampler one returned, a few times per thousand calls,
-// wrong rows for columns 16..31 of a wave (lanes 16-31 / 48-63 of loads issued in its batch head came back with other rays' data;
-// a delay or a full vmcnt wait behind the loads hid it, the cause inside the memory pipeline was not found: NOTEBOOK.md, round 4).  One
-// workgroup per CU is immune by construction and was clean over 10^5 concurrent calls (tests/test_render_gpu.py, tools/dbg_chunk*.py).
+// request is padded to NARROW_LDS_BYTES > 80 KiB).  This is a PERFORMANCE choice: two 4-wave workgroups per CU ("paired" narrow launches) are
+// 5-8 % slower than WIDE on whole frames in every stage (twice the weight stream per CU; the ELU kernels are bound by their VALU issue cycles,
+// not by a phase lock of their waves: tools/elu_chain_probe.hip) and only 5 % faster on a 1/8-frame shard.
+// (Round 4 also saw paired workgroups of DIFFERENT kernels return wrong rows — 16 consecutive rays of a refine wave — a few times per thousand
+// calls and excluded the configuration without finding the cause.  Round 5 found it (NOTEBOOK §19): not the batch-head loads but compiler-generated
+// PACKED FP32 arithmetic in the refine epilogue — loads, every layer's B operand and the last accumulators were bit-identical in the failing batches,
+// a v_pk_mul_f32 of the query-point arithmetic returned 0 in one 16-lane quarter of the wave; without packed-fp32 instructions the paired
+// configuration is clean over 134 100 concurrent chunks (121-209 bad chunks per 29 800 with them).  The library is built without them
+// (pronerf_amd/build.py NO_PACKED_FP32; tests/test_abi_cpu.py checks the disassembly), so the shape rule below no longer carries correctness.)
 enum { SHAPE_WIDE = PNRF_SHAPE_WIDE, SHAPE_NARROW = PNRF_SHAPE_NARROW };
-constexpr size_t NARROW_LDS_BYTES = 84 * 1024;      // two of them do not fit a CU's 160 KiB
+#ifndef PNRF_NARROW_LDS_BYTES
+#define PNRF_NARROW_LDS_BYTES (84 * 1024)
+#endif
+constexpr size_t NARROW_LDS_BYTES = PNRF_NARROW_LDS_BYTES;      // two of them do not fit a CU's 160 KiB (0: the paired shape of round 4, reproducer builds only — tools/coresidency_repro.py)
 // cols: columns of the launch (rays or ray samples); cpw: columns per wave of the stage's engine
 int stage_shape(const pnrf_mlp_t* h, int64_t cols, int cpw) {
   if (h->shape == SHAPE_WIDE || h->shape == SHAPE_NARROW) return h->shape;

@@ -105,16 +105,47 @@ def _packed_views(ref_rgb, ref_pose, n_samples, num_neighbor):
     return ent
 
 
+_MM_CHECKED = []     # at most one entry: (mm_input, its _version, ray_batch, its _version)
+
+
+def _check_mm_input(mm_input, ray_batch, n_pts):
+    """The reference's sampler consumes ``kwargs['mm_input']`` (run_S_eS_eN_alter_trt.py:625-628); the fused sampler recomputes the encoding
+    from ``ray_batch`` in its batch head.  That is the same thing only while ``mm_input`` IS the Pluecker encoding of ``ray_batch`` — what
+    ``render_path`` builds (trt.py:273-277).  So a caller's ``mm_input`` is verified, once per tensor (identity + in-place version, as
+    ``_packed_views`` does): every value within 8 ulp of max(|value|, 1) of ``ops.ray_encode(ray_batch)`` (the kernel's own encoding is bit-identical
+    to torch's on the CPU; a caller's GPU / fused-multiply-add evaluation may differ in the last bits), otherwise PnrfError — a different
+    ``mm_input`` would silently be ignored."""
+    if _MM_CHECKED:
+        m, mv, r, rv = _MM_CHECKED[0]
+        if m is mm_input and r is ray_batch and mv == mm_input._version and rv == ray_batch._version:
+            return
+    if mm_input.shape != (ray_batch.shape[0], 6 * n_pts):
+        raise PnrfError(f'render_rays: mm_input has shape {tuple(mm_input.shape)}, expected {(ray_batch.shape[0], 6 * n_pts)} (6 * N_point_ray_enc per ray)')
+    if mm_input.device != ray_batch.device:
+        raise PnrfError('render_rays: mm_input and ray_batch are on different devices')
+    want = ops.ray_encode(ray_batch, n_pts)
+    got = mm_input.to(torch.float32)
+    tol = 8 * torch.finfo(torch.float32).eps * torch.maximum(want.abs(), torch.ones_like(want))
+    bad = ~((got - want).abs() <= tol)              # NaN counts as different
+    if bool(bad.any()):
+        i = int(bad.any(1).nonzero()[0])
+        raise PnrfError(f'render_rays: mm_input is not the Pluecker encoding of ray_batch ({int(bad.sum())} values differ, first in row {i}: max |diff| '
+                        f'{float((got - want).abs().nan_to_num(float("inf")).max()):.3g}); the fused sampler encodes ray_batch itself (trt.py:273-277) and '
+                        'cannot honour a different mm_input — pass mm_input=None, or use ops.sampler_fwd on rays built from it')
+    _MM_CHECKED[:] = [(mm_input, mm_input._version, ray_batch, ray_batch._version)]
+
+
 def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., min_max_ray_net=None, refine_net=None,
                 N_point_ray_enc=0, embed_fn=None, embeddirs_fn=None, randomize=True, verbose=False, pytest=False, **kwargs):
     """Inference render of a ray batch (run_S_eS_eN_alter_trt.py:599-696).
 
     ray_batch [N,11] = [o'(3), d'(3), near, far, viewdir(3)] (NDC); or_ray_batch [N,11] the same in
-    camera/world space.  kwargs consumed: ``use_trt, num_neighbor, ref_rgb, ref_pose`` (``mm_input,
-    ro1, rd1, embed_rays`` are accepted and ignored: the kernels recompute the ray encoding and the
-    homogeneous rays from ray_batch / or_ray_batch, of which they are pure functions,
-    trt.py:250-277).  Returns ``{'rgb_map0', 'rgb_map1', 'depth_map'}``.
+    camera/world space.  kwargs consumed: ``use_trt, num_neighbor, ref_rgb, ref_pose, mm_input``; ``mm_input`` (the
+    reference's sampler input, trt.py:625-628) is VERIFIED to be the Pluecker encoding of ``ray_batch`` once per tensor
+    (``_check_mm_input``) and refused otherwise — the fused sampler recomputes that encoding in its batch head; ``ro1, rd1,
+    embed_rays`` are accepted and unused: the kernels build the homogeneous rays from or_ray_batch, of which they are pure
+    functions (trt.py:250-277).  Returns ``{'rgb_map0', 'rgb_map1', 'depth_map'}``.
     """
     if kwargs.get('use_trt'):                                # engines = engine files loaded into the modules (no TensorRT on ROCm)
         for m in (min_max_ray_net, refine_net, network_fine):
@@ -127,6 +158,8 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
                         f'(got {N_samples}, {num_neighbor}, {N_point_ray_enc})')
     if ray_batch.shape[-1] != 11 or or_ray_batch.shape[-1] != 11:
         raise PnrfError('render_rays: ray batches must be [N,11] (use_viewdirs=True)')
+    if kwargs.get('mm_input') is not None:
+        _check_mm_input(kwargs['mm_input'], ray_batch, 48)
     rgbd = _render_rgbd(ray_batch, or_ray_batch, min_max_ray_net, refine_net, network_fine, kwargs['ref_rgb'], kwargs['ref_pose'], N_samples, num_neighbor,
                         out=kwargs.get('out_rgbd'))
     rgb_map, depth_map = rgbd[:, :3], rgbd[:, 3]

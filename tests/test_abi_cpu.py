@@ -30,6 +30,20 @@ def test_header_symbols_exported(lib):
     assert lib.pnrf_abi_version() == 1
 
 
+def test_no_packed_fp32_instruction_in_any_kernel(lib):
+    """Round 5 (NOTEBOOK §19): compiler-generated packed-fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) returned wrong values in the
+    fused refine epilogue whenever a workgroup of another fused kernel shared the CU; the library is built with that target feature off.  The guard: every
+    gfx950 code object inside the built library is disassembled and must hold none of those opcodes — and the disassembly is a real one (MFMAs, LDS-DMA)."""
+    from pronerf_amd import build
+    assert build.NO_PACKED_FP32 == ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops'] and all(f in build.FLAGS for f in build.NO_PACKED_FP32)
+    cos = build.device_code_objects()
+    assert len(cos) >= 3, 'expected one gfx950 code object per translation unit with kernels'
+    ops = build.device_opcodes()
+    assert sum(ops.values()) > 100000 and ops['v_mfma_f32_16x16x32_bf16'] > 1000 and ops['global_load_lds_dwordx4'] > 100
+    found = {k: ops[k] for k in build.PACKED_FP32_OPCODES if ops[k]}
+    assert not found, f'packed fp32 instructions in the library: {found}'
+
+
 def test_linspace_matches_torch(lib):
     from pronerf_amd import ops
     for n in (1, 2, 7, 48, 64, 255):

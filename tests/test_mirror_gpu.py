@@ -151,6 +151,23 @@ def test_render_rays_like_the_reference_driver(dev, golden_dir, name):
     assert orc.psnr(rgb1.reshape(-1, 3).cpu(), torch.from_numpy(g['rgb'])) > 46.4
     np.testing.assert_allclose(depth_map.reshape(-1).cpu().numpy(), g['depth'], rtol=0, atol=2e-2)
     from pronerf_amd.ops import PnrfError
+    # mm_input (trt.py:625-628) is verified, not ignored: the reference-built one passes (and is remembered by identity), one that is not the
+    # encoding of ray_batch — a changed value, a NaN, another shape — is refused instead of silently rendering something else
+    mm = fr['mm_input'].to(dev)
+    trt.render(rays, or_rays, (Hh, Ww, 3), mm_input=mm, ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)
+    assert trt._MM_CHECKED and trt._MM_CHECKED[0][0] is mm
+    for tamper in ('value', 'nan', 'shape', 'inplace'):
+        bad = mm.clone() if tamper != 'inplace' else mm
+        if tamper == 'value':
+            bad[rays.shape[0] // 2, 7] += 1e-3
+        elif tamper == 'nan':
+            bad[0, 0] = float('nan')
+        elif tamper == 'shape':
+            bad = bad[:, :282].contiguous()
+        else:
+            bad[3, 5] += 1e-3                   # the remembered tensor changed in place: its version moved, so it is checked again
+        with pytest.raises(PnrfError):
+            trt.render(rays, or_rays, (Hh, Ww, 3), mm_input=bad, ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)
     with pytest.raises(PnrfError):
         trt.render(rays, or_rays, (Hh, Ww, 3), ref_rgb=ref_rgb, ref_pose=ref_pose, **{**fwd, 'use_trt': True})
     with pytest.raises(PnrfError):

@@ -13,7 +13,8 @@ HIPCC = next((c for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil
 
 @pytest.mark.skipif(HIPCC is None, reason='hipcc not found')
 @pytest.mark.parametrize('src,extra', [('tools/hgemm_probe.hip', ['-I', os.path.join(ROOT, 'pronerf_amd', 'csrc'), '-std=c++17']),
-                                       ('tools/mfma_ceiling.hip', [])])
+                                       ('tools/mfma_ceiling.hip', []),
+                                       ('tools/foreign_kernels.hip', [])])
 def test_probe_compiles(tmp_path, src, extra):
     out = str(tmp_path / 'probe.o')
     r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O1', '-c', os.path.join(ROOT, src), '-o', out] + extra, capture_output=True, text=True, timeout=600)
@@ -24,3 +25,4 @@ def test_probe_compiles(tmp_path, src, extra):
 def test_build_module_knows_the_ceiling_probe():
     from pronerf_amd import build as b
     assert os.path.exists(b.CEILING_SRC) and b.CEILING_BIN.startswith(b.LIBDIR)
+    assert os.path.exists(b.FOREIGN_SRC) and b.FOREIGN_LIB.startswith(b.LIBDIR)        # the co-residency stress test's stand-in kernels

@@ -15,7 +15,10 @@ __device__ __forceinline__ u32x4 rnd(unsigned seed) {
   return u;
 }
 constexpr float LOG2E = 1.4426950408889634f;
-// MODE 0: MFMAs only; 1: dependent chain per gap; 2: pipelined over four gaps; 3: pipelined over two gaps (exp | rest)
+// MODE 0: MFMAs only; 1: dependent chain per gap; 2: pipelined over four gaps; 3: pipelined over two gaps (exp | rest);
+// 4 (round 5): the pair finished in fp16 — even gap: v_exp_f32 clamp + v_fma_mixlo_f16 (L e - L, rounded once, straight into the low half of the packed dword);
+//    odd gap: v_exp_f32 clamp, v_cvt_pk_f16_f32 of the two pre-activations, v_fma_mixhi_f16, v_pk_max_f16 — 7 instructions per pair instead of 8.5 (exp fma med3 x2 + cvt),
+//    same bits (rounding is monotone: round(max(y, f)) = max(round y, round f)); with SSQ the |x|^2 of the pair is ONE v_dot2_f32_f16 on the packed dword instead of two v_fma_f32
 template <int MODE, int WAVES, bool SSQ>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, int iters, unsigned long long* cyc) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[4096];
@@ -53,6 +56,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
         if (f & 1) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(packed[f >> 1]) : "v"(m3prev), "v"(m3));
         m3prev = m3; m3 = md; e2 = fm; e1 = ex;
         pend[f] = md;
+      } else if (MODE == 4) {
+        const float y = pend[f];
+        if (!(f & 1)) {
+          asm volatile("v_exp_f32 %0, %2 clamp\n\ts_nop 0\n\tv_fma_mixlo_f16 %1, %0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(e1), "+v"(packed[f >> 1]) : "v"(y), "v"(LOG2E), "v"(-LOG2E));
+        } else {
+          int ypk;
+          asm volatile("v_exp_f32 %0, %3 clamp\n\tv_cvt_pk_f16_f32 %2, %4, %3\n\tv_fma_mixhi_f16 %1, %0, %5, %6 op_sel_hi:[0,0,0]\n\tv_pk_max_f16 %1, %1, %2"
+                       : "=&v"(e1), "+v"(packed[f >> 1]), "=&v"(ypk) : "v"(y), "v"(pend[f - 1]), "v"(LOG2E), "v"(-LOG2E));
+          if (SSQ) asm volatile("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(ssq) : "v"(packed[f >> 1]));
+        }
       } else if (MODE == 3) {             // gap f: exp of f+1; fma, med3, |x|^2, cvt of f
         const float ex = __builtin_amdgcn_exp2f(pend[(f + 1) & 15]);
         const float t = fmaf(e1, LOG2E, -LOG2E);
@@ -98,12 +111,16 @@ int main() {
     RUN(1, 4, false, "1 wave / SIMD, ELU as a dependent chain per gap (refine)");
     RUN(2, 4, false, "1 wave / SIMD, ELU pipelined over four gaps");
     RUN(3, 4, false, "1 wave / SIMD, ELU pipelined over two gaps");
+    RUN(4, 4, false, "1 wave / SIMD, pair finished in fp16: exp.clamp, fma_mix, cvt_pk, pk_max (round 5)");
+    RUN(4, 4, true, "1 wave / SIMD, the same + |x|^2 as one v_dot2_f32_f16 per pair");
     RUN(1, 4, true, "1 wave / SIMD, dependent chain + |x|^2 (sampler pass 1)");
     RUN(2, 4, true, "1 wave / SIMD, pipelined over four gaps + |x|^2");
     RUN(0, 8, false, "2 waves / SIMD, MFMAs only");
     RUN(1, 8, false, "2 waves / SIMD, ELU as a dependent chain per gap (refine)");
     RUN(2, 8, false, "2 waves / SIMD, ELU pipelined over four gaps");
     RUN(3, 8, false, "2 waves / SIMD, ELU pipelined over two gaps");
+    RUN(4, 8, false, "2 waves / SIMD, pair finished in fp16: exp.clamp, fma_mix, cvt_pk, pk_max (round 5)");
+    RUN(4, 8, true, "2 waves / SIMD, the same + |x|^2 as one v_dot2_f32_f16 per pair");
     RUN(1, 8, true, "2 waves / SIMD, dependent chain + |x|^2 (sampler pass 1)");
     RUN(2, 8, true, "2 waves / SIMD, pipelined over four gaps + |x|^2");
   }
