@@ -212,15 +212,18 @@ int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* d
  * Guarantee: the depths / add / mul of the rays of passes 2 and 3 are identical to pnrf_sampler_fwd's (split fp16 resp. exact fp32:
  * fp32-grade); those of the other rays are fp16-grade (measured <= 6e-4 (far - near), tested <= 2e-3) and their SORT INDICES equal
  * pnrf_sampler_fwd's under the error model — a statistical bound (fp16 roundings treated as independent zero-mean errors; subnormals and
- * fp32 accumulation error are covered by the 2e-6 allowance), not a proof: kappa = 4 is >= 4x the largest margin any ray has needed on
- * synthetic, heavy-tailed, x4-scaled and optimizer-trained weights (0 index mismatches on 762 048 rays each down to kappa = 1;
- * tools/kappa_scan.py, tests/test_fullframe_gpu.py).  Where exactness matters more than 0.5 ms per frame, PNRF_VARIANT_SAMPLER_SPLIT
- * renders every ray fp32-grade.
+ * fp32 accumulation error are covered by the 2e-6 allowance), not a proof.  kappa = 2 (round 5; 4 before): the bound s is >= 2.7 sigma of the
+ * measured error where it is tightest (largest |error| / s over 524 288 depths: 0.8 .. 1.9 on seven weight sets, tools/sampler_twopass_model.py),
+ * so the threshold is >= 7.6 sigma of the difference of two errors; it is 2x the smallest kappa that was ever clean and >= 4x the first that
+ * was not (0 index mismatches on 762 048 rays x synthetic, heavy-tailed, x4-scaled and optimizer-trained weights down to kappa = 1; one ray
+ * of 3 M at 0.5: tools/kappa_scan.py, tests/test_fullframe_gpu.py).  It halves the second pass (7.5 % of the bench frame's rays instead of
+ * 14.6 %).  Where exactness matters more than 0.5 ms per frame, PNRF_VARIANT_SAMPLER_SPLIT renders every ray fp32-grade;
+ * pnrf_ctx_set_sampler_kappa restores a wider margin per context.
  * kappa < 0 selects PNRF_SAMPLER_KAPPA; kappa = 0 leaves only the fp32 round-off allowance (tests); NaN and values >= 1e30 are refused.
  * workspace: dev, 16-byte aligned, >= pnrf_sampler_workspace_bytes(n) bytes, contents irrelevant (its counters are reset on the stream
  * by every call); concurrent calls need separate workspaces.  Handles set to SAMPLER_SPLIT run the split kernel for every ray + pass 3;
  * SAMPLER_F32* handles run their single kernel. */
-#define PNRF_SAMPLER_KAPPA 4.0f
+#define PNRF_SAMPLER_KAPPA 2.0f
 int64_t pnrf_sampler_workspace_bytes(int64_t n);
 int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
                         float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,

@@ -15,7 +15,7 @@ __device__ __forceinline__ u32x4 rnd(unsigned seed) {
   return u;
 }
 constexpr float LOG2E = 1.4426950408889634f;
-// MODE 0: MFMAs only; 1: dependent chain per gap; 2: pipelined over four gaps; 3: pipelined over two gaps (exp | rest);
+// MODE 5 (round 5): as 1 with two accumulators in turn.  MODE 0: MFMAs only; 1: dependent chain per gap; 2: pipelined over four gaps; 3: pipelined over two gaps (exp | rest);
 // 4 (round 5): the pair finished in fp16 — even gap: v_exp_f32 clamp + v_fma_mixlo_f16 (L e - L, rounded once, straight into the low half of the packed dword);
 //    odd gap: v_exp_f32 clamp, v_cvt_pk_f16_f32 of the two pre-activations, v_fma_mixhi_f16, v_pk_max_f16 — 7 instructions per pair instead of 8.5 (exp fma med3 x2 + cvt),
 //    same bits (rounding is monotone: round(max(y, f)) = max(round y, round f)); with SSQ the |x|^2 of the pair is ONE v_dot2_f32_f16 on the packed dword instead of two v_fma_f32
@@ -25,8 +25,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
   for (int i = threadIdx.x; i < 4096; i += WAVES * 64) lds[i] = rnd(i * 7 + 1);
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  f32x16 acc, pend;
-  for (int i = 0; i < 16; ++i) { acc[i] = 0.f; pend[i] = 0.01f * (float)((lane + i) % 7) - 0.03f; }
+  f32x16 acc, acc2, pend;
+  for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; pend[i] = 0.01f * (float)((lane + i) % 7) - 0.03f; }
   f16x8 b[16];
   for (int i = 0; i < 16; ++i) b[i] = __builtin_bit_cast(f16x8, rnd(blockIdx.x * 4096 + threadIdx.x * 16 + i));
   f16x8 q[8];
@@ -40,8 +40,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
     for (int f = 0; f < 16; ++f) {
       const f16x8 a = q[f & 7];
       q[f & 7] = __builtin_bit_cast(f16x8, lds[(((it * 16 + f + 8) & 63) * 64) + lane]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[f], acc, 0, 0, 0);
-      if (MODE == 1) {                    // the whole activation of element f in this gap
+      if (MODE == 5 && (f & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[f], acc2, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[f], acc, 0, 0, 0);
+      if (MODE == 1 || MODE == 5) {                    // the whole activation of element f in this gap
         const float y = pend[f];
         const float t = fmaf(__builtin_amdgcn_exp2f(y), LOG2E, -LOG2E);
         const float v = __builtin_amdgcn_fmed3f(y, t, 0.f);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
     }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { pend[i] = acc[i] * 1e-3f; acc[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { pend[i] = (MODE == 5 ? acc[i] + acc2[i] : acc[i]) * 1e-3f; acc[i] = 0.f; acc2[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) b[i] = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, b[i]) ^ u32x4{(unsigned)packed[i] & 0x03ff03ffu, 0, 0, 0});
   }
@@ -113,6 +114,7 @@ int main() {
     RUN(3, 4, false, "1 wave / SIMD, ELU pipelined over two gaps");
     RUN(4, 4, false, "1 wave / SIMD, pair finished in fp16: exp.clamp, fma_mix, cvt_pk, pk_max (round 5)");
     RUN(4, 4, true, "1 wave / SIMD, the same + |x|^2 as one v_dot2_f32_f16 per pair");
+    RUN(5, 4, false, "1 wave / SIMD, ELU chain per gap, TWO accumulators alternating (no MFMA waits for its predecessor)");
     RUN(1, 4, true, "1 wave / SIMD, dependent chain + |x|^2 (sampler pass 1)");
     RUN(2, 4, true, "1 wave / SIMD, pipelined over four gaps + |x|^2");
     RUN(0, 8, false, "2 waves / SIMD, MFMAs only");
@@ -121,6 +123,7 @@ int main() {
     RUN(3, 8, false, "2 waves / SIMD, ELU pipelined over two gaps");
     RUN(4, 8, false, "2 waves / SIMD, pair finished in fp16: exp.clamp, fma_mix, cvt_pk, pk_max (round 5)");
     RUN(4, 8, true, "2 waves / SIMD, the same + |x|^2 as one v_dot2_f32_f16 per pair");
+    RUN(5, 8, false, "2 waves / SIMD, ELU chain per gap, TWO accumulators alternating (no MFMA waits for its predecessor)");
     RUN(1, 8, true, "2 waves / SIMD, dependent chain + |x|^2 (sampler pass 1)");
     RUN(2, 8, true, "2 waves / SIMD, pipelined over four gaps + |x|^2");
   }

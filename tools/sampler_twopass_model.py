@@ -54,12 +54,13 @@ def pass1(w, o, d):
     return xh @ f16(Ws[-1]).T + bs[-1], torch.stack(S, 1)
 
 
-def model_std(w, S):
-    """per-ray std bound of the 8 depth logits from the layer norms S [n, 6] (x_1 .. x_6)."""
+def model_std(w, S, norm='max'):
+    """per-ray std bound of the 8 depth logits from the layer norms S [n, 6] (x_1 .. x_6).  norm='max': C_l = the largest column norm (strict under
+    independence: what the kernel uses); 'mean': C_l = |W_l|_F^2 / 256, the amplification of an error spread evenly over the inputs (an estimate, not a bound)."""
     Ws = [np.asarray(x, dtype=np.float64) for x in w['W']]
     V = torch.zeros(S.shape[0], dtype=torch.float64)
     for l, Wl in enumerate(Ws[1:-1]):
-        C = float((Wl ** 2).sum(0).max())
+        C = float((Wl ** 2).sum(0).max()) if norm == 'max' else float((Wl ** 2).sum() / Wl.shape[1])
         V = C * (2 * C_RND * S[:, l] + V)
     M = torch.as_tensor((Ws[-1][:8] ** 2).max(1))           # [8]
     return torch.sqrt(M[None, :] * (2 * C_RND * S[:, -1] + V)[:, None])
@@ -69,11 +70,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rays', type=int, default=65536)
     ap.add_argument('--kappa', type=float, nargs='*', default=[4.0, 6.0, 8.0])
+    ap.add_argument('--norm', default='max', choices=('max', 'mean'))
+    ap.add_argument('--all-sets', action='store_true', help='also the heavy-tailed, x4 and optimizer-trained sets of tests/test_fullframe_gpu.py')
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
-    for seed, kind in [(0, 'trained'), (3, 'trained'), (2, 'spread'), (1, 'default')]:
+    sets = [(0, 'trained'), (3, 'trained'), (2, 'spread'), (1, 'default')] + ([(0, 'heavy'), (0, 'x4'), (0, 'optimizer')] if args.all_sets else [])
+    for seed, kind in sets:
         scene = synth.make_scene(seed, H=H, W=W, focal=FOCAL, rotate=True)
-        w = synth.make_weights(seed, kind)['sampler']
+        w = synth.weight_set(seed, kind)['sampler']
+        Wn = [np.asarray(x, dtype=np.float64) for x in w['W']][1:-1]
+        print(f'({seed},{kind}) column norms^2 per hidden layer, max / mean: ' + ', '.join(f'{(x ** 2).sum(0).max():.2f} / {(x ** 2).sum() / x.shape[1]:.2f}' for x in Wn))
         ro, rd = orc.get_rays(H, W, scene['K'], scene['c2w'])
         o, d = orc.ndc_rays(H, W, float(scene['K'][0, 0]), 1.0, ro, rd)
         sel = torch.linspace(0, H * W - 1, args.rays).long()
@@ -83,7 +89,7 @@ def main():
             y1, S = pass1(w, o, d)
         d1 = torch.sigmoid(y1[:, :8])
         err = (d1 - depth.double()).abs()
-        s = d1 * (1 - d1) * model_std(w, S)                                            # span = far - near = 1
+        s = d1 * (1 - d1) * model_std(w, S, args.norm)                                            # span = far - near = 1
         ds, idx = torch.sort(depth, dim=1, stable=True)
         d1s, idx1 = torch.sort(d1.float(), dim=1, stable=True)
         s_sorted = torch.gather(s, 1, idx1)
