@@ -9,7 +9,8 @@
 * rgb / depth of the whole frame against the oracle's eager fp32 graph run on the device, three weight seeds.
 
 Tolerances: BASELINE.json north_star / BASELINE.md §4 — indices identical; RGB error PSNR >= 46.4 dB (moves a 27 dB image PSNR by
-<= 0.05 dB); depth map within 1e-2 absolute (measured 2e-3 .. 5e-3) and 2e-3 relative RMS; sampler depths within 2e-6.
+<= 0.05 dB); depth map: `depth_bars` below — the same 46.4 dB error-PSNR gate as rgb (NDC depths live in [0, 1]) and bars in grey levels of the
+reference's own 8-bit depth PNG (99 % within half a level, 99.9 % within one, none beyond 2.5) — plus 2e-3 relative RMS; sampler depths within 2e-6.
 """
 import os
 
@@ -40,6 +41,25 @@ def dev():
 
 
 _ORACLE = {}
+
+
+GREY = 1.0 / 255.0       # one level of the reference's own depth output: to8b(depth / max(depth)), an 8-bit PNG (run_S_eS_eN_alter_trt.py:360-361)
+
+
+def depth_bars(got, ref, tag=''):
+    """The depth channel's tolerance, derived instead of fitted.  BASELINE.json asks for RGB / depth "within a stated fp tolerance
+    (PSNR-equivalent)": NDC depths live in [0, 1] like colours, so (i) the depth map's error PSNR (peak 1) must clear the SAME 46.4 dB gate as rgb; and the
+    reference's depth product is an 8-bit image, so (ii) 99 % of the pixels are within half a grey level (1/510: they round to the same or the adjacent
+    level), (iii) 99.9 % within one level (1/255) and (iv) no pixel is off by more than 2.5 levels (the old 1e-2 absolute bar, now with a unit).
+    Returns the measured figures for the log."""
+    e = (got.double() - ref.double()).abs().flatten()
+    mse = float((e ** 2).mean())
+    psnr = float('inf') if mse == 0 else -10.0 * float(np.log10(mse))
+    q99, q999 = (float(torch.quantile(e[::max(1, e.numel() // 1000000)], q)) for q in (0.99, 0.999))
+    mx = float(e.max())
+    print(f'[depth bars{tag}] error PSNR {psnr:.1f} dB (gate 46.4), 99 % <= {q99 / GREY:.3f} grey levels (bar 0.5), 99.9 % <= {q999 / GREY:.3f} (bar 1), max {mx / GREY:.2f} (bar 2.5)')
+    assert psnr >= 46.4 and q99 <= 0.5 * GREY and q999 <= GREY and mx <= 2.5 * GREY, (psnr, q99, q999, mx)
+    return psnr, q99, q999, mx
 
 
 def depth_relrms(a, b):
@@ -175,7 +195,7 @@ def test_fern_8k_rays_vs_the_reference(dev, golden_dir):
     rel = float(((got[m, :3].double() - torch.from_numpy(g['rgb'])[m].double()) ** 2).mean().sqrt() / (torch.from_numpy(g['rgb'])[m].double() ** 2).mean().sqrt())
     print(f'[fern 8k] rgb PSNR vs the reference {ps:.1f} dB, rel. RMS {rel:.2e}, max depth error {float((got[m, 3] - torch.from_numpy(g["depth"])[m]).abs().max()):.2e}')
     assert ps > 46.4 and rel < 1e-2
-    np.testing.assert_allclose(got[m, 3].numpy(), g['depth'][tie_free], rtol=0, atol=1e-2)
+    depth_bars(got[m, 3], torch.from_numpy(g['depth'])[m], ' vs the reference\'s own rays')
     assert depth_relrms(got[m, 3], torch.from_numpy(g['depth'])[m]) < 2e-3
     # the border rays alone (their epi features are partly zero-padded): same bar
     border = torch.from_numpy((g['oob_taps'] > 0) & tie_free)
@@ -213,7 +233,8 @@ def test_full_frame_with_optimizer_trained_nets(dev):
     print(f'\n[full frame, optimizer-trained nets] {int(free.sum())} of {N} rays compared, index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
           f'max depth error {derr:.2e}, depth rel. RMS {depth_relrms(rgbd[free, 3], ref["depth"][free]):.2e}; second pass {n2 / N:.2%}, third pass {n3} rays')
     assert int((~free).sum()) <= 2e-3 * N and mism == 0
-    assert ps > 46.4 and rel < 2e-2 and derr < 2e-2
+    assert ps > 46.4 and rel < 2e-2
+    depth_bars(rgbd[free, 3], ref['depth'][free], ' optimizer-trained nets')
     assert bool(torch.isfinite(rgbd).all())
 
 
@@ -243,7 +264,8 @@ def test_full_frame_rgb_vs_eager_oracle_on_device(dev, seed):
           f'max depth error {derr:.2e}')
     assert int((~free).sum()) <= 1e-3 * N
     assert mism == 0
-    assert ps > 46.4 and rel < 1e-2 and derr < 1e-2 and depth_relrms(rgbd[free, 3], ref['depth'][free]) < 2e-3
+    assert ps > 46.4 and rel < 1e-2 and depth_relrms(rgbd[free, 3], ref['depth'][free]) < 2e-3
+    depth_bars(rgbd[free, 3], ref['depth'][free], f' seed {seed}')
     assert bool(torch.isfinite(rgbd).all())
 
 
@@ -273,4 +295,5 @@ def test_full_frame_rgb_vs_the_cpu_oracle(dev):
     print(f'\n[full frame vs CPU oracle] {int(free.sum())} of 65536 rays outside the tie set: index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
           f'max depth error {derr:.2e}')
     assert int((~free).sum()) <= 16 and mism == 0
-    assert ps > 46.4 and rel < 1e-2 and derr < 1e-2 and depth_relrms(got[free, 3], ref['depth'][free]) < 2e-3
+    assert ps > 46.4 and rel < 1e-2 and depth_relrms(got[free, 3], ref['depth'][free]) < 2e-3
+    depth_bars(got[free, 3], ref['depth'][free], ' vs the CPU oracle')
