@@ -355,7 +355,9 @@ int pnrf_trainer_create(const float* const* W, const float* const* b, const int*
                         int n_layers, int64_t max_rays, int max_samples, pnrf_trainer_t** out);
 int pnrf_trainer_free(pnrf_trainer_t* t);
 /* Weight-gradient kernel of the square layers: tile 0 = chosen by shape and row count (default), 64 / 128 = forced where the shape allows;
- * min_rows_128 = row count from which the 128 x 128-tile kernel is used (0 = default).  Configuration, not on the step path. */
+ * min_rows_128 = row count from which the 128 x 128-tile kernel is used (0 = default).  tile 256 / 255 (round 5) leave that choice alone and switch
+ * the 256 x 128-tile form of the grouped split-fp16 gradients on from min_rows_128 rows (0: from the first row) / off; default: from 32 768 rows.
+ * Configuration, not on the step path. */
 int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t min_rows_128);
 
 /* kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment of the joint optimizer, 4 / 5 those of the NeRF-only

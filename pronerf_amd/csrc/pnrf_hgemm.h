@@ -36,6 +36,7 @@
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 struct HGemmArgs {
   const float* A; int lda;                     // [M, K] fp32
@@ -579,6 +580,160 @@ __device__ __forceinline__ void dwh_body(const DwhArgs& a, const int bx, const i
     }
   }
 }
+// ---- the same product on a 256 x 128 output tile (round 5): the workgroup reads ALL 256 columns of dZ and 128 columns of X, so a 256 x 256 gradient is two
+// tiles per split and dZ is the only operand fetched twice (1.5x the operand bytes at L2 instead of 2x with four 128 x 128 tiles; FETCH_SIZE of the grouped
+// launch at 262 144 rows was 6.6 GB for 5.13 GB of operands).  Wave (wm, wn) = 64 dZ columns x 64 X columns = 4 x 4 MFMA tiles x two accumulators = 128
+// registers; the X fragments come in two halves per chunk; ONE register set of fetched rows per operand, one chunk ahead of the chunk being stored.
+// LDS per buffer: dZ [hi | lo][256][40] + X [hi | lo][128][40] halfs = 60 KiB, two buffers.  Loader: every thread a 4-row x 4-column piece of dZ (8 row
+// groups x 64 column quads) and a 2-row x 4-column piece of X (16 row pairs x 32 column quads); same column-major layout and swizzle as dwh_body.
+constexpr int DHW_ZP = 256 * DH_COL, DHW_XP = 128 * DH_COL, DHW_BUF = 2 * DHW_ZP + 2 * DHW_XP;      // halfs
+constexpr int DHW_BYTES = 2 * DHW_BUF * 2;                                                             // 122 880
+__device__ __forceinline__ void dwh_body_wide(const DwhArgs& a, const int bx, const int by, unsigned char* smem, float* s_red) {
+  _Float16* const sm = (_Float16*)smem;
+  const int tn = bx;                                                  // a.out == 256: one tile row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int64_t r_begin = by * a.rows_per;
+  const int64_t r_end = r_begin + a.rows_per < a.R ? r_begin + a.rows_per : a.R;
+  const int chunks = (int)((r_end - r_begin + DH_KC - 1) / DH_KC);
+  const float z_scale = a.dz_amax ? hg_scale_for(hg_slot_read(a.dz_amax, s_red)) : 1.f;
+
+  f32x4_t accm[4][4], accx[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { accm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  // ---- loader
+  const int zrg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), zcq = threadIdx.x & 63;      // dZ: rows 4 zrg .. + 3 of the chunk, columns 4 zcq .. + 3
+  const int xrp = threadIdx.x >> 5, xcq = threadIdx.x & 31;                                              // X: rows 2 xrp, 2 xrp + 1, columns 4 xcq .. + 3 of the tile
+  const int xcol = tn * 128 + 4 * xcq;
+  const int64_t zspan = ((r_end - r_begin - 1) * (int64_t)a.ldz + a.out) * 4, xspan = ((r_end - r_begin - 1) * (int64_t)a.ldx + a.in) * 4;
+  const __amdgpu_buffer_rsrc_t zrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.dZ + r_begin * a.ldz), 0, (int)(unsigned)(zspan < 0xffffffffll ? zspan : 0xffffffffll), HG_BUF_FLAGS);
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + r_begin * a.ldx), 0, (int)(unsigned)(xspan < 0xffffffffll ? xspan : 0xffffffffll), HG_BUF_FLAGS);
+  const unsigned zvoff = (unsigned)((4 * zrg * a.ldz + 4 * zcq) * 4), xvoff = (unsigned)((2 * xrp * a.ldx + xcol) * 4);
+  const unsigned zchunk = (unsigned)(DH_KC * a.ldz * 4), zrow = (unsigned)(a.ldz * 4), xchunk = (unsigned)(DH_KC * a.ldx * 4), xrow = (unsigned)(a.ldx * 4);
+  bool xon[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) xon[e] = xcol + e < a.in;
+  f32x4_t stz[4], stx[2];
+  auto fetch = [&](int kc) {
+    const bool in = kc < chunks;
+    const unsigned zs = in ? (unsigned)kc * zchunk : 0xffff0000u, xs = in ? (unsigned)kc * xchunk : 0xffff0000u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stz[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(zrs, zvoff, zs + k * zrow, 0));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) stx[k] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, xs + k * xrow, 0));
+  };
+  f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
+  const int z_off = 4 * zcq * DH_COL + 4 * (zrg ^ (2 * ((zcq >> 2) & 3)));
+  const int x_off = 4 * xcq * DH_COL + 4 * ((xrp >> 1) ^ (2 * ((xcq >> 2) & 3))) + 2 * (xrp & 1);
+  auto store = [&](int buf) {
+    _Float16* zh = sm + buf * DHW_BUF + z_off;
+    _Float16* zl = zh + DHW_ZP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f16x4_t h, l;
+      float cs = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float raw = stz[k][e];
+        cs += raw;
+        const float x = raw * z_scale;
+        const _Float16 xh = (_Float16)x;
+        h[k] = xh;
+        l[k] = (_Float16)((x - (float)xh) * HG_LO_SCALE);
+      }
+      colsum[e] += cs;
+      *(f16x4_t*)(zh + e * DH_COL) = h;
+      *(f16x4_t*)(zl + e * DH_COL) = l;
+    }
+    _Float16* xh = sm + buf * DHW_BUF + 2 * DHW_ZP + x_off;
+    _Float16* xl = xh + DHW_XP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f16x2_t h, l;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float x = xon[e] ? stx[k][e] : 0.f;
+        const _Float16 hh = (_Float16)x;
+        h[k] = hh;
+        l[k] = (_Float16)((x - (float)hh) * HG_LO_SCALE);
+      }
+      *(f16x2_t*)(xh + e * DH_COL) = h;
+      *(f16x2_t*)(xl + e * DH_COL) = l;
+    }
+  };
+  auto frag_off = [&](int col0) { return (col0 + c16) * DH_COL + 8 * (g ^ ((col0 >> 4) & 3)); };
+  auto mma_chunk = [&](int buf) {
+    const _Float16* zh = sm + buf * DHW_BUF;
+    const _Float16* zl = zh + DHW_ZP;
+    const _Float16* xh = zh + 2 * DHW_ZP;
+    const _Float16* xl = xh + DHW_XP;
+    f16x8_t ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int o = frag_off(wm * 64 + 16 * i); ah[i] = *(const f16x8_t*)(zh + o); al[i] = *(const f16x8_t*)(zl + o); }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      f16x8_t bh[2], bl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { const int o = frag_off(wn * 64 + 32 * jj + 16 * j); bh[j] = *(const f16x8_t*)(xh + o); bl[j] = *(const f16x8_t*)(xl + o); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accx[i][2 * jj + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][2 * jj + j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accm[i][2 * jj + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], accm[i][2 * jj + j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accx[i][2 * jj + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][2 * jj + j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // chunk q in LDS buffer q & 1, chunk q + 1 in the register set, fetched while chunk q - 1 was multiplied
+  fetch(0);
+  store(0);
+  fetch(1);
+  __syncthreads();
+  for (int q = 0; q < chunks; ++q) {
+    mma_chunk(q & 1);
+    store((q + 1) & 1);                                          // past the last chunk: zeros
+    fetch(q + 2);
+    __syncthreads();
+  }
+
+  const float inv = HG_LO_INV, unscale = 1.f / z_scale;
+  float* p = a.part + (size_t)by * a.out * a.in;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = wm * 64 + 16 * i + 4 * g + e, n = tn * 128 + wn * 64 + 16 * j + c16;
+        if (n < a.in) p[(size_t)m * a.in + n] = (accm[i][j][e] + accx[i][j][e] * inv) * unscale;
+      }
+  if (a.db_part && tn == 0) {
+    __syncthreads();
+    float* red = (float*)sm;                                     // [8 row groups][256 columns]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[zrg * 256 + 4 * zcq + e] = colsum[e];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r * 256 + threadIdx.x];
+      a.db_part[(size_t)by * a.out + threadIdx.x] = sum;
+    }
+  }
+}
 __global__ __launch_bounds__(512) void dwh_kernel(DwhArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DH_BYTES];
   __shared__ float s_red[16];
@@ -606,7 +761,7 @@ __global__ __launch_bounds__(512) void layer_bwd_kernel(HGemmArgs g, DwhArgs d, 
 // The weight gradients of several layers in one launch (their dZ / X buffers must all still exist): blocks [first[j], first[j + 1]) belong to
 // job j as (tile, split) = (b % tiles, b / tiles).
 constexpr int DH_GROUP_MAX = 24;
-struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int tiles[DH_GROUP_MAX]; int splits[DH_GROUP_MAX]; int n; };
+struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int tiles[DH_GROUP_MAX]; int splits[DH_GROUP_MAX]; int n; unsigned wide; };   // wide: bit j = job j runs dwh_body_wide
 // Workgroups go to the XCDs round robin (blockIdx % 8) and every tile of a split reads the split's rows — of X or of dZ — again.  Jobs start at
 // multiples of 8 and, where the split count is one too, block b of a job is (tile (b / 8) % tiles, split b % 8 + 8 (b / (8 tiles))): the tiles of a
 // split run on ONE XCD at about the same time and its L2 fetches the rows once (at 262 144 rows the grouped launch is bound by HBM; FETCH_SIZE
@@ -615,7 +770,7 @@ struct DwhGroupArgs { DwhArgs j[DH_GROUP_MAX]; int first[DH_GROUP_MAX + 1]; int 
 #define PNRF_DWG_PLAIN 0
 #endif
 __global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DH_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DHW_BYTES > DH_BYTES ? DHW_BYTES : DH_BYTES];
   __shared__ float s_red[16];
   int j = 0;
   while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
@@ -623,7 +778,8 @@ __global__ __launch_bounds__(512) void dwh_group_kernel(DwhGroupArgs g) {
   if (b >= tiles * splits) return;                             // padding up to the next multiple of 8
   int tile = b % tiles, split = b / tiles;
   if (!PNRF_DWG_PLAIN && splits % 8 == 0) { const int q = b >> 3; tile = q % tiles; split = (b & 7) + 8 * (q / tiles); }
-  dwh_body(g.j[j], tile, split, smem, s_red);
+  if ((g.wide >> j) & 1u) dwh_body_wide(g.j[j], tile, split, smem, s_red);
+  else dwh_body(g.j[j], tile, split, smem, s_red);
 }
 
 // ------------------------------------------------------------------------------------------ layer chains of the 4096-row nets, handed over in LDS

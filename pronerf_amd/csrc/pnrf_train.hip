@@ -1152,6 +1152,7 @@ struct pnrf_trainer {
   float *M2 = nullptr, *V2 = nullptr;            // second Adam state over the NeRF layers only (stage 1: `optimizer` next to `s_optimizer`)
   int64_t step = 0, step2 = 0;
   int dw_tile = 0;                               // 0: by shape and row count; 64 / 128: force that weight-gradient kernel where it applies
+  int64_t dw_wide_min_rows = 32768;              // grouped split-fp16 weight gradients: 256 x 128 tiles (dwh_body_wide) from this many rows on (pnrf_trainer_set_dw_kernel(.., tile 256 / 129))
   int64_t dw128_min_rows = 65536;
   // hipGraph replay of an iteration (pnrf_trainer_set_graph): the batch is copied into the trainer's own staging buffers by one kernel, so
   // every pointer and scalar argument inside the captured launch sequence is fixed; one instantiated graph per configuration key
@@ -1246,7 +1247,8 @@ int launch_tgemm(const GemmArgs& a, hipStream_t s) {
 // `in` counts the columns of X; with gap >= 0 column `gap` of X is padding and dW has in - 1 columns
 // defer != NULL: if the split-fp16 kernel is the one to use, its arguments and grid go to *defer instead of a launch (layer_bwd dispatches it
 // together with the layer's input-gradient product)
-struct DwDefer { DwhArgs args; int tiles, splits; bool set; int wgs = 128; };      // wgs (in): workgroups the deferred gradient should spread over
+struct DwDefer { DwhArgs args; int tiles, splits; bool set; int wgs = 128; bool allow_wide = false, wide = false; };   // wgs (in): workgroups the deferred gradient should
+                                                                                                                   // spread over; allow_wide (in): the grouped launch may use 256 x 128 tiles
 int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, const float* dz_amax, float* dW, float* db, int in, int gap, int out,
             int64_t R, hipStream_t s, DwDefer* defer = nullptr) {
   PNRF_REQUIRE(out <= DB_MAX_OUT, PNRF_E_SHAPE, "pnrf_trainer: layer output %d wider than the bias-partial buffer (%d)", out, DB_MAX_OUT);
@@ -1260,6 +1262,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
   const bool use128 = !use_h && !use_head && can128 && t->dw_tile != 64 && R >= t->dw128_min_rows;
   const int max_splits = out <= HEAD_MAX ? HEAD_MAX_SPLITS : (out % 128 == 0 && in % 128 == 0) ? DW128_MAX_SPLITS : DW_MAX_SPLITS;   // what the pool was sized for
   int tiles;
+  bool wide_h = false;
   int64_t splits, rows_per;
   // the partials are written and then read again by the reduction: hold them to half of the operand bytes (26 layers x 64 .. 128 splits
   // were 1 GB per iteration, the reduction kernel alone 0.22 ms of 2.5)
@@ -1268,8 +1271,13 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
     tiles = 1;
     splits = R / 128 < HEAD_MAX_SPLITS ? R / 128 : HEAD_MAX_SPLITS;      // partials are a few KB each: as many workgroups as there are CUs
   } else if (use_h) {
-    tiles = ((out + 127) / 128) * ((in + 127) / 128);
-    splits = ((defer ? defer->wgs : 256) + tiles - 1) / tiles;         // one workgroup per CU (half of the CUs when the launch is shared with the dX product) ...
+    // 256 x 128 tiles (dwh_body_wide: dZ is the only operand read twice) for the 256-wide gradients of the grouped launch from 32 768 rows on — below that
+    // the launch wants the workgroups more than the bytes
+    wide_h = defer && defer->allow_wide && out == 256 && in >= 128 && ldz % 4 == 0 && ldx % 4 == 0 && aligned16(X) && aligned16(dZ) && R >= t->dw_wide_min_rows;
+    const int tiles_sq = ((out + 127) / 128) * ((in + 127) / 128);
+    tiles = wide_h ? (in + 127) / 128 : tiles_sq;
+    splits = ((defer ? defer->wgs : 256) + tiles_sq - 1) / tiles_sq;   // one workgroup per CU (half of the CUs when the launch is shared with the dX product) ...
+                                                                       // (the wide form keeps the split count — and with it the partials' traffic — of the square tiles)
     if (splits > by_traffic) splits = by_traffic;               // ... unless the partials would outweigh the operands
     const int64_t by_rows = (R + DH_KC - 1) / DH_KC;
     if (splits > by_rows) splits = by_rows;
@@ -1308,7 +1316,7 @@ int gemm_dw(pnrf_trainer* t, const float* X, int ldx, const float* dZ, int ldz, 
     hipLaunchKernelGGL(head_dw_kernel, dim3((unsigned)splits), dim3(256), 0, s, h);
   } else if (use_h) {
     DwhArgs h = {dZ, ldz, X, ldx, part, db_part, out, in, R, rows_per, dz_amax};
-    if (defer) { defer->args = h; defer->tiles = tiles; defer->splits = (int)splits; defer->set = true; }
+    if (defer) { defer->args = h; defer->tiles = tiles; defer->splits = (int)splits; defer->set = true; defer->wide = wide_h; }
     else hipLaunchKernelGGL(dwh_kernel, dim3(tiles, (unsigned)splits), dim3(512), 0, s, h);
   } else if (use128)
     hipLaunchKernelGGL(dw_splitk128_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, s, dZ, ldz, X, ldx, part, out, in, R, rows_per, db_part);
@@ -1330,6 +1338,8 @@ int group_dw(pnrf_trainer* t, const DwDefer& d) {
   PNRF_REQUIRE(t->grp.n < DH_GROUP_MAX, PNRF_E_STATE, "pnrf_trainer: more than %d grouped weight gradients", DH_GROUP_MAX);
   DwhGroupArgs& g = t->grp;
   g.j[g.n] = d.args; g.first[g.n] = t->grp_blocks; g.tiles[g.n] = d.tiles; g.splits[g.n] = d.splits;
+  if (g.n == 0) g.wide = 0;
+  if (d.wide) g.wide |= 1u << g.n;
   t->grp_blocks += (d.tiles * d.splits + 7) & ~7;               // jobs start on XCD 0 (dwh_group_kernel)
   ++g.n;
   return 0;
@@ -1791,8 +1801,14 @@ static void drop_graphs(pnrf_trainer* t) {
 // 65 536), 64 / 128 = force that tile where the shape allows it.  A configuration step, like pnrf_mlp_set_variant: the library reads no
 // environment.  (The two kernels differ in fp32 summation order only; tests/test_train_gpu.py runs the same batch through both.)
 extern "C" int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t min_rows_128) {
-  PNRF_REQUIRE(t && (tile == 0 || tile == 64 || tile == 128) && min_rows_128 >= 0, PNRF_E_ARG, "pnrf_trainer_set_dw_kernel: tile must be 0, 64 or 128");
+  PNRF_REQUIRE(t && (tile == 0 || tile == 64 || tile == 128 || tile == 255 || tile == 256) && min_rows_128 >= 0, PNRF_E_ARG,
+               "pnrf_trainer_set_dw_kernel: tile must be 0, 64, 128 (or 256 / 255: the wide grouped tiles on / off)");
   drop_graphs(t);
+  if (tile == 255 || tile == 256) {
+    t->dw_wide_min_rows = tile == 255 ? INT64_MAX : (min_rows_128 > 0 ? min_rows_128 : 1);
+    return 0;
+  }
+  t->dw_wide_min_rows = 32768;
   t->dw_tile = tile;
   t->dw128_min_rows = tile == 128 ? (min_rows_128 > 0 ? min_rows_128 : 256) : (min_rows_128 > 0 ? min_rows_128 : 65536);
   return 0;
@@ -1951,6 +1967,7 @@ int nerf_backward(pnrf_trainer* t, int64_t R, bool want_dpts, hipStream_t s) {
     const TLin& lf = t->L[L_FEAT];
     auto dw_job = [&](const float* X, int ldx, const float* dZ, int ldz, const float* amax_slot, const TLin& l) -> int {
       DwDefer d;
+      d.allow_wide = true;
       // partials per gradient: at 32 768 rows 16 splits (the reduction of the partials is what shrinks: iteration 0.985 -> 0.960 ms), at 262 144 rows
       // 32 (16: 4.29 -> 4.50 ms — the grouped launch is bound by HBM there and wants the parallelism)
       d.wgs = R >= 65536 ? 128 : 64;

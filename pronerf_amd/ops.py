@@ -551,7 +551,8 @@ class Trainer:
         return t
 
     def set_dw_kernel(self, tile=0, min_rows_128=0):
-        """Weight-gradient kernel of the square layers: 0 = by shape and row count, 64 / 128 = forced (pnrf_trainer_set_dw_kernel)."""
+        """Weight-gradient kernel of the square layers: 0 = by shape and row count, 64 / 128 = forced; 256 / 255 = the grouped gradients' 256 x 128 tiles
+        on from ``min_rows_128`` rows / off (pnrf_trainer_set_dw_kernel)."""
         check(_lib.load().pnrf_trainer_set_dw_kernel(self.handle, int(tile), int(min_rows_128)), 'pnrf_trainer_set_dw_kernel')
 
     def set_graph(self, enable=True):
