@@ -25,6 +25,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
   for (int i = threadIdx.x; i < 4096; i += WAVES * 64) lds[i] = rnd(i * 7 + 1);
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  f32x4 c4[4];
+  for (int i = 0; i < 4; ++i) c4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x16 acc, acc2, pend;
   for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; pend[i] = 0.01f * (float)((lane + i) % 7) - 0.03f; }
   f16x8 b[16];
@@ -40,9 +43,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
     for (int f = 0; f < 16; ++f) {
       const f16x8 a = q[f & 7];
       q[f & 7] = __builtin_bit_cast(f16x8, lds[(((it * 16 + f + 8) & 63) * 64) + lane]);
-      if (MODE == 5 && (f & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[f], acc2, 0, 0, 0);
+      if (MODE == 6) {           // the same 32 pipe cycles as two v_mfma_f32_16x16x32_f16 on two of four accumulators (tile f & 1 of a pair x two 16-column blocks), one A fragment
+        c4[(f & 1) * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[f], c4[(f & 1) * 2 + 0], 0, 0, 0);
+        c4[(f & 1) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[(f + 8) & 15], c4[(f & 1) * 2 + 1], 0, 0, 0);
+      } else if (MODE == 5 && (f & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[f], acc2, 0, 0, 0);
       else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[f], acc, 0, 0, 0);
-      if (MODE == 1 || MODE == 5) {                    // the whole activation of element f in this gap
+      if (MODE == 1 || MODE == 5 || MODE == 6) {                    // the whole activation of element f in this gap
         const float y = pend[f];
         const float t = fmaf(__builtin_amdgcn_exp2f(y), LOG2E, -LOG2E);
         const float v = __builtin_amdgcn_fmed3f(y, t, 0.f);
@@ -80,7 +86,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void k(float* out, 
     }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { pend[i] = (MODE == 5 ? acc[i] + acc2[i] : acc[i]) * 1e-3f; acc[i] = 0.f; acc2[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { pend[i] = (MODE == 6 ? c4[i >> 2][i & 3] : MODE == 5 ? acc[i] + acc2[i] : acc[i]) * 1e-3f; acc[i] = 0.f; acc2[i] = 0.f; }
+    if (MODE == 6) for (int i = 0; i < 4; ++i) c4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) b[i] = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, b[i]) ^ u32x4{(unsigned)packed[i] & 0x03ff03ffu, 0, 0, 0});
   }
@@ -115,6 +122,8 @@ int main() {
     RUN(4, 4, false, "1 wave / SIMD, pair finished in fp16: exp.clamp, fma_mix, cvt_pk, pk_max (round 5)");
     RUN(4, 4, true, "1 wave / SIMD, the same + |x|^2 as one v_dot2_f32_f16 per pair");
     RUN(5, 4, false, "1 wave / SIMD, ELU chain per gap, TWO accumulators alternating (no MFMA waits for its predecessor)");
+    RUN(6, 4, false, "1 wave / SIMD, ELU chain per gap, 2 x 16x16x32 on four accumulators (the NeRF stage's engine shape)");
+    RUN(6, 4, true, "1 wave / SIMD, the same + |x|^2");
     RUN(1, 4, true, "1 wave / SIMD, dependent chain + |x|^2 (sampler pass 1)");
     RUN(2, 4, true, "1 wave / SIMD, pipelined over four gaps + |x|^2");
     RUN(0, 8, false, "2 waves / SIMD, MFMAs only");
@@ -124,6 +133,8 @@ int main() {
     RUN(4, 8, false, "2 waves / SIMD, pair finished in fp16: exp.clamp, fma_mix, cvt_pk, pk_max (round 5)");
     RUN(4, 8, true, "2 waves / SIMD, the same + |x|^2 as one v_dot2_f32_f16 per pair");
     RUN(5, 8, false, "2 waves / SIMD, ELU chain per gap, TWO accumulators alternating (no MFMA waits for its predecessor)");
+    RUN(6, 8, false, "2 waves / SIMD, ELU chain per gap, 2 x 16x16x32 on four accumulators (the NeRF stage's engine shape)");
+    RUN(6, 8, true, "2 waves / SIMD, the same + |x|^2");
     RUN(1, 8, true, "2 waves / SIMD, dependent chain + |x|^2 (sampler pass 1)");
     RUN(2, 8, true, "2 waves / SIMD, pipelined over four gaps + |x|^2");
   }
