@@ -31,7 +31,7 @@ def test_no_row_changes_beside_foreign_kernels_and_the_rccl_gather():
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert lines, (r.returncode, r.stdout[-1000:], r.stderr[-3000:])
     j = json.loads(lines[-1])
-    for phase in ('narrow_1024', 'wide_8192', 'chunked_4_streams', 'frame_gather_rccl_ws1'):
+    for phase in ('narrow_1024', 'narrow_1024_beside_mfma', 'wide_8192', 'chunked_4_streams', 'frame_gather_rccl_ws1'):
         assert j[phase]['rows_differ'] == 0 and j[phase]['rows_compared'] > 0, (phase, j[phase])
     assert j['narrow_1024']['calls'] == calls and j['frame_gather_rccl_ws1']['backend'] == 'nccl'
     assert r.returncode == 0 and j['total_rows_differ'] == 0

@@ -8,7 +8,8 @@ all-gather and the index_select of ``FrameGather`` run beside the next frame.  T
 and compares EVERY output row of EVERY call with the rows of an undisturbed one-call frame:
 
   narrow   1024-ray calls (4-wave workgroups: 240 VGPRs, 84 KiB LDS) beside tools/foreign_kernels.hip kind 1 (random 16-byte gathers, 4 waves,
-           48 VGPRs, 16 KiB LDS), kind 2 (LDS-DMA ring of 64 KiB, the weight stream's instruction) and kind 0 (1 wave, 16 VGPRs) on three streams
+           48 VGPRs, 16 KiB LDS), kind 2 (LDS-DMA ring of 64 KiB, the weight stream's instruction) and kind 0 (1 wave, 16 VGPRs) on three streams;
+           and again beside kind 3 (v_mfma_f32_16x16x32_bf16 loop, 240 VGPRs per wave: another stream's bf16 GEMM) on all three
   wide     8192-ray calls with the 8-wave shape forced (2 x 240 VGPRs per SIMD lane, ~72 KiB LDS) beside kinds 0 and 2 (<= 32 VGPRs: they fit)
   chunked  the frame as 745 calls on four streams (ChunkedRenderer) beside the three foreign streams
   gather   whole frames through FrameGather with the collective forced on in a one-rank RCCL group and a permutation as gather index:
@@ -98,8 +99,8 @@ def main(argv=None):
             it = max(it + 1, int(it * min(8.0, target_us / max(us, 1.0))))
         return it, round(us, 1)
 
-    GR = {0: 2048, 1: 512, 2: 256}
-    iters = {k: tune(k, GR[k], 150.0) for k in (0, 1, 2)}
+    GR = {0: 2048, 1: 512, 2: 256, 3: 256}
+    iters = {k: tune(k, GR[k], 150.0) for k in (0, 1, 2, 3)}
     res = {'library': a.variant or 'shipped', 'foreign_kernels': {str(k): {'grid': GR[k], 'iters': iters[k][0], 'us_alone': iters[k][1]} for k in iters}}
 
     bad = torch.zeros((), dtype=torch.int64, device=dev)
@@ -149,6 +150,9 @@ def main(argv=None):
 
     # ---- narrow beside gather / dma / small
     phase_calls('narrow_1024', rend, 1024, a.calls, (1, 2, 0))
+    # ---- narrow beside a bf16 MFMA kernel with 240 registers per wave (a GEMM of another stream): the aggressor of tools/pkf32_coexec_probe.hip — with packed
+    # fp32 in the library this phase is where the SHIPPED narrow shape returns wrong rows (profiles/r05_coresidency_stress_packed_fp32.json); without, none
+    phase_calls('narrow_1024_beside_mfma', rend, 1024, a.calls, (3, 3, 3))
     # ---- wide (forced) beside small / dma
     rw = Renderer(weights, max_rays=8192, device=dev, shape='wide')
     rw.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])

@@ -6,6 +6,8 @@
 //                     gathers at random addresses (the refine head's texel traffic through the same TA / L1)
 //   kind 2  "dma":    4 waves, 64 KiB of LDS filled by LDS-DMA (global_load_lds_dwordx4 through M0, the weight stream's instruction) and
 //                     read back with ds_read_b128 — the other fused kernels' footprint without their arithmetic
+//   kind 3  "mfma":   4 waves, 240 VGPRs, no LDS: a loop of v_mfma_f32_16x16x32_bf16 — what a bf16 GEMM of another stream looks like to the SIMD; it fits beside a
+//                     NARROW fused workgroup (240 + 240 of 512 registers) and is the aggressor of tools/pkf32_coexec_probe.hip's reproducer
 // Every index is masked into the buffer, every loop is bounded by `iters`: nothing here can fault or spin.
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/foreign_kernels.hip -o pronerf_amd/lib/libforeign_kernels.so   (pronerf_amd.build.build_foreign_kernels)
 #include <hip/hip_runtime.h>
@@ -95,6 +97,25 @@ __global__ __launch_bounds__(256) void foreign_dma(const uint4* buf, uint32_t ma
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
 }
 
+__global__ __launch_bounds__(256) void foreign_mfma(const uint4* buf, uint32_t mask, int iters, uint32_t* sink, uint32_t* where) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  record_placement(where);
+  asm volatile("v_mov_b32 v239, 0" ::: "v239");                  // 240 registers per wave
+  const uint4 w = buf[(blockIdx.x * 256u + threadIdx.x) & mask];
+  const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(w.x & 0x3f803f80u, w.y & 0x3f803f80u, w.z & 0x3f803f80u, w.w & 0x3f803f80u));
+  const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(w.y & 0x3f803f80u, w.z & 0x3f803f80u, w.w & 0x3f803f80u, w.x & 0x3f803f80u));
+  f32x4 c[4];
+  for (int k = 0; k < 4; ++k) c[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[k & 3], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int k = 0; k < 4; ++k) s += c[k][0] + c[k][1] + c[k][2] + c[k][3];
+  if (s == 12345.678f) sink[0] = 1u;
+}
+
 }  // namespace
 
 // buf: device buffer of `bytes` bytes (a power of two >= 64 KiB), read only; sink: 1 word; where: NULL or 4 words per workgroup.
@@ -108,6 +129,7 @@ extern "C" int foreign_launch(int kind, void* stream, int grid, int iters, const
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)foreign_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return -2; attr = true; }
     hipLaunchKernelGGL(foreign_dma, dim3(grid), dim3(256), 65536, st, (const uint4*)buf, mask, iters, (uint32_t*)sink, (uint32_t*)where);
-  } else return -1;
+  } else if (kind == 3) hipLaunchKernelGGL(foreign_mfma, dim3(grid), dim3(256), 0, st, (const uint4*)buf, mask, iters, (uint32_t*)sink, (uint32_t*)where);
+  else return -1;
   return (int)hipGetLastError();
 }

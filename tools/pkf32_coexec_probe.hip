@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256) void victim(unsigned* dump, int iters, const f
   for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.01f * (float)((hash(gid * 8 + i) & 255) - 128)); b[i] = (_Float16)(0.01f * (float)((hash(gid * 8 + i + 77777) & 255) - 128)); }
   unsigned x = 0;
   ((volatile unsigned*)smem)[threadIdx.x] = gid;
+#ifdef VICTIM_OVFL          // the fused fp16 kernels run with MODE.FP16_OVFL = 1 (PrecF16::enter); the NeRF stage's bf16 kernel beside them does not
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+#endif
+#if defined(BIG_VGPR) || defined(VICTIM_BIG)             // 240 registers per wave like the fused kernels: victim + aggressor fill 480 of the SIMD's 512
+  asm volatile("v_mov_b32 v239, 0" ::: "v239");
+#endif
   for (int it = 0; it < iters; ++it) {
     f32x16 fin;
     for (int i = 0; i < 16; ++i) fin[i] = 0.001f * (float)((int)(hash(it * 16 + i) & 1023) - 512);
@@ -110,6 +116,12 @@ __global__ __launch_bounds__(256) void aggressor(float* sink, int iters, const u
   for (int k = 0; k < 4; ++k) c4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   float v[8];
   for (int i = 0; i < 8; ++i) v[i] = 0.001f * (float)(gid + i);
+#if defined(BIG_VGPR) || defined(AGGR_BIG)
+  asm volatile("v_mov_b32 v239, 0" ::: "v239");
+#endif
+#ifdef AGGR_OVFL
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+#endif
   for (int it = 0; it < iters; ++it) {
     if (KIND == 0) {
 #pragma unroll
@@ -201,8 +213,16 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(got.data(), dump, ndump * 4, hipMemcpyDeviceToHost));
   size_t self = 0;
   for (size_t i = 0; i < ndump; ++i) self += got[i] != ref[i];
-#ifdef NO_PK
+#ifdef BUILD_NAME
+  const char* build = BUILD_NAME;
+#elif defined(NO_PK)
   const char* build = "no packed fp32 instructions (-packed-fp32-ops)";
+#elif defined(VICTIM_OVFL) && defined(BIG_VGPR)
+  const char* build = "packed fp32; victim with MODE.FP16_OVFL; 240 VGPRs per wave on both sides";
+#elif defined(VICTIM_OVFL)
+  const char* build = "packed fp32; victim with MODE.FP16_OVFL";
+#elif defined(BIG_VGPR)
+  const char* build = "packed fp32; 240 VGPRs per wave on both sides";
 #else
   const char* build = "packed fp32 (default flags)";
 #endif
