@@ -105,34 +105,42 @@ def _packed_views(ref_rgb, ref_pose, n_samples, num_neighbor):
     return ent
 
 
-_MM_CHECKED = []     # at most one entry: (mm_input, its _version, ray_batch, its _version)
+_MM_CHECKED = []     # at most one entry: (weakref to mm_input, its _version, weakref to ray_batch, its _version) — weak, so that a verified 878 MB encoding is not kept alive by this module
 
 
 def _check_mm_input(mm_input, ray_batch, n_pts):
     """The reference's sampler consumes ``kwargs['mm_input']`` (run_S_eS_eN_alter_trt.py:625-628); the fused sampler recomputes the encoding
     from ``ray_batch`` in its batch head.  That is the same thing only while ``mm_input`` IS the Pluecker encoding of ``ray_batch`` — what
     ``render_path`` builds (trt.py:273-277).  So a caller's ``mm_input`` is verified, once per tensor (identity + in-place version, as
-    ``_packed_views`` does): every value within 8 ulp of max(|value|, 1) of ``ops.ray_encode(ray_batch)`` (the kernel's own encoding is bit-identical
-    to torch's on the CPU; a caller's GPU / fused-multiply-add evaluation may differ in the last bits), otherwise PnrfError — a different
-    ``mm_input`` would silently be ignored."""
+    ``_packed_views`` does; weak references: a tensor that has been freed cannot match): every value within 8 ulp of max(|value|, 1) of
+    ``ops.ray_encode(ray_batch)`` (the kernel's own encoding is bit-identical to torch's on the CPU; a caller's GPU / fused-multiply-add evaluation
+    may differ in the last bits), in chunks of 65 536 rays; otherwise PnrfError — a different ``mm_input`` would silently be ignored."""
+    import weakref
     if _MM_CHECKED:
         m, mv, r, rv = _MM_CHECKED[0]
-        if m is mm_input and r is ray_batch and mv == mm_input._version and rv == ray_batch._version:
+        if m() is mm_input and r() is ray_batch and mv == mm_input._version and rv == ray_batch._version:
             return
     if mm_input.shape != (ray_batch.shape[0], 6 * n_pts):
         raise PnrfError(f'render_rays: mm_input has shape {tuple(mm_input.shape)}, expected {(ray_batch.shape[0], 6 * n_pts)} (6 * N_point_ray_enc per ray)')
     if mm_input.device != ray_batch.device:
         raise PnrfError('render_rays: mm_input and ray_batch are on different devices')
-    want = ops.ray_encode(ray_batch, n_pts)
-    got = mm_input.to(torch.float32)
-    tol = 8 * torch.finfo(torch.float32).eps * torch.maximum(want.abs(), torch.ones_like(want))
-    bad = ~((got - want).abs() <= tol)              # NaN counts as different
-    if bool(bad.any()):
-        i = int(bad.any(1).nonzero()[0])
-        raise PnrfError(f'render_rays: mm_input is not the Pluecker encoding of ray_batch ({int(bad.sum())} values differ, first in row {i}: max |diff| '
-                        f'{float((got - want).abs().nan_to_num(float("inf")).max()):.3g}); the fused sampler encodes ray_batch itself (trt.py:273-277) and '
-                        'cannot honour a different mm_input — pass mm_input=None, or use ops.sampler_fwd on rays built from it')
-    _MM_CHECKED[:] = [(mm_input, mm_input._version, ray_batch, ray_batch._version)]
+    eps8 = 8 * torch.finfo(torch.float32).eps
+    n_bad, first, worst = 0, None, 0.0
+    for a in range(0, ray_batch.shape[0], 65536):
+        want = ops.ray_encode(ray_batch[a:a + 65536].contiguous(), n_pts)
+        diff = (mm_input[a:a + 65536].to(torch.float32) - want).abs()
+        bad = ~(diff <= eps8 * want.abs().clamp_min(1.0))          # NaN counts as different
+        nb = int(bad.sum())
+        if nb:
+            if first is None:
+                first = a + int(bad.any(1).nonzero()[0])
+            n_bad += nb
+            worst = max(worst, float(diff.nan_to_num(float('inf')).max()))
+    if n_bad:
+        raise PnrfError(f'render_rays: mm_input is not the Pluecker encoding of ray_batch ({n_bad} values differ, first in row {first}: max |diff| {worst:.3g}); '
+                        'the fused sampler encodes ray_batch itself (trt.py:273-277) and cannot honour a different mm_input — pass mm_input=None, or use '
+                        'ops.sampler_fwd on rays built from it')
+    _MM_CHECKED[:] = [(weakref.ref(mm_input), mm_input._version, weakref.ref(ray_batch), ray_batch._version)]
 
 
 def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,

@@ -155,7 +155,7 @@ def test_render_rays_like_the_reference_driver(dev, golden_dir, name):
     # encoding of ray_batch — a changed value, a NaN, another shape — is refused instead of silently rendering something else
     mm = fr['mm_input'].to(dev)
     trt.render(rays, or_rays, (Hh, Ww, 3), mm_input=mm, ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)
-    assert trt._MM_CHECKED and trt._MM_CHECKED[0][0] is mm
+    assert trt._MM_CHECKED and trt._MM_CHECKED[0][0]() is mm
     for tamper in ('value', 'nan', 'shape', 'inplace'):
         bad = mm.clone() if tamper != 'inplace' else mm
         if tamper == 'value':
