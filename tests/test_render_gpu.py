@@ -282,7 +282,8 @@ def test_chunked_renderer_streams_equal_the_one_call_frame(dev):
 def test_concurrent_streams_never_change_a_row(dev):
     """Regression test of round 4: calls on four streams at once (a context each) with the narrow shape forced and with the per-launch default —
     250 x 1024-ray calls per frame, three frames each: every row equals the one-call frame.  (Two 4-wave workgroups of different fused kernels
-    on one CU returned wrong rows a few times per thousand calls; a CU now holds at most one fused-MLP workgroup.)"""
+    on one CU returned wrong rows a few times per thousand calls; round 5 found the cause — compiler-generated packed-fp32 instructions in the refine
+    epilogue, DESIGN.md §4.5 — and the library is built without them; a CU still holds at most one fused-MLP workgroup, for speed.)"""
     from pronerf_amd.render import ChunkedRenderer, Renderer
     Hh, Ww = 400, 640
     scene = synth.make_scene(4, H=Hh, W=Ww, rotate=True)
