@@ -19,7 +19,9 @@ in HBM before the timed region, exactly like the reference's timed loop
 [n,4] rgb+depth tiles are all-gathered over RCCL inside the timed region, the gather of frame i behind the render of frame i + 1
 ("strong" scaling: the frame is fixed).
 
-Rank 0 prints ONE JSON line (see the driver contract); at N=1 it carries `roofline`, `cpu_baseline`
+Rank 0 prints ONE JSON line (see the driver contract).  Every line carries `frame_sha256` â€” the assembled frame of the last timed step: the same
+digest at every N â€” and, at N > 1, `per_rank` (device, rays, render ms alone, gather ms alone: measured behind the timed region, so that a scaling
+line explains itself).  At N=1 it carries `roofline`, `cpu_baseline`
 (the CPU oracle on the host cores, 65 536 rays of the same frame) and `gpu_eager_baseline`: the oracle's
 eager fp32 torch graph on the same GPU, whole frame in one call, device events â€” BASELINE.md Â§4 item 2,
 "the reference single-GPU PyTorch rays/s" that BASELINE.json's >= 10x target is measured against.  No
@@ -30,7 +32,9 @@ Also after the timed region, at N=1 (each can be switched off): `steady_state` â
 package cap / shader clock polled from rocm-smi meanwhile (the path is power-limited: DESIGN.md 4.4); `shard_rehearsal` â€” this GPU's time on the
 first / middle / last rank's share of the frame at N = 2, 4, 8 (contiguous and block-cyclic) and on 1024- / 4096-ray calls; `chunked_1024` â€” the
 same frame as 745 calls of <= 1024 rays (the literal reading of configs[1]): on one stream, over four streams, and each as one hipGraph, next to
-the one-call figure; `variants` â€” the frame with other operand types / the round-2 sampler; `train` â€” the training iterations of configs[3] /
+the one-call figure; `variants` â€” the frame with other operand types / the round-2 sampler; `weights_optimizer` â€” the frame on the only
+optimizer-trained nets in the tree (the fixture the package's own stage-1 / stage-2 drivers produced: more second-pass rays, the NeRF-class fine net),
+with its rgb PSNR against the eager oracle; `train` â€” the training iterations of configs[3] /
 configs[4] (stage-2 iteration at 4096 rays x 17 views of 756x1008; stage-1 exploration iterations at 64 and 256 samples per ray) with their
 algorithmic TFLOP/s, a per-kernel table measured in the run, HBM bytes from the newest committed profiles/r*_train_pmc_summary.json (quoted with
 its provenance, refused when the trainer's sources changed since) and the same iteration as eager torch autograd + torch.optim.Adam on this GPU.

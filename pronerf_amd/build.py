@@ -57,17 +57,43 @@ TRAINER_ONLY = ('pnrf_train.hip', 'pnrf_tchain.h', 'pnrf_hgemm.h')     # sources
 INFERENCE_ONLY = ('pnrf_mlp_kernels.hip',)                           # ... and the one no trainer kernel is built from (the trainer has its own chains)
 
 
+def _code_only(text: str) -> str:
+    """C / C++ source without comments and with runs of white space folded: what the compiler sees.  String and character literals are kept verbatim."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '/' and i + 1 < n and text[i + 1] == '/':
+            while i < n and text[i] != '\n':
+                i += 1
+        elif c == '/' and i + 1 < n and text[i + 1] == '*':
+            j = text.find('*/', i + 2)
+            i = n if j < 0 else j + 2
+            out.append(' ')
+        elif c in '"\'':
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == '\\' else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return ' '.join(''.join(out).split())
+
+
 def _digest(scope='all'):
-    """sha256 over the kernel sources + build flags.  scope 'all': every file (the library's .sha256 stamp, trainer profiles);
+    """sha256 over the kernel sources + build flags.  scope 'all': every file, byte for byte (the library's .sha256 stamp);
     'inference': without the trainer-only sources — what the rendering kernels are built from (tools/profile_round.sh records it, bench.py
     compares it before quoting a profile), so that work on the trainer does not void the frame's PMC profile; 'training': without the fused
-    inference kernels' source, for the trainer's profile (tools/profile_train.sh)."""
+    inference kernels' source, for the trainer's profile (tools/profile_train.sh).  The two profile scopes hash the CODE — comments stripped, white
+    space folded (_code_only) — so that a comment in the header does not void a profile of kernels it did not change (round 5: twice)."""
     h = hashlib.sha256()
     files = sorted(os.listdir(CSRC)) + ['../../include/pronerf_hip.h']
     for f in files:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p) and not (scope == 'inference' and f in TRAINER_ONLY) and not (scope == 'training' and f in INFERENCE_ONLY):
-            h.update(f.encode()); h.update(open(p, 'rb').read())
+            h.update(f.encode())
+            h.update(open(p, 'rb').read() if scope == 'all' else _code_only(open(p, encoding='utf-8', errors='replace').read()).encode())
     h.update(' '.join(FLAGS).encode())
     return h.hexdigest()
 

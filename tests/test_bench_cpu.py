@@ -49,3 +49,7 @@ def test_profile_numbers_are_refused_when_the_kernel_sources_changed():
     # the frame's profile is keyed to the sources the rendering kernels are built from; the trainer's to everything
     from pronerf_amd import build
     assert now == build._digest('inference') != build._digest('all') == bench.csrc_digest('all') != build._digest('training')
+    # the profile scopes hash code, not comments or layout: a comment in the header must not void a profile of kernels it did not change
+    assert build._code_only('int a = 1; // c\n/* x\n y */ const char* s = "//not /*c*/"; char q = \'"\';\n\n  int   b;') == \
+        'int a = 1; const char* s = "//not /*c*/"; char q = \'"\'; int b;'
+    assert build._code_only('x = 1; /* a */') == build._code_only('x = 1;   // b') != build._code_only('x = 2;')
