@@ -25,7 +25,8 @@ ARCH = 'gfx950'
 # No packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) in any kernel of the library.  Round 5 traced round 4's "co-residency
 # hazard" to them: in the fused refine kernel's scalar epilogue — where the SLP vectorizer had paired the fp32 arithmetic — a v_pk_mul_f32 returned 0 in one
 # 16-lane quarter of a wave a few times per thousand calls, but only while a workgroup of a DIFFERENT fused kernel shared the CU (loads, every layer's B
-# operand and the last accumulators bit-identical in the failing batches; 121 / 209 / 102 bad chunks per 29 800 with packed fp32, 0 per 134 100 without:
+# operand and the last accumulators bit-identical in the failing batches; 121 / 209 / 102 bad chunks per 29 800 with packed fp32, 0 per 283 100 without;
+# tools/pkf32_coexec_probe.hip reproduces it in a micro-kernel: victim in MODE.FP16_OVFL, 240-register windows on both waves, a 16x16x32 bf16 MFMA partner:
 # NOTEBOOK §19, profiles/r05_coresidency_*).  The feature is switched off for the device compilation (the host pass prints "not a recognized feature" for
 # it, filtered below); tests/test_abi_cpu.py disassembles the built library and fails on any packed-fp32 opcode.
 NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']

@@ -1722,9 +1722,11 @@ int launch_mlp(K kern, const A& a, int tpb, size_t lds, int nbatch, hipStream_t 
 // (Round 4 also saw paired workgroups of DIFFERENT kernels return wrong rows — 16 consecutive rays of a refine wave — a few times per thousand
 // calls and excluded the configuration without finding the cause.  Round 5 found it (NOTEBOOK §19): not the batch-head loads but compiler-generated
 // PACKED FP32 arithmetic in the refine epilogue — loads, every layer's B operand and the last accumulators were bit-identical in the failing batches,
-// a v_pk_mul_f32 of the query-point arithmetic returned 0 in one 16-lane quarter of the wave; without packed-fp32 instructions the paired
-// configuration is clean over 134 100 concurrent chunks (121-209 bad chunks per 29 800 with them).  The library is built without them
-// (pronerf_amd/build.py NO_PACKED_FP32; tests/test_abi_cpu.py checks the disassembly), so the shape rule below no longer carries correctness.)
+// a v_pk_mul_f32 of the query-point arithmetic returned 0 in the wave's last 16 lanes; tools/pkf32_coexec_probe.hip reproduces it in a micro-kernel and
+// names the ingredients: the victim in MODE.FP16_OVFL, 240-register windows on both waves of the SIMD, a v_mfma_f32_16x16x32_bf16 partner (the NeRF
+// stage).  Without packed-fp32 instructions the paired configuration is clean over 283 100 concurrent chunks (121-209 bad chunks per 29 800 with them).
+// The library is built without them (pronerf_amd/build.py NO_PACKED_FP32; tests/test_abi_cpu.py checks the disassembly), so the shape rule below no
+// longer carries correctness.)
 enum { SHAPE_WIDE = PNRF_SHAPE_WIDE, SHAPE_NARROW = PNRF_SHAPE_NARROW };
 #ifndef PNRF_NARROW_LDS_BYTES
 #define PNRF_NARROW_LDS_BYTES (84 * 1024)
