@@ -10,9 +10,9 @@ python3 -c "from pronerf_amd import build; print(build._digest('inference'))" > 
 python3 bench.py --steps 20 --warmup 10 --no-train > "$OUT/bench.json"
 python3 -c "import json,sys; j=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]); json.dump(j['shard_rehearsal'], open('$OUT/shard_rehearsal.json','w'), indent=1)"
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gpu-eager-baseline --no-sustained --no-chunked --no-variants --no-train --no-shard-rehearsal --steady-seconds 0 > "$OUT/bench_under_rocprof.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-gpu-eager-baseline --no-sustained --no-chunked --no-variants --no-train --no-shard-rehearsal --no-optimizer-weights --steady-seconds 0 > "$OUT/bench_under_rocprof.json"
 echo "stats done"
-LIGHT="--no-cpu-baseline --no-gpu-eager-baseline --no-sustained --no-chunked --no-variants --no-train --no-shard-rehearsal --steady-seconds 0"
+LIGHT="--no-cpu-baseline --no-gpu-eager-baseline --no-sustained --no-chunked --no-variants --no-train --no-shard-rehearsal --no-optimizer-weights --steady-seconds 0"
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
   D="$OUT/pmc_$(echo $C | tr ' ' '_')"
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$D" -- python3 bench.py --steps 3 --warmup 1 $LIGHT > "$D.json"
