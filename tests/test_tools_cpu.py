@@ -14,7 +14,9 @@ HIPCC = next((c for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil
 @pytest.mark.skipif(HIPCC is None, reason='hipcc not found')
 @pytest.mark.parametrize('src,extra', [('tools/hgemm_probe.hip', ['-I', os.path.join(ROOT, 'pronerf_amd', 'csrc'), '-std=c++17']),
                                        ('tools/mfma_ceiling.hip', []),
-                                       ('tools/foreign_kernels.hip', [])])
+                                       ('tools/foreign_kernels.hip', []),
+                                       ('tools/pkf32_coexec_probe.hip', ['-DVICTIM_OVFL', '-DBIG_VGPR']),      # the packed-fp32 fault's micro-reproducer
+                                       ('tools/valu_rate_probe.hip', []), ('tools/mfma_valu_overlap_probe.hip', []), ('tools/elu_chain_probe.hip', [])])
 def test_probe_compiles(tmp_path, src, extra):
     out = str(tmp_path / 'probe.o')
     r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O1', '-c', os.path.join(ROOT, src), '-o', out] + extra, capture_output=True, text=True, timeout=600)
