@@ -216,7 +216,8 @@ int pnrf_sampler_fwd(const pnrf_mlp_t* h, const float* rays, int64_t n, float* d
  * measured error where it is tightest (largest |error| / s over 524 288 depths: 0.8 .. 1.9 on seven weight sets, tools/sampler_twopass_model.py),
  * so the threshold is >= 7.6 sigma of the difference of two errors; it is 2x the smallest kappa that was ever clean and >= 4x the first that
  * was not (0 index mismatches on 762 048 rays x synthetic, heavy-tailed, x4-scaled and optimizer-trained weights down to kappa = 1; one ray
- * of 3 M at 0.5: tools/kappa_scan.py, tests/test_fullframe_gpu.py).  It halves the second pass (7.5 % of the bench frame's rays instead of
+ * of 3 M at 0.5: tools/kappa_scan.py, tests/test_fullframe_gpu.py; 0 of 45.7 M rays of 60 further weight sets at kappa = 2 and at 1:
+ * tools/kappa_population.py).  It halves the second pass (7.5 % of the bench frame's rays instead of
  * 14.6 %).  Where exactness matters more than 0.5 ms per frame, PNRF_VARIANT_SAMPLER_SPLIT renders every ray fp32-grade;
  * pnrf_ctx_set_sampler_kappa restores a wider margin per context.
  * kappa < 0 selects PNRF_SAMPLER_KAPPA; kappa = 0 leaves only the fp32 round-off allowance (tests); NaN and values >= 1e30 are refused.
