@@ -781,7 +781,7 @@ def main():
             if sus:                            # context for `frac`: the spec peak is not reachable at this chip's power limit with real operand bits
                 res['roofline']['sustained'] = dict(sus, frac_of_sustained=kern[dom]['achieved_tflops'] / sus['random_operands_tflops'])
             n2 = rend.ctx.sampler_stats()
-            res['sampler_two_pass'] = {'rays_second_pass': n2, 'fraction': n2 / n_total, 'kappa': 2.0,
+            res['sampler_two_pass'] = {'rays_second_pass': n2, 'fraction': n2 / n_total, 'kappa': rend.ctx.sampler_kappa(),
                                        'what': 'rays whose depth order the plain-fp16 pass could not decide (adjacent sorted gap <= kappa x its own '
                                                'error bound): re-rendered by the split-fp16 kernel'}
             one_call = outs[0][:count].clone()

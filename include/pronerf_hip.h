@@ -192,8 +192,12 @@ int pnrf_composite_fwd(const float* raw, const float* z, const float* rays_d, in
                        float* depth, int64_t n, int s, void* stream);
 
 /* ---- fused stages ---------------------------------------------------------------------------
- * Sampler: Pluecker ray encoding -> fp32 MLP (exact f32 MFMA) -> sigmoid, depth affine, stable
- * ascending sort of the 8 depths, permutation of add/mul.  rays dev [n,11].  Outputs dev:
+ * Sampler: Pluecker ray encoding -> MLP -> sigmoid, depth affine, stable ascending sort of the 8 depths,
+ * permutation of add/mul.  Arithmetic of a DEFAULT handle: every layer product in SPLIT fp16 (hi + lo planes, three
+ * v_mfma_f32_16x16x32_f16 per product, fp32 accumulation: fp32-grade, 22 significand bits per operand), every ray in one pass —
+ * the exact-index form; SAMPLER_F32 / SAMPLER_F32_FULL handles run the exact fp32 FMA chain (v_mfma_f32_16x16x4_f32) instead.
+ * (The frame path pnrf_render_rays_fwd runs pnrf_sampler_fwd_ws below: a plain-fp16 first pass + this kernel on the undecided
+ * rays.)  rays dev [n,11].  Outputs dev:
  * depth_sorted[n,8], add_sorted[n,8], mul_sorted[n,8]; optional (NULL to skip) sort_idx[n,8]
  * (int64, the "sampler indices"), mm_rgb[n,3], depth_raw[n,8] (sigmoid output before the sort).
  * (run_S_eS_eN_alter_trt.py:628-635) */
@@ -229,15 +233,17 @@ int64_t pnrf_sampler_workspace_bytes(int64_t n);
 int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
                         float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,
                         int64_t workspace_bytes, float kappa, void* stream);
-/* Refine: bf16 MLP on refine_in[n,144] -> sigmoid/tanh -> interval refinement -> query points.
+/* Refine: MLP on refine_in[n,144] -> sigmoid/tanh -> interval refinement -> query points.  Arithmetic of a DEFAULT handle: fp16
+ * operands (v_mfma_f32_32x32x16_f16, 11 significand bits, MODE.FP16_OVFL saturation), fp32 accumulation; a handle set to
+ * PNRF_VARIANT_BF16 runs bf16 operands (8 bits; the round-2 default).
  * Outputs dev: z[n,8], pts[n,8,3]  (run_S_eS_eN_alter_trt.py:668-681). */
 int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
                     const float* depth_sorted, float* z, float* pts, int64_t n, void* stream);
 /* Projection + refine in ONE kernel: what pnrf_refine_input_fwd followed by pnrf_refine_fwd compute, without the refine_in [n,144]
- * round trip through HBM.  NOT bit for bit: the colours go straight into bf16 operands, so the head uses a linearised projection
+ * round trip through HBM.  NOT bit for bit: the colours go straight into the MFMA operands (fp16 on a DEFAULT handle, bf16 on a PNRF_VARIANT_BF16 one), so the head uses a linearised projection
  * p(z) = A + z B per (ray, view) with FMA contraction and v_rcp_f32 for 1 / (1 - d - eps) and 1 / p.z, and skips grid_sample's normalise /
- * un-normalise round trip: pixel coordinates move by a few fp32 ulps (~1e-4 px), colours by ~1e-4 of the local texel difference, 20x
- * below the bf16 rounding applied next (tests/test_ops_gpu.py bounds z within 2e-3 of the two-kernel path).  The operator that replays
+ * un-normalise round trip: pixel coordinates move by a few fp32 ulps (~1e-4 px), colours by ~1e-4 of the local texel difference, well
+ * below the operand rounding applied next (fp16: 5e-4 relative) (tests/test_ops_gpu.py bounds z within 2e-3 of the two-kernel path).  The operator that replays
  * the reference's fp32 projection sequence exactly is pnrf_refine_input_fwd.  Here every workgroup projects the samples of its 256 rays into the four neighbour views, fetches
  * the colours and encodes the sample Pluecker values in the head of its batch, straight into the MFMA operand registers.
  * rays, or_rays dev [n,11]; depth_sorted dev [n,8]; img4 dev [4,Hf,Wf,4] (pnrf_images_pack); proj dev [4,3,4]; eps as pnrf_refine_input_fwd.
@@ -252,7 +258,8 @@ int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float*
 int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays,
                           const float* depth_sorted, const float* jitter, int jitter_dir, float* z, float* pts,
                           float* rgb0, int64_t n, void* stream);
-/* NeRF: positional encoding of pts/viewdirs -> bf16 MLP -> alpha compositing with the sampler's
+/* NeRF: positional encoding of pts/viewdirs -> MLP (DEFAULT handle: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation;
+ * PNRF_VARIANT_F16: fp16 operands) -> alpha compositing with the sampler's
  * density modulation.  pts dev [n,8,3]; rays dev [n,11]; z, add_sorted, mul_sorted dev [n,8].
  * Outputs dev: rgbd[n,4] = (r,g,b,depth); raw[n,8,4] optional (NULL to skip).  h may be a PNRF_NET_NERF or a
  * PNRF_NET_NERFCLS handle (the fine-net class mismatch of the released scripts).
@@ -293,6 +300,8 @@ int pnrf_render_rays_fwd(pnrf_ctx_t* ctx, const float* rays, const float* or_ray
  * context has), 0 = only the fp32 round-off allowance; NaN and values >= 1e30 are refused.  A larger kappa sends more rays through the
  * fp32-grade second pass; PNRF_VARIANT_SAMPLER_SPLIT on the sampler handle sends all of them (the exact path). */
 int pnrf_ctx_set_sampler_kappa(pnrf_ctx_t* ctx, float kappa);
+/* The kappa this context's calls run with (PNRF_SAMPLER_KAPPA unless pnrf_ctx_set_sampler_kappa chose another): what bench.py reports. */
+int pnrf_ctx_get_sampler_kappa(const pnrf_ctx_t* ctx, float* kappa);
 /* Rays the sampler's second pass rendered in the context's most recent pnrf_render_rays_fwd (waits for the device; diagnostics). */
 int pnrf_ctx_sampler_stats(pnrf_ctx_t* ctx, int64_t* rays_second_pass);
 /* Rays whose hidden activations reached the fp16 limit in the split-fp16 kernel and were therefore rendered by the exact-fp32 kernel (the
@@ -358,8 +367,11 @@ int pnrf_trainer_free(pnrf_trainer_t* t);
 /* Weight-gradient kernel of the square layers: tile 0 = chosen by shape and row count (default), 64 / 128 = forced where the shape allows;
  * min_rows_128 = row count from which the 128 x 128-tile kernel is used (0 = default).  tile 256 / 255 (round 5) leave that choice alone and switch
  * the 256 x 128-tile form of the grouped split-fp16 gradients on from min_rows_128 rows (0: from the first row) / off; default: from 32 768 rows.
- * Configuration, not on the step path. */
+ * The two choices are independent: tile 0 / 64 / 128 do not touch the wide-tile threshold either.  Configuration, not on the step path. */
 int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t min_rows_128);
+/* Diagnostics of the most recent iteration's grouped weight-gradient launch: number of gradients it held and which of them (bit k = k-th) ran on
+ * the 256 x 128 tiles.  Host state; lets a test assert that the tile shape it forced is the one that ran. */
+int pnrf_trainer_dw_group_info(const pnrf_trainer_t* t, int* n_jobs, unsigned* wide_mask);
 
 /* kind 0 parameters, 1 gradients, 2 / 3 Adam first / second moment of the joint optimizer, 4 / 5 those of the NeRF-only
  * optimizer; W, b: host or device (NULL to skip). */

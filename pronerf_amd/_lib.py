@@ -64,6 +64,7 @@ SIGNATURES = {
     'pnrf_render_rays_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _i64, _p]),
     'pnrf_ctx_sampler_stats': (_i, [_p, C.POINTER(_i64)]),
     'pnrf_ctx_set_sampler_kappa': (_i, [_p, _f]),
+    'pnrf_ctx_get_sampler_kappa': (_i, [_p, C.POINTER(_f)]),
     'pnrf_ctx_sampler_saturated': (_i, [_p, C.POINTER(_i64)]),
     'pnrf_ctx_profile_begin': (_i, [_p, _i]),
     'pnrf_ctx_profile_end': (_i, [_p, C.POINTER(C.c_float), C.POINTER(_i)]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     'pnrf_trainer_write': (_i, [_p, _i, _i, _p, _p, _p]),
     'pnrf_trainer_set_step': (_i, [_p, _i64, _i64]),
     'pnrf_trainer_set_dw_kernel': (_i, [_p, _i, _i64]),
+    'pnrf_trainer_dw_group_info': (_i, [_p, C.POINTER(_i), C.POINTER(C.c_uint)]),
     'pnrf_trainer_set_graph': (_i, [_p, _i]),
     'pnrf_trainer_set_products': (_i, [_p, _i]),
     'pnrf_trainer_flat': (_i, [_p, _i, C.POINTER(_p), C.POINTER(_i64)]),

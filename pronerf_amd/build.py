@@ -214,7 +214,7 @@ def build_variant(name: str, extra_flags=(), csrc: str = CSRC, include: str = IN
     if _quiet(r.stdout):
         print(_quiet(r.stdout))
     if r.returncode != 0:
-        raise RuntimeError(f'hipcc failed building variant {name}')
+        raise RuntimeError(f'hipcc failed building variant {name} (exit {r.returncode}); last lines of its output:\n' + '\n'.join(r.stdout.splitlines()[-30:]))
     return out
 
 

@@ -854,6 +854,12 @@ extern "C" int pnrf_ctx_set_sampler_kappa(pnrf_ctx_t* c, float kappa) {
   return 0;
 }
 
+extern "C" int pnrf_ctx_get_sampler_kappa(const pnrf_ctx_t* c, float* kappa) {
+  PNRF_REQUIRE(c && kappa, PNRF_E_ARG, "pnrf_ctx_get_sampler_kappa: null argument");
+  *kappa = c->kappa < 0.f ? PNRF_SAMPLER_KAPPA : c->kappa;
+  return 0;
+}
+
 extern "C" int pnrf_ctx_sampler_stats(pnrf_ctx_t* c, int64_t* rays_second_pass) {
   PNRF_REQUIRE(c && rays_second_pass, PNRF_E_ARG, "pnrf_ctx_sampler_stats: null argument");
   int v[2] = {0, 0};

@@ -1152,7 +1152,7 @@ struct pnrf_trainer {
   float *M2 = nullptr, *V2 = nullptr;            // second Adam state over the NeRF layers only (stage 1: `optimizer` next to `s_optimizer`)
   int64_t step = 0, step2 = 0;
   int dw_tile = 0;                               // 0: by shape and row count; 64 / 128: force that weight-gradient kernel where it applies
-  int64_t dw_wide_min_rows = 32768;              // grouped split-fp16 weight gradients: 256 x 128 tiles (dwh_body_wide) from this many rows on (pnrf_trainer_set_dw_kernel(.., tile 256 / 129))
+  int64_t dw_wide_min_rows = 32768;              // grouped split-fp16 weight gradients: 256 x 128 tiles (dwh_body_wide) from this many rows on (pnrf_trainer_set_dw_kernel(.., tile 256 / 255))
   int64_t dw128_min_rows = 65536;
   // hipGraph replay of an iteration (pnrf_trainer_set_graph): the batch is copied into the trainer's own staging buffers by one kernel, so
   // every pointer and scalar argument inside the captured launch sequence is fixed; one instantiated graph per configuration key
@@ -1199,6 +1199,7 @@ struct pnrf_trainer {
   float* amax = nullptr;                         // [N_AMAX] max |dL/dZ| per gradient buffer write, this iteration
   size_t pool_cap = 0, pool_used = 0;            // split-K partials of the iteration's weight gradients (floats); reset per iteration
   DwJobs jobs;                                   // ... and who sums them (dw_reduce_kernel, one launch per iteration)
+  int grp_last_n = 0; unsigned grp_last_wide = 0;   // the most recent grouped launch (pnrf_trainer_dw_group_info)
   DwhGroupArgs grp;                              // split-fp16 weight gradients waiting for the iteration's one grouped launch (flush_dw_group): the 256-wide
   int grp_blocks = 0;                            // layers of all three nets; their gradient / activation buffers stay untouched until then
   float* d_hs[6] = {};                           // the sampler net's hidden gradients (d_hk holds the refine net's until the grouped launch)
@@ -1349,6 +1350,7 @@ int flush_dw_group(pnrf_trainer* t, hipStream_t s) {
   t->grp.first[t->grp.n] = t->grp_blocks;
   hipLaunchKernelGGL(dwh_group_kernel, dim3((unsigned)t->grp_blocks), dim3(512), 0, s, t->grp);
   PNRF_LAUNCH_CHECK();
+  t->grp_last_n = t->grp.n; t->grp_last_wide = t->grp.wide;
   t->grp.n = 0; t->grp_blocks = 0;
   return 0;
 }
@@ -1808,9 +1810,16 @@ extern "C" int pnrf_trainer_set_dw_kernel(pnrf_trainer_t* t, int tile, int64_t m
     t->dw_wide_min_rows = tile == 255 ? INT64_MAX : (min_rows_128 > 0 ? min_rows_128 : 1);
     return 0;
   }
-  t->dw_wide_min_rows = 32768;
-  t->dw_tile = tile;
+  t->dw_tile = tile;                        // (the wide-tile threshold is a separate choice: left as it is)
   t->dw128_min_rows = tile == 128 ? (min_rows_128 > 0 ? min_rows_128 : 256) : (min_rows_128 > 0 ? min_rows_128 : 65536);
+  return 0;
+}
+
+// What the most recent iteration's grouped weight-gradient launch (dwh_group_kernel) held: number of gradients in it, and which of them ran on
+// the 256 x 128 tiles (bit k = k-th job).  Host state only; tests assert with it that a forced tile shape was really the one that ran.
+extern "C" int pnrf_trainer_dw_group_info(const pnrf_trainer_t* t, int* n_jobs, unsigned* wide_mask) {
+  PNRF_REQUIRE(t && n_jobs && wide_mask, PNRF_E_ARG, "pnrf_trainer_dw_group_info: null argument");
+  *n_jobs = t->grp_last_n; *wide_mask = t->grp_last_wide;
   return 0;
 }
 

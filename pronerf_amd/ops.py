@@ -387,9 +387,15 @@ class RenderContext:
         return int(v.value)
 
     def set_sampler_kappa(self, kappa):
-        """Threshold of the two-pass sampler for this context (pnrf_ctx_set_sampler_kappa): negative = the library default (4), 0 = only the
-        fp32 round-off allowance; NaN / inf are refused."""
+        """Threshold of the two-pass sampler for this context (pnrf_ctx_set_sampler_kappa): negative = the library default (PNRF_SAMPLER_KAPPA of
+        include/pronerf_hip.h; ``sampler_kappa()`` reports it), 0 = only the fp32 round-off allowance; NaN / inf are refused."""
         check(_lib.load().pnrf_ctx_set_sampler_kappa(self.handle, float(kappa)), 'pnrf_ctx_set_sampler_kappa')
+
+    def sampler_kappa(self):
+        """The threshold this context's calls run with (pnrf_ctx_get_sampler_kappa)."""
+        v = C.c_float()
+        check(_lib.load().pnrf_ctx_get_sampler_kappa(self.handle, C.byref(v)), 'pnrf_ctx_get_sampler_kappa')
+        return float(v.value)
 
     def profile_begin(self, max_frames=64):
         """Record per-stage events on the next ``max_frames`` render_rays calls (pnrf_ctx_profile_begin)."""
@@ -554,6 +560,13 @@ class Trainer:
         """Weight-gradient kernel of the square layers: 0 = by shape and row count, 64 / 128 = forced; 256 / 255 = the grouped gradients' 256 x 128 tiles
         on from ``min_rows_128`` rows / off (pnrf_trainer_set_dw_kernel)."""
         check(_lib.load().pnrf_trainer_set_dw_kernel(self.handle, int(tile), int(min_rows_128)), 'pnrf_trainer_set_dw_kernel')
+
+    def dw_group_info(self):
+        """(gradients in the most recent iteration's grouped weight-gradient launch, bit mask of those that ran on 256 x 128 tiles)
+        (pnrf_trainer_dw_group_info)."""
+        n, m = C.c_int(), C.c_uint()
+        check(_lib.load().pnrf_trainer_dw_group_info(self.handle, C.byref(n), C.byref(m)), 'pnrf_trainer_dw_group_info')
+        return int(n.value), int(m.value)
 
     def set_graph(self, enable=True):
         """Replay the iterations as hipGraphs, or (default) launch their kernels one by one (pnrf_trainer_set_graph)."""

@@ -17,6 +17,14 @@ N_SAMPLES = 8
 NUM_NEIGHBOR = 4
 FLIP = np.diag([1.0, -1.0, -1.0]).astype(np.float32)
 
+# Named operating points of the renderer (``Renderer(preset=...)``; the per-net kernel variants of include/pronerf_hip.h).
+#   'default'  what bench.py's headline times: two-pass sampler (statistical index parity, fp16-grade depths on the undecided-free rays),
+#              fp16 refine, bf16 NeRF MLP — rendering error 56 .. 59 dB against the fp32 reference renderer; holds the "PSNR within 0.05 dB
+#              of the reference" gate for images of up to ~36 dB PSNR, with 2x headroom up to ~33 dB (real LLFF scenes: 25 .. 28 dB).
+#   'quality'  every ray through the split-fp16 sampler (exact indices, fp32-grade depths) + fp16 NeRF operands: 63 .. 65 dB rendering error,
+#              +0.8 ms per 762 048-ray frame; the choice for scenes a net fits beyond ~35 dB and wherever index parity must be exact.
+PRESETS = {'default': {}, 'quality': {'sampler': 'sampler_split', 'nerf': 'f16'}}
+
 
 def select_neighbors(c2w, poses, num_neighbor=NUM_NEIGHBOR):
     """Indices of the ``num_neighbor`` source cameras closest to the target camera centre,
@@ -113,13 +121,17 @@ class Renderer:
     ``ops.PackedMLP`` (a module's ``packed()``, or one loaded from an engine file).
     """
 
-    def __init__(self, weights, max_rays: int, device='cuda:0', variants=None, shape=None):
-        """variants: optional {'sampler' | 'refine' | 'nerf': kernel variant} (``ops.PackedMLP.set_variant``; parity tests and A/B
+    def __init__(self, weights, max_rays: int, device='cuda:0', variants=None, shape=None, preset='default'):
+        """preset: 'default' | 'quality' (``PRESETS`` above); ``variants`` override single nets of it.  variants: optional {'sampler' | 'refine' | 'nerf': kernel variant} (``ops.PackedMLP.set_variant``; parity tests and A/B
         timing — the default kernels are the product path).  shape: optional workgroup shape for the three nets ('wide' | 'narrow' |
         'auto', or a dict per net; ``ops.PackedMLP.set_shape``) — default: chosen per launch from the ray count."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise ops.PnrfError('Renderer needs a GPU device (pronerf_amd has no CPU path)')
+        if preset not in PRESETS:
+            raise ops.PnrfError(f'Renderer: preset must be one of {sorted(PRESETS)}, got {preset!r}')
+        self.preset = preset
+        variants = {**PRESETS[preset], **(variants or {})}
         def pack(net, w):
             if isinstance(w, ops.PackedMLP):                  # already packed (module.packed(), an engine file)
                 if w.net not in net:

@@ -156,6 +156,18 @@ def test_render_rays_like_the_reference_driver(dev, golden_dir, name):
     mm = fr['mm_input'].to(dev)
     trt.render(rays, or_rays, (Hh, Ww, 3), mm_input=mm, ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)
     assert trt._MM_CHECKED and trt._MM_CHECKED[0][0]() is mm
+    # row slices of the verified pair (the reference's per-chunk calling pattern) resolve to their bases: no second verification, no sync
+    real_encode = trt.ops.ray_encode
+    trt.ops.ray_encode = lambda *a, **k: (_ for _ in ()).throw(AssertionError('a slice of a verified mm_input was verified again'))
+    try:
+        half = rays.shape[0] // 2
+        out = trt.render_rays(rays[5:half], or_rays[5:half], mm_input=mm[5:half], ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)
+        assert torch.equal(out['rgb_map1'], rgb1.reshape(-1, 3)[5:half]) and trt._MM_CHECKED[0][0]() is mm
+    finally:
+        trt.ops.ray_encode = real_encode
+    with pytest.raises(PnrfError):           # a slice of mm_input that belongs to OTHER rows of the frame is not a hit, and is refused
+        trt.render_rays(rays[5:half], or_rays[5:half], mm_input=mm[6:half + 1], ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)
+    trt.render(rays, or_rays, (Hh, Ww, 3), mm_input=mm, ref_rgb=ref_rgb, ref_pose=ref_pose, ro1=ro1, rd1=rd1, **fwd)      # remembered again
     for tamper in ('value', 'nan', 'shape', 'inplace'):
         bad = mm.clone() if tamper != 'inplace' else mm
         if tamper == 'value':

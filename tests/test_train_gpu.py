@@ -734,6 +734,8 @@ def test_weight_gradient_kernels_agree(dev, tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(dict(np.load(out)))
     a, b = outs
+    for o in outs:
+        o.pop('group_info'); o.pop('rows')
     assert sorted(a) == sorted(b) and len(a) == 52
     differ = 0
     for k in a:
@@ -741,3 +743,41 @@ def test_weight_gradient_kernels_agree(dev, tmp_path):
         assert np.abs(a[k] - b[k]).max() <= 2e-5 * scale, (k, np.abs(a[k] - b[k]).max() / scale)
         differ += int(not np.array_equal(a[k], b[k]))
     assert differ >= 4          # (some of) the seven square NeRF layers, 3072 rows each, did go through the other kernel
+
+
+def test_wide_weight_gradient_tiles_agree_with_the_square_ones_and_with_fp64(dev, tmp_path):
+    """The grouped split-fp16 weight gradients on 256 x 128 tiles (dwh_body_wide — the default from 32 768 rows on: the stage-2 iteration and both
+    exploration workloads) against the same launch on 128 x 128 tiles and against the fp64 oracle, on a batch that reaches the grouped launch
+    (>= 8192 rows), with a row count that is not a multiple of 32 (10 296) and the skip layer's 319 input columns (not a multiple of 128).
+    The wide form keeps the square form's split count, so every partial sum has the same order: BIT-identical gradients.  The worker records which
+    jobs of the grouped launch ran wide: all ten 256-row gradients (pts1..7 incl. the skip layer, feature) with tile 256, none with 255."""
+    import subprocess
+    worker = os.path.join(os.path.dirname(__file__), 'dw_tile_worker.py')
+    outs = {}
+    for tile in ('256', '255'):
+        out = str(tmp_path / f't{tile}.npz')
+        r = subprocess.run([sys.executable, worker, out, tile], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tile] = dict(np.load(out))
+    wide, sq = outs['256'], outs['255']
+    assert int(wide['rows']) == 10296 and int(wide['rows']) % 32 != 0
+    n_w, m_w = (int(v) for v in wide['group_info'])
+    n_s, m_s = (int(v) for v in sq['group_info'])
+    assert n_w == n_s and n_w >= 9, (n_w, n_s)
+    assert m_s == 0 and bin(m_w).count('1') >= 8, (bin(m_w), bin(m_s))       # the wide bit really was set (and really was not)
+    keys = [k for k in wide if k[0] in 'Wb' and k[1:].isdigit()]
+    assert len(keys) == 52
+    for k in keys:
+        assert np.array_equal(wide[k], sq[k]), (k, np.abs(wide[k] - sq[k]).max())
+    # ... and the pair against the fp64 oracle, held to the fp32 CPU run's own distance from it (the bound of the 12 x 16 test above)
+    b = _batch(0, 33, 39, 7)
+    _, _, _, g64 = _oracle_grads(b, 1, False, 0.0, torch.float64)
+    _, _, _, g32 = _oracle_grads(b, 1, False, 0.0, torch.float32)
+    cmax = max(max(rel(g32[li][0], g64[li][0]), rel(g32[li][1], g64[li][1])) for li in range(26))
+    ratios = []
+    for li in range(26):
+        eW, eb = rel(torch.from_numpy(wide[f'W{li}']), g64[li][0]), rel(torch.from_numpy(wide[f'b{li}']), g64[li][1])
+        cW, cb = rel(g32[li][0], g64[li][0]), rel(g32[li][1], g64[li][1])
+        assert eW < 2.5 * cmax and eb < 2.5 * cmax, (li, eW, eb, cmax)
+        ratios += [eW / (cW + 1e-5), eb / (cb + 1e-5)]
+    assert float(np.median(ratios)) < 2.0, sorted(ratios)[-8:]
