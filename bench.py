@@ -163,7 +163,7 @@ def gpu_eager_baseline(weights, scene, dev, reps=5):
             'torch': torch.__version__}, rgb
 
 
-def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2):
+def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2, fixture='pictures'):
     """The frame on the only optimizer-shaped nets in the tree (tests/golden/trained_synth_scene.npz: this package's stage-1 + stage-2 drivers on the
     synthetic LLFF scene; sampler, refine and the NeRF-CLASS fine net the trainers save — run_S_eS_eN_alter_trt.py:468-481 loads exactly such a
     checkpoint): ms per frame, the share of rays the two-pass sampler sends through its second pass (27 % here against 15 % on the seeded set the
@@ -172,9 +172,12 @@ def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2):
     from pronerf_amd.render import Renderer
     from pronerf_amd.workloads import timed_ms
     try:
-        w = synthetic.load_trained_fixture()
-    except (OSError, KeyError) as e:
-        return {'skipped': f'fixture not readable: {e}'}
+        w = synthetic.load_trained_fixture(fixture)
+        if fixture == 'scene3d':      # the nets trained on the consistent 3-D scene, on THAT scene: hold-out pose 0 at the Fern frame size (tests/llff_synth.py Scene3D)
+            scene = synthetic.scene3d_frame(0, 4)
+            assert scene['H'] * scene['W'] == n_total
+    except (OSError, KeyError, ImportError, AssertionError) as e:
+        return {'skipped': f'fixture not usable: {e!r}'}
     rend = Renderer({k: w[k] for k in ('sampler', 'refine', 'nerf')}, max_rays=n_total, device=dev)
     rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W)
@@ -186,9 +189,19 @@ def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2):
     torch.cuda.synchronize()
     prof, _ = rend.ctx.profile_end()
     n2, n3 = rend.ctx.sampler_stats(), rend.ctx.sampler_saturated()
-    res = {'weights': 'tests/golden/trained_synth_scene.npz (optimizer-trained: stage-1 4000 + stage-2 3000 iterations; NeRF-class fine net)',
+    res = {'weights': f"tests/golden/{synthetic.FIXTURES[fixture]} (optimizer-trained: stage-1 {int(w['info']['stage1_iters'])} + stage-2 {int(w['info']['stage2_iters'])} iterations; NeRF-class fine net)"
+                      + ('; frame = hold-out pose 0 of the consistent 3-D scene those nets were trained on, at 756 x 1008' if fixture == 'scene3d' else '; frame = the seeded bench scene'),
            'ms_per_frame': ms, 'rays_per_s': n_total / ms * 1e3, 'kernels_ms': prof,
            'sampler_two_pass': {'rays_second_pass': n2, 'fraction': n2 / n_total, 'rays_third_pass': n3}}
+    if fixture == 'scene3d':          # the reference's quality figure on this frame: PSNR against the ground-truth picture (pixel (4j, 4i) is the ray of its pixel (j, i))
+        small = out[:, :3].reshape(756, 1008, 3)[::4, ::4].reshape(-1, 3)
+        gt = torch.as_tensor(scene['gt_small']).reshape(-1, 3).to(dev)
+        res['psnr_vs_ground_truth_db'] = float(-10.0 * torch.log10(((small - gt) ** 2).mean()))
+        vq = Renderer({k: w[k] for k in ('sampler', 'refine', 'nerf')}, max_rays=n_total, device=dev, preset='quality')
+        vq.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+        outq = torch.empty(n_total, 4, device=dev)
+        res['quality_preset_ms_per_frame'] = timed_ms(lambda: vq.render_rays(rays, or_rays, out=outq), frames, 5)[0]
+        del vq
     if eager_reps > 0:
         from oracle import pronerf_oracle as orc                        # checker only, after every timed loop of this leg
         torch.backends.cuda.matmul.allow_tf32 = False
@@ -210,6 +223,9 @@ def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2):
                     ems.append(t1.elapsed_time(t2))
         mse = float(((out[:, :3].double() - ref['rgb'].double()) ** 2).mean())
         res['hip_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mse))) if mse > 0 else float('inf')
+        if fixture == 'scene3d':
+            mq = float(((outq[:, :3].double() - ref['rgb'].double()) ** 2).mean())
+            res['quality_preset_vs_eager_rgb_psnr_db'] = (10.0 * float(np.log10(1.0 / mq))) if mq > 0 else float('inf')
         res['eager_ms_per_frame'] = sum(ems) / len(ems)
         res['vs_eager'] = res['eager_ms_per_frame'] / ms
         del ref, wd, fr
@@ -840,6 +856,7 @@ def main():
                                            'target); the reference publishes no number for this metric')
             if not args.no_optimizer_weights:
                 res['weights_optimizer'] = optimizer_weights_leg(scene, dev, n_total, eager_reps=0 if args.no_gpu_eager_baseline else min(2, args.eager_reps))
+                res['weights_scene3d'] = optimizer_weights_leg(scene, dev, n_total, eager_reps=0 if args.no_gpu_eager_baseline else min(2, args.eager_reps), fixture='scene3d')
             if not args.no_train:
                 del rend
                 torch.cuda.empty_cache()

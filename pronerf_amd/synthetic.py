@@ -218,13 +218,46 @@ def make_scene(seed: int = 0, H: int = 24, W: int = 32, Hf: int | None = None, W
     return {'H': H, 'W': W, 'focal': float(focal), 'K': K, 'c2w': c2w, 'poses': poses, 'images': images}
 
 
+# optimizer-trained nets in the tree (tools/make_trained_fixture.py): 'pictures' = fitted to twenty independent pictures on a rig (round 4);
+# 'scene3d' = fitted to ONE ray-cast 3-D scene (round 6, tests/llff_synth.py Scene3D): hold-out views 33.8 .. 37.3 dB, a sampler that has learned surfaces
+FIXTURES = {'pictures': 'trained_synth_scene.npz', 'scene3d': 'trained_scene3d.npz'}
+
+
+def scene3d_frame(view=0, scale=4):
+    """The consistent scene of the 'scene3d' fixture as a frame dict like ``make_scene``'s: hold-out pose ``view`` of its LLFF directory (rebuilt in a
+    temporary directory, once per process) rendered at ``scale`` x the training resolution (4: the Fern frame, 756 x 1008 — NDC rays do not depend on
+    the pixel grid), neighbour cameras / images = the training views in the loader's greedy COLMAP order (189 x 252 pictures)."""
+    import os
+    import sys
+    import tempfile
+    key = (view, scale)
+    if key not in _SCENE3D:
+        tests = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests')
+        if tests not in sys.path:
+            sys.path.insert(0, tests)
+        import llff_synth
+        from . import load_llff as L
+        if 'root' not in _SCENE3D:
+            _SCENE3D['tmp'] = tempfile.TemporaryDirectory()
+            _SCENE3D['root'] = llff_synth.make_dataset(os.path.join(_SCENE3D['tmp'].name, 'scene'), seed=2, n=20, H=189, W=252, factor=4, consistent=True, n_points=3000)
+        images, poses, bds, _, i_test, i_ref = L.load_llff_data_infer(_SCENE3D['root'], factor=4, llffhold=8)
+        H, W, focal = int(poses[0, 0, 4]) * scale, int(poses[0, 1, 4]) * scale, float(poses[0, 2, 4]) * scale
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+        _SCENE3D[key] = {'H': H, 'W': W, 'focal': focal, 'K': K, 'c2w': poses[view, :3, :4].astype(np.float32), 'poses': poses[i_ref][:, :3, :4].astype(np.float32),
+                         'images': images[i_ref].astype(np.float32), 'gt_small': images[view].astype(np.float32)}
+    return _SCENE3D[key]
+
+
+_SCENE3D = {}
+
+
 def load_trained_fixture(path=None):
     """The optimizer-trained nets of tests/golden/trained_synth_scene.npz (tools/make_trained_fixture.py: this package's stage-1 and stage-2
     drivers on the synthetic LLFF scene) as weight dicts: 'sampler', 'refine' (stacks of 7), 'nerf' = the NeRF-class fine net in pack order
     (pts_linears 0..7, feature, alpha, views, rgb: what ``Renderer`` takes) and 'nerfcls' = the same by name (what the oracle takes)."""
     import os
-    if path is None:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'trained_synth_scene.npz')
+    if path is None or path in FIXTURES:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', FIXTURES[path or 'pictures'])
     g = np.load(path)
     L = [(g[f'W{i}'], g[f'b{i}']) for i in range(26)]
     stack = lambda a, b: {'W': [W for W, _ in L[a:b]], 'b': [x for _, x in L[a:b]]}
@@ -233,6 +266,14 @@ def load_trained_fixture(path=None):
             'info': {k: g[k] for k in ('stage1_iters', 'stage2_iters', 'stage1_loss', 'stage2_loss')}}
 
 
+def scene_for(seed: int, kind: str, **kw):
+    """The frame a weight set is tested on: ``make_scene(seed, **kw)``, or — kind 'scene' — the scene those nets were trained on (hold-out view 0 at the Fern frame size)."""
+    return scene3d_frame(0, 4) if kind == 'scene' else make_scene(seed, **kw)
+
+
 def weight_set(seed: int, kind: str):
-    """``make_weights(seed, kind)``, or the optimizer-trained fixture for kind 'optimizer' (the seed then only names the scene)."""
+    """``make_weights(seed, kind)``, or the optimizer-trained fixtures: kind 'optimizer' (independent pictures) / 'scene' (the consistent 3-D scene); the seed
+    then only names the frame."""
+    if kind == 'scene':
+        return load_trained_fixture('scene3d')
     return load_trained_fixture() if kind == 'optimizer' else make_weights(seed, kind)

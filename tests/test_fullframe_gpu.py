@@ -27,9 +27,11 @@ H, W, FOCAL = 756, 1008, 815.13
 N = H * W
 TIE = 1e-6
 # 'heavy' / 'x4': adversarial sets for the two-pass sampler (Student-t(3) hidden weights; hidden layers x4 each = activations up to the fp16 range);
-# 'optimizer': the nets this package's own trainers produced on the synthetic LLFF scene (tests/golden/trained_synth_scene.npz)
-WEIGHT_SETS = [(0, 'trained'), (2, 'spread'), (3, 'trained'), (1, 'default'), (0, 'heavy'), (0, 'x4'), (0, 'optimizer')]
-NEW_KINDS = ('heavy', 'x4', 'optimizer')
+# 'optimizer': the nets this package's own trainers produced on the synthetic LLFF pictures (tests/golden/trained_synth_scene.npz);
+# 'scene' (round 6): the nets trained on the geometrically consistent 3-D scene (tests/golden/trained_scene3d.npz), on THAT scene's hold-out pose at the
+# Fern frame size — a sampler that has learned surfaces: the 8 depths of a ray bunch there, 60 .. 80 % of the rays go through the second pass
+WEIGHT_SETS = [(0, 'trained'), (2, 'spread'), (3, 'trained'), (1, 'default'), (0, 'heavy'), (0, 'x4'), (0, 'optimizer'), (0, 'scene')]
+NEW_KINDS = ('heavy', 'x4', 'optimizer', 'scene')
 
 
 @pytest.fixture(scope='module')
@@ -75,7 +77,8 @@ def oracle_sampler_full_frame(seed, kind):
     key = (seed, kind)
     if key not in _ORACLE:
         torch.set_num_threads(min(16, os.cpu_count() or 1))
-        scene = synth.make_scene(seed, H=H, W=W, focal=FOCAL, rotate=True)
+        scene = synth.scene_for(seed, kind, H=H, W=W, focal=FOCAL, rotate=True)
+        assert (scene['H'], scene['W']) == (H, W)
         w = synth.weight_set(seed, kind)
         rays_o, rays_d = orc.get_rays(H, W, scene['K'], scene['c2w'])
         vd = (rays_d / rays_d.norm(dim=-1, keepdim=True)).reshape(-1, 3)
@@ -134,7 +137,7 @@ def test_full_frame_sampler_indices(dev, seed, kind, variant):
         assert 0 < n2 <= int(same.sum()) <= n2 + 64 or kind == 'spread'          # (rows of pass 1 that coincide with the split result in all 24 values: a handful at most)
         # the second pass stays a minority — except on the heavy-tailed set, whose largest column norms make the error bound flag every ray
         # (safe: everything is then rendered fp32-grade, at the split kernel's speed)
-        assert n2 <= (1.0 if kind == 'heavy' else 0.6 if kind in NEW_KINDS else 0.35) * N
+        assert n2 <= (1.0 if kind == 'heavy' else 0.9 if kind == 'scene' else 0.6 if kind in NEW_KINDS else 0.35) * N
         assert int(out[7]) == 0 or kind == 'x4'                                  # the exact-fp32 third pass has nothing to do unless activations reach the fp16 limit
         assert float(derr_row[same].max()) <= 2e-6 if bool(same.any()) else True
         assert float(derr_row[coarse].max()) <= 2e-3 if bool(coarse.any()) else True
@@ -202,14 +205,17 @@ def test_fern_8k_rays_vs_the_reference(dev, golden_dir):
     assert orc.psnr(got[border, :3], torch.from_numpy(g['rgb'])[border]) > 46.4
 
 
-def test_full_frame_with_optimizer_trained_nets(dev):
-    """The whole frame with the nets an optimizer produced (sampler, refine and the NeRF-CLASS fine net the trainers save: tests/golden/
-    trained_synth_scene.npz) against the oracle's eager fp32 graph on the device: indices, rgb, depth — the acceptance the reference applies to
-    a trained Fern checkpoint (run_S_eS_eN_alter_trt.py:351-373), on the weights that exist here."""
+@pytest.mark.parametrize('fixture', ['pictures', 'scene3d'])
+def test_full_frame_with_optimizer_trained_nets(dev, fixture):
+    """The whole frame with the nets an optimizer produced (sampler, refine and the NeRF-CLASS fine net the trainers save) against the oracle's eager
+    fp32 graph on the device: indices, rgb, depth — the acceptance the reference applies to a trained Fern checkpoint
+    (run_S_eS_eN_alter_trt.py:351-373), on the weights that exist here: 'pictures' (tests/golden/trained_synth_scene.npz, on a seeded frame) and
+    'scene3d' (tests/golden/trained_scene3d.npz on ITS scene: hold-out pose 0 at the Fern frame size, the 17 training pictures as neighbour pool;
+    the frame is also held against the ray-cast ground truth there)."""
     from pronerf_amd.render import Renderer
     torch.backends.cuda.matmul.allow_tf32 = False
-    scene = synth.make_scene(0, H=H, W=W, focal=FOCAL, rotate=True)
-    w = synth.load_trained_fixture()
+    scene = synth.scene_for(0, 'scene' if fixture == 'scene3d' else 'optimizer', H=H, W=W, focal=FOCAL, rotate=True)
+    w = synth.load_trained_fixture(fixture)
     rend = Renderer({k: w[k] for k in ('sampler', 'refine', 'nerf')}, max_rays=N, device=dev)
     rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     fr = orc.frame_setup(scene)
@@ -230,11 +236,16 @@ def test_full_frame_with_optimizer_trained_nets(dev):
     rel = float(((rgbd[free, :3].double() - ref['rgb'][free].double()) ** 2).mean().sqrt() / (ref['rgb'][free].double() ** 2).mean().sqrt())
     derr = float((rgbd[free, 3] - ref['depth'][free]).abs().max())
     n2, n3 = rend.ctx.sampler_stats(), rend.ctx.sampler_saturated()
-    print(f'\n[full frame, optimizer-trained nets] {int(free.sum())} of {N} rays compared, index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
+    if fixture == 'scene3d':              # pixel (4j, 4i) of the 756 x 1008 frame IS the ray of pixel (j, i) of the 189 x 252 ground-truth picture of the same pose
+        small = rgbd[:, :3].reshape(H, W, 3)[::4, ::4]
+        ps_gt = orc.psnr(small.reshape(-1, 3), torch.as_tensor(scene['gt_small']).reshape(-1, 3).to(dev))
+        print(f'\n[full frame, scene3d nets] hold-out view 0 at 756 x 1008, every 4th pixel: PSNR vs the ray-cast ground truth {ps_gt:.2f} dB')
+        assert ps_gt > 33.0               # 37.28 dB in tests/test_quality_gate_gpu.py (the same rays rendered at 189 x 252)
+    print(f'\n[full frame, optimizer-trained nets: {fixture}] {int(free.sum())} of {N} rays compared, index mismatches {mism}, rgb PSNR {ps:.1f} dB, rel. RMS {rel:.2e}, '
           f'max depth error {derr:.2e}, depth rel. RMS {depth_relrms(rgbd[free, 3], ref["depth"][free]):.2e}; second pass {n2 / N:.2%}, third pass {n3} rays')
-    assert int((~free).sum()) <= 2e-3 * N and mism == 0
+    assert int((~free).sum()) <= (2e-2 if fixture == 'scene3d' else 2e-3) * N and mism == 0          # bunched depths: more fp32 ties
     assert ps > 46.4 and rel < 2e-2
-    depth_bars(rgbd[free, 3], ref['depth'][free], ' optimizer-trained nets')
+    depth_bars(rgbd[free, 3], ref['depth'][free], f' optimizer-trained nets: {fixture}')
     assert bool(torch.isfinite(rgbd).all())
 
 
@@ -297,3 +308,35 @@ def test_full_frame_rgb_vs_the_cpu_oracle(dev):
     assert int((~free).sum()) <= 16 and mism == 0
     assert ps > 46.4 and rel < 1e-2 and depth_relrms(got[free, 3], ref['depth'][free]) < 2e-3
     depth_bars(got[free, 3], ref['depth'][free], ' vs the CPU oracle')
+
+
+def test_two_pass_sampler_on_a_population_of_weight_sets(dev):
+    """The statistical guarantee of the default sampler (include/pronerf_hip.h: sort indices equal the split-fp16 kernel's) sampled wider than the eight
+    sets above, inside the suite: 4 scenes x 3 kinds of seeded weights + the scene-trained nets on three poses of their scene, every ray of the 756 x 1008
+    frame, at the SHIPPED kappa and at half of it; rays whose split-kernel sorted depths are closer than 2e-6 are ties.  (tools/kappa_population.py
+    is the long form: 20 scenes x 60 sets, 45.7 M rays.)  Also holds pnrf_ctx_get_sampler_kappa to the header."""
+    from pronerf_amd import ops
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'pronerf_hip.h')).read()
+    import re
+    kappa = float(re.search(r'#define PNRF_SAMPLER_KAPPA ([0-9.]+)f', hdr).group(1))
+    cases = [(seed, kind, synth.make_scene(seed, H=H, W=W, focal=FOCAL, rotate=True)) for seed in (100, 101, 102, 103) for kind in ('trained', 'spread', 'default')]
+    cases += [(v, 'scene', synth.scene3d_frame(v, 4)) for v in (0, 8, 16)]
+    tot = {k: [0, 0, 0, 0] for k in (kappa, kappa / 2)}        # rays, ties, differ, second pass
+    for seed, kind, scene in cases:
+        w = synth.weight_set(seed, kind)
+        rays, _ = ops.frame_rays(scene['K'], scene['c2w'], H, W, near=0., far=1., device=dev)
+        mlp = ops.PackedMLP(ops.NET_SAMPLER, w['sampler']['W'], w['sampler']['b'])
+        s_ds, s_idx = ops.sampler_fwd(mlp, rays, want_idx=True, want_rgb=False)[:2]
+        tie = (s_ds[:, 1:] - s_ds[:, :-1]).min(1)[0] <= 2e-6
+        for k in tot:
+            o = ops.sampler_fwd(mlp, rays, want_idx=True, want_rgb=False, two_pass=True, kappa=k)
+            d = int(((o[1] != s_idx).any(1) & ~tie).sum())
+            t = tot[k]
+            t[0] += N; t[1] += int(tie.sum()); t[2] += d; t[3] += int(o[6])
+            assert d == 0, (seed, kind, k, d)
+        del mlp
+    for k, t in tot.items():
+        print(f'\n[kappa population] kappa {k:g}: {t[0]} rays of {len(cases)} weight set x frame pairs, {t[1]} ties, {t[2]} differ from the split kernel, second pass {t[3] / t[0]:.1%}')
+    w = synth.make_weights(0, 'trained')
+    from pronerf_amd.render import Renderer
+    assert Renderer(w, max_rays=64, device=dev).ctx.sampler_kappa() == kappa

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two-pass sampler: rays sent to the second pass and rays whose sort indices differ from the split-fp16 kernel's, as a function of kappa, on the
-full 1008 x 756 frame for the weight sets of tests/test_fullframe_gpu.py (synthetic, heavy-tailed, x4-scaled, optimizer-trained).  Rays whose split-kernel sorted depths are closer than 2e-6 are ties."""
+full 1008 x 756 frame for the weight sets of tests/test_fullframe_gpu.py (synthetic, heavy-tailed, x4-scaled, optimizer-trained on pictures, and — 'scene' — trained on the consistent 3-D scene and run on its hold-out pose).  Rays whose split-kernel sorted depths are closer than 2e-6 are ties."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,8 +8,8 @@ from pronerf_amd import ops, synthetic as synth
 from pronerf_amd.render import Renderer
 dev = torch.device('cuda:0')
 H, W, FOCAL = 756, 1008, 815.13
-for seed, kind in ((0, 'trained'), (3, 'trained'), (2, 'spread'), (1, 'default'), (0, 'heavy'), (0, 'x4'), (0, 'optimizer')):
-    scene = synth.make_scene(seed, H=H, W=W, focal=FOCAL, rotate=True)
+for seed, kind in ((0, 'trained'), (3, 'trained'), (2, 'spread'), (1, 'default'), (0, 'heavy'), (0, 'x4'), (0, 'optimizer'), (0, 'scene')):
+    scene = synth.scene_for(seed, kind, H=H, W=W, focal=FOCAL, rotate=True)
     w = synth.weight_set(seed, kind)
     rays, _ = ops.frame_rays(scene['K'], scene['c2w'], H, W, near=0., far=1., device=dev)
     mlp = ops.PackedMLP(ops.NET_SAMPLER, w['sampler']['W'], w['sampler']['b'])
