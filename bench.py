@@ -202,6 +202,12 @@ def optimizer_weights_leg(scene, dev, n_total, frames=20, eager_reps=2, fixture=
         outq = torch.empty(n_total, 4, device=dev)
         res['quality_preset_ms_per_frame'] = timed_ms(lambda: vq.render_rays(rays, or_rays, out=outq), frames, 5)[0]
         del vq
+        keep = out.clone()
+        frac, var = rend.calibrate(rays, or_rays)                      # Renderer.calibrate: the exact single-pass sampler once most rays are re-rendered anyway
+        res['calibrated'] = {'second_pass_fraction_seen': frac, 'sampler_variant_chosen': var,
+                             'ms_per_frame': timed_ms(lambda: rend.render_rays(rays, or_rays, out=out), frames, 5)[0]}
+        out.copy_(keep)                                                # the comparisons below are the default preset's frame
+        del keep
     if eager_reps > 0:
         from oracle import pronerf_oracle as orc                        # checker only, after every timed loop of this leg
         torch.backends.cuda.matmul.allow_tf32 = False
