@@ -52,22 +52,27 @@ def driver_K(scene):
     return np.asarray(scene['K'], dtype=np.float32).astype(np.float64)
 
 
-def build_models(helpers, weights):
-    S, NB = synth.N_SAMPLES, synth.NUM_NEIGHBOR
+FERN_SHAPE = dict(n_pts=synth.N_POINT_RAY_ENC, mmnetdepth=synth.MMNETDEPTH, num_neighbor=synth.NUM_NEIGHBOR, netdepth=synth.NETDEPTH)
+
+
+def build_models(helpers, weights, shape=FERN_SHAPE):
+    """The reference's modules as its create_nerf builds them from --mmnetdepth / --N_point_ray_enc / --num_neighbor / --netdepth
+    (run_S_eS_eN_alter_trt.py:427-457)."""
+    S, NB = synth.N_SAMPLES, shape['num_neighbor']
     sd = synth.state_dicts(weights)
-    sampler = helpers.MinMaxRaySamplerTRT_Net(D=synth.MMNETDEPTH, W=synth.MMNETWIDTH, input_ch=6 * synth.N_POINT_RAY_ENC,
+    sampler = helpers.MinMaxRaySamplerTRT_Net(D=shape['mmnetdepth'], W=synth.MMNETWIDTH, input_ch=6 * shape['n_pts'],
                                               output_ch=3 * S + 3, skips=[10000], N_samples=S)
-    refine = helpers.MinMaxRayEpiSamplerTRT_Net(D=synth.MMNETDEPTH, W=synth.MMNETWIDTH, input_ch=6 * S + 3 * NB * S,
+    refine = helpers.MinMaxRayEpiSamplerTRT_Net(D=shape['mmnetdepth'], W=synth.MMNETWIDTH, input_ch=6 * S + 3 * NB * S,
                                                 output_ch=4 * S + 3, skips=[10000], N_samples=S)
-    nerf = helpers.DoNeRFTRT(D=synth.NETDEPTH, W=synth.NETWIDTH, n_in=synth.POS_CH + synth.DIR_CH, n_out=4, skip='auto')
+    nerf = helpers.DoNeRFTRT(D=shape['netdepth'], W=synth.NETWIDTH, n_in=synth.POS_CH + synth.DIR_CH, n_out=4, skip='auto')
     sampler.load_state_dict(sd['sampler']); refine.load_state_dict(sd['refine']); nerf.load_state_dict(sd['nerf'])
     return sampler.eval(), refine.eval(), nerf.eval()
 
 
-def reference_frame(helpers, trt, scene):
+def reference_frame(helpers, trt, scene, shape=FERN_SHAPE):
     """The reference's per-frame setup, op for op, through the reference's own helpers
     (render_path, run_S_eS_eN_alter_trt.py:245-302; render_path itself needs a GPU)."""
-    S, NB, P = synth.N_SAMPLES, synth.NUM_NEIGHBOR, synth.N_POINT_RAY_ENC
+    S, NB, P = synth.N_SAMPLES, shape['num_neighbor'], shape['n_pts']
     H, W = scene['H'], scene['W']
     K = torch.from_numpy(scene['K']); c2w = torch.from_numpy(scene['c2w']); Kd = driver_K(scene)
     poses = torch.from_numpy(scene['poses']); images = scene['images']
@@ -100,12 +105,14 @@ def reference_frame(helpers, trt, scene):
                 embed_rays=embed_rays, rays_o=rays_o, rays_d=rays_d)
 
 
-def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, rotate=False, sigma_t=0.05, take=None, sel=None, slim=False):
+def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, rotate=False, sigma_t=0.05, take=None, sel=None, slim=False, shape=FERN_SHAPE,
+                   n_views=None):
+    """shape: the reference's free shape arguments (FERN_SHAPE = fern_trt.txt); n_views: size of the neighbour pool (default: num_neighbor)."""
     torch.manual_seed(3407)
-    weights = synth.make_weights(seed, kind)
-    scene = synth.make_scene(seed, H=H, W=W, Hf=Hf, Wf=Wf, rotate=rotate, sigma_t=sigma_t)
-    sampler, refine, nerf = build_models(helpers, weights)
-    fr = reference_frame(helpers, trt, scene)
+    weights = synth.make_weights(seed, kind, **shape)
+    scene = synth.make_scene(seed, H=H, W=W, Hf=Hf, Wf=Wf, rotate=rotate, sigma_t=sigma_t, n_views=n_views or shape['num_neighbor'])
+    sampler, refine, nerf = build_models(helpers, weights, shape)
+    fr = reference_frame(helpers, trt, scene, shape)
     N_full = fr['rays'].shape[0]
     if sel is None:
         sel = np.arange(N_full) if take is None else np.linspace(0, N_full - 1, take).astype(np.int64)
@@ -145,9 +152,9 @@ def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, r
         with torch.no_grad():
             ret = trt.render_rays(fr['rays'], fr['or_rays'], network_fn=None, network_query_fn=query,
                                   N_samples=synth.N_SAMPLES, network_fine=nerf, min_max_ray_net=sampler,
-                                  refine_net=refine, N_point_ray_enc=synth.N_POINT_RAY_ENC, embed_fn=embed_fn,
+                                  refine_net=refine, N_point_ray_enc=shape['n_pts'], embed_fn=embed_fn,
                                   embeddirs_fn=embeddirs_fn, randomize=False, raw_noise_std=0., perturb=False,
-                                  use_trt=False, mm_input=fr['mm_input'], num_neighbor=synth.NUM_NEIGHBOR,
+                                  use_trt=False, mm_input=fr['mm_input'], num_neighbor=shape['num_neighbor'],
                                   ref_rgb=fr['ref_rgb'], ref_pose=fr['ref_pose'], ro1=fr['ro1'], rd1=fr['rd1'],
                                   embed_rays=fr['embed_rays'])
     finally:
@@ -162,6 +169,8 @@ def run_infer_case(helpers, iw, trt, name, seed, kind, H, W, Hf=None, Wf=None, r
         seed=np.int64(seed), kind=np.array(kind), H=np.int64(H), W=np.int64(W),
         Hf=np.int64(scene['images'].shape[1]), Wf=np.int64(scene['images'].shape[2]),
         rotate=np.bool_(rotate), sigma_t=np.float64(sigma_t), sel=sel, n_full=np.int64(N_full),
+        n_pts=np.int64(shape['n_pts']), mmnetdepth=np.int64(shape['mmnetdepth']), num_neighbor=np.int64(shape['num_neighbor']), netdepth=np.int64(shape['netdepth']),
+        n_views=np.int64(scene['poses'].shape[0]),
         rays=g(fr['rays']), or_rays=g(fr['or_rays']), ref_nos=g(fr['ref_nos']), proj=g(fr['proj']),
         mm_input_head=g(fr['mm_input'])[:, :12], mm_input_tail=g(fr['mm_input'])[:, -6:],
         mm_rgb=g(cap['mm_rgb']), depth_raw=g(cap['depth_raw']),
@@ -418,6 +427,22 @@ def main_infer(helpers, iw, trt):
     run_infer_case(helpers, iw, trt, 'infer_trained_fern_756x1008', 4, 'trained', 756, 1008, rotate=True, take=512)
 
 
+# Off-Fern shapes (round 6): the reference's own render_rays with other --N_point_ray_enc / --mmnetdepth / --num_neighbor / --netdepth
+# (its argparse defaults are not the Fern values: run_S_eS_eN_alter_trt.py:62-82, 110-118).  (name, seed, kind, H, W, shape, pool of views)
+SHAPE_CASES = [
+    ('infer_shape_p32_d8_nb3_24x32', 5, 'trained', 24, 32, dict(n_pts=32, mmnetdepth=8, num_neighbor=3, netdepth=8), 5),
+    ('infer_shape_p64_d5_nb6_nd7_20x28', 6, 'trained', 20, 28, dict(n_pts=64, mmnetdepth=5, num_neighbor=6, netdepth=7), 7),
+    ('infer_shape_p8_d2_nb1_nd3_16x20', 7, 'default', 16, 20, dict(n_pts=8, mmnetdepth=2, num_neighbor=1, netdepth=3), 3),
+    ('infer_shape_p48_d9_nb8_nd4_16x20', 8, 'trained', 16, 20, dict(n_pts=48, mmnetdepth=9, num_neighbor=8, netdepth=4), 9),
+]
+
+
+def main_shapes():
+    helpers, iw, trt = load_reference()
+    for name, seed, kind, H, W, shape, nv in SHAPE_CASES:
+        run_infer_case(helpers, iw, trt, name, seed, kind, H, W, rotate=True, sigma_t=0.1, shape=shape, n_views=nv)
+
+
 def fern_8k_selection(H=756, W=1008, seed=12):
     """More than 8192 rays of the 756x1008 frame, stratified: the two outermost rows / columns on every side (whose samples project outside the
     neighbour images) and one seeded random pixel in each cell of an 84 x 84 grid over the frame (8 8xx rays after de-duplication)."""
@@ -443,5 +468,7 @@ def main_fern_8k():
 if __name__ == '__main__':
     if '--fern-8k' in sys.argv:
         main_fern_8k()
+    elif '--shapes' in sys.argv:
+        main_shapes()
     else:
         main()

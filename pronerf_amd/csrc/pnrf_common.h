@@ -72,6 +72,9 @@ struct pnrf_mlp {
   void* d_blob_f16;      // refine / NeRF handles: the stream of the default engine with fp16 operands (refine: as d_blob; NeRF: as d_blob_b16)
   uint32_t nslots_f16;
   float* d_tvals;        // sampler only: t = torch.linspace(0,1,48) of the ray points (trt.py:556-557)
+  int nhid;              // hidden 256 -> 256 layers behind layer 0: sampler / refine mmnetdepth - 1 (Fern: 5), DoNeRFTRT netdepth - 2 (Fern: 6); class net: 0 (fixed structure)
+  int nb;                // refine: neighbour views (num_neighbor, 1 .. 8; Fern: 4); other nets: 0
+  int npts;              // sampler: ray points of the encoding (N_point_ray_enc; Fern: 48); other nets: 0
   int device;
   int variant;           // PNRF_VARIANT_* (pnrf_mlp_set_variant); 0 = default kernels
   int shape;             // workgroup shape of the fused stages (pnrf_mlp_set_shape): PNRF_SHAPE_AUTO = per launch from the column count, or one forced

@@ -73,7 +73,7 @@ constexpr int P1_NSLOTS = P1_SLOTS_USED + P1_SLOTS_PAD;
 constexpr int P1_NBIAS = (1 + S_NHID) * W_HID + 32;                                   // [tile][half][16], log2(e)-scaled for the ELU layers
 static_assert(P1_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position static");
 // constants of the per-ray error model (two-pass sampler), computed from the weights at pack time
-constexpr int P1_NCONST = 8;               // [0..4] C_l = max_j sum_i W_l[i,j]^2 of the hidden layers l = 1..5; [5] max_{k<8, j} W_out[k,j]^2 / log2(e)^2; [6], [7] unused
+constexpr int P1_NCONST = 8;               // at least this many: [0] max_{k<8, j} W_out[k,j]^2 / log2(e)^2; [1 + l] C_l = max_j sum_i W_l[i,j]^2 of hidden layer l (p1_nconst)
 // output tile of pass 1: half 0 holds the 8 depth logits (registers 0-7) and add (8-15), half 1 mul (0-7) and rgb (8-10)
 __host__ __device__ constexpr int sampler_p1_out(int g, int h) {
   if (h == 0) return g;                    // depth 0..7, add 8..15
@@ -95,6 +95,46 @@ constexpr int R_SLOTS_PAD = (NSLOTS - R_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int R_NSLOTS = R_SLOTS_USED + R_SLOTS_PAD;
 constexpr int R_NBIAS = (1 + R_NHID) * W_HID + 32 * R_NT_LAST;
 static_assert(SLOTS_HID % NSLOTS == 0, "hidden layers must keep the ring position static");
+// Free shape parameters of the reference's configs (run_S_eS_eN_alter_trt.py:62-82, 110-118, 427-457), round 6.  Width 256 and 8 samples per ray
+// stay fixed; free are
+//   mmnetdepth   sampler / refine: any number nhid = mmnetdepth - 1 >= 1 of hidden 256 -> 256 layers.  A hidden layer occupies a multiple of NSLOTS
+//                ring slots in every stream, so the ring position of every later layer — a template constant of the kernels — does not depend on
+//                nhid: the layer loop simply runs nhid times (netdepth of DoNeRFTRT likewise: nhid = netdepth - 2);
+//   num_neighbor refine: 1 .. 8 neighbour views, refine input 48 + 24 nb.  A lane half holds NV = ceil(nb / 2) views: layer 0 has 3 NV + 3 k-steps
+//                (RefineL0<NV>; NV = 2 is the Fern stream); views NV h + vv >= nb are padding with zero weights;
+//   N_point_ray_enc  sampler: any number of ray points (input 6 P): the fused kernels run the FOLDED first layer Wf = sum_p W0[:, 6p:6p+6], K = 6
+//                whatever P is; the unfolded stream (module-level forward, PNRF_VARIANT_SAMPLER_F32_FULL) exists for P = 48 only.
+constexpr int MAX_NHID = 31;
+constexpr int MAX_NB = 8;
+template <int NV>
+struct RefineL0 {
+  static_assert(NV >= 1 && NV <= 4, "1 .. 8 neighbour views");
+  static constexpr int KS0 = 3 * NV + 3;
+  static constexpr int SLOTS_L0 = layer_slots_bf16<KS0, NT_HID>();
+  static constexpr int POS_H = SLOTS_L0 % NSLOTS;
+  static constexpr int POS_LAST = POS_H;                                          // nhid x SLOTS_HID is a multiple of NSLOTS
+  static constexpr int SLOTS_PAD = (NSLOTS - (SLOTS_L0 + R_SLOTS_LAST) % NSLOTS) % NSLOTS;
+};
+static_assert(RefineL0<2>::KS0 == R_KS0 && RefineL0<2>::POS_H == R_POS_H && RefineL0<2>::POS_LAST == R_POS_LAST && RefineL0<2>::SLOTS_PAD == R_SLOTS_PAD, "NV = 2 is the Fern stream");
+__host__ __device__ constexpr int refine_nv(int nb) { return (nb + 1) / 2; }
+__host__ __device__ constexpr int refine_slots(int nhid, int nv) {
+  const int used = (((3 * nv + 3) * NT_HID + SLOT_FRAGS - 1) / SLOT_FRAGS) + nhid * SLOTS_HID + R_SLOTS_LAST;
+  return used + (NSLOTS - used % NSLOTS) % NSLOTS;
+}
+static_assert(refine_slots(R_NHID, 2) == R_NSLOTS, "refine_slots");
+// stream sizes / bias counts as functions of the hidden-layer count (the constants above are the Fern values)
+__host__ __device__ constexpr int pad_slots(int used) { return used + (NSLOTS - used % NSLOTS) % NSLOTS; }
+__host__ __device__ constexpr int s_nslots(int nhid) { return pad_slots(S_SLOTS_L0 + nhid * S_SLOTS_H + S_SLOTS_LAST); }
+__host__ __device__ constexpr int sf_nslots(int nhid) { return pad_slots(SF_SLOTS_L0 + nhid * S_SLOTS_H + S_SLOTS_LAST); }
+__host__ __device__ constexpr int sh_nslots(int nhid) { return pad_slots(SH_SLOTS_L0 + nhid * SH_SLOTS_H + SH_SLOTS_LAST); }
+__host__ __device__ constexpr int p1_slots_used(int nhid) { return P1_SLOTS_L0 + nhid * P1_SLOTS_H + P1_SLOTS_LAST; }
+__host__ __device__ constexpr int p1_nslots(int nhid) { return pad_slots(p1_slots_used(nhid)); }
+__host__ __device__ constexpr int p1_nconst(int nhid) { return 1 + nhid < P1_NCONST ? P1_NCONST : 1 + nhid; }      // [0] output layer, [1 + l] hidden layer l
+__host__ __device__ constexpr int s_nbias(int nhid) { return (1 + nhid) * W_HID + 16 * S_NT_LAST; }
+__host__ __device__ constexpr int p1_nbias(int nhid) { return (1 + nhid) * W_HID + 32; }
+__host__ __device__ constexpr int r_nbias(int nhid) { return (1 + nhid) * W_HID + 32 * R_NT_LAST; }
+static_assert(s_nslots(S_NHID) == S_NSLOTS && sf_nslots(S_NHID) == SF_NSLOTS && sh_nslots(S_NHID) == SH_NSLOTS && p1_nslots(S_NHID) == P1_NSLOTS &&
+              s_nbias(S_NHID) == S_NBIAS && p1_nbias(S_NHID) == P1_NBIAS && r_nbias(R_NHID) == R_NBIAS, "Fern values");
 
 // ---- nerf (bf16)
 constexpr int N_IN = 63, N_INV = 27, N_OUT = 4, N_NHID = 6;
@@ -109,6 +149,9 @@ constexpr int N_SLOTS_USED = N_SLOTS_L0 + N_NHID * SLOTS_HID + N_SLOTS_LAST;
 constexpr int N_SLOTS_PAD = (NSLOTS - N_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int N_NSLOTS = N_SLOTS_USED + N_SLOTS_PAD;
 constexpr int N_NBIAS = (1 + N_NHID) * W_HID + 32;
+__host__ __device__ constexpr int n_nslots(int nhid) { return pad_slots(N_SLOTS_L0 + nhid * SLOTS_HID + N_SLOTS_LAST); }
+__host__ __device__ constexpr int n_nbias(int nhid) { return (1 + nhid) * W_HID + 32; }
+static_assert(n_nslots(N_NHID) == N_NSLOTS && n_nbias(N_NHID) == N_NBIAS, "Fern values");
 
 // ---- nerf class (bf16): the `NeRF` module that stages 1/2 train (run_nerf_helpers.py:792-847).
 // Engine layers: E0 pts0 (63->256) | E1-E4 pts1-4 | E5 pts5 ([63+256]->256) | E6,E7 pts6,7 |
@@ -150,6 +193,16 @@ __host__ __device__ constexpr int sampler_in0(int kk, int q) { return 4 * kk + q
 __host__ __device__ constexpr int refine_in0(int ks, int h, int j) {
   const int n = 8 * ks + j;
   return n < 48 ? 48 + (((2 * h + n / 24) * 8 + (n % 24) / 3) * 3 + n % 3) : (4 * h + (n - 48) / 6) * 6 + (n - 48) % 6;
+}
+// ... for nv views per lane half and nb views in all: value n = 8 ks + j of half h is colour (n % 24) of view nv h + n / 24 (padding, -1, when that
+// view does not exist) for n < 24 nv, else Pluecker value n - 24 nv of the half's four samples.  refine_in0_nv(2, 4, ..) = refine_in0(..).
+__host__ __device__ constexpr int refine_in0_nv(int nv, int nb, int ks, int h, int j) {
+  const int n = 8 * ks + j;
+  if (n < 24 * nv) {
+    const int view = nv * h + n / 24;
+    return view < nb ? 48 + ((view * 8 + (n % 24) / 3) * 3 + n % 3) : -1;
+  }
+  return (4 * h + (n - 24 * nv) / 6) * 6 + (n - 24 * nv) % 6;
 }
 // nerf layer 0: slot n = ks*8+j.  n<30: (freq k=n/3, coord c=n%3), half 0 = sin, half 1 = cos;
 // n=30: x0|x2, n=31: x1|pad.  Feature order of the embedder: [x, sin f0 x, cos f0 x, ...]
@@ -202,6 +255,9 @@ constexpr int NB_SLOTS_USED = NB_SLOTS_L0 + N_NHID * NB_SLOTS_H + NB_SLOTS_LAST;
 constexpr int NB_SLOTS_PAD = (NSLOTS - NB_SLOTS_USED % NSLOTS) % NSLOTS;
 constexpr int NB_NSLOTS = NB_SLOTS_USED + NB_SLOTS_PAD;
 static_assert(NB_SLOTS_H % NSLOTS == 0, "hidden layers must keep the ring position");
+__host__ __device__ constexpr int nb_nslots(int nhid) { return pad_slots(NB_SLOTS_L0 + nhid * NB_SLOTS_H + NB_SLOTS_LAST); }
+__host__ __device__ constexpr int nb_nbias(int nhid) { return ((1 + nhid) * (W_HID / 16) + 2) * 16; }
+static_assert(nb_nslots(N_NHID) == NB_NSLOTS, "Fern values");
 // NeRF class on the same engine: E0 | E1-E4 | E5 ([h, pos] -> 256: 8 + 2 k-steps) | E6, E7 | E89 ([h, views] -> 128 ReLU + alpha: 9
 // k-steps, 8 view tiles + the alpha tile = 5 tile pairs) | E10 (128 -> 3: 4 k-steps, 1 pair)
 constexpr int CB_KS5 = NB_KS_H + NB_KS0;                                                // 10

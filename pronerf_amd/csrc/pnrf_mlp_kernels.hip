@@ -124,6 +124,7 @@ __device__ __forceinline__ void moment(float ox, float oy, float oz, float dx, f
 // ------------------------------------------------------------------------------------------ sampler
 struct SamplerArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
+  int nhid;                                        // hidden 256 -> 256 layers behind layer 0 (mmnetdepth - 1; the Fern configs: 5)
   int64_t n; int nbatch;
   const float* rays; const float* tvals;           // fused producer
   const float* x; const int* in0;                  // module-level producer
@@ -245,15 +246,20 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
     };
     layer_f32<KS4_0, NT16_HID, 0>(
         st, ringlane, biaslane, [&](int kk) { return B0[kk]; }, [&](int to, int r, float v) { X[to][r] = act_f32(v, ACT_ELU); }, [](int) {}, pend);
-    static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
-    for (int l = 0; l < 4; l += 2) {
+    // ping-pong X -> Y -> X ...: pairs of layers, then the odd one; the output layer reads Y (an even count ends in X: moved over)
+    const int nhid = a.nhid;
+    for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(X, Y, l);
       hidden(Y, X, l + 1);
     }
-    hidden(X, Y, 4);
+    if (nhid & 1) hidden(X, Y, nhid - 1);
+    else {
+#pragma unroll
+      for (int t = 0; t < NT16_HID; ++t) Y[t] = X[t];
+    }
     f32x4 fin0, fin1;
     layer_f32<S_KS4_H, S_NT_LAST, POS_LAST>(
-        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int kk) { return Y[kk >> 2][kk & 3]; },
+        st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int kk) { return Y[kk >> 2][kk & 3]; },
         [&](int, int r, float v) { fin0[r] = v; }, [&](int r) { Y[NT16_HID - 1][r] = act_f32(pend[r], ACT_ELU); }, fin1);
 #pragma unroll
     for (int i = 0; i < SLOTS_PAD; ++i) st.begin();
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
   st.prologue();                  // the first slots are on their way while the bias table is fetched
   // the handle's bias table is shared with the exact-fp32 kernels (true scale); this kernel's stream is packed for log2(e)-scaled
   // activations (elu_scaled): the biases of the six ELU layers are scaled here, the output layer's stay as they are
-  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = i < (1 + S_NHID) * W_HID ? a.bias[i] * LOG2E : a.bias[i];
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = i < (1 + a.nhid) * W_HID ? a.bias[i] * LOG2E : a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
   young_half_priority<NW>();
@@ -431,15 +437,19 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
     layer_h16x2<1, SH_NTP_H, 0>(
         st, ringlane, biaslane, [&](int, int pl) { return pl == 0 ? P0h : P0l; },
         [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { store_piece(Xh, Xl, tp, pcx, mn, cr); }, [](int) {}, pm, pc);
-    static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
-    for (int l = 0; l < 4; l += 2) {
+    const int nhid = a.nhid;
+    for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(Xh, Xl, Yh, Yl, l);
       hidden(Yh, Yl, Xh, Xl, l + 1);
     }
-    hidden(Xh, Xl, Yh, Yl, 4);
+    if (nhid & 1) hidden(Xh, Xl, Yh, Yl, nhid - 1);
+    else {                                  // an even count ends in X: the output layer reads Y
+#pragma unroll
+      for (int k = 0; k < SH_KS_H; ++k) { Yh[k] = Xh[k]; Yl[k] = Xl[k]; }
+    }
     f32x4 fm[2], fc[2];
     layer_h16x2<SH_KS_H, 1, SH_POS_LAST>(
-        st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int ks, int pl) { return pl == 0 ? Yh[ks] : Yl[ks]; },
+        st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int ks, int pl) { return pl == 0 ? Yh[ks] : Yl[ks]; },
         [&](int, int, f32x4(&)[2], f32x4(&)[2]) {}, [&](int pcx) { store_piece(Yh, Yl, SH_NTP_H - 1, pcx, pm, pc); }, fm, fc);
 #pragma unroll
     for (int i = 0; i < SH_SLOTS_PAD; ++i) st.begin();
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
   const float* biaslane = bias_lds + h * 16;
   constexpr float INV = 1.f / H16_LO_SCALE;
   constexpr float C2 = 2.f * 7.947285970052083e-08f;                  // 2 c, c = 2^-22 / 3
-  const float m_out = a.p1c[5];
+  const float m_out = a.p1c[0];              // p1c: [0] output-layer constant, [1 + l] C_l of hidden layer l
 
   for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
     const int64_t row = (int64_t)batch * (NW * 32) + wave * 32 + col;
@@ -632,17 +642,22 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
                                                          [&](int pc) { P1Epi{in, sq_in}(NT_HID - 1, pc, pend); }, np);
       pend[0] = np[0];
       ovf |= sq_in >= OVF2;
-      V = a.p1c[l] * fmaf(C2, sq_in, V);
+      V = a.p1c[1 + l] * fmaf(C2, sq_in, V);
       sq_in = 0.f;
     };
-    static_assert(S_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
-    for (int l = 0; l < 4; l += 2) {
+    const int nhid = a.nhid;
+    for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(Bn, Bo, l, sq_a, sq_b);
       hidden(Bo, Bn, l + 1, sq_b, sq_a);
     }
-    hidden(Bn, Bo, 4, sq_a, sq_b);
+    if (nhid & 1) hidden(Bn, Bo, nhid - 1, sq_a, sq_b);
+    else {                                  // an even count ends in Bn (its last tile still pending, its |x|^2 in sq_a): the output layer reads Bo / sq_b
+#pragma unroll
+      for (int k = 0; k < KS_HID; ++k) Bo[k] = Bn[k];
+      sq_b = sq_a;
+    }
     f32x16 fin[1];
-    layer_bf16<1, KS_HID, 1, P1_POS_LAST, 16, true>(st, ringlane, biaslane + (1 + S_NHID) * W_HID, [&](int, int ks) { return Bo[ks]; },
+    layer_bf16<1, KS_HID, 1, P1_POS_LAST, 16, true>(st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int, int ks) { return Bo[ks]; },
                                                      [&](int, int, f32x16(&)[1]) {}, [&](int pc) { P1Epi{Bo, sq_b}(NT_HID - 1, pc, pend); }, fin);
 #pragma unroll
     for (int i = 0; i < P1_SLOTS_PAD; ++i) st.begin();
@@ -809,6 +824,7 @@ extern "C" int pnrf_debug_set_ehead(float* buf, const float* rays_base) {
 #endif
 struct RefineArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
+  int nhid, nb;                                     // hidden 256 -> 256 layers behind layer 0 (mmnetdepth - 1; Fern: 5); neighbour views (num_neighbor; Fern: 4)
   int64_t n; int nbatch;
   const float* x;                                   // refine_in [n,144] (HEAD = 0)
   const float* or_rays; const float4* img4; const float* proj; int Hf, Wf; float eps;   // HEAD = 1: the projection runs in the kernel
@@ -822,9 +838,13 @@ struct RefineArgs {
 // HEAD 0: the 144 inputs of a ray come from refine_in [n,144] in memory; 1: they are produced in the batch head — neighbour projection +
 // bilinear colour fetch + sample Pluecker (run_S_eS_eN_alter_trt.py:637-661), each lane for its own two views and four samples
 // (refine_in0): no [n,144] round trip through HBM, one kernel launch less per frame.
-template <int NCB, int NW, int MODE, int HEAD = 0, class P = PrecBf16>
+// NV: neighbour views per lane half = ceil(num_neighbor / 2) (Fern: 2).  A lane half holds 24 NV colour values + 24 Pluecker values = 3 NV + 3
+// k-steps of layer 0 (refine_in0_nv); a view index >= a.nb is padding (zero weights in the stream; its inputs are fetched from the last real view).
+template <int NCB, int NW, int MODE, int HEAD = 0, class P = PrecBf16, int NV = 2>
 __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(RefineArgs a) {
   constexpr bool FUSED = MODE != 0;
+  using RL = RefineL0<NV>;
+  constexpr int KS0 = RL::KS0;
   static_assert(HEAD == 0 || (NCB == 1 && MODE == 1), "the projecting head exists for the fused inference stage");
   constexpr int TPB = 64 * NW;
   constexpr bool F16 = std::is_same<P, PrecF16>::value;
@@ -874,13 +894,21 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
       if constexpr (HEAD == 0) {
         // refine_in0: a lane's 72 inputs are two contiguous runs of the natural row — the colours of its two views [48 + 48h, 96 + 48h) and
         // the Pluecker values of its four samples [24h, 24h + 24): 18 aligned 16-byte loads
-        const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * R_IN;
+        const float* xr = a.x + (valid[cb] ? row[cb] : a.n - 1) * (48 + 24 * a.nb);
         static_assert(refine_in0(0, 1, 0) == 96 && refine_in0(5, 1, 7) == 143 && refine_in0(6, 1, 0) == 24 && refine_in0(8, 0, 7) == 23, "runs of refine_in0");
-        const float4* xc = (const float4*)(xr + 48 + 48 * h);
+        static_assert(refine_in0_nv(2, 4, 0, 1, 0) == 96 && refine_in0_nv(2, 4, 5, 1, 7) == 143 && refine_in0_nv(2, 4, 6, 1, 0) == 24 && refine_in0_nv(2, 3, 3, 1, 0) == -1, "refine_in0_nv");
         const float4* xp = (const float4*)(xr + 24 * h);
 #pragma unroll
-        for (int ks = 0; ks < R_KS0; ++ks) {
-          const float4 lo = ks < 6 ? xc[2 * ks] : xp[2 * (ks - 6)], hi = ks < 6 ? xc[2 * ks + 1] : xp[2 * (ks - 6) + 1];
+        for (int ks = 0; ks < KS0; ++ks) {
+          float4 lo, hi;
+          if (ks < 3 * NV) {                 // colours of view NV h + ks / 3 (a view beyond nb: zeros — its row does not hold it)
+            const int view = NV * h + ks / 3;
+            const float4* xc = (const float4*)(xr + 48 + 24 * (view < a.nb ? view : 0)) + 2 * (ks % 3);
+            lo = xc[0]; hi = xc[1];
+            if (view >= a.nb) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+          } else {
+            lo = xp[2 * (ks - 3 * NV)]; hi = xp[2 * (ks - 3 * NV) + 1];
+          }
           const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           Bo[cb][ks] = P::pack(v);
         }
@@ -891,20 +919,22 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         const float o0 = orr[0], o1 = orr[1], o2 = orr[2], w0 = orr[3], w1 = orr[4], w2 = orr[5];
         const float dn8[8] = {e_d0[cb].x, e_d0[cb].y, e_d0[cb].z, e_d0[cb].w, e_d1[cb].x, e_d1[cb].y, e_d1[cb].z, e_d1[cb].w};
         const int plane = a.Hf * a.Wf;
-        float feat[72];
-        // 16 projections per lane (view vv = p / 8, sample p % 8) in a software pipeline: the four texel fetches of projection p + D are issued
+        float feat[8 * KS0];
+        // 8 NV projections per lane (view vv = p / 8, sample p % 8) in a software pipeline: the four texel fetches of projection p + D are issued
         // before projection p is blended, so D projections (4 D x 16 B per lane) are in flight.  The fences keep the compiler from hoisting
         // all 64 fetches to the top of the batch (256 registers of texels: it spilled 187).
         constexpr int D = 4;
         float wt[D][4];
         float4 tx[D][4];
-        ViewRay vr[2];
+        ViewRay vr[NV];
+        int view[NV];                    // a view index beyond nb - 1 is padding (zero weights): it projects into the last real view instead
         float z3d[8];
 #pragma unroll
-        for (int vv = 0; vv < 2; ++vv) {
+        for (int vv = 0; vv < NV; ++vv) {
+          view[vv] = NV * h + vv < a.nb ? NV * h + vv : a.nb - 1;
           float M[12];
 #pragma unroll
-          for (int i = 0; i < 12; ++i) M[i] = a.proj[(2 * h + vv) * 12 + i];
+          for (int i = 0; i < 12; ++i) M[i] = a.proj[view[vv] * 12 + i];
           vr[vv] = view_ray(o0, o1, o2, w0, w1, w2, M);
         }
 #pragma unroll
@@ -914,7 +944,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         auto texel = [&](uint32_t view_off, uint32_t idx) { return *(const float4*)(imb + ((view_off + idx) << 4)); };
         auto issue = [&](auto pc) {
           constexpr int p = decltype(pc)::value, vv = p / 8, sl = p % D;
-          const uint32_t vo = (uint32_t)((2 * h + vv) * plane);
+          const uint32_t vo = (uint32_t)(view[vv] * plane);
           const Taps t = project_taps_fast(vr[vv], z3d[p % 8], a.Hf, a.Wf);
           tx[sl][0] = texel(vo, t.i00); tx[sl][1] = texel(vo, t.i01); tx[sl][2] = texel(vo, t.i10); tx[sl][3] = texel(vo, t.i11);
           wt[sl][0] = t.a00; wt[sl][1] = t.a01; wt[sl][2] = t.a10; wt[sl][3] = t.a11;
@@ -929,11 +959,11 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         };
         static_for<D>([&](auto pc) { issue(pc); });
         __builtin_amdgcn_sched_barrier(0);
-        static_for<16>([&](auto pc) {
+        static_for<8 * NV>([&](auto pc) {
           constexpr int p = decltype(pc)::value;
           blend(pc);
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (p + D < 16) {
+          if constexpr (p + D < 8 * NV) {
             issue(std::integral_constant<int, p + D>{});
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -947,7 +977,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
             const float dn = h ? dn8[4 + u] : dn8[u];
             float m0, m1, m2;
             moment(r[0], r[1], r[2], r[3], r[4], r[5], dn, hx, hy, hz, m0, m1, m2);
-            float* q = feat + 48 + 6 * u;
+            float* q = feat + 24 * NV + 6 * u;
             q[0] = hx; q[1] = hy; q[2] = hz; q[3] = m0; q[4] = m1; q[5] = m2;
           }
         }
@@ -955,11 +985,11 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
         if (MODE == 1 && valid[cb] && g_dbg_ehead) {
           float* d = g_dbg_ehead + (((a.rays - g_dbg_rays_base) / 11 + row[cb]) * 2 + h) * DBG_STRIDE;
 #pragma unroll
-          for (int i = 0; i < 72; ++i) d[48 + i] = feat[i];
+          for (int i = 0; i < 8 * KS0 && i < 72; ++i) d[48 + i] = feat[i];
         }
 #endif
 #pragma unroll
-        for (int ks = 0; ks < R_KS0; ++ks) {
+        for (int ks = 0; ks < KS0; ++ks) {
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = feat[8 * ks + j];
@@ -980,7 +1010,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
 #endif
     auto hidden = [&](v8(&in)[NCB][KS_HID], v8(&out)[NCB][KS_HID], int l) {
       f32x16 np[NCB];
-      layer_bf16<NCB, KS_HID, NT_HID, R_POS_H, RP, F16>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
+      layer_bf16<NCB, KS_HID, NT_HID, RL::POS_H, RP, F16>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; },
                                                    HiddenEpi<NCB, ACT_ELU, RP, P>{out}, [&](int pc) { HiddenEpi<NCB, ACT_ELU, RP, P>{in}(NT_HID - 1, pc, pend); }, np);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
@@ -988,17 +1018,23 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
       dbg_cks(1 + l, dbg_xor<KS_HID>(in[0]));        // `in` = the previous layer's output, complete since this call's first tile
 #endif
     };
-    layer_bf16<NCB, R_KS0, NT_HID, 0, RP, F16>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_ELU, RP, P>{Bn}, [](int) {}, pend);
+    layer_bf16<NCB, KS0, NT_HID, 0, RP, F16>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < KS0 ? ks : 0]; }, HiddenEpi<NCB, ACT_ELU, RP, P>{Bn}, [](int) {}, pend);
 #ifdef PNRF_DEBUG_EHEAD
-    dbg_cks(0, dbg_xor<R_KS0>(Bo[0]));                 // the packed inputs
+    dbg_cks(0, dbg_xor<(KS0 < KS_HID ? KS0 : KS_HID)>(Bo[0]));                 // the packed inputs
 #endif
-    static_assert(R_NHID == 5, "ping-pong schedule below is written for 5 hidden layers");
-    for (int l = 0; l < 4; l += 2) {
+    const int nhid = a.nhid;              // pairs of layers, then the odd one; the output layer reads Bo (an even count ends in Bn: moved over)
+    for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(Bn, Bo, l);
       hidden(Bo, Bn, l + 1);
     }
-    hidden(Bn, Bo, 4);
-    const float* blast = biaslane + (1 + R_NHID) * W_HID;
+    if (nhid & 1) hidden(Bn, Bo, nhid - 1);
+    else {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int k = 0; k < KS_HID; ++k) Bo[cb][k] = Bn[cb][k];
+    }
+    const float* blast = biaslane + (1 + nhid) * W_HID;
     auto pre_last = [&](int pc) { HiddenEpi<NCB, ACT_ELU, 2, P>{Bo}(NT_HID - 1, pc, pend); };
     f32x16 fin[NCB];
     if (!FUSED) {
@@ -1015,23 +1051,23 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
             }
           }
       };
-      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, store_tile, pre_last, fin);
+      layer_bf16<NCB, KS_HID, R_NT_LAST, RL::POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, store_tile, pre_last, fin);
       store_tile(R_NT_LAST - 1, 0, fin);
       store_tile(R_NT_LAST - 1, 1, fin);
 #pragma unroll
-      for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
+      for (int i = 0; i < RL::SLOTS_PAD; ++i) st.begin();
       continue;
     }
     if constexpr (MODE == 1) {
-      layer_bf16<NCB, KS_HID, 1, R_POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
+      layer_bf16<NCB, KS_HID, 1, RL::POS_LAST, BF16_PIECES, F16>(st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x16(&)[NCB]) {}, pre_last, fin);
 #ifdef PNRF_DEBUG_EHEAD
       dbg_cks(6, dbg_xor<KS_HID>(Bo[0]));              // the last hidden layer's output
 #endif
 #pragma unroll
-      for (int i = 0; i < (R_SLOTS_LAST - 1) + R_SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
+      for (int i = 0; i < (R_SLOTS_LAST - 1) + RL::SLOTS_PAD; ++i) st.begin();     // rgb tile (unused at inference) + pad
     } else {                   // training: tile 0 = refine + offsets, tile 1 = rgb head (rgb_map0, refine2.py:637)
       f32x16 t1[NCB];
-      layer_bf16<NCB, KS_HID, R_NT_LAST, R_POS_LAST, BF16_PIECES, F16>(
+      layer_bf16<NCB, KS_HID, R_NT_LAST, RL::POS_LAST, BF16_PIECES, F16>(
           st, ringlane, blast, [&](int cb, int ks) { return Bo[cb][ks]; },
           [&](int, int pc, f32x16(&acc)[NCB]) {
 #pragma unroll
@@ -1041,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
           },
           pre_last, t1);
 #pragma unroll
-      for (int i = 0; i < R_SLOTS_PAD; ++i) st.begin();
+      for (int i = 0; i < RL::SLOTS_PAD; ++i) st.begin();
       if (a.rgb0 && h == 0) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -1132,6 +1168,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
 
 struct NerfArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
+  int nhid;                                         // DoNeRFTRT: hidden 256 -> 256 layers behind layer 0 (netdepth - 2; the Fern configs: 6); unused by the class net
   int64_t n;                                        // fused: rays; module-level: rows
   int nbatch;
   const float* pts; const float* rays;              // fused producer
@@ -1305,7 +1342,8 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
         for (int cb = 0; cb < NCB; ++cb) pend[cb] = np[cb];
       };
       layer_bf16<NCB, N_KS0, NT_HID, 0>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks]; }, HiddenEpi<NCB, ACT_RELU>{Bn}, [](int) {}, pend);
-      static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
+      // This 32x32x16 form (PNRF_VARIANT_BF16_32X32, the module-level forward) is built for the Fern depth only — its launchers check: a run-time
+      // layer count made it spill (48 .. 144 bytes, three formulations); the default 16x16x32 engine (nerf16_kernel) takes any netdepth.
       for (int l = 0; l < N_NHID; l += 2) {
         hidden(Bn, Bo, l);
         hidden(Bo, Bn, l + 1);
@@ -1561,13 +1599,19 @@ __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfA
           for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
       layer_b16<NB_KS0, NB_NTP_H, 0, NCB, v8>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
-      static_assert(N_NHID == 6, "ping-pong schedule below is written for 6 hidden layers");
-      for (int l = 0; l < N_NHID; l += 2) {
+      const int nhid = a.nhid;            // pairs of layers end in Bn; the last layer of an odd count ends in Bo: moved over for the output layer
+      for (int l = 0; l < nhid; l += 2) { // (two layer bodies whatever the count: the odd tail is a branch inside the pair, not a third body)
         hidden(Bn, Bo, l);
-        hidden(Bo, Bn, l + 1);
+        if (l + 1 < nhid) hidden(Bo, Bn, l + 1);
+        else {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int k = 0; k < NB_KS_H; ++k) Bn[cb][k] = Bo[cb][k];
+        }
       }
       layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB, v8, PNRF_LAST_TMAX>(
-          st, ringlane, biaslane + (1 + N_NHID) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
+          st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
           [&](int, int, f32x4(&)[2][NCB], int) {}, [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, fin);
 #pragma unroll
       for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
@@ -1746,7 +1790,7 @@ size_t narrow_lds(size_t lds) { return lds > NARROW_LDS_BYTES ? lds : NARROW_LDS
 static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted, float* mul_sorted,
                           int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace, bool ws_clean, float kappa, void* stream) {
   SamplerArgs a = {};
-  a.bias = h->d_bias; a.nbias = h->nbias;
+  a.bias = h->d_bias; a.nbias = h->nbias; a.nhid = h->nhid;
   a.n = n; a.nbatch = (int)((n + 127) / 128);
   a.rays = rays; a.tvals = h->d_tvals;
   a.depth_sorted = depth_sorted; a.add_sorted = add_sorted; a.mul_sorted = mul_sorted;
@@ -1812,6 +1856,8 @@ static int sampler_launch(const pnrf_mlp_t* h, const float* rays, int64_t n, flo
     return launch_f32_list(f, counters, counters + 16 + n);
   }
   if (h->variant == PNRF_VARIANT_SAMPLER_F32_FULL) {
+    PNRF_REQUIRE(h->npts == S_NPTS && h->d_blob, PNRF_E_SHAPE, "PNRF_VARIANT_SAMPLER_F32_FULL (the unfolded first layer) is built for N_point_ray_enc = %d; this sampler has %d "
+                 "(every other variant runs the folded first layer and takes any N_point_ray_enc)", S_NPTS, h->npts);
     a.blob = h->d_blob; a.nslots = h->nslots;
     return launch_mlp(sampler_kernel<1>, a, 512, lds, a.nbatch, st);
   }
@@ -1861,19 +1907,46 @@ extern "C" int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64
 }
 
 // The fused refine stage in its two workgroup shapes (256 / 128 rays per batch; stage_shape) and two operand types
-template <int MODE, int HEAD>
-static int refine_launch(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
+template <int MODE, int HEAD, int NV>
+static int refine_launch_nv(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const bool bf16 = h->variant == PNRF_VARIANT_BF16;
+  if constexpr (NV > 2 && HEAD == 1) {          // (its projecting head with 3 / 4 views per lane does not fit the register file beside bf16 packing: it would spill)
+    PNRF_REQUIRE(!bf16, PNRF_E_SHAPE, "PNRF_VARIANT_BF16 of the projecting refine stage exists for num_neighbor <= 4 (this net: %d); the default fp16 stage takes 1 .. 8", h->nb);
+    a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
+    if (stage_shape(h, n, 32) == SHAPE_NARROW) {
+      a.nbatch = (int)((n + 127) / 128);
+      return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecF16, NV>, a, 256, narrow_lds(lds), a.nbatch, st);
+    }
+    a.nbatch = (int)((n + 255) / 256);
+    return launch_mlp(refine_kernel<1, 8, MODE, HEAD, PrecF16, NV>, a, 512, lds, a.nbatch, st);
+  } else {
   if (!bf16) { a.blob = h->d_blob_f16; a.nslots = h->nslots_f16; }
   if (stage_shape(h, n, 32) == SHAPE_NARROW) {
     a.nbatch = (int)((n + 127) / 128);
-    if (bf16) return launch_mlp(refine_kernel<1, 4, MODE, HEAD>, a, 256, narrow_lds(lds), a.nbatch, st);
-    return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecF16>, a, 256, narrow_lds(lds), a.nbatch, st);
+    if (bf16) return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecBf16, NV>, a, 256, narrow_lds(lds), a.nbatch, st);
+    return launch_mlp(refine_kernel<1, 4, MODE, HEAD, PrecF16, NV>, a, 256, narrow_lds(lds), a.nbatch, st);
   }
   a.nbatch = (int)((n + 255) / 256);
-  if (bf16) return launch_mlp(refine_kernel<1, 8, MODE, HEAD>, a, 512, lds, a.nbatch, st);
-  return launch_mlp(refine_kernel<1, 8, MODE, HEAD, PrecF16>, a, 512, lds, a.nbatch, st);
+  if (bf16) return launch_mlp(refine_kernel<1, 8, MODE, HEAD, PrecBf16, NV>, a, 512, lds, a.nbatch, st);
+  return launch_mlp(refine_kernel<1, 8, MODE, HEAD, PrecF16, NV>, a, 512, lds, a.nbatch, st);
+  }
+}
+// ... for the handle's number of neighbour views (NV = views per lane half, pnrf_layout.h) and hidden layers
+template <int MODE, int HEAD>
+static int refine_launch(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
+  a.nhid = h->nhid; a.nb = h->nb;
+  if constexpr (MODE == 2) {                    // the training-time epilogue belongs to the trainer's shapes
+    PNRF_REQUIRE(h->nb == 4, PNRF_E_SHAPE, "pnrf_refine_train_fwd is built for num_neighbor = 4, this refine net has %d", h->nb);
+    return refine_launch_nv<MODE, HEAD, 2>(h, a, n, st);
+  } else {
+    switch (refine_nv(h->nb)) {
+      case 1: return refine_launch_nv<MODE, HEAD, 1>(h, a, n, st);
+      case 2: return refine_launch_nv<MODE, HEAD, 2>(h, a, n, st);
+      case 3: return refine_launch_nv<MODE, HEAD, 3>(h, a, n, st);
+      default: return refine_launch_nv<MODE, HEAD, 4>(h, a, n, st);
+    }
+  }
 }
 
 extern "C" int pnrf_refine_train_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* rays, const float* depth_sorted,
@@ -1905,8 +1978,8 @@ extern "C" int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, cons
 extern "C" int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
                                        const float* proj, int nb, int Hf, int Wf, float eps, float* z, float* pts, int64_t n, void* stream) {
   PNRF_REQUIRE(h && h->net == PNRF_NET_REFINE, PNRF_E_ARG, "pnrf_refine_project_fwd: handle is not a refine net");
-  PNRF_REQUIRE(n >= 0 && nb == 4 && Hf >= 2 && Wf >= 2 && (int64_t)Hf * Wf * nb < (int64_t)1 << 27, PNRF_E_ARG,
-               "pnrf_refine_project_fwd: bad sizes (nb must be 4, got %d; nb * Hf * Wf must stay below 2^27 texels)", nb);
+  PNRF_REQUIRE(n >= 0 && nb == h->nb && Hf >= 2 && Wf >= 2 && (int64_t)Hf * Wf * nb < (int64_t)1 << 27, PNRF_E_ARG,
+               "pnrf_refine_project_fwd: bad sizes (nb must be the refine net's num_neighbor = %d, got %d; nb * Hf * Wf must stay below 2^27 texels)", h->nb, nb);
   if (n == 0) return 0;
   PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && proj && z && pts, PNRF_E_ARG, "pnrf_refine_project_fwd: null pointer");
 
@@ -1946,7 +2019,7 @@ int pnrf_nerf_fwd_queue_impl(const pnrf_mlp_t* h, const float* pts, const float*
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = n;
   a.pts = pts; a.rays = rays; a.z = z; a.add = add_sorted; a.mul = mul_sorted; a.rgbd = rgbd; a.raw = raw;
-  a.noise = noise; a.white_bkgd = white_bkgd; a.clampv = clampv; a.S = S;
+  a.noise = noise; a.white_bkgd = white_bkgd; a.clampv = clampv; a.S = S; a.nhid = h->nhid;
   a.queue = h->variant == PNRF_VARIANT_BF16_32X32 ? nullptr : queue;          // (nerf_kernel, the 32x32x16 variant, keeps the static stride)
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   const int rows = 256;
@@ -1975,6 +2048,7 @@ int pnrf_nerf_fwd_queue_impl(const pnrf_mlp_t* h, const float* pts, const float*
   if (f16) return launch_mlp(nerf16_kernel<false, 2, PrecF16>, a, 512, lds16, a.nbatch, st);
   if (h->variant == PNRF_VARIANT_NERF_4X64) return launch_mlp(nerf16_kernel<false, 4>, a, 256, lds16, a.nbatch, st);
   if (b16) return launch_mlp(nerf16_kernel<false, 2>, a, 512, lds16, a.nbatch, st);
+  PNRF_REQUIRE(h->nhid == N_NHID, PNRF_E_SHAPE, "PNRF_VARIANT_BF16_32X32 is built for netdepth %d; this net has netdepth %d — the default engine takes any", N_NHID + 2, h->nhid + 2);
   return launch_mlp(nerf_kernel<1, 8, true, false>, a, 512, lds, a.nbatch, st);
 }
 
@@ -1986,7 +2060,9 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
   const size_t lds = RING_BYTES + (size_t)h->nbias * 4;
   if (h->net == PNRF_NET_SAMPLER) {
     SamplerArgs a = {};
-    a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
+    PNRF_REQUIRE(h->npts == S_NPTS && h->d_blob, PNRF_E_SHAPE, "pnrf_mlp_fwd: the module-level sampler forward (unfolded first layer) is built for N_point_ray_enc = %d, "
+                 "this sampler has %d; the fused operators (pnrf_sampler_fwd / pnrf_render_rays_fwd) take any", S_NPTS, h->npts);
+    a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias; a.nhid = h->nhid;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
     a.x = x; a.in0 = h->d_in0; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
     return launch_mlp(sampler_kernel<0>, a, 512, lds, a.nbatch, (hipStream_t)stream);
@@ -1995,19 +2071,31 @@ extern "C" int pnrf_mlp_fwd(const pnrf_mlp_t* h, const float* x, const float* x_
     RefineArgs a = {};
     a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
     a.n = m; a.nbatch = (int)((m + 127) / 128);
-    a.x = x; a.y = y; a.outmap = h->d_out; a.head_act = head_act;
+    a.x = x; a.y = y; a.outmap = h->d_out; a.head_act = head_act; a.nhid = h->nhid; a.nb = h->nb;
     // operand type as the fused stage's (pnrf_refine_fwd / pnrf_refine_project_fwd): fp16 by default, bf16 for PNRF_VARIANT_BF16, so that a
     // module-level parity check exercises the arithmetic the render path runs
-    if (h->variant == PNRF_VARIANT_BF16) return launch_mlp(refine_kernel<1, 4, 0>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
-    a.blob = h->d_blob_f16; a.nslots = h->nslots_f16;
-    return launch_mlp(refine_kernel<1, 4, 0, 0, PrecF16>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
+    const bool bf16 = h->variant == PNRF_VARIANT_BF16;
+    if (!bf16) { a.blob = h->d_blob_f16; a.nslots = h->nslots_f16; }
+    auto go = [&](auto nvc) {
+      constexpr int NV = decltype(nvc)::value;
+      return bf16 ? launch_mlp(refine_kernel<1, 4, 0, 0, PrecBf16, NV>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream)
+                  : launch_mlp(refine_kernel<1, 4, 0, 0, PrecF16, NV>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
+    };
+    switch (refine_nv(h->nb)) {
+      case 1: return go(std::integral_constant<int, 1>{});
+      case 2: return go(std::integral_constant<int, 2>{});
+      case 3: return go(std::integral_constant<int, 3>{});
+      default: return go(std::integral_constant<int, 4>{});
+    }
   }
   NerfArgs a = {};
   a.blob = h->d_blob; a.bias = h->d_bias; a.nslots = h->nslots; a.nbias = h->nbias;
   a.n = m; a.nbatch = (int)((m + 127) / 128);
-  a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out; a.S = 8;
+  a.x = x; a.xv = x_views; a.in0 = h->d_in0; a.inx = h->d_inx; a.y = y; a.outmap = h->d_out; a.S = 8; a.nhid = h->nhid;
   // (4-wave workgroups: LDS-exclusive like the narrow shapes of the fused stages — one fused-MLP workgroup per CU)
   if (h->net == PNRF_NET_NERFCLS) return launch_mlp(nerf_kernel<1, 4, false, true>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
+  PNRF_REQUIRE(h->nhid == N_NHID, PNRF_E_SHAPE, "pnrf_mlp_fwd: the module-level DoNeRFTRT forward is built for netdepth %d; this net has netdepth %d — "
+               "the fused operators (pnrf_nerf_fwd / pnrf_render_rays_fwd) take any", N_NHID + 2, h->nhid + 2);
   return launch_mlp(nerf_kernel<1, 4, false, false>, a, 256, narrow_lds(lds), a.nbatch, (hipStream_t)stream);
 }
 

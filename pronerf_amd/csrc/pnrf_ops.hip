@@ -177,8 +177,8 @@ __global__ void images_pack_kernel(const float* __restrict__ in, float4* __restr
   }
 }
 
-// Projection + sample Pluecker -> refine_in[n,144]   (trt.py:637-661)
-// Workgroup = 64 consecutive rays x 4 neighbours: lane = ray, wave = neighbour view, loop over the 8 samples.  Consecutive rays
+// Projection + sample Pluecker -> refine_in[n, 48 + 24 nb]   (trt.py:637-661; nb = 4: [n,144])
+// Workgroup = 64 consecutive rays x 4 waves: lane = ray, wave = neighbour view k, k + 4 (nb <= 8), loop over the 8 samples.  Consecutive rays
 // are consecutive pixels, so for a fixed (view, sample) the 64 lanes of a wave fetch adjacent texels (coalesced 16-byte taps, each
 // cache line fetched once) — with one thread per (ray, view, sample) in ray-major order a wave touched 256 unrelated lines and
 // the L2 hit rate was 63 %.  The [64 rays][144] tile is transposed through LDS and written out as one contiguous 36 KiB block.
@@ -186,10 +186,11 @@ constexpr int RI_TILE = 64;
 __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restrict__ rays, const float* __restrict__ or_rays, const float* __restrict__ depth_sorted,
                                     const float4* __restrict__ img4, const float* __restrict__ proj, int nb, int Hf, int Wf, float eps,
                                     float* __restrict__ out, int64_t n) {
-  __shared__ float sM[4 * 12];
-  __shared__ float sT[144 * (RI_TILE + 1)];          // [feature][ray] (+1: conflict-free column writes)
-  if (threadIdx.x < 48) sM[threadIdx.x] = proj[threadIdx.x];
-  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  __shared__ float sM[8 * 12];
+  __shared__ float sT[(48 + 24 * 8) * (RI_TILE + 1)];          // [feature][ray] (+1: conflict-free column writes)
+  if ((int)threadIdx.x < 12 * nb) sM[threadIdx.x] = proj[threadIdx.x];
+  const int F = 48 + 24 * nb;
+  const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6;
   const int64_t plane = (int64_t)Hf * Wf;
   const int64_t ntiles = (n + RI_TILE - 1) / RI_TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restri
     const float o0 = orr[0], o1 = orr[1], o2 = orr[2], e0 = orr[3], e1 = orr[4], e2 = orr[5];
     const float4 da = *(const float4*)(depth_sorted + ray * 8), db = *(const float4*)(depth_sorted + ray * 8 + 4);
     const float dn8[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+    for (int k = kw; k < nb; k += 4) {
     const float* M = sM + k * 12;
     const float4* im = img4 + (int64_t)k * plane;
 #pragma unroll
@@ -225,7 +227,9 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restri
       sT[(f + 1) * (RI_TILE + 1) + lane] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.y, a00), ieee_mul(t01.y, a01)), ieee_mul(t10.y, a10)), ieee_mul(t11.y, a11));
       sT[(f + 2) * (RI_TILE + 1) + lane] = ieee_add(ieee_add(ieee_add(ieee_mul(t00.z, a00), ieee_mul(t01.z, a01)), ieee_mul(t10.z, a10)), ieee_mul(t11.z, a11));
     }
+    }
     {                                                                                            // trt.py:656-658: wave k encodes samples 2k, 2k+1
+      const int k = kw;
       const float* r = rays + ray * 11;
       float hx, hy, hz;
       unit_dir(r[3], r[4], r[5], hx, hy, hz);
@@ -241,10 +245,10 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const float* __restri
       }
     }
     __syncthreads();
-    const int64_t nvalid = (n - ray0 < RI_TILE ? n - ray0 : RI_TILE) * 144;                       // contiguous block of the output
-    float* dst = out + ray0 * 144;
-    for (int e = threadIdx.x; e < RI_TILE * 144; e += 256)
-      if (e < nvalid) dst[e] = sT[(e % 144) * (RI_TILE + 1) + e / 144];
+    const int64_t nvalid = (n - ray0 < RI_TILE ? n - ray0 : RI_TILE) * F;                         // contiguous block of the output
+    float* dst = out + ray0 * F;
+    for (int e = threadIdx.x; e < RI_TILE * F; e += 256)
+      if (e < nvalid) dst[e] = sT[(e % F) * (RI_TILE + 1) + e / F];
   }
 }
 
@@ -680,7 +684,7 @@ extern "C" int pnrf_images_pack(const float* img_nchw, float* out_nhwc4, int nv,
 
 extern "C" int pnrf_refine_input_fwd(const float* rays, const float* or_rays, const float* depth_sorted, const float* img4,
                                      const float* proj, int nb, int Hf, int Wf, float eps, float* refine_in, int64_t n, void* stream) {
-  PNRF_REQUIRE(n >= 0 && nb == 4 && Hf >= 2 && Wf >= 2, PNRF_E_ARG, "pnrf_refine_input_fwd: bad sizes (nb must be 4, got %d)", nb);
+  PNRF_REQUIRE(n >= 0 && nb >= 1 && nb <= 8 && Hf >= 2 && Wf >= 2, PNRF_E_ARG, "pnrf_refine_input_fwd: bad sizes (nb must be 1 .. 8, got %d)", nb);
   if (n == 0) return 0;
   PNRF_REQUIRE(rays && or_rays && depth_sorted && img4 && proj && refine_in, PNRF_E_ARG, "pnrf_refine_input_fwd: null pointer");
   hipLaunchKernelGGL(refine_input_kernel, dim3(grid_for((n + RI_TILE - 1) / RI_TILE, 1)), dim3(256), 0, (hipStream_t)stream, rays, or_rays, depth_sorted,

@@ -373,18 +373,37 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   PNRF_REQUIRE(net == PNRF_NET_SAMPLER || net == PNRF_NET_REFINE || net == PNRF_NET_NERF, PNRF_E_ARG,
                "pnrf_mlp_pack: unknown net kind %d", net);
   const int prec = net == PNRF_NET_SAMPLER ? PREC_F32 : PREC_BF16;
-  const int nhid = net == PNRF_NET_SAMPLER ? S_NHID : net == PNRF_NET_REFINE ? R_NHID : N_NHID;
-  const int in0 = net == PNRF_NET_SAMPLER ? S_IN : net == PNRF_NET_REFINE ? R_IN : N_IN;
+  // Supported shapes (pnrf_layout.h, "free shape parameters"): width 256 and 8 samples per ray are fixed; free are the number of hidden layers
+  // (mmnetdepth / netdepth), the sampler's ray points (N_point_ray_enc: input 6 P) and the refine net's neighbour views (num_neighbor: input 48 + 24 nb)
+  static const char* SUPPORTED = "supported: hidden width 256, N_samples 8 (sampler 6*P -> D x 256 -> 27, any P >= 1; refine 48 + 24*nb -> D x 256 -> 35, nb = 1..8; "
+                                 "DoNeRFTRT 63 -> (netdepth - 1) x 256 -> [256 + 27] -> 4 with 3 <= netdepth <= 8; sampler / refine depth 2 <= D <= 32; the NeRF class: D = 8, skips = [4])";
+  const int nhid = n_layers - 2;
+  PNRF_REQUIRE(n_layers >= 3 && nhid <= MAX_NHID, PNRF_E_SHAPE, "pnrf_mlp_pack: net %d with %d Linear layers; %s", net, n_layers, SUPPORTED);
+  const int in0 = in_dim[0];
+  int npts = 0, nbv = 0;
+  if (net == PNRF_NET_SAMPLER) {
+    npts = in0 / 6;
+    PNRF_REQUIRE(in0 >= 6 && in0 % 6 == 0, PNRF_E_SHAPE, "pnrf_mlp_pack: sampler input width %d is not 6 * N_point_ray_enc; %s", in0, SUPPORTED);
+  } else if (net == PNRF_NET_REFINE) {
+    nbv = (in0 - 48) / 24;
+    PNRF_REQUIRE(in0 >= 72 && (in0 - 48) % 24 == 0 && nbv <= MAX_NB, PNRF_E_SHAPE, "pnrf_mlp_pack: refine input width %d is not 48 + 24 * num_neighbor with 1 <= num_neighbor <= %d; %s",
+                 in0, MAX_NB, SUPPORTED);
+  } else {
+    PNRF_REQUIRE(in0 == N_IN, PNRF_E_SHAPE, "pnrf_mlp_pack: NeRF input width %d, kernels encode 10 positional octaves (63); %s", in0, SUPPORTED);
+    // the reference's skip='auto' puts the view encoding at layer 7 D / 8 (run_nerf_helpers.py:1190-1201): the last layer only up to D = 8
+    PNRF_REQUIRE(n_layers <= 8, PNRF_E_SHAPE, "pnrf_mlp_pack: DoNeRFTRT with netdepth %d: from 9 layers on skip='auto' feeds the view encoding into a hidden layer; %s", n_layers, SUPPORTED);
+  }
   const int outN = net == PNRF_NET_SAMPLER ? S_OUT : net == PNRF_NET_REFINE ? R_OUT : N_OUT;
   const int last_in = net == PNRF_NET_NERF ? W_HID + N_INV : W_HID;
-  PNRF_REQUIRE(n_layers == nhid + 2, PNRF_E_SHAPE, "pnrf_mlp_pack: net %d expects %d layers, got %d", net, nhid + 2, n_layers);
   for (int l = 0; l < n_layers; ++l) {
     const int ei = l == 0 ? in0 : (l == n_layers - 1 ? last_in : W_HID);
     const int eo = l == n_layers - 1 ? outN : W_HID;
     PNRF_REQUIRE(W[l] && b[l], PNRF_E_ARG, "pnrf_mlp_pack: null weight/bias at layer %d", l);
     PNRF_REQUIRE(in_dim[l] == ei && out_dim[l] == eo, PNRF_E_SHAPE,
-                 "pnrf_mlp_pack: net %d layer %d is %dx%d, kernels are built for %dx%d", net, l, out_dim[l], in_dim[l], eo, ei);
+                 "pnrf_mlp_pack: net %d layer %d is %dx%d where %dx%d is needed; %s", net, l, out_dim[l], in_dim[l], eo, ei, SUPPORTED);
   }
+  const bool full_stream = net != PNRF_NET_SAMPLER || npts == S_NPTS;      // the sampler's unfolded stream (module-level forward, SAMPLER_F32_FULL): P = 48 only
+  const int nv = refine_nv(nbv);
 
   std::vector<Layer> Ls(n_layers);
   for (int l = 0; l < n_layers; ++l) {
@@ -400,12 +419,13 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   Layer& Z = Ls[n_layers - 1];
   if (net == PNRF_NET_SAMPLER) {
     F.nk = S_KS0; F.in_map.assign(S_KS0 * 4, -1);
-    for (int kk = 0; kk < S_KS0; ++kk) for (int q = 0; q < 4; ++q) F.in_map[kk * 4 + q] = sampler_in0(kk, q);
+    for (int kk = 0; kk < S_KS0; ++kk) for (int q = 0; q < 4; ++q) F.in_map[kk * 4 + q] = full_stream ? sampler_in0(kk, q) : -1;
     Z.nt = S_NT_LAST; Z.out_map.assign(16 * S_NT_LAST, -1);
     for (int tt = 0; tt < S_NT_LAST; ++tt) for (int q = 0; q < 4; ++q) for (int r = 0; r < 4; ++r) Z.out_map[tt * 16 + 4 * q + r] = sampler_out(tt, q, r);
   } else if (net == PNRF_NET_REFINE) {
-    F.nk = R_KS0; F.in_map.assign(R_KS0 * 16, -1);
-    for (int ks = 0; ks < R_KS0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) F.in_map[(ks * 2 + h) * 8 + j] = refine_in0(ks, h, j);
+    const int ks0 = 3 * nv + 3;
+    F.nk = ks0; F.in_map.assign(ks0 * 16, -1);
+    for (int ks = 0; ks < ks0; ++ks) for (int h = 0; h < 2; ++h) for (int j = 0; j < 8; ++j) F.in_map[(ks * 2 + h) * 8 + j] = refine_in0_nv(nv, nbv, ks, h, j);
     Z.nt = R_NT_LAST; Z.out_map.assign(64, -1);
     for (int h = 0; h < 2; ++h) for (int g = 0; g < 16; ++g) {
       Z.out_map[acc_row(g, h)] = refine_out0(g, h);
@@ -436,8 +456,9 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   size_t slots = 0;
   for (auto& L : Ls) slots += layer_slots(L, prec);
   slots += (NSLOTS - slots % NSLOTS) % NSLOTS;
-  const uint32_t expect = net == PNRF_NET_SAMPLER ? S_NSLOTS : net == PNRF_NET_REFINE ? R_NSLOTS : N_NSLOTS;
+  const uint32_t expect = net == PNRF_NET_SAMPLER ? s_nslots(nhid) : net == PNRF_NET_REFINE ? refine_slots(nhid, nv) : n_nslots(nhid);
   PNRF_REQUIRE(slots == expect, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (%zu slots, kernels expect %u)", slots, expect);
+  if (!full_stream) slots = 0;                   // no unfolded stream for this sampler
 
   std::vector<char> blob(slots * SLOT_BYTES, 0);
   const int tile_rows = prec == PREC_BF16 ? 32 : 16;
@@ -446,7 +467,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   std::vector<float> bias(nbias, 0.f);
   size_t so = 0, bo = 0;
   for (auto& L : Ls) {
-    pack_layer(L, prec, blob.data() + so * SLOT_BYTES);
+    if (full_stream) pack_layer(L, prec, blob.data() + so * SLOT_BYTES);
     pack_bias(L, prec, bias.data() + bo);
     so += layer_slots(L, prec);
     bo += (size_t)L.nt * tile_rows;
@@ -471,7 +492,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (int o = 0; o < W_HID; ++o)
       for (int j = 0; j < 6; ++j) {
         double acc = 0.0;
-        for (int pnt = 0; pnt < S_IN / 6; ++pnt) acc += (double)W[0][(size_t)o * S_IN + 6 * pnt + j];
+        for (int pnt = 0; pnt < npts; ++pnt) acc += (double)W[0][(size_t)o * in0 + 6 * pnt + j];
         wfold[(size_t)o * 6 + j] = (float)acc;
       }
     std::vector<Layer> Lf = Ls;
@@ -480,7 +501,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (int kk = 0; kk < 2; ++kk) for (int q = 0; q < 4; ++q) G.in_map[kk * 4 + q] = (4 * kk + q < 6) ? 4 * kk + q : -1;
     for (auto& L : Lf) slots_fold += layer_slots(L, prec);
     slots_fold += (NSLOTS - slots_fold % NSLOTS) % NSLOTS;
-    PNRF_REQUIRE(slots_fold == (size_t)SF_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (folded stream %zu slots, expected %d)", slots_fold, SF_NSLOTS);
+    PNRF_REQUIRE(slots_fold == (size_t)sf_nslots(nhid), PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (folded stream %zu slots, expected %d)", slots_fold, sf_nslots(nhid));
     blob_fold.assign(slots_fold * SLOT_BYTES, 0);
     size_t sf = 0;
     for (auto& L : Lf) { pack_layer(L, prec, blob_fold.data() + sf * SLOT_BYTES); sf += layer_slots(L, prec); }
@@ -502,7 +523,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     auto hs = [&](const Layer& L) { return ((size_t)(L.nt / 2) * L.nk * 4 + SLOT_FRAGS - 1) / SLOT_FRAGS; };
     for (auto& L : Lh) slots_h16 += hs(L);
     slots_h16 += (NSLOTS - slots_h16 % NSLOTS) % NSLOTS;
-    PNRF_REQUIRE(slots_h16 == (size_t)SH_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (f16x2 stream %zu slots, expected %d)", slots_h16, SH_NSLOTS);
+    PNRF_REQUIRE(slots_h16 == (size_t)sh_nslots(nhid), PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (f16x2 stream %zu slots, expected %d)", slots_h16, sh_nslots(nhid));
     blob_h16.assign(slots_h16 * SLOT_BYTES, 0);
     size_t sh = 0;
     for (auto& L : Lh) { pack_layer_h16x2(L, blob_h16.data() + sh * SLOT_BYTES); sh += hs(L); }
@@ -524,8 +545,8 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     Layer& Y = Lp[n_layers - 1];
     Y.nt = 1; Y.out_map.assign(32, -1);
     for (int hh = 0; hh < 2; ++hh) for (int g = 0; g < 16; ++g) Y.out_map[acc_row(g, hh)] = sampler_p1_out(g, hh);
-    blob_p1.assign((size_t)P1_NSLOTS * SLOT_BYTES, 0);
-    bias_p1.assign(P1_NBIAS, 0.f);
+    blob_p1.assign((size_t)p1_nslots(nhid) * SLOT_BYTES, 0);
+    bias_p1.assign(p1_nbias(nhid), 0.f);
     size_t sp = 0, bp = 0;
     for (int l = 0; l < n_layers; ++l) {
       const Layer& L = Lp[l];
@@ -535,20 +556,20 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
       sp += l == 0 ? P1_SLOTS_L0 : layer_slots(L, PREC_BF16);
       bp += (size_t)L.nt * 32;
     }
-    PNRF_REQUIRE(sp == (size_t)P1_SLOTS_USED && bp == (size_t)P1_NBIAS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (pass-1 stream %zu slots, %zu bias floats)", sp, bp);
-    p1c.assign(P1_NCONST, 0.f);
-    for (int l = 1; l <= S_NHID; ++l) {                             // C_l = max over input features j of the column norm sum_i W_l[i,j]^2
+    PNRF_REQUIRE(sp == (size_t)p1_slots_used(nhid) && bp == (size_t)p1_nbias(nhid), PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (pass-1 stream %zu slots, %zu bias floats)", sp, bp);
+    p1c.assign(p1_nconst(nhid), 0.f);             // [0] output-layer constant, [1 + l] C of hidden layer l (sampler_p1_kernel)
+    for (int l = 1; l <= nhid; ++l) {                             // C_l = max over input features j of the column norm sum_i W_l[i,j]^2
       double cmax = 0.0;
       for (int j = 0; j < W_HID; ++j) {
         double cn = 0.0;
         for (int i = 0; i < W_HID; ++i) { const double w = (double)W[l][(size_t)i * W_HID + j]; cn += w * w; }
         cmax = cn > cmax ? cn : cmax;
       }
-      p1c[l - 1] = (float)(cmax * (1.0 + 1e-6));
+      p1c[l] = (float)(cmax * (1.0 + 1e-6));
     }
     double mmax = 0.0;                                              // depth rows of the output layer
     for (int k = 0; k < 8; ++k) for (int j = 0; j < W_HID; ++j) { const double w = (double)W[n_layers - 1][(size_t)k * W_HID + j]; mmax = w * w > mmax ? w * w : mmax; }
-    p1c[5] = (float)(mmax / (LOG2E_D * LOG2E_D) * (1.0 + 1e-6));
+    p1c[0] = (float)(mmax / (LOG2E_D * LOG2E_D) * (1.0 + 1e-6));
   }
 
   // DoNeRFTRT: second stream for the 16x16x32 engine (layer_b16): 16-row tiles in pairs, 32-deep k-steps
@@ -578,7 +599,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     size_t nb = 0;
     for (auto& L : Lb) { slots_b16 += bs(L); nb += (size_t)L.nt * 16; }
     slots_b16 += (NSLOTS - slots_b16 % NSLOTS) % NSLOTS;
-    PNRF_REQUIRE(slots_b16 == (size_t)NB_NSLOTS, PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (b16 stream %zu slots, expected %d)", slots_b16, NB_NSLOTS);
+    PNRF_REQUIRE(slots_b16 == (size_t)nb_nslots(nhid), PNRF_E_SHAPE, "pnrf_mlp_pack: internal layout mismatch (b16 stream %zu slots, expected %d)", slots_b16, nb_nslots(nhid));
     blob_b16.assign(slots_b16 * SLOT_BYTES, 0);
     slots_f16 = slots_b16;
     blob_f16.assign(slots_f16 * SLOT_BYTES, 0);                             // ... and with fp16 operands (the default of the NeRF stage)
@@ -595,11 +616,14 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
   pnrf_mlp* h = new pnrf_mlp();
   memset(h, 0, sizeof(*h));
   h->net = net; h->prec = prec; h->in_dim = in0; h->in_dim_x = net == PNRF_NET_NERF ? N_INV : 0; h->out_dim = outN;
+  h->nhid = nhid; h->nb = nbv; h->npts = npts;
   h->nslots = (uint32_t)slots; h->nbias = (int)nbias;
   h->n_in0 = (int)in0_map.size(); h->n_inx = (int)inx_map.size(); h->n_out = (int)out_map.size();
   hipError_t e = hipGetDevice(&h->device);
-  if (e == hipSuccess) e = hipMalloc(&h->d_blob, blob.size());
-  if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !blob.empty()) {
+    e = hipMalloc(&h->d_blob, blob.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, nbias * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->d_bias, bias.data(), nbias * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_in0, in0_map.size() * sizeof(int));
@@ -626,7 +650,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_f16, blob_f16.data(), blob_f16.size(), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
-    h->nslots_p1 = P1_NSLOTS; h->nbias_p1 = P1_NBIAS; h->n_p1c = P1_NCONST;
+    h->nslots_p1 = p1_nslots(nhid); h->nbias_p1 = p1_nbias(nhid); h->n_p1c = p1_nconst(nhid);
     e = hipMalloc(&h->d_blob_p1, blob_p1.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_blob_p1, blob_p1.data(), blob_p1.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_p1, bias_p1.size() * sizeof(float));
@@ -641,7 +665,7 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_b16, bias_b16.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_b16.data(), bias_b16.size() * sizeof(float), hipMemcpyHostToDevice);
   }
-  if (e == hipSuccess && net == PNRF_NET_SAMPLER) {
+  if (e == hipSuccess && net == PNRF_NET_SAMPLER && full_stream) {
     float tv[S_NPTS];
     pnrf_linspace(0.f, 1.f, S_NPTS, tv);
     e = hipMalloc((void**)&h->d_tvals, sizeof(tv));
@@ -697,9 +721,10 @@ struct EngineHeader {
   uint32_t nslots_p1;                 // format 2: pass-1 stream of the two-pass sampler, its bias table and error-model constants
   int32_t nbias_p1, n_p1c;
   uint32_t nslots_f16;                // format 3: fp16-operand stream of the refine / NeRF stages
-  uint8_t reserved[8];
+  uint16_t nhid, nb, npts;            // format 4: the net's free shape parameters (hidden layers behind layer 0, neighbour views, ray points)
+  uint8_t reserved[2];
 };
-static constexpr uint32_t ENGINE_FORMAT = 3;
+static constexpr uint32_t ENGINE_FORMAT = 4;
 static constexpr int ENGINE_SECTIONS = 14;
 static_assert(sizeof(EngineHeader) == 128, "engine header is 128 bytes");
 static const char ENGINE_MAGIC[8] = {'P', 'N', 'R', 'F', 'E', 'N', 'G', 0};
@@ -727,22 +752,26 @@ static int sections(pnrf_mlp* h, int n_tvals, Section* s) {
 }
 
 // what pnrf_mlp_pack produces for a net kind (the counts the kernels rely on)
-static void expected_counts(int net, EngineHeader* w) {
+static void expected_counts(int net, int nhid, int nb, int npts, EngineHeader* w) {
   memset(w, 0, sizeof(*w));
+  w->nhid = (uint16_t)nhid; w->nb = (uint16_t)nb; w->npts = (uint16_t)npts;
   switch (net) {
-    case PNRF_NET_SAMPLER:
-      w->prec = PREC_F32; w->in_dim = S_IN; w->out_dim = S_OUT; w->nslots = S_NSLOTS; w->nslots_fold = SF_NSLOTS; w->nslots_h16 = SH_NSLOTS;
-      w->nbias = S_NBIAS; w->n_in0 = S_KS0 * 4; w->n_out = 16 * S_NT_LAST; w->n_tvals = S_NPTS;
-      w->nslots_p1 = P1_NSLOTS; w->nbias_p1 = P1_NBIAS; w->n_p1c = P1_NCONST;
+    case PNRF_NET_SAMPLER: {
+      const bool full = npts == S_NPTS;
+      w->prec = PREC_F32; w->in_dim = 6 * npts; w->out_dim = S_OUT; w->nslots = full ? s_nslots(nhid) : 0; w->nslots_fold = sf_nslots(nhid); w->nslots_h16 = sh_nslots(nhid);
+      w->nbias = s_nbias(nhid); w->n_in0 = S_KS0 * 4; w->n_out = 16 * S_NT_LAST; w->n_tvals = full ? S_NPTS : 0;
+      w->nslots_p1 = p1_nslots(nhid); w->nbias_p1 = p1_nbias(nhid); w->n_p1c = p1_nconst(nhid);
       break;
+    }
     case PNRF_NET_REFINE:
-      w->prec = PREC_BF16; w->in_dim = R_IN; w->out_dim = R_OUT; w->nslots = R_NSLOTS; w->nbias = R_NBIAS; w->n_in0 = R_KS0 * 16; w->n_out = R_NT_LAST * 32;
-      w->nslots_f16 = R_NSLOTS;
+      w->prec = PREC_BF16; w->in_dim = 48 + 24 * nb; w->out_dim = R_OUT; w->nslots = refine_slots(nhid, refine_nv(nb)); w->nbias = r_nbias(nhid);
+      w->n_in0 = (3 * refine_nv(nb) + 3) * 16; w->n_out = R_NT_LAST * 32;
+      w->nslots_f16 = w->nslots;
       break;
     case PNRF_NET_NERF:
-      w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = N_OUT; w->nslots = N_NSLOTS; w->nslots_b16 = NB_NSLOTS;
-      w->nbias = N_NBIAS; w->nbias_b16 = ((1 + N_NHID) * (W_HID / 16) + 2) * 16; w->n_in0 = N_KS0 * 16; w->n_inx = N_KSX * 16; w->n_out = 32;
-      w->nslots_f16 = NB_NSLOTS;
+      w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = N_OUT; w->nslots = n_nslots(nhid); w->nslots_b16 = nb_nslots(nhid);
+      w->nbias = n_nbias(nhid); w->nbias_b16 = nb_nbias(nhid); w->n_in0 = N_KS0 * 16; w->n_inx = N_KSX * 16; w->n_out = 32;
+      w->nslots_f16 = w->nslots_b16;
       break;
     default:      // PNRF_NET_NERFCLS
       w->prec = PREC_BF16; w->in_dim = N_IN; w->in_dim_x = N_INV; w->out_dim = 4; w->nslots = C_NSLOTS; w->nslots_b16 = CB_NSLOTS;
@@ -794,6 +823,7 @@ extern "C" int pnrf_mlp_serialize(const pnrf_mlp_t* hc, void* buf, int64_t capac
   hd.nslots = h->nslots; hd.nslots_fold = h->nslots_fold; hd.nslots_h16 = h->nslots_h16; hd.nslots_b16 = h->nslots_b16;
   hd.nbias_b16 = h->nbias_b16; hd.nbias = h->nbias; hd.n_in0 = h->n_in0; hd.n_inx = h->n_inx; hd.n_out = h->n_out; hd.n_tvals = n_tvals;
   hd.nslots_p1 = h->nslots_p1; hd.nbias_p1 = h->nbias_p1; hd.n_p1c = h->n_p1c; hd.nslots_f16 = h->nslots_f16;
+  hd.nhid = (uint16_t)h->nhid; hd.nb = (uint16_t)h->nb; hd.npts = (uint16_t)h->npts;
   hd.payload_bytes = payload;
   hd.checksum = fnv1a((const uint8_t*)buf + sizeof(EngineHeader), payload);
   memcpy(buf, &hd, sizeof(hd));
@@ -813,15 +843,20 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
   PNRF_REQUIRE(hd.net == PNRF_NET_SAMPLER || hd.net == PNRF_NET_REFINE || hd.net == PNRF_NET_NERF || hd.net == PNRF_NET_NERFCLS, PNRF_E_ARG,
                "pnrf_mlp_deserialize: unknown net kind %d", hd.net);
   PNRF_REQUIRE(hd.nbias_b16 >= 0 && hd.nbias >= 0 && hd.n_in0 >= 0 && hd.n_inx >= 0 && hd.n_out >= 0 && (hd.n_tvals == 0 || hd.n_tvals == S_NPTS) &&
-                   hd.nslots > 0 && hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
+                   hd.nslots < (1u << 16) && hd.nslots_fold < (1u << 16) && hd.nslots_h16 < (1u << 16) && hd.nslots_b16 < (1u << 16) &&
                    hd.nbias < (1 << 24) && hd.nbias_b16 < (1 << 24) && hd.n_in0 < (1 << 20) && hd.n_inx < (1 << 20) && hd.n_out < (1 << 20) &&
                    hd.nslots_p1 < (1u << 16) && hd.nslots_f16 < (1u << 16) && hd.nbias_p1 >= 0 && hd.nbias_p1 < (1 << 24) && hd.n_p1c >= 0 && hd.n_p1c < (1 << 10),
                PNRF_E_ARG, "pnrf_mlp_deserialize: implausible section counts");
   {
     // section counts the kernels of this net kind index with compile-time constants: an image whose counts differ (a crafted file with a
     // matching non-cryptographic checksum, or a stale one under the same layout tag) would make them read past the buffers
+    const bool shape_ok = hd.net == PNRF_NET_NERFCLS ? (hd.nhid == 0 && hd.nb == 0 && hd.npts == 0)
+                          : (hd.nhid >= 1 && hd.nhid <= MAX_NHID && (hd.net == PNRF_NET_REFINE ? (hd.nb >= 1 && hd.nb <= MAX_NB) : hd.nb == 0) &&
+                             (hd.net == PNRF_NET_SAMPLER ? (hd.npts >= 1 && hd.npts < 4096) : hd.npts == 0));
+    PNRF_REQUIRE(shape_ok, PNRF_E_ARG, "pnrf_mlp_deserialize: shape parameters (hidden layers %u, views %u, ray points %u) outside what net kind %d supports",
+                 hd.nhid, hd.nb, hd.npts, hd.net);
     EngineHeader want;
-    expected_counts(hd.net, &want);
+    expected_counts(hd.net, hd.nhid, hd.nb, hd.npts, &want);
     PNRF_REQUIRE(hd.prec == want.prec && hd.in_dim == want.in_dim && hd.in_dim_x == want.in_dim_x && hd.out_dim == want.out_dim &&
                      hd.nslots == want.nslots && hd.nslots_fold == want.nslots_fold && hd.nslots_h16 == want.nslots_h16 &&
                      hd.nslots_b16 == want.nslots_b16 && hd.nbias_b16 == want.nbias_b16 && hd.nbias == want.nbias && hd.n_in0 == want.n_in0 &&
@@ -835,6 +870,7 @@ extern "C" int pnrf_mlp_deserialize(const void* buf, int64_t size, pnrf_mlp_t** 
   h->nslots = hd.nslots; h->nslots_fold = hd.nslots_fold; h->nslots_h16 = hd.nslots_h16; h->nslots_b16 = hd.nslots_b16;
   h->nbias_b16 = hd.nbias_b16; h->nbias = hd.nbias; h->n_in0 = hd.n_in0; h->n_inx = hd.n_inx; h->n_out = hd.n_out;
   h->nslots_p1 = hd.nslots_p1; h->nbias_p1 = hd.nbias_p1; h->n_p1c = hd.n_p1c; h->nslots_f16 = hd.nslots_f16;
+  h->nhid = hd.nhid; h->nb = hd.nb; h->npts = hd.npts;
   Section sec[ENGINE_SECTIONS];
   const int ns = sections(h, hd.n_tvals, sec);
   size_t payload = 0;

@@ -280,9 +280,11 @@ def images_pack(img_nchw):
 def refine_input(rays, or_rays, depth_sorted, img4, proj, eps=1e-5):
     rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
     img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
-    nb, Hf, Wf, _ = img4.shape
+    nb, Hf, Wf, _ = img4.shape                   # any 1 .. 8 neighbour views: refine_in is [n, 48 + 24 nb] (nb = 4: 144)
+    if proj.shape[0] != nb:
+        raise PnrfError(f'refine_input: {nb} packed images but {proj.shape[0]} projection matrices')
     n = rays.shape[0]
-    out = torch.empty(n, 144, device=rays.device, dtype=f32)
+    out = torch.empty(n, 48 + 24 * nb, device=rays.device, dtype=f32)
     check(_lib.load().pnrf_refine_input_fwd(_ptr(rays), _ptr(or_rays), _ptr(depth_sorted), _ptr(img4), _ptr(proj), nb, Hf, Wf, eps,
                                             _ptr(out), n, _stream()), 'pnrf_refine_input_fwd')
     return out
@@ -326,7 +328,7 @@ def sampler_fwd(mlp: PackedMLP, rays, want_idx=True, want_rgb=True, want_raw=Fal
 
 
 def refine_fwd(mlp: PackedMLP, refine_in, rays, depth_sorted):
-    refine_in = _chk(refine_in, 'refine_in', (144,)); rays = _chk(rays, 'rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
+    refine_in = _chk(refine_in, 'refine_in', (mlp.in_dim,)); rays = _chk(rays, 'rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
     n, dev = rays.shape[0], rays.device
     z = torch.empty(n, 8, device=dev, dtype=f32); pts = torch.empty(n, 8, 3, device=dev, dtype=f32)
     check(_lib.load().pnrf_refine_fwd(mlp.handle, _ptr(refine_in), _ptr(rays), _ptr(depth_sorted), _ptr(z), _ptr(pts), n, _stream()), 'pnrf_refine_fwd')
@@ -338,6 +340,8 @@ def refine_project_fwd(mlp: PackedMLP, rays, or_rays, depth_sorted, img4, proj, 
     rays = _chk(rays, 'rays', (11,)); or_rays = _chk(or_rays, 'or_rays', (11,)); depth_sorted = _chk(depth_sorted, 'depth_sorted', (8,))
     img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
     nb, Hf, Wf, _ = img4.shape
+    if proj.shape[0] != nb:
+        raise PnrfError(f'refine_project_fwd: {nb} packed images but {proj.shape[0]} projection matrices')
     n, dev = rays.shape[0], rays.device
     z = torch.empty(n, 8, device=dev, dtype=f32); pts = torch.empty(n, 8, 3, device=dev, dtype=f32)
     check(_lib.load().pnrf_refine_project_fwd(mlp.handle, _ptr(rays), _ptr(or_rays), _ptr(depth_sorted), _ptr(img4), _ptr(proj), nb, Hf, Wf, eps,
@@ -413,6 +417,8 @@ class RenderContext:
         img4 = _chk(img4, 'img4', (4,)); proj = _chk(proj, 'proj', (3, 4))
         n = rays.shape[0]
         nb, Hf, Wf, _ = img4.shape
+        if proj.shape[0] != nb:
+            raise PnrfError(f'render_rays: {nb} packed neighbour images but {proj.shape[0]} projection matrices')
         if out is not None:
             if not isinstance(out, torch.Tensor) or out.device != rays.device or out.dtype != f32 or tuple(out.shape) != (n, 4) or not out.is_contiguous():
                 raise PnrfError(f'render_rays: out must be a contiguous float32 tensor [{n}, 4] on {rays.device}, got '

@@ -137,8 +137,8 @@ class Renderer:
                 if w.net not in net:
                     raise ops.PnrfError(f'Renderer: packed network of kind {w.net} where one of {net} is needed')
                 return w
-            # 8 Linear layers = DoNeRFTRT; 12 = the NeRF class (pts0..7, feature, alpha, views, rgb)
-            kind = net[0] if len(net) == 1 else (ops.NET_NERFCLS if len(w['W']) == 12 else ops.NET_NERF)
+            # DoNeRFTRT (any depth) ends in its 4-wide output layer; the NeRF class (pts0..7, feature, alpha, views, rgb) in its 3-wide rgb head
+            kind = net[0] if len(net) == 1 else (ops.NET_NERFCLS if (len(w['W']) == 12 and tuple(w['W'][-1].shape)[0] == 3) else ops.NET_NERF)
             return ops.PackedMLP(kind, w['W'], w['b'])
         with torch.cuda.device(self.device):
             self.sampler = pack((ops.NET_SAMPLER,), weights['sampler'])
@@ -152,6 +152,7 @@ class Renderer:
                     if w is not None:
                         getattr(self, k).set_shape(w)
             self.ctx = ops.RenderContext(self.sampler, self.refine, self.nerf, max_rays)
+        self.num_neighbor = (self.refine.in_dim - 48) // 24           # the refine net's input is 6 x 8 Pluecker values + 3 x 8 colours per neighbour view
         self.img4 = None
         self.proj = None
         self.ref_nos = None
@@ -178,10 +179,11 @@ class Renderer:
         return cls(packed, max_rays, device)
 
     # ---- per frame (outside the timed region, like run_S_eS_eN_alter_trt.py:281-302)
-    def set_views(self, c2w, poses, images_nhwc, K, num_neighbor=NUM_NEIGHBOR):
+    def set_views(self, c2w, poses, images_nhwc, K, num_neighbor=None):
         """Pick the neighbours of the target pose, upload + interleave their images, build the
-        projection matrices.  images_nhwc: [n_views,H,W,3] numpy/torch in [0,1]."""
-        ref = select_neighbors(c2w, poses, num_neighbor)
+        projection matrices.  images_nhwc: [n_views,H,W,3] numpy/torch in [0,1].  num_neighbor: None = what the refine net was built for
+        (``self.num_neighbor``; 4 in the Fern configs) — any other value is refused by the kernels."""
+        ref = select_neighbors(c2w, poses, self.num_neighbor if num_neighbor is None else num_neighbor)
         self.ref_nos = ref
         imgs = images_nhwc[ref] if isinstance(images_nhwc, np.ndarray) else images_nhwc[torch.as_tensor(ref)]
         nchw = torch.as_tensor(imgs, dtype=torch.float32).permute(0, 3, 1, 2).contiguous().to(self.device)   # H2D (trt.py:286)

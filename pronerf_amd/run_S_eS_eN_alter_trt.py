@@ -185,13 +185,15 @@ def render_rays(ray_batch, or_ray_batch, network_fn, network_query_fn, N_samples
                 raise PnrfError(f'render_rays(use_trt=True): {type(m).__name__} has no engine file loaded (module.load_engine(path), '
                                 'written by --export_only / save_engine); with use_trt=False the parameters are packed on first use')
     num_neighbor = kwargs['num_neighbor']
-    if N_samples != 8 or num_neighbor != 4 or N_point_ray_enc not in (0, 48):
-        raise PnrfError(f'render_rays: kernels are built for N_samples=8, num_neighbor=4, N_point_ray_enc=48 '
-                        f'(got {N_samples}, {num_neighbor}, {N_point_ray_enc})')
+    n_pts = getattr(min_max_ray_net, 'input_ch', 288) // 6            # what the modules were built with (create_nerf: 6 * N_point_ray_enc, 48 + 24 * num_neighbor)
+    nb_net = (getattr(refine_net, 'input_ch', 144) - 48) // 24
+    if N_samples != 8 or num_neighbor != nb_net or N_point_ray_enc not in (0, n_pts):
+        raise PnrfError(f'render_rays: N_samples must be 8 (the kernels\' sample count) and num_neighbor / N_point_ray_enc must be the ones the refine / sampler '
+                        f'modules were built with ({nb_net} / {n_pts}); got N_samples={N_samples}, num_neighbor={num_neighbor}, N_point_ray_enc={N_point_ray_enc}')
     if ray_batch.shape[-1] != 11 or or_ray_batch.shape[-1] != 11:
         raise PnrfError('render_rays: ray batches must be [N,11] (use_viewdirs=True)')
     if kwargs.get('mm_input') is not None:
-        _check_mm_input(kwargs['mm_input'], ray_batch, 48)
+        _check_mm_input(kwargs['mm_input'], ray_batch, n_pts)
     rgbd = _render_rgbd(ray_batch, or_ray_batch, min_max_ray_net, refine_net, network_fine, kwargs['ref_rgb'], kwargs['ref_pose'], N_samples, num_neighbor,
                         out=kwargs.get('out_rgbd'))
     rgb_map, depth_map = rgbd[:, :3], rgbd[:, 3]

@@ -130,9 +130,10 @@ class _PackedNet(nn.Module):
 
 
 class MinMaxRay_Net(_PackedNet):
-    """Sampler backbone, raw outputs (helpers:1440-1471).  The kernels are built for the fern
-    configuration: D=6, W=256, no skip inside the stack, input 288 / output 27 (sampler) or
-    input 144 / output 35 (refine)."""
+    """Sampler backbone, raw outputs (helpers:1440-1471).  Shapes the kernels take (round 6: the reference's free ``--mmnetdepth``,
+    ``--N_point_ray_enc``, ``--num_neighbor``, run_S_eS_eN_alter_trt.py:62-82, 427-457): W = 256, no skip inside the stack, any depth D >= 2,
+    sampler 6 * N_point_ray_enc -> 27 (any number of ray points), refine 48 + 24 * num_neighbor -> 35 (1 .. 8 neighbour views); N_samples = 8.
+    The Fern configs are D = 6, 288 -> 27 and 144 -> 35."""
 
     def __init__(self, D=8, W=256, input_ch=3, output_ch=3, skips=[4]):
         super().__init__()
@@ -140,16 +141,17 @@ class MinMaxRay_Net(_PackedNet):
         self.fc_backbone = nn.ModuleList([nn.Linear(input_ch, W)] +
                                          [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + input_ch, W) for i in range(D - 1)])
         self.fc_output = nn.Linear(W, output_ch)
-        if (input_ch, output_ch) == (288, 27):
+        if output_ch == 27 and input_ch >= 6 and input_ch % 6 == 0:
             self._NET = ops.NET_SAMPLER
-        elif (input_ch, output_ch) == (144, 35):
+        elif output_ch == 35 and input_ch >= 72 and (input_ch - 48) % 24 == 0 and (input_ch - 48) // 24 <= 8:
             self._NET = ops.NET_REFINE
-        self._supported = (D == 6 and W == 256 and not any(0 <= s < D - 1 for s in skips) and self._NET is not None)
+        self._supported = (2 <= D <= 32 and W == 256 and not any(0 <= s < D - 1 for s in skips) and self._NET is not None)
 
     def _linears(self):
         if not self._supported:
             raise PnrfError(f'{type(self).__name__}(D={self.D}, W={self.W}, input_ch={self.input_ch}, skips={self.skips}): '
-                            'the HIP kernels are built for D=6, W=256, no skips, 288->27 or 144->35')
+                            'the HIP kernels take W=256, no skips inside the stack, 2 <= D <= 32, and 6*N_point_ray_enc -> 27 (sampler) or '
+                            '48 + 24*num_neighbor -> 35 with 1 <= num_neighbor <= 8 (refine); N_samples = 8')
         return list(self.fc_backbone) + [self.fc_output]
 
     def forward(self, x):
@@ -191,18 +193,22 @@ class DoNeRFTRT(_PackedNet):
         super().__init__()
         self.D, self.W, self.n_in, self.n_out = D, W, n_in, n_out
         pos_in = 63
-        self._supported = (D == 8 and W == 256 and skip == 'auto' and n_in == 90 and n_out == 4)
-        self.inputLocations = {0: (0, pos_in), D - 1: (pos_in, n_in)}
+        # skip='auto' (helpers:1190-1201): the view encoding enters at layer 7 D // 8 — the LAST layer for D <= 8 (the Fern configs: D = 8), a hidden
+        # ReLU layer from D = 9 on.  The kernels take the first form at any depth 3 .. 8; the module is built as the reference builds it either way.
+        view_at = D * 7 // 8
+        self._supported = (3 <= D <= 8 and view_at == D - 1 and W == 256 and skip == 'auto' and n_in == 90 and n_out == 4)
+        self.inputLocations = {0: (0, pos_in), view_at: (pos_in, n_in)}
         layers = [nn.Linear(pos_in, W)]
         for i in range(1, D):
-            layers.append(nn.Linear((n_in - pos_in) + W if i == D - 1 else W, W if i != D - 1 else n_out))
+            layers.append(nn.Linear((n_in - pos_in) + W if i == view_at else W, W if i != D - 1 else n_out))
         self.layers = nn.ModuleList(layers)
         for l in self.layers:
             nn.init.kaiming_normal_(l.weight)          # helpers:1243-1244
 
     def _linears(self):
         if not self._supported:
-            raise PnrfError("DoNeRFTRT: the HIP kernels are built for D=8, W=256, skip='auto', n_in=90, n_out=4")
+            raise PnrfError("DoNeRFTRT: the HIP kernels take W=256, skip='auto', n_in=90 (63 + 27), n_out=4 and depth 3 <= D <= 8 (from D = 9 on the "
+                            "reference's skip='auto' feeds the view encoding into a hidden layer, helpers:1190-1201)")
         return list(self.layers)
 
     def forward(self, input_pts, input_views):

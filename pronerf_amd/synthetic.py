@@ -28,9 +28,9 @@ POS_CH = 3 + 6 * MULTIRES          # 63
 DIR_CH = 3 + 6 * MULTIRES_VIEWS    # 27
 
 
-def nerf_layer_dims():
-    """(in,out) of DoNeRFTRT(D=8,W=256,skip='auto') (run_nerf_helpers.py:1190-1239)."""
-    dims = [(POS_CH, NETWIDTH)] + [(NETWIDTH, NETWIDTH)] * (NETDEPTH - 2) + [(NETWIDTH + DIR_CH, 4)]
+def nerf_layer_dims(netdepth=NETDEPTH):
+    """(in,out) of DoNeRFTRT(D=netdepth,W=256,skip='auto') (run_nerf_helpers.py:1190-1239)."""
+    dims = [(POS_CH, NETWIDTH)] + [(NETWIDTH, NETWIDTH)] * (netdepth - 2) + [(NETWIDTH + DIR_CH, 4)]
     return dims
 
 
@@ -64,8 +64,10 @@ def _mlp(rs, dims, kind):
     return Ws, bs
 
 
-def make_weights(seed: int = 0, kind: str = 'trained'):
-    """Three weight sets as lists of numpy arrays (torch layout ``W[out,in]``).
+def make_weights(seed: int = 0, kind: str = 'trained', n_pts: int = N_POINT_RAY_ENC, mmnetdepth: int = MMNETDEPTH, num_neighbor: int = NUM_NEIGHBOR,
+                 netdepth: int = NETDEPTH):
+    """Three weight sets as lists of numpy arrays (torch layout ``W[out,in]``).  n_pts / mmnetdepth / num_neighbor / netdepth: the reference's free
+    shape arguments (``--N_point_ray_enc --mmnetdepth --num_neighbor --netdepth``, run_S_eS_eN_alter_trt.py:62-82, 427-457); defaults = fern_trt.txt.
 
     kind:
       'default'  module default initialisation (sampler/refine: nn.Linear default;
@@ -83,14 +85,16 @@ def make_weights(seed: int = 0, kind: str = 'trained'):
     adversarial, kind = kind, ('trained' if kind in ('heavy', 'x4') else kind)
     rs = np.random.RandomState(1000003 * (seed + 1) + {'default': 0, 'spread': 1, 'trained': 2}[kind])
     S = N_SAMPLES
-    sW, sb = _mlp(rs, SAMPLER_DIMS, 'default' if kind != 'trained' else 'trained')
-    rW, rb = _mlp(rs, REFINE_DIMS, 'default' if kind != 'trained' else 'trained')
+    sampler_dims = [6 * n_pts] + [MMNETWIDTH] * mmnetdepth + [3 * N_SAMPLES + 3]
+    refine_dims = [6 * N_SAMPLES + 3 * num_neighbor * N_SAMPLES] + [MMNETWIDTH] * mmnetdepth + [4 * N_SAMPLES + 3]
+    sW, sb = _mlp(rs, sampler_dims, 'default' if kind != 'trained' else 'trained')
+    rW, rb = _mlp(rs, refine_dims, 'default' if kind != 'trained' else 'trained')
     if adversarial == 'heavy':
         # the sampler's hidden weights redrawn from Student's t with 3 degrees of freedom at the variance of the 'trained' draw: a few
         # weights per row 5-20 x the rest (what the column-norm constants of the two-pass sampler's error model have to cover)
         ts = np.random.RandomState(7000003 * (seed + 1))
         for i in range(len(sW) - 1):
-            fi = SAMPLER_DIMS[i]
+            fi = sampler_dims[i]
             sW[i] = (ts.standard_t(3, size=sW[i].shape) * np.sqrt(2.0 / fi / 3.0)).astype(np.float32)
     if adversarial == 'x4':
         # the sampler's hidden layers x4 each (weights and biases), its output layer / 4^6: activations up to the fp16 range (the saturated
@@ -99,7 +103,7 @@ def make_weights(seed: int = 0, kind: str = 'trained'):
             sW[i] = sW[i] * 4.0; sb[i] = sb[i] * 4.0
         sW[-1] = sW[-1] / 4.0 ** (len(sW) - 1)
     nW, nb = [], []
-    for fi, fo in nerf_layer_dims():
+    for fi, fo in nerf_layer_dims(netdepth):
         nW.append((rs.randn(fo, fi) * np.sqrt(2.0 / fi)).astype(np.float32))
         nb.append(_uniform(rs, (fo,), 1.0 / np.sqrt(fi)))
     perm = np.array([5, 2, 7, 0, 3, 6, 1, 4])

@@ -13,8 +13,18 @@ import torch
 from oracle import pronerf_oracle as orc
 from oracle import synth
 
+# infer_shape_*: the reference's render_rays with OTHER --N_point_ray_enc / --mmnetdepth / --num_neighbor / --netdepth than fern_trt.txt (round 6;
+# oracle/gen_golden.py --shapes): the oracle — parameterised, never Fern-specific — is pinned on those shapes too
+SHAPE_CASES = ['infer_shape_p32_d8_nb3_24x32', 'infer_shape_p64_d5_nb6_nd7_20x28', 'infer_shape_p8_d2_nb1_nd3_16x20', 'infer_shape_p48_d9_nb8_nd4_16x20']
 INFER_CASES = ['infer_trained_24x32', 'infer_default_24x32', 'infer_spread_20x28_img48x64',
-               'infer_trained_oob_16x24', 'infer_trained_fern_756x1008']
+               'infer_trained_oob_16x24', 'infer_trained_fern_756x1008'] + SHAPE_CASES
+
+
+def case_shape(g):
+    """(make_weights kwargs, neighbour pool size) of a golden: the Fern shape unless the fixture records another."""
+    if 'n_pts' not in g:
+        return {}, synth.NUM_NEIGHBOR
+    return dict(n_pts=int(g['n_pts']), mmnetdepth=int(g['mmnetdepth']), num_neighbor=int(g['num_neighbor']), netdepth=int(g['netdepth'])), int(g['n_views'])
 
 
 def load(golden_dir, name):
@@ -22,11 +32,12 @@ def load(golden_dir, name):
 
 
 def rebuild(g):
+    shape, n_views = case_shape(g)
     scene = synth.make_scene(int(g['seed']), H=int(g['H']), W=int(g['W']), Hf=int(g['Hf']), Wf=int(g['Wf']),
-                             rotate=bool(g['rotate']), sigma_t=float(g['sigma_t']))
-    fr = orc.frame_setup(scene)
+                             rotate=bool(g['rotate']), sigma_t=float(g['sigma_t']), n_views=n_views)
+    fr = orc.frame_setup(scene, num_neighbor=shape.get('num_neighbor', 4), n_pts=shape.get('n_pts', 48))
     sel = torch.from_numpy(g['sel'])
-    w = synth.make_weights(int(g['seed']), str(g['kind']))
+    w = synth.make_weights(int(g['seed']), str(g['kind']), **shape)
     return scene, fr, sel, w
 
 
@@ -50,7 +61,7 @@ def test_render_rays_infer_matches_reference(golden_dir, name):
     _, fr, sel, w = rebuild(g)
     # feed the reference's own rays so that this test isolates render_rays from frame setup
     rays = torch.from_numpy(g['rays']); or_rays = torch.from_numpy(g['or_rays'])
-    out = orc.render_rays_infer(w, rays, or_rays, fr['images'], torch.from_numpy(g['proj']))
+    out = orc.render_rays_infer(w, rays, or_rays, fr['images'], torch.from_numpy(g['proj']), n_pts=case_shape(g)[0].get('n_pts', 48))
     tie_free = np.diff(g['depth_sorted'], axis=1).min(axis=1) > 1e-6
     np.testing.assert_allclose(out['depth_raw'].numpy(), g['depth_raw'], rtol=0, atol=2e-6)
     np.testing.assert_array_equal(out['sort_idx'].numpy()[tie_free], g['sort_idx'][tie_free])
