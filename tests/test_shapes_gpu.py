@@ -110,15 +110,10 @@ def test_full_frame_on_off_fern_shapes_vs_eager_oracle(dev, shape):
     N = H * W
     scene = synth.make_scene(11, H=H, W=W, focal=FOCAL, rotate=True, n_views=shape['num_neighbor'] + 2)
     w = synth.make_weights(11, 'trained', **shape)
-    rend = Renderer(w, max_rays=N, device=dev)
-    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     fr = orc.frame_setup(scene, num_neighbor=shape['num_neighbor'], n_pts=shape['n_pts'])
-    np.testing.assert_array_equal(rend.ref_nos, fr['ref_nos'].numpy())
-    rays, or_rays = rend.frame_rays(scene['K'], scene['c2w'], H, W)
-    assert torch.equal(rays.cpu(), fr['rays'])
-    rgbd, idx = rend.render_rays(rays, or_rays, want_idx=True)
     wd = {k: {'W': [torch.as_tensor(x).to(dev) for x in v['W']], 'b': [torch.as_tensor(x).to(dev) for x in v['b']]} for k, v in w.items()}
     ref = {}
+    rays, or_rays = fr['rays'].to(dev), fr['or_rays'].to(dev)
     with torch.no_grad():                       # in chunks: the eager graph holds [n, 6 P] and [n * 8, 256] intermediates
         outs = [orc.render_rays_infer(wd, rays[a:a + 131072], or_rays[a:a + 131072], fr['images'].to(dev), fr['proj'].to(dev), n_pts=shape['n_pts'])
                 for a in range(0, N, 131072)]
@@ -126,20 +121,30 @@ def test_full_frame_on_off_fern_shapes_vs_eager_oracle(dev, shape):
             ref[k] = torch.cat([o[k] for o in outs])
         del outs
     free = (ref['depth_sorted'][:, 1:] - ref['depth_sorted'][:, :-1]).min(dim=1)[0] > 4e-6
-    mism = int((idx[free] != ref['sort_idx'][free]).any(1).sum())
-    ps = orc.psnr(rgbd[free, :3], ref['rgb'][free])
-    derr = float((rgbd[free, 3] - ref['depth'][free]).abs().max())
-    n2 = rend.ctx.sampler_stats()
-    print(f'\n[shapes, full frame] {shape}: {int(free.sum())} of {N} rays compared, index mismatches {mism}, rgb PSNR {ps:.1f} dB, max depth error {derr:.2e}, '
-          f'second pass {n2 / N:.1%}')
-    # depth map: the derived bars of tests/test_fullframe_gpu.py (error PSNR clears the rgb gate; 99 % of the pixels within half a grey level of the reference's
-    # 8-bit depth image, 99.9 % within one); the largest single error is reported, and bounded loosely — these deeper 'trained' stacks amplify more than Fern's
-    e = (rgbd[free, 3].double() - ref['depth'][free].double()).abs()
-    dpsnr = -10.0 * float(torch.log10((e ** 2).mean()))
-    q99, q999 = (float(torch.quantile(e[::max(1, e.numel() // 1000000)], q)) for q in (0.99, 0.999))
-    print(f'[shapes, full frame] depth: error PSNR {dpsnr:.1f} dB, 99 % <= {q99 * 255:.3f} grey levels, 99.9 % <= {q999 * 255:.3f}, max {derr * 255:.2f}')
-    assert int((~free).sum()) <= 2e-3 * N and mism == 0 and ps > 46.4 and bool(torch.isfinite(rgbd).all())
-    assert dpsnr >= 46.4 and q99 <= 0.5 / 255 and q999 <= 1.0 / 255 and derr < 6e-2
+    assert int((~free).sum()) <= 2e-3 * N
+    # Tolerances.  rgb: error PSNR >= 46.4 dB.  Depth map, 'quality' preset (fp32-grade sampler depths): the derived bars of
+    # tests/test_fullframe_gpu.py — error PSNR clears the rgb gate, 99 % of the pixels within half a grey level of the reference's 8-bit depth image,
+    # 99.9 % within one, none beyond 2.5.  'default' preset: the PSNR-equivalent gate, 99 % within one level, 99.9 % within four — the fp16-grade
+    # depths of its undecided-free rays go through deeper 'trained' stacks here than Fern's (mmnetdepth 8: 99.9 % <= 2.6 levels; Fern: <= 0.74).
+    bars = {'default': (1.0, 4.0, 6e-2 * 255), 'quality': (0.5, 1.0, 2.5)}
+    for preset in ('default', 'quality'):
+        rend = Renderer(w, max_rays=N, device=dev, preset=preset)
+        rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+        np.testing.assert_array_equal(rend.ref_nos, fr['ref_nos'].numpy())
+        r2, o2 = rend.frame_rays(scene['K'], scene['c2w'], H, W)
+        assert torch.equal(r2, rays) and torch.equal(o2, or_rays)
+        rgbd, idx = rend.render_rays(r2, o2, want_idx=True)
+        mism = int((idx[free] != ref['sort_idx'][free]).any(1).sum())
+        ps = orc.psnr(rgbd[free, :3], ref['rgb'][free])
+        e = (rgbd[free, 3].double() - ref['depth'][free].double()).abs()
+        dpsnr = -10.0 * float(torch.log10((e ** 2).mean()))
+        q99, q999 = (float(torch.quantile(e[::max(1, e.numel() // 1000000)], q)) * 255 for q in (0.99, 0.999))
+        mx = float(e.max()) * 255
+        print(f'\n[shapes, full frame] {shape} [{preset}]: {int(free.sum())} of {N} rays compared, index mismatches {mism}, rgb PSNR {ps:.1f} dB; depth error PSNR '
+              f'{dpsnr:.1f} dB, 99 % <= {q99:.3f} grey levels, 99.9 % <= {q999:.3f}, max {mx:.2f}; second pass {rend.ctx.sampler_stats() / N:.1%}')
+        assert mism == 0 and ps > 46.4 and bool(torch.isfinite(rgbd).all())
+        assert dpsnr >= 46.4 and q99 <= bars[preset][0] and q999 <= bars[preset][1] and mx <= bars[preset][2]
+        del rend
 
 
 @pytest.mark.parametrize('n_pts,mmnetdepth', [(32, 8), (64, 5), (8, 2), (1, 3), (48, 7)])
