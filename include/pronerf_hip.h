@@ -50,7 +50,19 @@ const char* pnrf_last_error(void);
  * Pack one network's nn.Linear parameters (HOST pointers, torch layout W[out][in], n_layers
  * matrices) into the device-resident, pre-tiled weight stream consumed by the MFMA kernels.
  * Replaces load_state_dict + .to(device) for the three inference nets
- * (run_S_eS_eN_alter_trt.py:427-458, 468-481).  Synchronous; not on the render path. */
+ * (run_S_eS_eN_alter_trt.py:427-458, 468-481).  Synchronous; not on the render path.
+ *
+ * Shapes (round 6).  The reference sizes its modules from --mmnetdepth, --N_point_ray_enc, --num_neighbor, --netdepth
+ * (run_S_eS_eN_alter_trt.py:62-82, 110-118, 427-457); the Fern configs are 6 / 48 / 4 / 8.  Hidden width 256 and 8 samples per ray are fixed; taken are
+ *   PNRF_NET_SAMPLER  6 P -> D x 256 (ELU) -> 27      any number of ray points P >= 1 (the fused kernels run the folded first layer, K = 6), 2 <= D <= 32
+ *   PNRF_NET_REFINE   48 + 24 nb -> D x 256 -> 35     num_neighbor nb = 1 .. 8, 2 <= D <= 32
+ *   PNRF_NET_NERF     63 -> (D - 1) x 256 (ReLU) -> [256 + 27] -> 4     DoNeRFTRT, 3 <= netdepth D <= 8 (from 9 on the reference's skip='auto' moves the
+ *                                                                        view input into a hidden layer, run_nerf_helpers.py:1190-1201)
+ *   PNRF_NET_NERFCLS  the NeRF class with D = 8, skips = [4], use_viewdirs (12 Linear layers: pts0..7, feature, alpha, views, rgb)
+ * No skip connections inside the sampler / refine stacks (mmnetskips beyond the depth, as in the Fern configs).  Everything else returns PNRF_E_SHAPE and
+ * the message lists this set.  Three things exist for the Fern values only and say so: the sampler's UNFOLDED first layer (pnrf_mlp_fwd on a sampler handle,
+ * PNRF_VARIANT_SAMPLER_F32_FULL: P = 48), PNRF_VARIANT_BF16_32X32 and pnrf_mlp_fwd on a DoNeRFTRT handle (netdepth 8), the training entry points (the
+ * trainer's shapes).  pnrf_mlp_kind reports in_dim, from which P = in_dim / 6 resp. nb = (in_dim - 48) / 24 follow. */
 int pnrf_mlp_pack(int net, const float* const* W, const float* const* b, const int* in_dim,
                   const int* out_dim, int n_layers, pnrf_mlp_t** out);
 int pnrf_mlp_free(pnrf_mlp_t* h);
@@ -166,7 +178,7 @@ int pnrf_warp_train_fwd(const float* img, const float* depth, const float* ro1, 
 /* Neighbour images [nv,3,Hf,Wf] -> texel-interleaved [nv,Hf,Wf,4] used by the fused projection
  * (replaces the x8 image replication of run_S_eS_eN_alter_trt.py:296-298). */
 int pnrf_images_pack(const float* img_nchw, float* out_nhwc4, int nv, int Hf, int Wf, void* stream);
-/* Projection + sample Pluecker: refine_in[n,144] = [pluecker(8 samples)(48), epi(96)] with
+/* Projection + sample Pluecker: refine_in[n, 48 + 24 nb] (nb = 4: [n,144]) = [pluecker(8 samples)(48), epi(24 nb)], nb = 1 .. 8, with
  * epi index (k*8+s)*3+c  (run_S_eS_eN_alter_trt.py:637-661).  rays,or_rays dev [n,11];
  * depth_sorted dev [n,8]; img4 dev [nb,Hf,Wf,4]; proj dev [nb,3,4]; eps = 1e-5 (stage 1: 1e-6). */
 int pnrf_refine_input_fwd(const float* rays, const float* or_rays, const float* depth_sorted,
@@ -233,7 +245,7 @@ int64_t pnrf_sampler_workspace_bytes(int64_t n);
 int pnrf_sampler_fwd_ws(const pnrf_mlp_t* h, const float* rays, int64_t n, float* depth_sorted, float* add_sorted,
                         float* mul_sorted, int64_t* sort_idx, float* mm_rgb, float* depth_raw, void* workspace,
                         int64_t workspace_bytes, float kappa, void* stream);
-/* Refine: MLP on refine_in[n,144] -> sigmoid/tanh -> interval refinement -> query points.  Arithmetic of a DEFAULT handle: fp16
+/* Refine: MLP on refine_in[n, 48 + 24 nb] (the handle's num_neighbor; Fern: [n,144]) -> sigmoid/tanh -> interval refinement -> query points.  Arithmetic of a DEFAULT handle: fp16
  * operands (v_mfma_f32_32x32x16_f16, 11 significand bits, MODE.FP16_OVFL saturation), fp32 accumulation; a handle set to
  * PNRF_VARIANT_BF16 runs bf16 operands (8 bits; the round-2 default).
  * Outputs dev: z[n,8], pts[n,8,3]  (run_S_eS_eN_alter_trt.py:668-681). */
@@ -246,7 +258,8 @@ int pnrf_refine_fwd(const pnrf_mlp_t* h, const float* refine_in, const float* ra
  * below the operand rounding applied next (fp16: 5e-4 relative) (tests/test_ops_gpu.py bounds z within 2e-3 of the two-kernel path).  The operator that replays
  * the reference's fp32 projection sequence exactly is pnrf_refine_input_fwd.  Here every workgroup projects the samples of its 256 rays into the four neighbour views, fetches
  * the colours and encodes the sample Pluecker values in the head of its batch, straight into the MFMA operand registers.
- * rays, or_rays dev [n,11]; depth_sorted dev [n,8]; img4 dev [4,Hf,Wf,4] (pnrf_images_pack); proj dev [4,3,4]; eps as pnrf_refine_input_fwd.
+ * rays, or_rays dev [n,11]; depth_sorted dev [n,8]; img4 dev [nb,Hf,Wf,4] (pnrf_images_pack); proj dev [nb,3,4]; eps as pnrf_refine_input_fwd;
+ * nb must be the handle's num_neighbor (1 .. 8; 4 in the Fern configs: a lane half then projects two views, ceil(nb / 2) in general).
  * This is the refine stage of pnrf_render_rays_fwd.  (run_S_eS_eN_alter_trt.py:637-681; inverse_warp.py:584-619) */
 int pnrf_refine_project_fwd(const pnrf_mlp_t* h, const float* rays, const float* or_rays, const float* depth_sorted,
                             const float* img4, const float* proj, int nb, int Hf, int Wf, float eps, float* z,
