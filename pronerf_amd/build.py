@@ -152,23 +152,67 @@ def device_code_objects(lib: str = LIB):
     return out
 
 
+_DISASM = {}
+
+
+def _disassembly(lib: str = LIB):
+    """[(llvm-objdump -d -C text, llvm-readelf --notes text)] per gfx950 code object of the library; cached per (path, mtime) — the two consumers below
+    (and the tests that call both) disassemble 30 MB of text once."""
+    import tempfile
+    key = (os.path.abspath(lib), os.path.getmtime(lib))
+    if key not in _DISASM:
+        llvm = os.path.join(os.path.dirname(_hipcc()), '..', 'lib', 'llvm', 'bin')
+        if not os.path.exists(os.path.join(llvm, 'llvm-objdump')):
+            llvm = '/opt/rocm/lib/llvm/bin'
+        out = []
+        for co in device_code_objects(lib):
+            with tempfile.NamedTemporaryFile(suffix='.co') as f:
+                f.write(co); f.flush()
+                dis = subprocess.run([os.path.join(llvm, 'llvm-objdump'), '-d', f'--mcpu={ARCH}', '-C', f.name], stdout=subprocess.PIPE, text=True, check=True).stdout
+                notes = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes', f.name], stdout=subprocess.PIPE, text=True, check=True).stdout
+            out.append((dis, notes))
+        _DISASM.clear()
+        _DISASM[key] = out
+    return _DISASM[key]
+
+
 def device_opcodes(lib: str = LIB):
     """Counter of the instruction mnemonics in every gfx950 code object of the library (llvm-objdump -d)."""
     import collections
-    import tempfile
-    objdump = os.path.join(os.path.dirname(_hipcc()), '..', 'lib', 'llvm', 'bin', 'llvm-objdump')
-    if not os.path.exists(objdump):
-        objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
     ops = collections.Counter()
-    for co in device_code_objects(lib):
-        with tempfile.NamedTemporaryFile(suffix='.co') as f:
-            f.write(co); f.flush()
-            txt = subprocess.run([objdump, '-d', f'--mcpu={ARCH}', f.name], stdout=subprocess.PIPE, text=True, check=True).stdout
+    for txt, _ in _disassembly(lib):
         for line in txt.splitlines():
             t = line.split()
             if len(t) >= 2 and line.startswith('\t') and (t[0].startswith(('v_', 's_', 'ds_', 'global_', 'buffer_', 'flat_', 'scratch_'))):
                 ops[t[0]] += 1
     return ops
+
+
+def device_kernels(lib: str = LIB):
+    """Static figures of every kernel in the library's gfx950 code objects: demangled name -> {'instr', 'mfma' (counts in the disassembly), 'vgpr',
+    'scratch' (bytes of private segment: spills), 'lds' (static bytes)} from llvm-objdump and the kernel descriptors' notes (llvm-readelf)."""
+    import collections
+    import re
+    out = {}
+    for dis, notes in _disassembly(lib):
+        cur, n, mf = None, collections.Counter(), collections.Counter()
+        for line in dis.splitlines():
+            m = re.match(r'^[0-9a-f]+ <(.+)>:', line)
+            if m:
+                cur = m.group(1)
+            elif cur and line.startswith('\t'):
+                n[cur] += 1
+                mf[cur] += 'v_mfma' in line
+        meta = {}
+        for blk in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
+            g = lambda k: (re.search(rf'\.{k}:\s+(\S+)', blk) or [None, '-1'])[1]
+            meta[g('symbol').replace('.kd', '')] = (int(g('vgpr_count')), int(g('private_segment_fixed_size')), int(g('group_segment_fixed_size')))
+        names = list(meta)
+        dem = subprocess.run(['c++filt'] + names, stdout=subprocess.PIPE, text=True).stdout.split('\n') if names else []
+        for sym, d in zip(names, dem):
+            k = d if d in n else sym
+            out[k.replace('(anonymous namespace)::', '')] = {'instr': n.get(k, 0), 'mfma': mf.get(k, 0), 'vgpr': meta[sym][0], 'scratch': meta[sym][1], 'lds': meta[sym][2]}
+    return out
 
 
 PACKED_FP32_OPCODES = ('v_pk_mul_f32', 'v_pk_add_f32', 'v_pk_fma_f32', 'v_pk_mov_b32')

@@ -114,7 +114,7 @@ def _rotmat2qvec(R):
     """COLMAP quaternion (w, x, y, z) of a rotation matrix (inverse of colmap_utils.qvec2rotmat)."""
     K = np.array([[R[0, 0] - R[1, 1] - R[2, 2], 0, 0, 0], [R[1, 0] + R[0, 1], R[1, 1] - R[0, 0] - R[2, 2], 0, 0],
                   [R[2, 0] + R[0, 2], R[2, 1] + R[1, 2], R[2, 2] - R[0, 0] - R[1, 1], 0],
-                  [R[1, 2] - R[2, 1], R[2, 0] - R[0, 2], R[0, 1] - R[1, 0], R[0, 0] + R[1, 1] + R[2, 2]]]) / 3.0
+                  [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1], R[0, 0] + R[1, 1] + R[2, 2]]]) / 3.0
     w, v = np.linalg.eigh(K)
     q = v[[3, 0, 1, 2], np.argmax(w)]
     return -q if q[0] < 0 else q

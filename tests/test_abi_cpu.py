@@ -44,6 +44,30 @@ def test_no_packed_fp32_instruction_in_any_kernel(lib):
     assert not found, f'packed fp32 instructions in the library: {found}'
 
 
+def test_frame_path_kernels_do_not_spill_and_the_fern_instances_kept_their_size(lib):
+    """Round 6 made the layer counts run-time arguments and templated the refine kernel on its views per lane half (the reference's free shape arguments).
+    Guard of what that must not cost: no kernel of the inference frame path — any shape — uses scratch memory (a spill in a fused-MLP loop is a 10 % kernel),
+    none exceeds the 256-register window two waves per SIMD leave, and the Fern instances still hold exactly the MFMAs of their layer bodies (a third
+    layer body appeared in the dominant kernel while this was written: 594 -> 850 MFMAs, 229 -> 250 VGPRs)."""
+    from pronerf_amd import build
+    k = build.device_kernels()
+    assert len(k) > 80
+    frame = {n: v for n, v in k.items() if n.startswith(('void sampler_p1_kernel', 'void sampler_h16_kernel', 'void sampler_kernel<2>', 'void nerf16_kernel'))
+             or ('refine_kernel<1, ' in n and ', 1, 1, PrecF16' in n)}
+    assert len(frame) >= 4 + 8 + 5, sorted(frame)
+    for n, v in frame.items():
+        assert v['scratch'] == 0, (n, v)
+        assert v['vgpr'] <= (512 if 'nerf16_kernel' in n and ', 4, PrecBf16, 4>' in n else 256), (n, v)      # (the 4 x 64-column NeRF shape owns a SIMD per wave)
+    fern = {'void sampler_p1_kernel<8>(SamplerArgs)': 424, 'void sampler_h16_kernel<8>(SamplerArgs)': 1248, 'void refine_kernel<1, 8, 1, 1, PrecF16, 2>(RefineArgs)': 472,
+            'void nerf16_kernel<false, 2, PrecBf16, 8>(NerfArgs)': 594, 'void nerf16_kernel<true, 2, PrecBf16, 8>(NerfArgs)': 1578}
+    for n, mfma in fern.items():
+        assert n in k, (n, [x for x in k if x.split('<')[0] == n.split('<')[0]])
+        assert k[n]['mfma'] == mfma, (n, k[n])
+    # every instance of the projecting refine stage: 8 tiles x (3 NV + 3) k-steps of layer 0 + three hidden-layer bodies + the output tile
+    for nv in (1, 2, 3, 4):
+        assert k[f'void refine_kernel<1, 8, 1, 1, PrecF16, {nv}>(RefineArgs)']['mfma'] == 8 * (3 * nv + 3) + 3 * 128 + 16
+
+
 def test_linspace_matches_torch(lib):
     from pronerf_amd import ops
     for n in (1, 2, 7, 48, 64, 255):
