@@ -19,6 +19,9 @@
 #ifndef PNRF_LAST_TMAX
 #define PNRF_LAST_TMAX 1          // output layers of the NeRF nets: 4 (3) rows, all in the first 16-row tile of the pair
 #endif
+#ifndef PNRF_OLD_PRIO
+#define PNRF_OLD_PRIO 0
+#endif
 #ifndef PNRF_YOUNG_PRIO
 #define PNRF_YOUNG_PRIO 1
 #endif
@@ -60,10 +63,31 @@ __device__ __forceinline__ float sum8_dpp(float v) {
 // arbitration to its older partner, finishes each tile late and makes the older half wait at the slot barrier
 // (tools/diag_stamps.py: 109 vs 600 cycles of barrier wait per tile).  One static s_setprio for that half
 // evens the pair out (cdna guide T5, static form).  The condition must be provably wave-uniform.
+// A WIDE fused workgroup (8 waves, two per SIMD) claims the SIMDs' whole register file: 256 VGPRs per wave whatever the kernel uses.
+// Round 6 (NOTEBOOK §22): with 240 + 240 registers allocated a 32-register wave of ANOTHER kernel fits beside the pair — and in that configuration (the
+// register file exactly full) the refine stage's slower wave half returned wrong rows, a few calls in 10^4, in code whose two-wave-per-SIMD form is clean
+// alone, clean at 232 + 232 (+ 32) registers and clean at 256 + 256: the third case of this family on this chip (round 4's paired workgroups, round 5's
+// packed fp32).  Nothing can be co-resident on a SIMD whose two waves own all 512 registers: the configuration is excluded by construction, at no cost
+// (the occupancy of these kernels is two waves per SIMD either way).  -DPNRF_WIDE_VGPRS=0 builds without the reservation (tools/wide_repro.py).
+#ifndef PNRF_WIDE_VGPRS
+#define PNRF_WIDE_VGPRS 256
+#endif
+template <int NW>
+__device__ __forceinline__ void own_the_simd() {
+#if PNRF_WIDE_VGPRS == 256
+  if constexpr (NW == 8) asm volatile("; a wide fused workgroup owns its SIMDs' register file" ::: "v255");
+#elif PNRF_WIDE_VGPRS == 248
+  if constexpr (NW == 8) asm volatile("; reserve 248" ::: "v247");
+#endif
+}
+
 template <int NW>
 __device__ __forceinline__ void young_half_priority() {
   if (NW == 8 && PNRF_YOUNG_PRIO) {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(PNRF_YOUNG_PRIO);
+#if PNRF_OLD_PRIO
+    else __builtin_amdgcn_s_setprio(PNRF_OLD_PRIO);
+#endif
   }
 }
 
@@ -122,6 +146,12 @@ __device__ __forceinline__ void moment(float ox, float oy, float oz, float dx, f
 }
 
 // ------------------------------------------------------------------------------------------ sampler
+// Diagnostic switch (tools/wide_repro.py): -DPNRF_FIXED_NHID compiles the Fern layer counts in instead of reading them from the launch arguments
+#ifdef PNRF_FIXED_NHID
+#define PNRF_NHID(runtime, fern) (fern)
+#else
+#define PNRF_NHID(runtime, fern) (runtime)
+#endif
 struct SamplerArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
   int nhid;                                        // hidden 256 -> 256 layers behind layer 0 (mmnetdepth - 1; the Fern configs: 5)
@@ -191,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
+  own_the_simd<NW>();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * q;
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void sampler_kernel(SamplerArgs a) {
     layer_f32<KS4_0, NT16_HID, 0>(
         st, ringlane, biaslane, [&](int kk) { return B0[kk]; }, [&](int to, int r, float v) { X[to][r] = act_f32(v, ACT_ELU); }, [](int) {}, pend);
     // ping-pong X -> Y -> X ...: pairs of layers, then the odd one; the output layer reads Y (an even count ends in X: moved over)
-    const int nhid = a.nhid;
+    const int nhid = PNRF_NHID(a.nhid, S_NHID);
     for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(X, Y, l);
       hidden(Y, X, l + 1);
@@ -361,6 +392,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = i < (1 + a.nhid) * W_HID ? a.bias[i] * LOG2E : a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+  own_the_simd<NW>();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * q;
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_h16_kernel(SamplerArgs a) 
     layer_h16x2<1, SH_NTP_H, 0>(
         st, ringlane, biaslane, [&](int, int pl) { return pl == 0 ? P0h : P0l; },
         [&](int tp, int pcx, f32x4(&mn)[2], f32x4(&cr)[2]) { store_piece(Xh, Xl, tp, pcx, mn, cr); }, [](int) {}, pm, pc);
-    const int nhid = a.nhid;
+    const int nhid = PNRF_NHID(a.nhid, S_NHID);
     for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(Xh, Xl, Yh, Yl, l);
       hidden(Yh, Yl, Xh, Xl, l + 1);
@@ -575,6 +607,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
   for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  own_the_simd<NW>();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
@@ -645,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sampler_p1_kernel(SamplerArgs a) {
       V = a.p1c[1 + l] * fmaf(C2, sq_in, V);
       sq_in = 0.f;
     };
-    const int nhid = a.nhid;
+    const int nhid = PNRF_NHID(a.nhid, S_NHID);
     for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(Bn, Bo, l, sq_a, sq_b);
       hidden(Bo, Bn, l + 1, sq_b, sq_a);
@@ -859,6 +892,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
   constexpr int COLS = 32 * NCB;
+  own_the_simd<NW>();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
@@ -1022,7 +1056,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
 #ifdef PNRF_DEBUG_EHEAD
     dbg_cks(0, dbg_xor<(KS0 < KS_HID ? KS0 : KS_HID)>(Bo[0]));                 // the packed inputs
 #endif
-    const int nhid = a.nhid;              // pairs of layers, then the odd one; the output layer reads Bo (an even count ends in Bn: moved over)
+    const int nhid = PNRF_NHID(a.nhid, R_NHID);              // pairs of layers, then the odd one; the output layer reads Bo (an even count ends in Bn: moved over)
     for (int l = 0; l + 1 < nhid; l += 2) {
       hidden(Bn, Bo, l);
       hidden(Bo, Bn, l + 1);
@@ -1213,6 +1247,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void nerf_kernel(NerfArg
   WStream<NW> st;
   st.init(a.blob, a.nslots, smem);
   st.prologue();
+  own_the_simd<NW>();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + h * 16;
@@ -1529,6 +1564,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfA
   }
   const float pe_vs = (float)(1 << g);
   const int64_t nrows = a.n * a.S;
+  own_the_simd<NW>();
   young_half_priority<NW>();
   const char* ringlane = smem + lane * 16;
   const float* biaslane = bias_lds + 4 * g;
@@ -1599,7 +1635,7 @@ __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfA
           for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
       layer_b16<NB_KS0, NB_NTP_H, 0, NCB, v8>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
-      const int nhid = a.nhid;            // pairs of layers end in Bn; the last layer of an odd count ends in Bo: moved over for the output layer
+      const int nhid = PNRF_NHID(a.nhid, N_NHID);            // pairs of layers end in Bn; the last layer of an odd count ends in Bo: moved over for the output layer
       for (int l = 0; l < nhid; l += 2) { // (two layer bodies whatever the count: the odd tail is a branch inside the pair, not a third body)
         hidden(Bn, Bo, l);
         if (l + 1 < nhid) hidden(Bo, Bn, l + 1);

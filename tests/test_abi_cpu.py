@@ -58,6 +58,14 @@ def test_frame_path_kernels_do_not_spill_and_the_fern_instances_kept_their_size(
     for n, v in frame.items():
         assert v['scratch'] == 0, (n, v)
         assert v['vgpr'] <= (512 if 'nerf16_kernel' in n and ', 4, PrecBf16, 4>' in n else 256), (n, v)      # (the 4 x 64-column NeRF shape owns a SIMD per wave)
+    # A WIDE fused workgroup (8 waves, two per SIMD) owns its SIMDs' register file: 256 VGPRs per wave in the kernel descriptor whatever the code uses
+    # (own_the_simd, pnrf_mlp_kernels.hip).  With 240 + 240 allocated a small wave of another stream's kernel fits beside the pair, and in exactly that
+    # configuration the refine stage returned wrong rows a few times in 10^4 calls (NOTEBOOK 22, tools/wide_repro.py); at 256 + 256 nothing can share the SIMD.
+    wide = {n: v for n, v in k.items() if (n.startswith(('void sampler_p1_kernel<8>', 'void sampler_h16_kernel<8>', 'void sampler_kernel<')) or
+                                           ('refine_kernel<1, 8,' in n) or ('nerf16_kernel<' in n and n.endswith(', 8>(NerfArgs)')) or ('nerf_kernel<1, 8,' in n))}
+    assert len(wide) >= 25, sorted(wide)          # 1 + 1 + 3 sampler, 18 refine, 4 nerf16, 2 nerf (32x32x16) instances
+    for n, v in wide.items():
+        assert v['vgpr'] == 256, (n, v)
     fern = {'void sampler_p1_kernel<8>(SamplerArgs)': 424, 'void sampler_h16_kernel<8>(SamplerArgs)': 1248, 'void refine_kernel<1, 8, 1, 1, PrecF16, 2>(RefineArgs)': 472,
             'void nerf16_kernel<false, 2, PrecBf16, 8>(NerfArgs)': 594, 'void nerf16_kernel<true, 2, PrecBf16, 8>(NerfArgs)': 1578}
     for n, mfma in fern.items():

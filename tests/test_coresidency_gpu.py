@@ -6,7 +6,12 @@ still become resident beside a fused workgroup is a kernel of another stream —
 bf16 GEMM.  This test runs that configuration on the one-GPU box: narrow 1024-ray calls beside gather / LDS-DMA / small foreign kernels and beside a bf16
 16x16x32 MFMA loop with 240 registers per wave (tools/foreign_kernels.hip), wide calls beside the two kinds that fit beside 2 x 240 registers, the chunked
 frame on four streams, and whole frames through a one-rank RCCL FrameGather with a permutation index.  The long run (10^5 calls per narrow phase) is
-profiles/r05_coresidency_stress.json; here ~6000 calls keep the suite short."""
+profiles/r05_coresidency_stress.json; here ~6000 calls keep the suite short.
+
+Round 6 (NOTEBOOK 22): the WIDE refine stage did return wrong rows beside the 1-wave small kernel — 2e-4 of the 8192-ray calls, always the slower half of a
+workgroup's waves — while its two waves per SIMD left 32 registers for a third.  Wide fused kernels now allocate the whole register file (256 per wave,
+checked statically by tests/test_abi_cpu.py): the phases `wide_8192_beside_small` / `narrow_1024_beside_small` run beside three streams of that kernel;
+profiles/r06_wide_repro.txt holds the long runs (0 of 450 000 wide calls with the reservation; 106 of 200 000 without)."""
 import json
 import os
 import socket
@@ -33,7 +38,7 @@ def test_no_row_changes_beside_foreign_kernels_and_the_rccl_gather():
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert lines, (r.returncode, r.stdout[-1000:], r.stderr[-3000:])
     j = json.loads(lines[-1])
-    for phase in ('narrow_1024', 'narrow_1024_beside_mfma', 'wide_8192', 'chunked_4_streams', 'frame_gather_rccl_ws1'):
+    for phase in ('narrow_1024', 'narrow_1024_beside_mfma', 'narrow_1024_beside_small', 'wide_8192', 'wide_8192_beside_small', 'chunked_4_streams', 'frame_gather_rccl_ws1'):
         assert j[phase]['rows_differ'] == 0 and j[phase]['rows_compared'] > 0, (phase, j[phase])
     assert j['narrow_1024']['calls'] == calls and j['frame_gather_rccl_ws1']['backend'] == 'nccl'
     assert r.returncode == 0 and j['total_rows_differ'] == 0

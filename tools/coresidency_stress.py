@@ -10,7 +10,9 @@ and compares EVERY output row of EVERY call with the rows of an undisturbed one-
   narrow   1024-ray calls (4-wave workgroups: 240 VGPRs, 84 KiB LDS) beside tools/foreign_kernels.hip kind 1 (random 16-byte gathers, 4 waves,
            48 VGPRs, 16 KiB LDS), kind 2 (LDS-DMA ring of 64 KiB, the weight stream's instruction) and kind 0 (1 wave, 16 VGPRs) on three streams;
            and again beside kind 3 (v_mfma_f32_16x16x32_bf16 loop, 240 VGPRs per wave: another stream's bf16 GEMM) on all three
-  wide     8192-ray calls with the 8-wave shape forced (2 x 240 VGPRs per SIMD lane, ~72 KiB LDS) beside kinds 0 and 2 (<= 32 VGPRs: they fit)
+  wide     8192-ray calls with the 8-wave shape forced beside kinds 0 and 2, and beside kind 0 on all three streams.  Until round 6 these kernels allocated
+           2 x 240 VGPRs per SIMD lane and a 16-register wave of kind 0 fitted beside them: in THAT configuration the refine stage's slower wave half returned
+           wrong rows 2e-4 of the calls (tools/wide_repro.py).  Wide fused kernels now allocate 256 registers per wave: nothing shares their SIMDs
   chunked  the frame as 745 calls on four streams (ChunkedRenderer) beside the three foreign streams
   gather   whole frames through FrameGather with the collective forced on in a one-rank RCCL group and a permutation as gather index:
            all_gather_into_tensor on RCCL's stream + index_select on the side stream beside the next frame's kernels (what bench.py times at N > 1)
@@ -153,10 +155,15 @@ def main(argv=None):
     # ---- narrow beside a bf16 MFMA kernel with 240 registers per wave (a GEMM of another stream): the aggressor of tools/pkf32_coexec_probe.hip — with packed
     # fp32 in the library this phase is where the SHIPPED narrow shape returns wrong rows (profiles/r05_coresidency_stress_packed_fp32.json); without, none
     phase_calls('narrow_1024_beside_mfma', rend, 1024, a.calls, (3, 3, 3))
-    # ---- wide (forced) beside small / dma
+    # ---- narrow beside three streams of the 1-wave small kernel (round 6: the kind beside which the WIDE refine stage failed; up to 17 of its waves fit a SIMD here)
+    phase_calls('narrow_1024_beside_small', rend, 1024, a.calls // 2, (0, 0, 0))
+    # ---- wide (forced) beside small / dma, and beside three streams of the small kernel.  Round 6: with 240 + 240 registers per SIMD a 16-register wave of the
+    # small kernel fitted beside a wide pair and the refine stage returned wrong rows for its slower wave half 2e-4 of the calls (tools/wide_repro.py, NOTEBOOK 22);
+    # wide fused kernels now allocate 256 registers per wave (own_the_simd): nothing shares a SIMD with them and these phases are clean
     rw = Renderer(weights, max_rays=8192, device=dev, shape='wide')
     rw.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
     phase_calls('wide_8192', rw, 8192, max(200, a.calls // 8), (0, 2, 0))
+    phase_calls('wide_8192_beside_small', rw, 8192, max(400, a.calls // 4), (0, 0, 0))
     del rw
     # ---- the frame as 745 calls on four streams beside the foreign streams
     ch = ChunkedRenderer(rend, 1024, 4)
