@@ -78,6 +78,8 @@ __device__ __forceinline__ void own_the_simd() {
   if constexpr (NW == 8) asm volatile("; a wide fused workgroup owns its SIMDs' register file" ::: "v255");
 #elif PNRF_WIDE_VGPRS == 248
   if constexpr (NW == 8) asm volatile("; reserve 248" ::: "v247");
+#elif PNRF_WIDE_VGPRS == 240
+  if constexpr (NW == 8) asm volatile("; reserve 240" ::: "v239");
 #endif
 }
 
