@@ -34,7 +34,10 @@ _COMMON = [
 _VARIANT = {
     # inference (run_S_eS_eN_alter_trt.py): TensorRT / ONNX switches are parsed for config compatibility only
     'trt': [('basedir', str, './logs_trt/'), ('use_trt', 'flag', False), ('export_only', 'flag', False), ('nerf_engine_path', str, None),
-            ('mm_engine_path', str, None), ('refine_engine_path', str, None), ('max_images', int, None)],
+            ('mm_engine_path', str, None), ('refine_engine_path', str, None), ('max_images', int, None),
+            # not in the reference: the renderer's operating point (pronerf_amd.render.PRESETS) — 'default', 'quality' (exact sampler + fp16 NeRF
+            # operands) or 'auto' (decided from the first rendered frame: the exact single-pass sampler when the two-pass form would re-render most rays)
+            ('pnrf_preset', str, 'default')],
     # stage 2 (run_S_eS_eN_alter_base_refine2.py)
     'refine2': [('basedir', str, './logs_epi_RR/'), ('pretrain_path', str, None), ('test_frames', 'ints', [3, 11]), ('max_steps', int, None)],
     # stage 1 (run_S_eS_eN_alter_base.py)

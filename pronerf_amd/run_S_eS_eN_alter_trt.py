@@ -210,6 +210,28 @@ def _render_rgbd(ray_batch, or_ray_batch, min_max_ray_net, refine_net, network_f
     return rgbd
 
 
+def apply_preset(preset, min_max_ray_net, refine_net, network_fine, probe=None):
+    """The renderer's operating point on the modules' packed handles (pronerf_amd.render.PRESETS; ``--pnrf_preset`` of the inference driver).
+    'quality': every ray through the split-fp16 sampler (exact indices) + fp16 NeRF operands.  'auto': ``probe`` = (ray_batch, or_ray_batch, ref_rgb,
+    ref_pose, n_samples, num_neighbor) is rendered once and the sampler switches to its exact single pass when the two-pass form re-rendered more
+    than 55 % of the rays (Renderer.calibrate: a sampler that has learned surfaces) — once per checkpoint, deterministic.  Returns what is in force."""
+    from .render import PRESETS
+    if preset not in ('default', 'quality', 'auto'):
+        raise PnrfError(f"pnrf_preset must be 'default', 'quality' or 'auto', got {preset!r}")
+    if preset == 'quality':
+        for net, variant in PRESETS['quality'].items():
+            {'sampler': min_max_ray_net, 'refine': refine_net, 'nerf': network_fine}[net].packed().set_variant(variant)
+        return 'quality'
+    if preset == 'auto' and probe is not None and min_max_ray_net.packed().variant == 'default':
+        rays, or_rays, ref_rgb, ref_pose, S, NB = probe
+        _render_rgbd(rays, or_rays, min_max_ray_net, refine_net, network_fine, ref_rgb, ref_pose, S, NB)
+        frac = _renderer(min_max_ray_net, refine_net, network_fine, rays.shape[0], rays.device).ctx.sampler_stats() / max(1, rays.shape[0])
+        if frac > 0.55:
+            min_max_ray_net.packed().set_variant('sampler_split')
+        return f"auto: second pass {frac:.1%} -> sampler {min_max_ray_net.packed().variant}"
+    return 'default'
+
+
 def render(rays, or_rays, sh, **kwargs):
     """Render and reshape to the image (run_S_eS_eN_alter_trt.py:211-221)."""
     all_ret = render_rays(rays, or_rays, **kwargs)
@@ -386,6 +408,11 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         sh = (H, W, 3)
         frame_ms = []
         b = 0
+        if i == 0 and render_kwargs.get('pnrf_preset', 'default') != 'default' and count > 0:      # the operating point, before anything is timed
+            render_kwargs['pnrf_preset_in_force'] = apply_preset(render_kwargs['pnrf_preset'], fwd['min_max_ray_net'], fwd['refine_net'], fwd['network_fine'],
+                                                                 probe=(rays, or_rays, ref_rgb, ref_pose, S, NB))
+            if verbose:
+                print('pnrf_preset:', render_kwargs['pnrf_preset_in_force'])
         for _ in range(n_timing_reps):                                                                                     # :327-332
             t1.record()
             if fg is not None:
@@ -488,6 +515,7 @@ def train(argv=None, device='cuda'):
         kw['engine_paths'] = engines
         kw['use_trt'] = True
     kw.update({'near': near, 'far': far, 'images': images[i_ref], 'poses': poses[i_ref], 'ref_K': K})   # :773-787
+    kw['pnrf_preset'] = getattr(args, 'pnrf_preset', 'default')
     if args.max_images is not None:
         i_test = i_test[:args.max_images]
     if args.render_test:

@@ -266,6 +266,43 @@ def _read_png(path):
     return np.asarray(Image.open(path).convert('RGB'))
 
 
+def test_frame_driver_on_the_scene_with_its_trained_checkpoint(dev, tmp_path):
+    """The reference's own acceptance, end to end through the drop-in driver (run_S_eS_eN_alter_trt.py:699-800, 351-353): the LLFF directory of the
+    geometrically consistent scene (tests/llff_synth.py Scene3D), a .tar checkpoint with the reference's keys holding the nets trained on it (the NeRF-class
+    fine net, as the released trainers save it), ``--render_test`` -> PSNR of the hold-out views against their ground-truth pictures, PNGs.
+    ``--pnrf_preset auto`` decides the sampler form from the first frame (a sampler that has learned surfaces: second pass 69 % -> the exact single pass);
+    'default' and 'quality' render the same views within 0.05 dB of each other."""
+    import llff_synth
+    from pronerf_amd import run_S_eS_eN_alter_trt as trt
+    root = llff_synth.make_dataset(str(tmp_path / 'scene'), seed=2, n=20, H=189, W=252, factor=4, consistent=True, n_points=3000)
+    w = synth.load_trained_fixture('scene3d')
+    stack = lambda d: {**{f'fc_backbone.{i}.{k}': torch.from_numpy(np.asarray(v[i])) for i in range(len(d['W']) - 1) for k, v in (('weight', d['W']), ('bias', d['b']))},
+                       'fc_output.weight': torch.from_numpy(np.asarray(d['W'][-1])), 'fc_output.bias': torch.from_numpy(np.asarray(d['b'][-1]))}
+    ck = str(tmp_path / '040000.tar')
+    torch.save({'global_step': 40000, 'mmr_network_fn_state_dict': stack(w['sampler']), 'refine_net_state_dict': stack(w['refine']),
+                'network_fine_state_dict': synth.nerfcls_state_dict(w['nerfcls'])}, ck)
+    body = (f'basedir = {tmp_path}/logs\ndatadir = {root}\nft_path = {ck}\nfactor = 4\nllffhold = 8\nN_samples = 8\nN_point_ray_enc = 48\n'
+            'mmnetdepth = 6\nmmnetskips = [10000]\nnum_neighbor = 4\nuse_viewdirs = True\n')
+    psnr = {}
+    for preset in ('auto', 'default', 'quality'):
+        cfg = tmp_path / f'{preset}.txt'
+        cfg.write_text(f'expname = {preset}\n' + body)
+        kw = trt.train(['--config', str(cfg), '--render_test', '--pnrf_preset', preset], device=dev)
+        psnr[preset] = kw['psnrs']
+        assert len(kw['psnrs']) == 3 and min(kw['psnrs']) > 33.0, (preset, kw['psnrs'])          # hold-out views 0, 8, 16: 37.3 / 36.4 / 33.8 dB
+        if preset == 'auto':
+            assert 'sampler_split' in kw['pnrf_preset_in_force'], kw['pnrf_preset_in_force']
+            assert sorted(os.listdir(tmp_path / 'logs' / 'auto' / 'renderonly_test_040000'))[:2] == ['000.png', '001.png']
+        elif preset == 'quality':
+            assert kw['pnrf_preset_in_force'] == 'quality'
+    print('\n[frame driver on the scene] hold-out PSNR vs ground truth:', {k: [round(x, 3) for x in v] for k, v in psnr.items()})
+    for a in ('auto', 'quality'):
+        assert max(abs(x - y) for x, y in zip(psnr[a], psnr['default'])) <= 0.05
+    from pronerf_amd.ops import PnrfError
+    with pytest.raises(PnrfError):
+        trt.apply_preset('fast', kw['min_max_ray_net'], kw['refine_net'], kw['network_fine'])
+
+
 def test_frame_driver_under_torchrun_shards_every_frame(dev, tmp_path):
     """Two processes (one GPU here, gloo; one per GPU over RCCL in production) run the inference script: every frame's rays are split
     over the ranks and gathered; rank 0 writes the same PNG bytes as the single-process run."""
