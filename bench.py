@@ -836,6 +836,7 @@ def main():
                         ('sampler_split', {'sampler': 'sampler_split'}, 'split-fp16 sampler kernel for every ray (PNRF_VARIANT_SAMPLER_SPLIT, the round-2 sampler)'),
                         ('nerf_f16', {'nerf': 'f16'}, 'NeRF MLP on fp16 operands too (PNRF_VARIANT_F16; raw output within the authors\' FP16-engine tolerance)'),
                         ('refine_bf16', {'refine': 'bf16'}, 'refine MLP on bf16 operands too (PNRF_VARIANT_BF16: every MLP behind the sampler in bf16)'),
+                        ('refine_16x16', {'refine': 'refine_16x16'}, 'refine stage on v_mfma_f32_16x16x32_f16, four lanes per ray, folded Pluecker inputs (PNRF_VARIANT_REFINE_16X16)'),
                         ('round2', {'sampler': 'sampler_split', 'refine': 'bf16'}, 'split sampler + bf16 refine: the kernels of the round-2 default')):
                     r2 = Renderer(weights, max_rays=count, device=dev, variants=vset)
                     r2.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])

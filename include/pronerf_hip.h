@@ -93,7 +93,9 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
  *   BF16              refine handles: bf16 operands (8 significand bits; the round-2 default); NeRF handles: same as DEFAULT;
  *   F16               NeRF handles: fp16 operands (11 significand bits, like the FP16 TensorRT engines of the reference's own fast path,
  *                     trt_infer_v2.py: raw output within the authors' 1e-3 tolerance) — same MFMA count, 5 % slower under the power limit;
- *   BF16_32X32        NeRF handles: the v_mfma_f32_32x32x16_bf16 engine (the refine net has one engine);
+ *   BF16_32X32        NeRF handles: the v_mfma_f32_32x32x16_bf16 engine;
+ *   REFINE_16X16      refine handles: the fused inference stage (pnrf_refine_fwd, pnrf_refine_project_fwd, pnrf_render_rays_fwd) on
+ *                     v_mfma_f32_16x16x32_f16 — the NeRF stage's engine shape, four lanes per ray instead of two; same fp16 operands;
  *   NERF_4X64         NeRF handles: bf16, 4 waves of 64 columns per workgroup (one wave per SIMD) instead of 8 waves of 32 — same arithmetic,
  *                     same packed stream, every weight fragment read from LDS feeds four MFMAs instead of two.
  * A variant is part of a handle's configuration, like its weights: set it right after pack / deserialize, before the handle is given to
@@ -107,6 +109,7 @@ int pnrf_mlp_kind(const pnrf_mlp_t* h, int* net, int* in_dim, int* in_dim_x, int
 #define PNRF_VARIANT_SAMPLER_SPLIT 5
 #define PNRF_VARIANT_BF16 6
 #define PNRF_VARIANT_F16 7
+#define PNRF_VARIANT_REFINE_16X16 8
 int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant);
 /* Workgroup shape of the fused stages (sampler passes, projection + refine, NeRF) launched from this handle — how a launch's columns (rays or
  * ray samples) are cut into batches and spread over the 256 CUs.  The reference renders any ray count through the same modules

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libpronerf_hip.so')
 
 NET_SAMPLER, NET_REFINE, NET_NERF, NET_NERFCLS = 0, 1, 2, 3
 # kernel variants of a packed handle (pnrf_mlp_set_variant)
-VARIANTS = {'default': 0, 'sampler_f32': 1, 'sampler_f32_full': 2, 'bf16_32x32': 3, 'nerf_4x64': 4, 'sampler_split': 5, 'bf16': 6, 'f16': 7}
+VARIANTS = {'default': 0, 'sampler_f32': 1, 'sampler_f32_full': 2, 'bf16_32x32': 3, 'nerf_4x64': 4, 'sampler_split': 5, 'bf16': 6, 'f16': 7, 'refine_16x16': 8}
 ABI_VERSION = 1
 
 

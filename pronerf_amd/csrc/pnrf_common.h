@@ -49,11 +49,11 @@ struct pnrf_mlp {
   int out_dim;
   void* d_blob;          // weight stream: nslots x 16 KiB
   uint32_t nslots;
-  void* d_blob_fold;     // sampler only: stream with the folded 6->256 first layer (fused path)
+  void* d_blob_fold;     // sampler: stream with the folded 6->256 first layer (fused path); refine: 16x16x32 stream with the folded Pluecker inputs (projecting head)
   uint32_t nslots_fold;
   void* d_blob_h16;      // sampler only: folded stream in split fp16 (hi / lo*2^11 planes) for layer_h16x2
   uint32_t nslots_h16;
-  void* d_blob_b16;      // DoNeRFTRT only: bf16 stream for the 16x16x32 engine (layer_b16)
+  void* d_blob_b16;      // DoNeRFTRT / NeRF class: bf16 stream for the 16x16x32 engine (layer_b16); refine: fp16 stream of layer_e16 (rows from memory)
   uint32_t nslots_b16;
   float* d_bias_b16;     // ... and its biases, [tile of 16 rows][16]
   int nbias_b16;

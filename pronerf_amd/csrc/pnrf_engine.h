@@ -560,6 +560,75 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
     for (int cb = 0; cb < NCB; ++cb) last[t][cb] = pend[t][cb];
 }
 
+// ------------------------------------------------------------------------------------------
+// ELU layer on v_mfma_f32_16x16x32_f16 ("e16", round 6): layer_b16's geometry — two 16-column blocks per wave, 16-row output tiles in pairs, 32-deep
+// k-steps, fragments (tp, ks, tile-in-pair) — with the deferred epilogue of the ELU nets: ONE activation per piece (v_exp, v_fma, v_med3, every second
+// time the conversion of the pair), one piece behind every fragment's two MFMAs, so that each 32-cycle gap on the pipe carries the same four VALU
+// instructions (layer_bf16 with PIECES = 16 is the same idea on 32-cycle MFMAs).
+//   Bf(cb, ks) -> B operand; epi1(tp, p, pend) / pre1(p): piece p = 0..15 = register p & 3 of column block (p >> 2) & 1 of tile p >> 3 of the deferred pair.
+//   Gap q = 2 ks + t of a pair.  Pairs tp > 0: piece p behind gap p G / 16 (G = 2 KS gaps).  First pair of a layer: the pieces finish the previous layer's
+//   last pair = this layer's k-step KS - 1 (gaps G - 2, G - 1), and an asm conversion must not be the operand of the very next MFMA (layer_bf16's note):
+//   all sixteen are out by gap G - 4.
+template <int KS, int NTP, int POS0, class VT, class ST, class BFn, class Epi1, class Pre1>
+__device__ __forceinline__ void layer_e16(ST& st, const char* ringlane, const float* biaslane, BFn Bf, Epi1 epi1, Pre1 pre1, f32x4 (&last)[2][2]) {
+  constexpr int NF = NTP * KS * 2, G = 2 * KS;
+  constexpr int AHEAD = NF < 8 ? NF : 8;
+  static_assert(G >= 4, "at least two k-steps");
+  auto frag_ptr = [&](int g) {
+    return (const VT*)(ringlane + ((POS0 + g / SLOT_FRAGS) % ST::RING_SLOTS) * SLOT_BYTES + (g % SLOT_FRAGS) * FRAG_BYTES);
+  };
+  f32x4 pend[2][2];
+  VT aq[AHEAD];
+  f32x4 nbias[2] = {*(const f32x4*)biaslane, *(const f32x4*)(biaslane + 16)};
+#pragma unroll
+  for (int tp = 0; tp < NTP; ++tp) {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[t][cb] = nbias[t];
+    if (tp + 1 < NTP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) nbias[t] = *(const f32x4*)(biaslane + (2 * (tp + 1) + t) * 16);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int f = (tp * KS + ks) * 2 + t;
+        if (f % SLOT_FRAGS == 0) {
+          st.wait_slot();
+#pragma unroll
+          for (int u = 0; u < AHEAD; ++u)
+            if (queue_fill(f, u, NF)) aq[(f + u) % AHEAD] = *frag_ptr(f + u);
+        }
+        const VT a = aq[f % AHEAD];
+        if (queue_refill(f, AHEAD, NF)) aq[f % AHEAD] = *frag_ptr(f + AHEAD);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[t][cb] = mfma_16x16x32(a, Bf(cb, ks), acc[t][cb]);
+        st.slot_issue(f % SLOT_FRAGS);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const int at = tp == 0 ? (p * (G - 3)) / 16 : (p * G) / 16;
+          if (2 * ks + t == at) {
+            if (tp == 0) pre1(p);
+            else epi1(tp - 1, p, pend);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) pend[t][cb] = acc[t][cb];
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) last[t][cb] = pend[t][cb];
+}
+
 // Row of a 32x32 accumulator tile held in register g of a lane in half h (cdna guide §3).
 __host__ __device__ constexpr int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 

@@ -136,6 +136,47 @@ __host__ __device__ constexpr int r_nbias(int nhid) { return (1 + nhid) * W_HID 
 static_assert(s_nslots(S_NHID) == S_NSLOTS && sf_nslots(S_NHID) == SF_NSLOTS && sh_nslots(S_NHID) == SH_NSLOTS && p1_nslots(S_NHID) == P1_NSLOTS &&
               s_nbias(S_NHID) == S_NBIAS && p1_nbias(S_NHID) == P1_NBIAS && r_nbias(R_NHID) == R_NBIAS, "Fern values");
 
+// ---- refine on the 16x16x32 engine (layer_e16, fp16 operands; refine16_kernel, round 6): 32-deep k-steps, 16-row tiles in pairs, two 16-column blocks
+// per wave.  Lane l: ray l & 15 of each block, group g = l >> 4.  A lane group holds NV4 = ceil(nb / 4) neighbour views x 8 samples x 3 colours, then
+//   FOLD = false (refine_in rows from memory, any row): the Pluecker values of its two samples 2g, 2g + 1: 24 NV4 + 12 inputs in 3 NV4 + 2 k-steps of 8 slots
+//                per group (the last 4 slots are padding);
+//   FOLD = true  (the projecting head): the 8 Pluecker 6-vectors of a ray's samples are ONE vector in exact arithmetic — the moment (o + t d) x d^ = o x d^
+//                does not depend on t (the sampler's folded first layer rests on the same identity, above) — so W0[:, 0:48] acts on them as
+//                Wp[256 x 6] = sum_s W0[:, 6s:6s+6]: group 0 holds that vector in slots 0..5 of ONE more k-step: 3 NV4 + 1 k-steps (Fern: 4 instead of 5).
+constexpr int R16_NTP_LAST = 2;                            // pair 0: refine + offsets (tile t, row 4g + r = sample 2g + t), pair 1: rgb (tile 2, rows 0..2)
+constexpr int R16_SLOTS_LAST = (R16_NTP_LAST * (W_HID / 32) * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;      // 2
+__host__ __device__ constexpr int refine16_nv(int nb) { return (nb + 3) / 4; }
+__host__ __device__ constexpr int refine16_ks0(int nv4, bool fold) { return 3 * nv4 + (fold ? 1 : 2); }
+template <int NV4, bool FOLD>
+struct RefineE16 {
+  static_assert(NV4 >= 1 && NV4 <= 2, "1 .. 8 neighbour views");
+  static constexpr int KS0 = refine16_ks0(NV4, FOLD);
+  static constexpr int SLOTS_L0 = (8 * KS0 * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS;
+  static constexpr int POS_H = SLOTS_L0 % NSLOTS;
+  static constexpr int POS_LAST = POS_H;                                          // a hidden layer is 8 slots
+  static constexpr int SLOTS_PAD = (NSLOTS - (SLOTS_L0 + R16_SLOTS_LAST) % NSLOTS) % NSLOTS;
+};
+__host__ __device__ constexpr int refine16_slots(int nhid, int nv4, bool fold) { return pad_slots(refine16_ks0(nv4, fold) + nhid * 8 + R16_SLOTS_LAST); }
+__host__ __device__ constexpr int r16_nbias(int nhid) { return (1 + nhid) * W_HID + 16 * 2 * R16_NTP_LAST; }
+// input that slot n = 8 ks + j of lane group g supplies; -1 = padding.  FOLD = false: index into refine_in = [pluecker(48: s*6+j), epi((k*8+s)*3+c)];
+// FOLD = true: index into [pluecker(6), epi(24 nb)]
+__host__ __device__ constexpr int refine16_in0(int nv4, int nb, int ks, int g, int j, bool fold) {
+  const int n = 8 * ks + j;
+  if (n < 24 * nv4) {
+    const int view = nv4 * g + n / 24;
+    return view < nb ? (fold ? 6 : 48) + ((view * 8 + (n % 24) / 3) * 3 + n % 3) : -1;
+  }
+  const int m = n - 24 * nv4;
+  if (fold) return (g == 0 && m < 6) ? m : -1;
+  return m < 12 ? (2 * g + m / 6) * 6 + m % 6 : -1;
+}
+// output row r16 = 4g + r of tile T -> network output [refine(8), offsets(24 = s*3+c), rgb(3)]
+__host__ __device__ constexpr int refine16_out(int T, int r16) {
+  const int g = r16 >> 2, r = r16 & 3;
+  if (T < 2) { const int s = 2 * g + T; return r == 0 ? s : 8 + 3 * s + (r - 1); }
+  return (T == 2 && r16 < 3) ? 32 + r16 : -1;
+}
+
 // ---- nerf (bf16)
 constexpr int N_IN = 63, N_INV = 27, N_OUT = 4, N_NHID = 6;
 constexpr int N_KS0 = 4;                                 // 63 padded to 64

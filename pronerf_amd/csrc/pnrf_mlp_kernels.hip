@@ -1202,6 +1202,227 @@ __global__ __launch_bounds__(64 * NW, NCB == 1 ? 2 : 1) void refine_kernel(Refin
   st.drain();
 }
 
+// ------------------------------------------------------------------------------------------ refine stage on the 16x16x32 engine (round 6)
+// refine16_kernel: the fused inference refine stage (projection head or refine_in rows -> ELU MLP -> interval refinement + query points) on layer_e16:
+// v_mfma_f32_16x16x32_f16, two blocks of 16 rays per wave, 8 (4) waves = 256 (128) rays per batch like refine_kernel<1, 8 (4)>.  Lane l: ray l & 15 of each
+// block, group g = l >> 4.  The four lanes of a ray share its head and its epilogue: group g projects the ray's 8 samples into views NV4 g .. NV4 g + NV4 - 1
+// and encodes samples 2g, 2g + 1 (refine16_in0), and the output pair lands as tile t, registers 0..3 of group g = [logit, offset xyz] of sample 2g + t
+// (refine16_out): no exchange between lanes anywhere.  Same arithmetic per ray as refine_kernel<.., PrecF16> (the same fp16 operands, fp32 accumulation in
+// another order).
+template <class P>
+struct HiddenEpiE16 {
+  typename P::v8 (&Bn)[2][NB_KS_H];
+  __device__ __forceinline__ void operator()(int tp, int p, f32x4 (&acc)[2][2]) const {
+    const int t = p >> 3, cb = (p >> 2) & 1, r = p & 3;
+    acc[t][cb][r] = elu_scaled(acc[t][cb][r]);          // the even one waits, activated, in its accumulator register
+    if (r & 1) {
+      i32x4_t w = __builtin_bit_cast(i32x4_t, Bn[cb][tp]);
+      w[2 * t + (r >> 1)] = P::cvt_pk(acc[t][cb][r - 1], acc[t][cb][r]);
+      Bn[cb][tp] = __builtin_bit_cast(typename P::v8, w);
+    }
+  }
+};
+
+template <int NW, int HEAD, int NV4>
+__global__ __launch_bounds__(64 * NW, 2) void refine16_kernel(RefineArgs a) {
+  using P = PrecF16;
+  using v8 = typename P::v8;
+  constexpr bool FOLD = HEAD == 1;          // the head that computes the Pluecker vector itself runs the folded first layer (pnrf_layout.h)
+  using RL = RefineE16<NV4, FOLD>;
+  using Epi = HiddenEpiE16<P>;
+  constexpr int KS0 = RL::KS0, TPB = 64 * NW;
+  static_assert(KS0 <= NB_KS_H, "layer 0 fits the hidden layers' operand registers");
+  P::enter();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = (float*)(smem + RING_BYTES);
+  WStream<NW> st;
+  st.init(a.blob, a.nslots, smem);
+  st.prologue();
+  for (int i = threadIdx.x; i < a.nbias; i += TPB) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  own_the_simd<NW>();
+  young_half_priority<NW>();
+  const char* ringlane = smem + lane * 16;
+  const float* biaslane = bias_lds + 4 * g;
+
+  // batch order: as refine_kernel (HEAD = 1: the workgroups of an XCD walk one band of the frame)
+  int jbase = 0, j0 = (int)blockIdx.x, jstep = (int)gridDim.x, jend = a.nbatch;
+  if (HEAD == 1 && (gridDim.x & 7) == 0 && a.nbatch >= (int)gridDim.x) {
+    const int per = (a.nbatch + 7) >> 3;
+    jbase = (int)(blockIdx.x & 7) * per; j0 = (int)(blockIdx.x >> 3); jstep = (int)(gridDim.x >> 3);
+    jend = a.nbatch - jbase < per ? a.nbatch - jbase : per;
+  }
+  for (int j = j0; j < jend; j += jstep) {
+    const int batch = jbase + j;
+    int64_t row[2];
+    bool valid[2];
+    v8 Bo[2][NB_KS_H], Bn[2][NB_KS_H];
+    float e_ray[2][6];           // origin, direction
+    float e_w[2][4];             // the group's window of e = [near, d0 .. d7, far]: e[2g .. 2g + 3]
+    static_for<2>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      row[cb] = (int64_t)batch * (NW * 32) + wave * 32 + cb * 16 + c16;
+      valid[cb] = row[cb] < a.n;
+      const int64_t rr = valid[cb] ? row[cb] : a.n - 1;
+      const float* r = a.rays + rr * 11;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) e_ray[cb][i] = r[i];
+      const float* ds = a.depth_sorted + rr * 8;
+      const float wl = ds[g > 0 ? 2 * g - 1 : 0], wh = ds[g < 3 ? 2 * g + 2 : 7];
+      e_w[cb][0] = g == 0 ? r[6] : wl; e_w[cb][1] = ds[2 * g]; e_w[cb][2] = ds[2 * g + 1]; e_w[cb][3] = g == 3 ? r[7] : wh;
+      float feat[8 * KS0];
+      if constexpr (HEAD == 0) {
+        // a lane's inputs are runs of the natural row: the 24 colours of each of its views at 48 + 24 view, the Pluecker values of its two samples at 12 g
+        const float* xr = a.x + rr * (48 + 24 * a.nb);
+#pragma unroll
+        for (int vv = 0; vv < NV4; ++vv) {
+          const int view = NV4 * g + vv;
+          const float4* xc = (const float4*)(xr + 48 + 24 * (view < a.nb ? view : 0));
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            float4 t = xc[q];
+            if (view >= a.nb) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            feat[24 * vv + 4 * q + 0] = t.x; feat[24 * vv + 4 * q + 1] = t.y; feat[24 * vv + 4 * q + 2] = t.z; feat[24 * vv + 4 * q + 3] = t.w;
+          }
+        }
+        const float4* xp = (const float4*)(xr + 12 * g);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float4 t = xp[q];
+          feat[24 * NV4 + 4 * q + 0] = t.x; feat[24 * NV4 + 4 * q + 1] = t.y; feat[24 * NV4 + 4 * q + 2] = t.z; feat[24 * NV4 + 4 * q + 3] = t.w;
+        }
+      } else {
+        // lane (ray, g): views NV4 g + vv x 8 samples (24 NV4 colours) + Pluecker of samples 2g, 2g + 1, in the order of refine16_in0; the projections in
+        // refine_kernel's software pipeline (D projections' texel fetches in flight)
+        const float* orr = a.or_rays + rr * 11;
+        const float o0 = orr[0], o1 = orr[1], o2 = orr[2], w0 = orr[3], w1 = orr[4], w2 = orr[5];
+        const float4 d0 = *(const float4*)ds, d1 = *(const float4*)(ds + 4);
+        const float dn8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const int plane = a.Hf * a.Wf;
+        constexpr int D = 4;
+        float wt[D][4];
+        float4 tx[D][4];
+        ViewRay vr[NV4];
+        int view[NV4];
+        float z3d[8];
+#pragma unroll
+        for (int vv = 0; vv < NV4; ++vv) {
+          view[vv] = NV4 * g + vv < a.nb ? NV4 * g + vv : a.nb - 1;        // a view beyond nb - 1 is padding (zero weights): it projects into the last real view
+          float M[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) M[i] = a.proj[view[vv] * 12 + i];
+          vr[vv] = view_ray(o0, o1, o2, w0, w1, w2, M);
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) z3d[s8] = __builtin_amdgcn_rcpf(1.f - dn8[s8] - a.eps);                     // trt.py:637
+        const char* imb = (const char*)a.img4;
+        auto texel = [&](uint32_t view_off, uint32_t idx) { return *(const float4*)(imb + ((view_off + idx) << 4)); };
+        auto issue = [&](auto pc) {
+          constexpr int p = decltype(pc)::value, vv = p / 8, sl = p % D;
+          const uint32_t vo = (uint32_t)(view[vv] * plane);
+          const Taps t = project_taps_fast(vr[vv], z3d[p % 8], a.Hf, a.Wf);
+          tx[sl][0] = texel(vo, t.i00); tx[sl][1] = texel(vo, t.i01); tx[sl][2] = texel(vo, t.i10); tx[sl][3] = texel(vo, t.i11);
+          wt[sl][0] = t.a00; wt[sl][1] = t.a01; wt[sl][2] = t.a10; wt[sl][3] = t.a11;
+        };
+        auto blend = [&](auto pc) {
+          constexpr int p = decltype(pc)::value, sl = p % D;
+          Taps t;
+          t.a00 = wt[sl][0]; t.a01 = wt[sl][1]; t.a10 = wt[sl][2]; t.a11 = wt[sl][3];
+          feat[3 * p + 0] = blend4(tx[sl][0].x, tx[sl][1].x, tx[sl][2].x, tx[sl][3].x, t);
+          feat[3 * p + 1] = blend4(tx[sl][0].y, tx[sl][1].y, tx[sl][2].y, tx[sl][3].y, t);
+          feat[3 * p + 2] = blend4(tx[sl][0].z, tx[sl][1].z, tx[sl][2].z, tx[sl][3].z, t);
+        };
+        static_for<D>([&](auto pc) { issue(pc); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<8 * NV4>([&](auto pc) {
+          constexpr int p = decltype(pc)::value;
+          blend(pc);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (p + D < 8 * NV4) {
+            issue(std::integral_constant<int, p + D>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        {                                                                                          // trt.py:656-658, folded: [d^, o x d^] in group 0
+          float hx, hy, hz, m0, m1, m2;
+          unit_dir(r[3], r[4], r[5], hx, hy, hz);
+          cross_rn(r[0], r[1], r[2], hx, hy, hz, m0, m1, m2);
+          float* q = feat + 24 * NV4;
+          q[0] = g == 0 ? hx : 0.f; q[1] = g == 0 ? hy : 0.f; q[2] = g == 0 ? hz : 0.f;
+          q[3] = g == 0 ? m0 : 0.f; q[4] = g == 0 ? m1 : 0.f; q[5] = g == 0 ? m2 : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 24 * NV4 + (FOLD ? 6 : 12); i < 8 * KS0; ++i) feat[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS0; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = feat[8 * ks + jj];
+        Bo[cb][ks] = P::pack(v);
+      }
+    });
+    // ping-pong as refine_kernel: layer 0 Bo -> Bn, hidden layers in pairs, the output layer reads Bo
+    f32x4 pend[2][2];
+    auto hidden = [&](v8(&in)[2][NB_KS_H], v8(&out)[2][NB_KS_H], int l) {
+      f32x4 np[2][2];
+      layer_e16<NB_KS_H, NB_NTP_H, RL::POS_H, v8>(st, ringlane, biaslane + (1 + l) * W_HID, [&](int cb, int ks) { return in[cb][ks]; }, Epi{out},
+                                                  [&](int p) { Epi{in}(NB_NTP_H - 1, p, pend); }, np);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) pend[t][cb] = np[t][cb];
+    };
+    layer_e16<KS0, NB_NTP_H, 0, v8>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < KS0 ? ks : 0]; }, Epi{Bn}, [](int) {}, pend);
+    const int nhid = PNRF_NHID(a.nhid, R_NHID);
+    for (int l = 0; l + 1 < nhid; l += 2) {
+      hidden(Bn, Bo, l);
+      hidden(Bo, Bn, l + 1);
+    }
+    if (nhid & 1) hidden(Bn, Bo, nhid - 1);
+    else {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int k = 0; k < NB_KS_H; ++k) Bo[cb][k] = Bn[cb][k];
+    }
+    f32x4 fin[2][2];
+    layer_e16<NB_KS_H, 1, RL::POS_LAST, v8>(st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int cb, int ks) { return Bo[cb][ks]; }, [&](int, int, f32x4(&)[2][2]) {},
+                                            [&](int p) { Epi{Bo}(NB_NTP_H - 1, p, pend); }, fin);
+#pragma unroll
+    for (int i = 0; i < (R16_SLOTS_LAST - 1) + RL::SLOTS_PAD; ++i) st.begin();     // rgb pair (unused at inference) + pad
+
+    // ---- fused epilogue: lane (ray, g) owns samples 2g, 2g + 1: tile t, reg 0 = refine logit, regs 1..3 = offset
+    static_for<2>([&](auto cbc) {
+      constexpr int cb = decltype(cbc)::value;
+      const float* r = e_ray[cb];
+      const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
+      const float* w = e_w[cb];
+      float zz[2], pp[6];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float lower = ieee_mul(0.5f, ieee_add(w[t + 1], w[t]));          // trt.py:673-675
+        const float upper = ieee_mul(0.5f, ieee_add(w[t + 2], w[t + 1]));
+        const float rf = sigmoid_fast(fin[t][cb][0]);
+        zz[t] = ieee_add(lower, ieee_mul(ieee_sub(upper, lower), rf));        // :676
+        const float fx = tanh_fast(fin[t][cb][1]), fy = tanh_fast(fin[t][cb][2]), fz = tanh_fast(fin[t][cb][3]);
+        pp[3 * t + 0] = ieee_add(ieee_add(ox, ieee_mul(dx, zz[t])), ieee_mul(1e-2f, fx));   // :679-681
+        pp[3 * t + 1] = ieee_add(ieee_add(oy, ieee_mul(dy, zz[t])), ieee_mul(1e-2f, fy));
+        pp[3 * t + 2] = ieee_add(ieee_add(oz, ieee_mul(dz, zz[t])), ieee_mul(1e-2f, fz));
+      }
+      if (valid[cb]) {
+        *(float2*)(a.z + row[cb] * 8 + 2 * g) = make_float2(zz[0], zz[1]);
+        float2* pq = (float2*)(a.pts + row[cb] * 24 + 6 * g);
+        pq[0] = make_float2(pp[0], pp[1]);
+        pq[1] = make_float2(pp[2], pp[3]);
+        pq[2] = make_float2(pp[4], pp[5]);
+      }
+    });
+  }
+  st.drain();
+}
+
 struct NerfArgs {
   const void* blob; const float* bias; uint32_t nslots; int nbias;
   int nhid;                                         // DoNeRFTRT: hidden 256 -> 256 layers behind layer 0 (netdepth - 2; the Fern configs: 6); unused by the class net
@@ -1970,10 +2191,34 @@ static int refine_launch_nv(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipSt
   return launch_mlp(refine_kernel<1, 8, MODE, HEAD, PrecF16, NV>, a, 512, lds, a.nbatch, st);
   }
 }
+// The inference stage on the 16x16x32 engine (refine16_kernel; PNRF_VARIANT_REFINE_16X16): its own stream and bias table (d_blob_b16 / d_bias_b16 of a refine handle)
+template <int HEAD, int NV4>
+static int refine16_launch_nv(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
+  const size_t lds = RING_BYTES + (size_t)h->nbias_b16 * 4;
+  if (stage_shape(h, n, 32) == SHAPE_NARROW) {
+    a.nbatch = (int)((n + 127) / 128);
+    return launch_mlp(refine16_kernel<4, HEAD, NV4>, a, 256, narrow_lds(lds), a.nbatch, st);
+  }
+  a.nbatch = (int)((n + 255) / 256);
+  return launch_mlp(refine16_kernel<8, HEAD, NV4>, a, 512, lds, a.nbatch, st);
+}
+template <int HEAD>
+static int refine16_launch(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
+  constexpr bool FOLD = HEAD == 1;          // the projecting head runs the folded first layer (d_blob_fold), rows from memory the full one (d_blob_b16)
+  const void* blob = FOLD ? h->d_blob_fold : h->d_blob_b16;
+  const uint32_t ns = FOLD ? h->nslots_fold : h->nslots_b16;
+  PNRF_REQUIRE(blob && h->d_bias_b16 && ns == (uint32_t)refine16_slots(h->nhid, refine16_nv(h->nb), FOLD), PNRF_E_ARG,
+               "refine handle without the stream of the 16x16x32 engine");
+  a.blob = blob; a.nslots = ns; a.bias = h->d_bias_b16; a.nbias = h->nbias_b16;
+  return refine16_nv(h->nb) == 1 ? refine16_launch_nv<HEAD, 1>(h, a, n, st) : refine16_launch_nv<HEAD, 2>(h, a, n, st);
+}
 // ... for the handle's number of neighbour views (NV = views per lane half, pnrf_layout.h) and hidden layers
 template <int MODE, int HEAD>
 static int refine_launch(const pnrf_mlp_t* h, RefineArgs& a, int64_t n, hipStream_t st) {
   a.nhid = h->nhid; a.nb = h->nb;
+  if constexpr (MODE == 1) {
+    if (h->variant == PNRF_VARIANT_REFINE_16X16) return refine16_launch<HEAD>(h, a, n, st);
+  }
   if constexpr (MODE == 2) {                    // the training-time epilogue belongs to the trainer's shapes
     PNRF_REQUIRE(h->nb == 4, PNRF_E_SHAPE, "pnrf_refine_train_fwd is built for num_neighbor = 4, this refine net has %d", h->nb);
     return refine_launch_nv<MODE, HEAD, 2>(h, a, n, st);

@@ -483,6 +483,54 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     for (auto& L : Ls) { pack_layer_f16(L, blob_f16.data() + sf * SLOT_BYTES); sf += layer_slots(L, prec); }
   }
 
+  // refine: the streams of the 16x16x32 engine (layer_e16 / refine16_kernel; fp16 operands, log2(e)-scaled like every refine stream) and their bias table:
+  // the full first layer for rows from memory, and for the projecting head the first layer with the eight Pluecker 6-vectors folded into one (fp64 sum)
+  std::vector<char> blob_r16, blob_r16f;
+  std::vector<float> bias_r16, wfold_r;
+  if (net == PNRF_NET_REFINE) {
+    const int nv4 = refine16_nv(nbv), fin = 6 + 24 * nbv;
+    wfold_r.assign((size_t)W_HID * fin, 0.f);
+    for (int o = 0; o < W_HID; ++o) {
+      for (int c = 0; c < 6; ++c) {
+        double acc = 0.0;
+        for (int sm = 0; sm < 8; ++sm) acc += (double)W[0][(size_t)o * in0 + 6 * sm + c];
+        wfold_r[(size_t)o * fin + c] = (float)acc;
+      }
+      for (int k = 0; k < 24 * nbv; ++k) wfold_r[(size_t)o * fin + 6 + k] = W[0][(size_t)o * in0 + 48 + k];
+    }
+    for (int fold = 0; fold < 2; ++fold) {
+      const int ks0 = refine16_ks0(nv4, fold != 0);
+      std::vector<Layer> Lr = Ls;
+      for (auto& L : Lr) {
+        L.nt = W_HID / 16; L.out_map = identity_out(W_HID);
+        L.nk = NB_KS_H; L.in_map.assign(NB_KS_H * 32, -1);
+        for (int ks = 0; ks < NB_KS_H; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) L.in_map[(ks * 4 + g) * 8 + j] = hidden_feat_h16(ks, g, j);
+      }
+      Layer& G = Lr[0];
+      if (fold) { G.W = wfold_r.data(); G.in_dim = fin; }
+      G.nk = ks0; G.in_map.assign(ks0 * 32, -1);
+      for (int ks = 0; ks < ks0; ++ks) for (int g = 0; g < 4; ++g) for (int j = 0; j < 8; ++j) G.in_map[(ks * 4 + g) * 8 + j] = refine16_in0(nv4, nbv, ks, g, j, fold != 0);
+      Layer& Y = Lr[n_layers - 1];
+      Y.nt = 2 * R16_NTP_LAST; Y.out_map.assign(16 * Y.nt, -1);
+      for (int T = 0; T < Y.nt; ++T) for (int r16 = 0; r16 < 16; ++r16) Y.out_map[T * 16 + r16] = refine16_out(T, r16);
+      auto bs = [&](const Layer& L) { return ((size_t)(L.nt / 2) * L.nk * 2 + SLOT_FRAGS - 1) / SLOT_FRAGS; };
+      size_t sl = 0, nb = 0;
+      for (auto& L : Lr) { sl += bs(L); nb += (size_t)L.nt * 16; }
+      sl += (NSLOTS - sl % NSLOTS) % NSLOTS;
+      PNRF_REQUIRE(sl == (size_t)refine16_slots(nhid, nv4, fold != 0) && nb == (size_t)r16_nbias(nhid), PNRF_E_SHAPE,
+                   "pnrf_mlp_pack: internal layout mismatch (refine 16x16 stream %zu slots, %zu bias floats)", sl, nb);
+      std::vector<char>& blob_x = fold ? blob_r16f : blob_r16;
+      blob_x.assign(sl * SLOT_BYTES, 0);
+      if (!fold) bias_r16.assign(nb, 0.f);
+      size_t sb = 0, bb = 0;
+      for (auto& L : Lr) {
+        pack_layer_b16(L, blob_x.data() + sb * SLOT_BYTES, true);
+        if (!fold) pack_bias(L, PREC_F32, bias_r16.data() + bb);
+        sb += bs(L); bb += (size_t)L.nt * 16;
+      }
+    }
+  }
+
   // sampler: second stream with the folded first layer Wf[256x6] = sum_p W0[:, 6p:6p+6] (fp64 sum)
   std::vector<char> blob_fold;
   std::vector<float> wfold;
@@ -665,6 +713,16 @@ extern "C" int pnrf_mlp_pack(int net, const float* const* W, const float* const*
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_b16, bias_b16.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_b16.data(), bias_b16.size() * sizeof(float), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && net == PNRF_NET_REFINE) {
+    h->nslots_b16 = (uint32_t)(blob_r16.size() / SLOT_BYTES); h->nbias_b16 = (int)bias_r16.size();
+    e = hipMalloc(&h->d_blob_b16, blob_r16.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_b16, blob_r16.data(), blob_r16.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias_b16, bias_r16.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_bias_b16, bias_r16.data(), bias_r16.size() * sizeof(float), hipMemcpyHostToDevice);
+    h->nslots_fold = (uint32_t)(blob_r16f.size() / SLOT_BYTES);
+    if (e == hipSuccess) e = hipMalloc(&h->d_blob_fold, blob_r16f.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob_fold, blob_r16f.data(), blob_r16f.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && net == PNRF_NET_SAMPLER && full_stream) {
     float tv[S_NPTS];
     pnrf_linspace(0.f, 1.f, S_NPTS, tv);
@@ -724,7 +782,7 @@ struct EngineHeader {
   uint16_t nhid, nb, npts;            // format 4: the net's free shape parameters (hidden layers behind layer 0, neighbour views, ray points)
   uint8_t reserved[2];
 };
-static constexpr uint32_t ENGINE_FORMAT = 4;
+static constexpr uint32_t ENGINE_FORMAT = 5;      // 5: refine handles carry the stream of the 16x16x32 engine (nslots_b16 / nbias_b16)
 static constexpr int ENGINE_SECTIONS = 14;
 static_assert(sizeof(EngineHeader) == 128, "engine header is 128 bytes");
 static const char ENGINE_MAGIC[8] = {'P', 'N', 'R', 'F', 'E', 'N', 'G', 0};
@@ -766,6 +824,7 @@ static void expected_counts(int net, int nhid, int nb, int npts, EngineHeader* w
     case PNRF_NET_REFINE:
       w->prec = PREC_BF16; w->in_dim = 48 + 24 * nb; w->out_dim = R_OUT; w->nslots = refine_slots(nhid, refine_nv(nb)); w->nbias = r_nbias(nhid);
       w->n_in0 = (3 * refine_nv(nb) + 3) * 16; w->n_out = R_NT_LAST * 32;
+      w->nslots_b16 = refine16_slots(nhid, refine16_nv(nb), false); w->nslots_fold = refine16_slots(nhid, refine16_nv(nb), true); w->nbias_b16 = r16_nbias(nhid);
       w->nslots_f16 = w->nslots;
       break;
     case PNRF_NET_NERF:
@@ -909,7 +968,7 @@ extern "C" int pnrf_mlp_set_variant(pnrf_mlp_t* h, int variant) {
   const bool sampler = h->net == PNRF_NET_SAMPLER;
   const bool ok = variant == PNRF_VARIANT_DEFAULT || (sampler && (variant == PNRF_VARIANT_SAMPLER_F32 || variant == PNRF_VARIANT_SAMPLER_F32_FULL || variant == PNRF_VARIANT_SAMPLER_SPLIT)) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_BF16_32X32) ||
-                  (!sampler && variant == PNRF_VARIANT_BF16) || ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_F16) ||
+                  (!sampler && variant == PNRF_VARIANT_BF16) || (h->net == PNRF_NET_REFINE && variant == PNRF_VARIANT_REFINE_16X16) || ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_F16) ||
                   ((h->net == PNRF_NET_NERF || h->net == PNRF_NET_NERFCLS) && variant == PNRF_VARIANT_NERF_4X64);
   PNRF_REQUIRE(ok, PNRF_E_ARG, "pnrf_mlp_set_variant: variant %d does not exist for net kind %d", variant, h->net);
   h->variant = variant;

@@ -5,7 +5,7 @@
 
 A config selects a library build (lib=<name> -> pronerf_amd/lib/libpronerf_hip_<name>.so, empty = the default build; see
 `python -m pronerf_amd.build --variant <name> [flags]`) and the kernel variants of its handles (pnrf_mlp_set_variant: sampler=
-default (two passes) | sampler_split | sampler_f32 | sampler_f32_full, refine= default (fp16) | bf16, nerf= default (fp16) | bf16 | bf16_32x32 | nerf_4x64) — explicit configuration, the library reads no environment.  shape=wide|narrow|single forces the workgroup shape of all three
+default (two passes) | sampler_split | sampler_f32 | sampler_f32_full, refine= default (fp16) | bf16 | refine_16x16, nerf= default (fp16) | bf16 | bf16_32x32 | nerf_4x64) — explicit configuration, the library reads no environment.  shape=wide|narrow|single forces the workgroup shape of all three
 stages (pnrf_mlp_set_shape).
 Every round renders `--frames` frames per config through pnrf_render_rays_fwd with the context's per-kernel events
 (pnrf_ctx_profile_begin / _end); reports median / min over the rounds per stage kernel on the bench workload (one 1008x756 frame).
