@@ -512,7 +512,7 @@ __device__ __forceinline__ void layer_b16(ST& st, const char* ringlane, const fl
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = nbias[t];
+      for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = nbias[t];        // (no moves: the compiler passes the bias registers as the first MFMAs' C operand)
     if (tp + 1 < NTP) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) nbias[t] = *(const f32x4*)(biaslane + (2 * (tp + 1) + t) * 16);

@@ -1858,20 +1858,24 @@ __global__ __launch_bounds__(64 * NW, NCB == 2 ? 2 : 1) void nerf16_kernel(NerfA
           for (int cb = 0; cb < NCB; ++cb) pend[t][cb] = np[t][cb];
       };
       layer_b16<NB_KS0, NB_NTP_H, 0, NCB, v8>(st, ringlane, biaslane, [&](int cb, int ks) { return Bo[cb][ks < NB_KS0 ? ks : 0]; }, Epi{Bn}, [](int, int) {}, pend);
-      const int nhid = PNRF_NHID(a.nhid, N_NHID);            // pairs of layers end in Bn; the last layer of an odd count ends in Bo: moved over for the output layer
-      for (int l = 0; l < nhid; l += 2) { // (two layer bodies whatever the count: the odd tail is a branch inside the pair, not a third body)
+      // Run-time layer count without a register move on any path: two layer bodies (Bn -> Bo, Bo -> Bn) in a loop that leaves after the first one when the
+      // count is odd, and the (small) output layer once per place the activations can end in.  (A single output layer behind an "odd: move Bo over to Bn"
+      // branch inside the loop made the compiler keep the activations in ONE register set and copy 64 + 112 registers per pair of layers on the main
+      // path — every layer read the low set; found in the disassembly in round 6, -DPNRF_FIXED_NHID had no such moves.)
+      const int nhid = PNRF_NHID(a.nhid, N_NHID);
+      auto last_layer = [&](v8(&in)[NCB][NB_KS_H]) {
+        layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB, v8, PNRF_LAST_TMAX>(
+            st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? in[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
+            [&](int, int, f32x4(&)[2][NCB], int) {}, [&](int pc, int cb0) { Epi{in}(NB_NTP_H - 1, pc, pend, cb0); }, fin);
+      };
+      bool in_bo = false;
+      for (int l = 0; l < nhid; l += 2) {
         hidden(Bn, Bo, l);
-        if (l + 1 < nhid) hidden(Bo, Bn, l + 1);
-        else {
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int k = 0; k < NB_KS_H; ++k) Bn[cb][k] = Bo[cb][k];
-        }
+        if (l + 1 >= nhid) { in_bo = true; break; }
+        hidden(Bo, Bn, l + 1);
       }
-      layer_b16<NB_KS_LAST, 1, NB_POS_LAST, NCB, v8, PNRF_LAST_TMAX>(
-          st, ringlane, biaslane + (1 + nhid) * W_HID, [&](int cb, int ks) { return ks < NB_KS_H ? Bn[cb][ks < NB_KS_H ? ks : 0] : Bx[cb]; },
-          [&](int, int, f32x4(&)[2][NCB], int) {}, [&](int pc, int cb0) { Epi{Bn}(NB_NTP_H - 1, pc, pend, cb0); }, fin);
+      if (in_bo) last_layer(Bo);
+      else last_layer(Bn);
 #pragma unroll
       for (int i = 0; i < NB_SLOTS_PAD; ++i) st.begin();
     } else {
