@@ -190,12 +190,13 @@ def device_opcodes(lib: str = LIB):
 
 def device_kernels(lib: str = LIB):
     """Static figures of every kernel in the library's gfx950 code objects: demangled name -> {'instr', 'mfma' (counts in the disassembly), 'vgpr',
-    'scratch' (bytes of private segment: spills), 'lds' (static bytes)} from llvm-objdump and the kernel descriptors' notes (llvm-readelf)."""
+    'scratch' (bytes of private segment: spills), 'lds' (static bytes), 'vmov' (registers moved by v_mov_b32 / v_mov_b64 between VGPRs: a cluster of
+    them in a fused-MLP kernel is a copy of its operand registers)} from llvm-objdump and the kernel descriptors' notes (llvm-readelf)."""
     import collections
     import re
     out = {}
     for dis, notes in _disassembly(lib):
-        cur, n, mf = None, collections.Counter(), collections.Counter()
+        cur, n, mf, mv = None, collections.Counter(), collections.Counter(), collections.Counter()
         for line in dis.splitlines():
             m = re.match(r'^[0-9a-f]+ <(.+)>:', line)
             if m:
@@ -203,6 +204,9 @@ def device_kernels(lib: str = LIB):
             elif cur and line.startswith('\t'):
                 n[cur] += 1
                 mf[cur] += 'v_mfma' in line
+                mm = re.match(r'\tv_mov_b(32|64)_e32 v\[?\d+(?::\d+\])?, v', line)
+                if mm:
+                    mv[cur] += 2 if mm.group(1) == '64' else 1
         meta = {}
         for blk in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
             g = lambda k: (re.search(rf'\.{k}:\s+(\S+)', blk) or [None, '-1'])[1]
@@ -211,7 +215,8 @@ def device_kernels(lib: str = LIB):
         dem = subprocess.run(['c++filt'] + names, stdout=subprocess.PIPE, text=True).stdout.split('\n') if names else []
         for sym, d in zip(names, dem):
             k = d if d in n else sym
-            out[k.replace('(anonymous namespace)::', '')] = {'instr': n.get(k, 0), 'mfma': mf.get(k, 0), 'vgpr': meta[sym][0], 'scratch': meta[sym][1], 'lds': meta[sym][2]}
+            out[k.replace('(anonymous namespace)::', '')] = {'instr': n.get(k, 0), 'mfma': mf.get(k, 0), 'vgpr': meta[sym][0], 'scratch': meta[sym][1], 'lds': meta[sym][2],
+                                                             'vmov': mv.get(k, 0)}
     return out
 
 

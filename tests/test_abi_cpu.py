@@ -48,29 +48,36 @@ def test_frame_path_kernels_do_not_spill_and_the_fern_instances_kept_their_size(
     """Round 6 made the layer counts run-time arguments and templated the refine kernel on its views per lane half (the reference's free shape arguments).
     Guard of what that must not cost: no kernel of the inference frame path — any shape — uses scratch memory (a spill in a fused-MLP loop is a 10 % kernel),
     none exceeds the 256-register window two waves per SIMD leave, and the Fern instances still hold exactly the MFMAs of their layer bodies (a third
-    layer body appeared in the dominant kernel while this was written: 594 -> 850 MFMAs, 229 -> 250 VGPRs)."""
+    layer body appeared in the dominant kernel while this was written: 594 -> 850 MFMAs, 229 -> 250 VGPRs) — and no frame kernel copies its operand
+    registers around: the first run-time-count form of the NeRF stage kept the activations in one register set and moved 64 + 112 registers per pair of
+    layers on the main path (1.5 % of the stage; found in the disassembly, not by a test: now there is one).  Its form today: two layer bodies + the
+    output layer once per register set the activations can end in (594 + 18 MFMAs)."""
     from pronerf_amd import build
     k = build.device_kernels()
     assert len(k) > 80
-    frame = {n: v for n, v in k.items() if n.startswith(('void sampler_p1_kernel', 'void sampler_h16_kernel', 'void sampler_kernel<2>', 'void nerf16_kernel'))
+    frame = {n: v for n, v in k.items() if n.startswith(('void sampler_p1_kernel', 'void sampler_h16_kernel', 'void sampler_kernel<2>', 'void nerf16_kernel', 'void refine16_kernel'))
              or ('refine_kernel<1, ' in n and ', 1, 1, PrecF16' in n)}
-    assert len(frame) >= 4 + 8 + 5, sorted(frame)
+    assert len(frame) >= 4 + 8 + 5 + 8, sorted(frame)
     for n, v in frame.items():
         assert v['scratch'] == 0, (n, v)
         assert v['vgpr'] <= (512 if 'nerf16_kernel' in n and ', 4, PrecBf16, 4>' in n else 256), (n, v)      # (the 4 x 64-column NeRF shape owns a SIMD per wave)
+        # register-to-register moves: the sort networks, the odd / even tails' out-of-line copies (<= 64 registers each) and the batch heads — never
+        # hundreds (the copies named above: 272 in the 8-wave DoNeRFTRT kernel)
+        assert v['vmov'] <= (420 if ', 4, PrecBf16, 4>' in n else 200), (n, v)
     # A WIDE fused workgroup (8 waves, two per SIMD) owns its SIMDs' register file: 256 VGPRs per wave in the kernel descriptor whatever the code uses
     # (own_the_simd, pnrf_mlp_kernels.hip).  With 240 + 240 allocated a small wave of another stream's kernel fits beside the pair, and in exactly that
     # configuration the refine stage returned wrong rows a few times in 10^4 calls (NOTEBOOK 22, tools/wide_repro.py); at 256 + 256 nothing can share the SIMD.
     wide = {n: v for n, v in k.items() if (n.startswith(('void sampler_p1_kernel<8>', 'void sampler_h16_kernel<8>', 'void sampler_kernel<')) or
-                                           ('refine_kernel<1, 8,' in n) or ('nerf16_kernel<' in n and n.endswith(', 8>(NerfArgs)')) or ('nerf_kernel<1, 8,' in n))}
-    assert len(wide) >= 25, sorted(wide)          # 1 + 1 + 3 sampler, 18 refine, 4 nerf16, 2 nerf (32x32x16) instances
+                                           ('refine_kernel<1, 8,' in n) or ('refine16_kernel<8,' in n) or ('nerf16_kernel<' in n and n.endswith(', 8>(NerfArgs)')) or ('nerf_kernel<1, 8,' in n))}
+    assert len(wide) >= 29, sorted(wide)          # 1 + 1 + 3 sampler, 18 refine + 4 refine16, 4 nerf16, 2 nerf (32x32x16) instances
     for n, v in wide.items():
         assert v['vgpr'] == 256, (n, v)
     fern = {'void sampler_p1_kernel<8>(SamplerArgs)': 424, 'void sampler_h16_kernel<8>(SamplerArgs)': 1248, 'void refine_kernel<1, 8, 1, 1, PrecF16, 2>(RefineArgs)': 472,
-            'void nerf16_kernel<false, 2, PrecBf16, 8>(NerfArgs)': 594, 'void nerf16_kernel<true, 2, PrecBf16, 8>(NerfArgs)': 1578}
+            'void nerf16_kernel<false, 2, PrecBf16, 8>(NerfArgs)': 594 + 18, 'void nerf16_kernel<true, 2, PrecBf16, 8>(NerfArgs)': 1578}
     for n, mfma in fern.items():
         assert n in k, (n, [x for x in k if x.split('<')[0] == n.split('<')[0]])
         assert k[n]['mfma'] == mfma, (n, k[n])
+    assert k['void nerf16_kernel<false, 2, PrecBf16, 8>(NerfArgs)']['vmov'] <= 64, k['void nerf16_kernel<false, 2, PrecBf16, 8>(NerfArgs)']
     # every instance of the projecting refine stage: 8 tiles x (3 NV + 3) k-steps of layer 0 + three hidden-layer bodies + the output tile
     for nv in (1, 2, 3, 4):
         assert k[f'void refine_kernel<1, 8, 1, 1, PrecF16, {nv}>(RefineArgs)']['mfma'] == 8 * (3 * nv + 3) + 3 * 128 + 16

@@ -11,4 +11,4 @@ lib = next((a[6:] for a in sys.argv[1:] if a.startswith('--lib=')), build.LIB)
 flt = [a for a in sys.argv[1:] if not a.startswith('--')]
 for k, v in sorted(build.device_kernels(lib).items()):
     if not flt or any(f in k for f in flt):
-        print(f"{v['instr']:7d} instr {v['mfma']:5d} mfma  vgpr {v['vgpr']:4d} scratch {v['scratch']:5d} lds {v['lds']:6d}  {k[:130]}")
+        print(f"{v['instr']:7d} instr {v['mfma']:5d} mfma  vgpr {v['vgpr']:4d} scratch {v['scratch']:5d} lds {v['lds']:6d} vmov {v['vmov']:4d}  {k[:130]}")
