@@ -125,3 +125,33 @@ def test_frame_with_the_16x16_refine_stage(dev):
     assert orc.psnr(out['r16'][:, :3], out['default'][:, :3]) > 60.0, orc.psnr(out['r16'][:, :3], out['default'][:, :3])
     print(f"\n[refine 16x16] frame vs the oracle: default {orc.psnr(out['default'][:, :3], o['rgb']):.1f} dB, 16x16 {orc.psnr(out['r16'][:, :3], o['rgb']):.1f} dB; "
           f"16x16 vs default {orc.psnr(out['r16'][:, :3], out['default'][:, :3]):.1f} dB")
+
+
+def test_frame_size_rows_agree_with_the_32x32_stage(dev):
+    """BASELINE configs[1] size (762 048 rays, 1008 x 756): the two refine stages over the same sampler output — every row finite, inside its interval, and
+    within fp16 noise of the other stage; wide (the launch's own shape) and forced-narrow workgroups bit-identical."""
+    from pronerf_amd import ops, synthetic
+    H, W = 756, 1008
+    w = synth.make_weights(0, 'trained')
+    scene = synthetic.make_scene(0, H=H, W=W, focal=815.13, rotate=True)
+    rays, orr = ops.frame_rays(scene['K'], scene['c2w'], H, W, device=dev)
+    sampler = ops.PackedMLP(ops.NET_SAMPLER, w['sampler']['W'], w['sampler']['b'])
+    ds = ops.sampler_fwd(sampler, rays, two_pass=True, want_idx=False, want_rgb=False)[0]
+    from pronerf_amd.render import Renderer
+    rend = Renderer(w, max_rays=H * W, device=dev)
+    rend.set_views(scene['c2w'], scene['poses'], scene['images'], scene['K'])
+    old = ops.PackedMLP(ops.NET_REFINE, w['refine']['W'], w['refine']['b'])
+    new = ops.PackedMLP(ops.NET_REFINE, w['refine']['W'], w['refine']['b'], variant='refine_16x16')
+    z0, p0 = ops.refine_project_fwd(old, rays, orr, ds, rend.img4, rend.proj)
+    z1, p1 = ops.refine_project_fwd(new, rays, orr, ds, rend.img4, rend.proj)
+    assert bool(torch.isfinite(z1).all()) and bool(torch.isfinite(p1).all())
+    e = torch.cat([rays[:, 6:7], ds, rays[:, 7:8]], 1)                                  # [near, d0..d7, far]: sample s lies between the midpoints around d_s (trt.py:673-676)
+    lo, hi = 0.5 * (e[:, :-2] + e[:, 1:-1]), 0.5 * (e[:, 1:-1] + e[:, 2:])
+    assert bool(((z1 >= lo - 1e-6) & (z1 <= hi + 1e-6)).all())
+    dz = (z1 - z0).abs()
+    print(f'\n[refine 16x16] frame size: max |dz| {float(dz.max()):.2e}, rel. RMS {relrms(z1.cpu(), z0.cpu()):.2e}, max |dpts| {float((p1 - p0).abs().max()):.2e}')
+    assert float(dz.max()) < 2e-3 and relrms(z1.cpu(), z0.cpu()) < 3e-4 and float((p1 - p0).abs().max()) < 3e-3
+    m = ops.PackedMLP(ops.NET_REFINE, w['refine']['W'], w['refine']['b'], variant='refine_16x16')
+    m.set_shape('narrow')
+    z2, p2 = ops.refine_project_fwd(m, rays, orr, ds, rend.img4, rend.proj)
+    assert torch.equal(z2, z1) and torch.equal(p2, p1)
